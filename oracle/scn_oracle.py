@@ -1,0 +1,447 @@
+"""CPU oracle for the sparse-convolution hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module.  The product path (``sparse_rcnn_amd``) never does.
+
+PARITY UNPINNED for the sparse-convolution arithmetic: that arithmetic lives in
+the third-party package ``facebookresearch/SparseConvNet`` (imported by the
+reference as ``sparseconvnet``; no version pinned, README.md:23-31), which is
+neither under /root/reference nor installed here, and the reference holds no
+tests or golden vectors for it.  What pins this restatement
+instead: (i) every operator below is checked against the dense ``torch.nn.functional``
+twin the reference itself pairs it with (module_factory.py:96-112, 231-239,
+255-264, 365-372, 402-412) in ``tests/test_oracle_dense.py``; (ii) the ROI crop
+(the one piece of hot-path arithmetic the reference owns) IS pinned by golden
+vectors generated from the reference's own ``roi_cut`` (``tests/golden/``).
+
+Index work is numpy (integer exact); feature work is torch-CPU fp32, organised
+the way the SparseConvNet CPU path is: per kernel offset gather rows ->
+``sgemm`` -> scatter-add, bias first, offsets ascending.
+
+Canonical order (DESIGN.md §"Canonical order"): the reference leaves the row
+numbering of strided-conv output sites and the order of rules inside an offset
+implementation-defined (hash-map iteration upstream).  Here, and in the HIP
+path: active rows are numbered by FIRST OCCURRENCE scanning input rows
+ascending; rules inside an offset are sorted by OUTPUT row ascending.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+# --------------------------------------------------------------------------
+# keys
+# --------------------------------------------------------------------------
+
+def pack_keys(coords: np.ndarray) -> np.ndarray:
+    """(x,y,z,b) int64 rows -> one uint64 key, b most significant.
+
+    Same packing as the device hash (csrc/scn_index.hip pack_key): 16 bits per
+    field.  Sorting keys sorts by (b, x, y, z).
+    """
+    c = np.asarray(coords, dtype=np.int64)
+    assert c.ndim == 2 and c.shape[1] == 4
+    assert (c >= 0).all() and (c < 65536).all(), "coordinate out of 16-bit range"
+    c = c.astype(np.uint64)
+    return (c[:, 3] << np.uint64(48)) | (c[:, 0] << np.uint64(32)) | (c[:, 1] << np.uint64(16)) | c[:, 2]
+
+
+def _first_occurrence_rows(keys: np.ndarray):
+    """Number distinct keys by first occurrence.  Returns (row_of_item, first_item_of_row)."""
+    if len(keys) == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64)
+    uniq, first_idx, inverse = np.unique(keys, return_index=True, return_inverse=True)
+    order = np.argsort(first_idx, kind="stable")          # unique-id sorted by first appearance
+    rank = np.empty(len(uniq), np.int64)
+    rank[order] = np.arange(len(uniq))
+    return rank[inverse.reshape(-1)], first_idx[order]
+
+
+# --------------------------------------------------------------------------
+# A3 InputLayer / A10 OutputLayer     (custom_operations.py:62-86, 7-10)
+# --------------------------------------------------------------------------
+
+def input_layer_rules(coords: np.ndarray):
+    """coords int64 [Npts,4] (x,y,z,b) -> (active coords [N,4] int64, point_row [Npts], counts [N]).
+
+    Rows are numbered by first occurrence in input-row order across the whole
+    batch (InputLayer).
+    """
+    coords = np.asarray(coords, dtype=np.int64).reshape(-1, 4)
+    prow, first = _first_occurrence_rows(pack_keys(coords))
+    n = len(first)
+    counts = np.bincount(prow, minlength=n).astype(np.int64)
+    return coords[first], prow, counts
+
+
+def input_layer_fwd(feats: torch.Tensor, prow: np.ndarray, n_active: int, mode: int) -> torch.Tensor:
+    """mode 0 copy (unique guaranteed) / 1 last / 2 first / 3 sum / 4 mean."""
+    feats = feats.detach()
+    idx = torch.from_numpy(np.asarray(prow, dtype=np.int64))
+    C = feats.shape[1]
+    if mode in (3, 4):
+        acc = torch.zeros(n_active, C, dtype=torch.float64)
+        acc.index_add_(0, idx, feats.double())
+        if mode == 4:
+            cnt = torch.bincount(idx, minlength=n_active).clamp_(min=1).double()
+            acc /= cnt[:, None]
+        return acc.to(feats.dtype)
+    out = torch.zeros(n_active, C, dtype=feats.dtype)
+    if mode == 0:
+        assert len(np.unique(prow)) == len(prow), "mode 0 requires unique coordinates"
+        out[idx] = feats
+    elif mode == 1:                                   # last writer wins
+        last = np.full(n_active, -1, np.int64)
+        np.maximum.at(last, prow, np.arange(len(prow)))
+        out = feats[torch.from_numpy(last)]
+    elif mode == 2:                                   # first writer wins
+        first = np.full(n_active, len(prow), np.int64)
+        np.minimum.at(first, prow, np.arange(len(prow)))
+        out = feats[torch.from_numpy(first)]
+    else:
+        raise ValueError(mode)
+    return out
+
+
+def input_layer_bwd(dY: torch.Tensor, prow: np.ndarray, mode: int) -> torch.Tensor:
+    idx = torch.from_numpy(np.asarray(prow, dtype=np.int64))
+    n_active = dY.shape[0]
+    g = dY[idx]
+    if mode == 4:
+        cnt = torch.bincount(idx, minlength=n_active).clamp_(min=1).to(dY.dtype)
+        g = g / cnt[idx][:, None]
+    elif mode in (1, 2):
+        ar = np.arange(len(prow))
+        if mode == 1:
+            win = np.full(n_active, -1, np.int64); np.maximum.at(win, prow, ar)
+        else:
+            win = np.full(n_active, len(prow), np.int64); np.minimum.at(win, prow, ar)
+        keep = torch.from_numpy(win[prow] == ar)
+        g = g * keep[:, None].to(g.dtype)
+    return g
+
+
+def output_layer_fwd(X: torch.Tensor, prow: np.ndarray) -> torch.Tensor:
+    return X[torch.from_numpy(np.asarray(prow, dtype=np.int64))]
+
+
+def output_layer_bwd(dY: torch.Tensor, prow: np.ndarray, n_active: int) -> torch.Tensor:
+    acc = torch.zeros(n_active, dY.shape[1], dtype=torch.float64)
+    acc.index_add_(0, torch.from_numpy(np.asarray(prow, dtype=np.int64)), dY.double())
+    return acc.to(dY.dtype)
+
+
+# --------------------------------------------------------------------------
+# A5 submanifold rulebook, A6/A7 strided rulebook
+# --------------------------------------------------------------------------
+
+def _lookup(sorted_keys, sorted_rows, q):
+    pos = np.searchsorted(sorted_keys, q)
+    pos[pos >= len(sorted_keys)] = 0
+    hit = sorted_keys[pos] == q
+    return np.where(hit, sorted_rows[pos], -1)
+
+
+def subm_rulebook(coords: np.ndarray, k: int = 3):
+    """Active coords [N,4] -> (nbr [k^3, N] int32, rules list of (in,out) int32 arrays per offset).
+
+    Offset o = ((dx+h)*k + (dy+h))*k + (dz+h), x slowest (Appendix B).  nbr[o, r]
+    is the row of site coords[r] + delta_o or -1.  rules[o] holds the pairs with
+    nbr >= 0, out ascending.
+    """
+    coords = np.asarray(coords, dtype=np.int64).reshape(-1, 4)
+    n = len(coords)
+    h = k // 2
+    nbr = np.full((k ** 3, n), -1, np.int32)
+    if n:
+        keys = pack_keys(coords)
+        order = np.argsort(keys, kind="stable")
+        sk, sr = keys[order], order.astype(np.int64)
+        o = 0
+        for dx in range(-h, h + 1):
+            for dy in range(-h, h + 1):
+                for dz in range(-h, h + 1):
+                    q = coords + np.array([dx, dy, dz, 0])
+                    ok = ((q[:, :3] >= 0) & (q[:, :3] < 65536)).all(1)
+                    qk = pack_keys(np.where(ok[:, None], q, 0))
+                    r = _lookup(sk, sr, qk)
+                    nbr[o] = np.where(ok, r, -1)
+                    o += 1
+    rules = []
+    for o in range(k ** 3):
+        out = np.nonzero(nbr[o] >= 0)[0].astype(np.int32)
+        rules.append((nbr[o][out].astype(np.int32), out))
+    return nbr, rules
+
+
+def strided_rulebook(coords: np.ndarray, s: int = 2):
+    """Fine coords [Nf,4] -> dict(coarse coords, parent, off, child table, rules).
+
+    size = stride = s.  Coarse site = floor(p/s); offset o = ((x%s)*s + y%s)*s + z%s.
+    Coarse rows numbered by first occurrence scanning fine rows ascending.
+    rules[o] = (fine rows, coarse rows), coarse ascending.
+    """
+    coords = np.asarray(coords, dtype=np.int64).reshape(-1, 4)
+    cc = coords.copy()
+    cc[:, :3] //= s
+    parent, first = _first_occurrence_rows(pack_keys(cc))
+    nc = len(first)
+    r = coords[:, :3] % s
+    off = ((r[:, 0] * s + r[:, 1]) * s + r[:, 2]).astype(np.int32)
+    child = np.full((s ** 3, nc), -1, np.int32)
+    child[off, parent] = np.arange(len(coords), dtype=np.int32)
+    rules = []
+    for o in range(s ** 3):
+        out = np.nonzero(child[o] >= 0)[0].astype(np.int32)
+        rules.append((child[o][out].astype(np.int32), out))
+    return dict(coords=cc[first], parent=parent.astype(np.int32), off=off, child=child, rules=rules)
+
+
+def rules_concat(rules):
+    """list of (in,out) -> (pairs [P,2] int32 offset-major, prefix [n_off+1] int64)."""
+    prefix = np.zeros(len(rules) + 1, np.int64)
+    for o, (i, _) in enumerate(rules):
+        prefix[o + 1] = prefix[o] + len(i)
+    if prefix[-1] == 0:
+        return np.zeros((0, 2), np.int32), prefix
+    pairs = np.concatenate([np.stack([i, j], 1) for i, j in rules]).astype(np.int32)
+    return pairs, prefix
+
+
+# --------------------------------------------------------------------------
+# A5-A7, A9 feature arithmetic: gather -> sgemm -> scatter-add
+# --------------------------------------------------------------------------
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a).astype(np.int64))
+
+
+def conv_fwd(X, rules, W, b, n_out):
+    """Y = 1 b^T; for o ascending: Y[out] += X[in] W[o].   W [n_off, Cin, Cout]."""
+    Y = torch.zeros(n_out, W.shape[2], dtype=X.dtype)
+    if b is not None:
+        Y += b
+    for o, (i, j) in enumerate(rules):
+        if len(i):
+            Y.index_add_(0, _t(j), X[_t(i)] @ W[o])
+    return Y
+
+
+def conv_bwd(X, dY, rules, W, has_bias=True):
+    """Returns dX [N_in,Cin], dW like W, db [Cout] or None."""
+    dX = torch.zeros_like(X)
+    dW = torch.zeros_like(W)
+    for o, (i, j) in enumerate(rules):
+        if len(i):
+            ti, tj = _t(i), _t(j)
+            g = dY[tj]
+            dX.index_add_(0, ti, g @ W[o].t())
+            dW[o] = X[ti].t() @ g
+    db = dY.sum(0) if has_bias else None
+    return dX, dW, db
+
+
+def swap_rules(rules):
+    """Deconvolution uses the encoder's rulebook with roles swapped (Appendix B)."""
+    return [(j, i) for (i, j) in rules]
+
+
+class _ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, W, b, rules, n_out):
+        ctx.rules = rules
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(X, W)
+        return conv_fwd(X, rules, W, b, n_out)
+
+    @staticmethod
+    def backward(ctx, dY):
+        X, W = ctx.saved_tensors
+        dX, dW, db = conv_bwd(X, dY.contiguous(), ctx.rules, W, ctx.has_bias)
+        return dX, dW, db, None, None
+
+
+def conv(X, W, b, rules, n_out):
+    return _ConvFn.apply(X, W, b, rules, n_out)
+
+
+def batchnorm_relu_fwd(X, gamma, beta, running_mean, running_var, eps=1e-4, momentum=0.9,
+                       leak=0.0, training=True):
+    """A8.  momentum is the RETAIN fraction (SparseConvNet convention, SURVEY §4.1 caveat).
+    Batch statistics are biased (divide by N) and so is the running_var update."""
+    if training:
+        mean = X.mean(0)
+        var = X.var(0, unbiased=False)
+        running_mean.mul_(momentum).add_(mean.detach() * (1 - momentum))
+        running_var.mul_(momentum).add_(var.detach() * (1 - momentum))
+    else:
+        mean, var = running_mean, running_var
+    y = (X - mean) / torch.sqrt(var + eps) * gamma + beta
+    return torch.where(y > 0, y, y * leak)
+
+
+def sparse_to_dense(X, coords, spatial_size, batch_size):
+    """A13: zeros [B,C,X,Y,Z]; out[b,:,x,y,z] = X[row]."""
+    sx, sy, sz = (int(v) for v in spatial_size)
+    out = torch.zeros(batch_size, X.shape[1], sx, sy, sz, dtype=X.dtype)
+    c = torch.from_numpy(np.asarray(coords, dtype=np.int64))
+    out[c[:, 3], :, c[:, 0], c[:, 1], c[:, 2]] = X
+    return out
+
+
+# --------------------------------------------------------------------------
+# A11 sparse ROI crop   (roi_select_sparse.py:125-180, roi_select_bbox_transform.py:56-70,
+#                        ndsis/utils/bbox.py:87-106)
+# --------------------------------------------------------------------------
+
+def round_boxes(boxes: np.ndarray) -> np.ndarray:
+    """fp boxes [BB,2,3] -> int64 (floor start, ceil stop)   (bbox.py:87-106)."""
+    boxes = np.asarray(boxes)
+    return np.stack([np.floor(boxes[:, 0]), np.ceil(boxes[:, 1])], 1).astype(np.int64)
+
+
+def transform_boxes(bbox_batch, spatial_size=None, clip=False):
+    """BBoxTransformerSlice.forward (roi_select_bbox_transform.py:56-70,87-97): list of fp [n_i,2,3] ->
+    (int64 [BB,2,3] floor/ceil (optionally clipped: start to [0,S-1], stop to [1,S], bbox.py:62-84),
+    per-sample counts, per-box sample index)."""
+    counts = [len(b) for b in bbox_batch]
+    raw = np.concatenate([np.asarray(b, dtype=np.float32).reshape(-1, 2, 3) for b in bbox_batch]) \
+        if bbox_batch else np.zeros((0, 2, 3), np.float32)
+    boxes = round_boxes(raw)
+    if clip:
+        s = np.asarray(spatial_size, dtype=np.int64)
+        boxes[:, 0] = np.clip(boxes[:, 0], 0, s - 1)
+        boxes[:, 1] = np.clip(boxes[:, 1], 1, s)
+    assoc = np.repeat(np.arange(len(counts), dtype=np.int64), counts)
+    return boxes, counts, assoc
+
+
+def roi_crop(coords: np.ndarray, boxes_int: np.ndarray, box_sample: np.ndarray):
+    """coords int64 [N,4], boxes_int int64 [BB,2,3], box_sample int64 [BB].
+
+    Returns (src_row [M] int64 box-major then ascending point row, box_of [M], is_inside [BB,N] bool).
+    Output coords = (x,y,z,box index); output feats = feats[src_row]
+    (roi_select_sparse.py:125-149,157-180).
+    """
+    coords = np.asarray(coords, dtype=np.int64).reshape(-1, 4)
+    bb = len(boxes_int)
+    if bb == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros((0, len(coords)), bool)
+    start = np.concatenate([boxes_int[:, 0], box_sample[:, None]], 1)          # [BB,4]
+    stop = np.concatenate([boxes_int[:, 1], box_sample[:, None] + 1], 1)
+    inside = ((start[:, None, :] <= coords[None]) & (coords[None] < stop[:, None, :])).all(-1)
+    box_of, src_row = np.nonzero(inside)                                       # row-major = box-major
+    return src_row.astype(np.int64), box_of.astype(np.int64), inside
+
+
+# --------------------------------------------------------------------------
+# A12 the benchmark topology, on the oracle ops (used as checker and CPU baseline)
+# --------------------------------------------------------------------------
+
+class OracleScene:
+    """Index state for one batch: levels of active coords + cached rulebooks."""
+
+    def __init__(self, coords_pts: np.ndarray):
+        self.coords0, self.prow, self.counts = input_layer_rules(coords_pts)
+        self.level_coords = [self.coords0]
+        self.subm = {}
+        self.strided = {}
+
+    def subm_rules(self, level, k=3):
+        key = (level, k)
+        if key not in self.subm:
+            self.subm[key] = subm_rulebook(self.level_coords[level], k)[1]
+        return self.subm[key]
+
+    def strided_rules(self, level):
+        if level not in self.strided:
+            rb = strided_rulebook(self.level_coords[level], 2)
+            self.strided[level] = rb
+            if len(self.level_coords) == level + 1:
+                self.level_coords.append(rb["coords"])
+        return self.strided[level]["rules"]
+
+    def n(self, level):
+        return len(self.level_coords[level])
+
+
+def unet_param_shapes(cin, channels):
+    """Ordered (name, shape) list for the A12 U-Net (SURVEY Appendix A.1 layer list)."""
+    shapes = []
+    L = len(channels)
+    for l, c in enumerate(channels):
+        if l == 0:
+            shapes += [(f"enc{l}.in.weight", (1, cin, c)), (f"enc{l}.in.bias", (c,))]
+        else:
+            shapes += [(f"enc{l}.in.weight", (8, channels[l - 1], c)), (f"enc{l}.in.bias", (c,))]
+        for u in range(2):
+            for v in range(2):
+                shapes += [(f"enc{l}.res{u}.conv{v}.weight", (27, c, c)), (f"enc{l}.res{u}.conv{v}.bias", (c,))]
+    for l in range(L - 2, -1, -1):
+        c, cup = channels[l], channels[l + 1]
+        shapes += [(f"dec{l}.up.weight", (8, cup, c)), (f"dec{l}.up.bias", (c,))]
+        shapes += [(f"dec{l}.nin.weight", (2 * c, c)), (f"dec{l}.nin.bias", (c,))]
+        for u in range(2):
+            for v in range(2):
+                shapes += [(f"dec{l}.res{u}.conv{v}.weight", (27, c, c)), (f"dec{l}.res{u}.conv{v}.bias", (c,))]
+    return shapes
+
+
+def init_unet_params(cin, channels, seed=0):
+    """N(0, sqrt(2/(Cin*k^3))) weights, small random biases so bias paths are exercised."""
+    g = torch.Generator().manual_seed(seed)
+    params = {}
+    for name, shape in unet_param_shapes(cin, channels):
+        if name.endswith("weight"):
+            fan = shape[-2] * (shape[0] if len(shape) == 3 else 1)
+            params[name] = torch.randn(shape, generator=g) * (2.0 / fan) ** 0.5
+        else:
+            params[name] = torch.randn(shape, generator=g) * 0.01
+    return params
+
+
+def unet_forward(scene: OracleScene, feats_pts: torch.Tensor, params: dict, channels):
+    """A12: encoder level = {SubM1 | Conv2s2} + 2x[x + SubM3(ReLU(SubM3(ReLU(x))))];
+    decoder level = ReLU -> Deconv2s2 -> Join(up, skip) -> NiN -> 2x residual
+    (module_factory.py:127-183, 513-578; custom_container.py:70-83: cat((upsampled, skip)))."""
+    P = params
+    relu = torch.relu
+    x = _InputFn.apply(feats_pts, scene)
+    skips = []
+    L = len(channels)
+
+    def residual(x, prefix, level):
+        rules = scene.subm_rules(level, 3)
+        n = scene.n(level)
+        for u in range(2):
+            y = conv(relu(x), P[f"{prefix}.res{u}.conv0.weight"], P[f"{prefix}.res{u}.conv0.bias"], rules, n)
+            y = conv(relu(y), P[f"{prefix}.res{u}.conv1.weight"], P[f"{prefix}.res{u}.conv1.bias"], rules, n)
+            x = x + y
+        return x
+
+    for l in range(L):
+        if l == 0:
+            ident = [(np.arange(scene.n(0), dtype=np.int32),) * 2]
+            x = conv(x, P["enc0.in.weight"], P["enc0.in.bias"], ident, scene.n(0))
+        else:
+            rules = scene.strided_rules(l - 1)
+            x = conv(x, P[f"enc{l}.in.weight"], P[f"enc{l}.in.bias"], rules, scene.n(l))
+        x = residual(x, f"enc{l}", l)
+        skips.append(x)
+    for l in range(L - 2, -1, -1):
+        rules = swap_rules(scene.strided_rules(l))
+        up = conv(relu(x), P[f"dec{l}.up.weight"], P[f"dec{l}.up.bias"], rules, scene.n(l))
+        x = torch.cat([up, skips[l]], 1) @ P[f"dec{l}.nin.weight"] + P[f"dec{l}.nin.bias"]
+        x = residual(x, f"dec{l}", l)
+    return x
+
+
+class _InputFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, scene):
+        ctx.scene = scene
+        return input_layer_fwd(feats, scene.prow, scene.n(0), 4)
+
+    @staticmethod
+    def backward(ctx, dY):
+        return input_layer_bwd(dY, ctx.scene.prow, 4), None

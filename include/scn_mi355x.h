@@ -1,0 +1,199 @@
+/*
+ * scn_mi355x.h -- C ABI of libscn_mi355x.so: the MI355X-native (gfx950) replacement for the
+ * native boundary of `sparseconvnet` (SCN), the un-vendored third-party package in which the
+ * reference's sparse-convolution hot path runs.
+ *
+ * What it replaces.  The reference (LeonhardFeiner/sparse_rcnn) reaches native code only through
+ * `import sparseconvnet as scn` (ndsis/modules/module_factory.py:5, model.py:6,
+ * custom_operations.py:4, roi_select_sparse.py:3).  Upstream, every scn Python layer forwards to
+ * a pybind11 module `sparseconvnet.SCN` (`Metadata_3`, `<Op>_updateOutput`, `<Op>_backward`); that
+ * module is NOT under /root/reference and cannot be cited by line, so each entry point below cites
+ * the REFERENCE call site whose work it performs.
+ *
+ * Conventions
+ *   - extern "C", plain pointers + sizes, no C++/torch types.  Every pointer is a DEVICE pointer
+ *     unless its name ends in `_host`.  `stream` is a hipStream_t passed as void*.
+ *   - Ownership: the caller owns every buffer (feature slabs, hash tables, rule tables, scratch).
+ *     The library allocates nothing and keeps no state besides the last-error string, so the
+ *     caller's stream-ordered allocator (PyTorch's caching allocator in the Python host layer)
+ *     governs lifetime.  Data-dependent sizes use two phases: a *_scan/_build call that returns
+ *     the size through a `_host` out-parameter (it synchronises `stream` once; documented per
+ *     function), then the caller allocates and calls the matching *_fill.
+ *   - Every function returns 0 on success or an SCN_E* code; scn_last_error_string() describes
+ *     the last failure on the calling thread.  Nothing aborts.
+ *   - Threading: functions are re-entrant; work is enqueued on `stream` and is asynchronous
+ *     except where a `_host` out-parameter is documented to synchronise.
+ *   - Feature slabs are row-major fp32 [rows][channels], channels contiguous.
+ *   - Coordinates on device are int32 [n][4] = (x, y, z, batch); hash keys pack 16 bits per field.
+ *   - Rule tables are int32 [n_off][n_out]: table[o][r] = input row feeding output row r through
+ *     kernel offset o, or -1.  Compacted rules are two int32 arrays (in_rows, out_rows), offset-major,
+ *     output row ascending inside an offset (the canonical order), with an int64
+ *     prefix[n_off+1].
+ */
+#ifndef SCN_MI355X_H
+#define SCN_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCN_OK 0
+#define SCN_EINVAL 1      /* bad argument (null pointer, negative size, unsupported shape) */
+#define SCN_ESIZE 2       /* size-constraint violation, e.g. (out-1)*stride+filter != in */
+#define SCN_EHASH 3       /* hash table too small / coordinate outside the 16-bit key range */
+#define SCN_EHIP 4        /* a HIP runtime call failed; see scn_last_error_string() */
+
+#define SCN_ABI_VERSION 1
+
+/* flags for the gather-GEMM entry points */
+#define SCN_F_RELU_IN 1      /* use max(X,0) as the input slab (fuses scn.ReLU before a conv, module_factory.py:88,173-176) */
+#define SCN_F_W_TRANSPOSED 2 /* use W[o]^T: W is [n_off][cout][cin] seen from this call (backward-data) */
+#define SCN_F_OFF_REVERSE 4  /* weight index n_off-1-o for table row o (SubM backward-data: R_o^T = R_{k^3-1-o}) */
+
+typedef void* scn_stream_t;
+
+int scn_abi_version(void);
+const char* scn_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Index path: scn.Metadata / InputLayer rules / rulebooks
+ * ---------------------------------------------------------------------------------------- */
+
+/* Power-of-two slot count the hash tables for n keys must have. */
+int64_t scn_hash_capacity(int64_t n);
+
+/* int64 [n][4] coords (x,y,z,batch) as the reference hands them over (ndsis/data/data.py:95-98, consumed at
+ * custom_operations.py:72-80) -> int32 [n][4].  *bad_host receives the number of rows with a field outside
+ * [0,65535] (synchronises stream); such input is rejected with SCN_EHASH. */
+int scn_coords_to_i32(const int64_t* coords, int64_t n, int32_t* out, int32_t* scratch1, int64_t* bad_host,
+                      scn_stream_t stream);
+
+/* Scratch bytes scn_dedup_build needs for n items. */
+int64_t scn_dedup_scratch_bytes(int64_t n);
+
+/* Row numbering by first occurrence (InputLayer rules: custom_operations.py:72-80 with mode 0-4;
+ * strided-conv output sites: module_factory.py:232-234).  Key of item i = (batch, x>>shift, y>>shift, z>>shift).
+ *   table_keys[cap], table_rows[cap]  hash of the distinct keys -> row id (kept by the caller as the grid of
+ *                                     this spatial size; used later by scn_subm_table)
+ *   item_row[n]      row id of every item        (InputLayer: point -> voxel row;  Convolution: fine row -> coarse row)
+ *   row_count[n]     multiplicity of each row, first *n_rows_host entries valid (may be NULL)
+ *   row_first[n]     smallest item index of each row (may be NULL)
+ *   row_coords[n][4] coordinates (shifted) of each row
+ *   n_rows_host      number of distinct rows (synchronises stream once) */
+int scn_dedup_build(const int32_t* coords, int64_t n, int shift, uint64_t* table_keys, int32_t* table_rows,
+                    int64_t cap, int32_t* item_row, int32_t* row_count, int32_t* row_first, int32_t* row_coords,
+                    void* scratch, int64_t* n_rows_host, scn_stream_t stream);
+
+/* Submanifold neighbour table for filter k (odd; reference uses 1 and 3: module_factory.py:383-385,404-406):
+ * table[o][r] = row of coords[r] + delta_o or -1, o = ((dx+h)k + (dy+h))k + (dz+h). */
+int scn_subm_table(const int32_t* coords, int64_t n, const uint64_t* table_keys, const int32_t* table_rows,
+                   int64_t cap, int k, int32_t* table, scn_stream_t stream);
+
+/* Children table of a size=stride=2 Convolution (module_factory.py:232-234): child[o][c] = fine row with parent c
+ * and offset o = ((x&1)*2 + (y&1))*2 + (z&1), or -1.  Also writes fine_off[n_fine] = that offset. */
+int scn_child_table(const int32_t* fine_coords, const int32_t* parent, int64_t n_fine, int64_t n_coarse,
+                    int32_t* child, int32_t* fine_off, scn_stream_t stream);
+
+/* Compaction of a rule table into (in,out) pairs -- wave ballot + prefix sum.
+ * Phase 1: counts; block_sums must hold scn_rules_blocks(n_off, n_out) int32; writes prefix (device, int64[n_off+1])
+ * and copies it to prefix_host (synchronises stream once). */
+int64_t scn_rules_blocks(int n_off, int64_t n_out);
+int scn_rules_scan(const int32_t* table, int n_off, int64_t n_out, int32_t* block_sums, int64_t* prefix,
+                   int64_t* prefix_host, scn_stream_t stream);
+/* Phase 2: in_rows/out_rows (and seg_of = offset index of each pair, may be NULL) of prefix_host[n_off] entries. */
+int scn_rules_fill(const int32_t* table, int n_off, int64_t n_out, const int32_t* block_sums, int32_t* in_rows,
+                   int32_t* out_rows, int32_t* seg_of, scn_stream_t stream);
+
+/* Sparse ROI crop indicator (roi_select_sparse.py:157-167 get_inside_indicator): boxes int32 [bb][8] =
+ * (start x,y,z,sample ; stop x,y,z,sample+1).  table[i][j] = j if point j lies in box i else -1; feed it to
+ * scn_rules_scan/_fill to obtain the box-major, ascending-point-row selection of select_features / select_coords
+ * (roi_select_sparse.py:125-149).  inside_u8 [bb][n] (may be NULL) receives the bool matrix roi_cut returns (:180). */
+int scn_roi_table(const int32_t* coords, int64_t n, const int32_t* boxes, int bb, int32_t* table, uint8_t* inside_u8,
+                  scn_stream_t stream);
+/* out_coords[m] = (x,y,z of coords[src_row[m]], box_of[m]) as int64 rows (select_coords, roi_select_sparse.py:136-149) */
+int scn_roi_coords(const int32_t* coords, const int32_t* src_row, const int32_t* box_of, int64_t m, int64_t* out_coords,
+                   scn_stream_t stream);
+/* boxes fp32 [bb][2][3] -> floor(start), ceil(stop) (ndsis/utils/bbox.py:87-106), optional clip start to [0,S-1] /
+ * stop to [1,S] (bbox.py:62-84), sample index appended -> int32 [bb][8] as scn_roi_table expects. */
+int scn_roi_boxes(const float* boxes, const int32_t* box_sample, int bb, const int32_t* spatial_size3_or_null,
+                  int32_t* out, scn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Feature path: gather-GEMM-scatter on fp32 MFMA
+ * ---------------------------------------------------------------------------------------- */
+
+/* Output-stationary gather GEMM:   Y[r] = residual[r] + bias + sum_o  in(X[table[o][r]]) . W[o']
+ * (SubmanifoldConvolution fwd, module_factory.py:404-406; Convolution fwd via the child table, :232-234;
+ *  NetworkInNetwork fwd with table == NULL (identity, n_off = 1), :366-367; and the backward-data of
+ *  SubM / Deconvolution / NiN with SCN_F_W_TRANSPOSED).
+ * W is [n_off][cin][cout] row-major as stored by the layer; with SCN_F_W_TRANSPOSED the call sees it as
+ * [n_off][cout_of_call][cin_of_call]^T, i.e. pass the layer's weight unchanged and swap cin/cout.
+ * bias, residual may be NULL.  relu_mask (may be NULL, [n_out][cout]): elements of Y are zeroed where relu_mask <= 0
+ * (fuses the ReLU backward that follows a backward-data GEMM). */
+int scn_gemm_table(const float* X, int64_t n_in, int cin, const int32_t* table, int n_off, int64_t n_out,
+                   const float* W, const float* bias, const float* residual, const float* relu_mask, float* Y,
+                   int cout, int flags, scn_stream_t stream);
+
+/* Rule-list gather GEMM with row scatter:  Y[out_rows[p]] = bias + in(X[in_rows[p]]) . W[o(p)]
+ * where every output row occurs in exactly one pair (Deconvolution fwd, module_factory.py:256-258; backward-data
+ * of Convolution).  prefix_host = int64[n_off+1] on the HOST. */
+int scn_gemm_rules(const float* X, int cin, const int32_t* in_rows, const int32_t* out_rows,
+                   const int64_t* prefix_host, int n_off, const float* W, const float* bias, const float* relu_mask,
+                   float* Y, int cout, int flags, scn_stream_t stream);
+
+/* Weight gradient:  dW[o] = sum_{p in R_o} in(X[in_rows[p]])^T . dY[out_rows[p]]     (dW fully overwritten)
+ * in_rows == out_rows == NULL means the identity rule list of length prefix_host[1] (NetworkInNetwork).
+ * scratch: scn_wgrad_scratch_bytes(...) bytes. */
+int64_t scn_wgrad_scratch_bytes(int cin, int cout, const int64_t* prefix_host, int n_off);
+int scn_wgrad_rules(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
+                    const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, void* scratch,
+                    int flags, scn_stream_t stream);
+
+/* db[c] = sum_r dY[r][c]   (bias gradient of every conv-type layer).  scratch: SCN_COLSUM_BLOCKS*c floats. */
+#define SCN_COLSUM_BLOCKS 512
+int scn_colsum(const float* dY, int64_t n, int c, float* db, void* scratch, scn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise / normalisation / IO
+ * ---------------------------------------------------------------------------------------- */
+
+/* scn.ReLU (module_factory.py:88) and scn.AddTable (:52-54,308) */
+int scn_relu_fwd(const float* X, int64_t count, float* Y, scn_stream_t stream);
+int scn_relu_bwd(const float* X, const float* dY, int64_t count, float* dX, scn_stream_t stream);
+int scn_add(const float* A, const float* B, int64_t count, float* Y, scn_stream_t stream);
+
+/* scn.BatchNormReLU / BatchNormLeakyReLU (module_factory.py:92-102): training statistics over all rows. */
+int64_t scn_bn_scratch_bytes(int c);
+int scn_bn_stats(const float* X, int64_t n, int c, float* mean, float* var_biased,
+                 void* scratch /* scn_bn_scratch_bytes(c) */, scn_stream_t stream);
+int scn_bn_fwd(const float* X, int64_t n, int c, const float* mean, const float* var, float eps, const float* gamma,
+               const float* beta, float leak, float* Y, scn_stream_t stream);
+/* dX, dgamma, dbeta for y = lrelu((x-mean)*invstd*gamma+beta); training=1 propagates through the batch statistics */
+int scn_bn_bwd(const float* X, const float* dY, int64_t n, int c, const float* mean, const float* var, float eps,
+               const float* gamma, const float* beta, float leak, int training, float* dX, float* dgamma, float* dbeta,
+               void* scratch /* scn_bn_scratch_bytes(c) */, scn_stream_t stream);
+
+/* InputLayerFunction (custom_operations.py:72-80): mode 0 copy, 1 last, 2 first, 3 sum, 4 mean.
+ * acc64: scratch of n_rows*c doubles (modes 3,4).  row_last (mode 1): scratch of n_rows int32. */
+int scn_input_fwd(const float* feats, const int32_t* item_row, const int32_t* row_count, const int32_t* row_first,
+                  int64_t n_items, int64_t n_rows, int c, int mode, float* Y, double* acc64, int32_t* row_last,
+                  scn_stream_t stream);
+int scn_input_bwd(const float* dY, const int32_t* item_row, const int32_t* row_count, const int32_t* row_first,
+                  const int32_t* row_last, int64_t n_items, int c, int mode, float* dfeats, scn_stream_t stream);
+/* OutputLayerFunction (custom_operations.py:7-10): Y[i] = X[item_row[i]]; backward = segment sum. */
+int scn_gather_rows(const float* X, const int32_t* rows, int64_t m, int c, float* Y, scn_stream_t stream);
+int scn_segment_sum(const float* dY, const int32_t* item_row, int64_t n_items, int64_t n_rows, int c, float* dX,
+                    double* acc64, scn_stream_t stream);
+
+/* scn.SparseToDense (module_factory.py:429-435): out [B][C][X][Y][Z] pre-zeroed by the caller. */
+int scn_sparse_to_dense_fwd(const float* X, const int32_t* coords, int64_t n, int c, const int64_t* size3_host,
+                            float* out, scn_stream_t stream);
+int scn_sparse_to_dense_bwd(const float* dOut, const int32_t* coords, int64_t n, int c, const int64_t* size3_host,
+                            float* dX, scn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCN_MI355X_H */

@@ -1,0 +1,23 @@
+"""sparse_rcnn_amd -- MI355X-native drop-in for the ``sparseconvnet`` (scn) operator API that the reference's
+ScanNet instance-segmentation code calls (ndsis/modules/{module_factory,model,custom_operations,roi_select_sparse}.py).
+
+    import sys, sparse_rcnn_amd
+    sys.modules["sparseconvnet"] = sparse_rcnn_amd      # then `import sparseconvnet as scn` resolves here
+
+Host code is Python/PyTorch-ROCm (device memory, streams, autograd, torch.distributed); all arithmetic runs in
+hand-written gfx950 HIP kernels behind the C ABI of include/scn_mi355x.h (libscn_mi355x.so).  No CPU fallback.
+"""
+from . import ioLayers                                                     # noqa: F401  (scn.ioLayers.*Function)
+from ._lib import ScnError, EXPORTS, LIB_PATH, load as load_library          # noqa: F401
+from .ioLayers import InputLayer, OutputLayer                              # noqa: F401
+from .metadata import Metadata                                             # noqa: F401
+from .modules import (AddTable, AveragePooling, BatchNormLeakyReLU, BatchNormReLU, ConcatTable,  # noqa: F401
+                      Convolution, Deconvolution, Identity, JoinTable, MaxPooling, NetworkInNetwork, ReLU,
+                      Sequential, SparseToDense, SubmanifoldConvolution)
+from .tensor import SparseConvNetTensor                                    # noqa: F401
+
+__all__ = [
+    "Metadata", "SparseConvNetTensor", "ioLayers", "InputLayer", "OutputLayer", "Sequential", "ConcatTable",
+    "AddTable", "JoinTable", "Identity", "ReLU", "BatchNormReLU", "BatchNormLeakyReLU", "Convolution",
+    "Deconvolution", "SubmanifoldConvolution", "NetworkInNetwork", "MaxPooling", "AveragePooling", "SparseToDense",
+]

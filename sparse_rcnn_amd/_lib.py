@@ -1,0 +1,106 @@
+"""ctypes binding of libscn_mi355x.so (C ABI declared in include/scn_mi355x.h).
+
+The product path has no CPU fallback: if the shared library is missing, or no MI355X is visible, every
+operator raises.  PyTorch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscn_mi355x.so")
+
+_lib = None
+
+p = C.c_void_p
+i32, i64, f32 = C.c_int, C.c_int64, C.c_float
+
+_SIGS = {
+    "scn_abi_version": (C.c_int, []),
+    "scn_last_error_string": (C.c_char_p, []),
+    "scn_hash_capacity": (i64, [i64]),
+    "scn_coords_to_i32": (C.c_int, [p, i64, p, p, C.POINTER(i64), p]),
+    "scn_dedup_scratch_bytes": (i64, [i64]),
+    "scn_dedup_build": (C.c_int, [p, i64, i32, p, p, i64, p, p, p, p, p, C.POINTER(i64), p]),
+    "scn_subm_table": (C.c_int, [p, i64, p, p, i64, i32, p, p]),
+    "scn_child_table": (C.c_int, [p, p, i64, i64, p, p, p]),
+    "scn_rules_blocks": (i64, [i32, i64]),
+    "scn_rules_scan": (C.c_int, [p, i32, i64, p, p, C.POINTER(i64), p]),
+    "scn_rules_fill": (C.c_int, [p, i32, i64, p, p, p, p, p]),
+    "scn_roi_table": (C.c_int, [p, i64, p, i32, p, p, p]),
+    "scn_roi_coords": (C.c_int, [p, p, p, i64, p, p]),
+    "scn_roi_boxes": (C.c_int, [p, p, i32, p, p, p]),
+    "scn_gemm_table": (C.c_int, [p, i64, i32, p, i32, i64, p, p, p, p, p, i32, i32, p]),
+    "scn_gemm_rules": (C.c_int, [p, i32, p, p, C.POINTER(i64), i32, p, p, p, p, i32, i32, p]),
+    "scn_wgrad_scratch_bytes": (i64, [i32, i32, C.POINTER(i64), i32]),
+    "scn_wgrad_rules": (C.c_int, [p, i32, p, i32, p, p, C.POINTER(i64), i32, p, p, i32, p]),
+    "scn_colsum": (C.c_int, [p, i64, i32, p, p, p]),
+    "scn_relu_fwd": (C.c_int, [p, i64, p, p]),
+    "scn_relu_bwd": (C.c_int, [p, p, i64, p, p]),
+    "scn_add": (C.c_int, [p, p, i64, p, p]),
+    "scn_bn_scratch_bytes": (i64, [i32]),
+    "scn_bn_stats": (C.c_int, [p, i64, i32, p, p, p, p]),
+    "scn_bn_fwd": (C.c_int, [p, i64, i32, p, p, f32, p, p, f32, p, p]),
+    "scn_bn_bwd": (C.c_int, [p, p, i64, i32, p, p, f32, p, p, f32, i32, p, p, p, p, p]),
+    "scn_input_fwd": (C.c_int, [p, p, p, p, i64, i64, i32, i32, p, p, p, p]),
+    "scn_input_bwd": (C.c_int, [p, p, p, p, p, i64, i32, i32, p, p]),
+    "scn_gather_rows": (C.c_int, [p, p, i64, i32, p, p]),
+    "scn_segment_sum": (C.c_int, [p, p, i64, i64, i32, p, p, p]),
+    "scn_sparse_to_dense_fwd": (C.c_int, [p, p, i64, i32, C.POINTER(i64), p, p]),
+    "scn_sparse_to_dense_bwd": (C.c_int, [p, p, i64, i32, C.POINTER(i64), p, p]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+F_RELU_IN, F_W_TRANSPOSED, F_OFF_REVERSE = 1, 2, 4
+COLSUM_BLOCKS = 512
+
+
+class ScnError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (no GPU needed).  Raises ScnError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ScnError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        if lib.scn_abi_version() != 1:
+            raise ScnError("libscn_mi355x.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def lib():
+    """Library handle for compute calls: additionally requires a visible GPU."""
+    l = load()
+    if not torch.cuda.is_available():
+        raise ScnError("sparse_rcnn_amd needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    return l
+
+
+def check(rc: int):
+    if rc != 0:
+        raise ScnError(f"libscn_mi355x error {rc}: {load().scn_last_error_string().decode()}")
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def host_i64(n):
+    return (i64 * n)()

@@ -1,0 +1,73 @@
+// Shared host-side helpers for libscn_mi355x (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/scn_mi355x.h"
+
+namespace scn {
+
+extern thread_local char g_err[512];
+
+inline int fail(int code, const char* fmt, const char* a = "", long long b = 0, long long c = 0) {
+    snprintf(g_err, sizeof(g_err), fmt, a, b, c);
+    return code;
+}
+
+#define SCN_HIP(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            snprintf(scn::g_err, sizeof(scn::g_err), "%s failed: %s (%s:%d)", #expr,                \
+                     hipGetErrorString(e_), __FILE__, __LINE__);                                    \
+            return SCN_EHIP;                                                                        \
+        }                                                                                           \
+    } while (0)
+
+#define SCN_LAUNCH_CHECK()                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = hipGetLastError();                                                          \
+        if (e_ != hipSuccess) {                                                                     \
+            snprintf(scn::g_err, sizeof(scn::g_err), "kernel launch failed: %s (%s:%d)",            \
+                     hipGetErrorString(e_), __FILE__, __LINE__);                                    \
+            return SCN_EHIP;                                                                        \
+        }                                                                                           \
+    } while (0)
+
+#define SCN_REQUIRE(cond)                                                                           \
+    do {                                                                                            \
+        if (!(cond)) {                                                                              \
+            snprintf(scn::g_err, sizeof(scn::g_err), "%s: requirement failed: %s", __func__, #cond); \
+            return SCN_EINVAL;                                                                      \
+        }                                                                                           \
+    } while (0)
+
+inline hipStream_t S(scn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Grid for HBM-bound elementwise kernels: cap and grid-stride (cdna_hip_programming.md Guideline 11).
+inline int ew_grid(int64_t work_items, int block) {
+    int64_t g = cdiv(work_items, block);
+    if (g > 256 * 8) g = 256 * 8;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace scn
+
+// ---- device-side key packing / hashing (shared by index kernels) ----
+#define SCN_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+
+__device__ __forceinline__ unsigned long long scn_pack_key(int x, int y, int z, int b) {
+    return ((unsigned long long)(unsigned)b << 48) | ((unsigned long long)(unsigned)x << 32) |
+           ((unsigned long long)(unsigned)y << 16) | (unsigned long long)(unsigned)z;
+}
+
+__device__ __forceinline__ unsigned long long scn_hash_slot(unsigned long long key, unsigned long long mask) {
+    unsigned long long h = key * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    return h & mask;
+}

@@ -1,0 +1,411 @@
+// Feature path of libscn_mi355x: gather-GEMM-scatter on the gfx950 fp32 matrix cores.
+//
+// Every conv-type layer of the reference's sparse backbone / mask head is one of three GEMM shapes
+// (DESIGN.md §Kernels):
+//   gemm_table : output-stationary.  Y[r] = sum_o X[table[o][r]] . W[o]   (SubM, Convolution, NiN and the
+//                backward-data of SubM / Deconvolution / NiN).  No atomics: an output row is owned by one wave.
+//   gemm_rules : rule list, every output row appears once (Deconvolution fwd, Convolution backward-data).
+//   wgrad_rules: dW[o] = sum_p X[in_p]^T . dY[out_p], K = number of rules; split over rule chunks, slabs
+//                reduced in fixed order (bitwise reproducible, no float atomics).
+//
+// Arithmetic is exact fp32 on v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD; MI355X_MICROARCH.md §Matrix cores).
+// A wave owns a 32x32 output tile: 16 accumulator VGPRs, A/B operands are ONE f32 VGPR each.
+//   lane l: m = l & 31 (tile row for A / tile column for B), h = l >> 5 (which of the 2 k of an MFMA step)
+//   K is consumed in chunks of 8: lane half h holds k = 8q + 4h + e, e = 0..3 (one float4 per lane for A),
+//   MFMA step e multiplies k = 8q+e (h=0 lanes) and k = 8q+4+e (h=1 lanes): a fixed permutation of the
+//   summation order, identical for A and B.
+//   C/D: acc[v] = D[(v&3) + 8*(v>>2) + 4*h][l & 31]   (cdna_hip_programming.md §3 fragment layout)
+#include "scn_common.h"
+
+using scn::S;
+using scn::cdiv;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >> 2) + 4 * h; }
+
+// One offset's contribution of a 32-row x 32-col tile:  acc += in(Xrow[0..cin)) . Wo[:, n0..n0+32)
+//   xrow : this lane's gathered input row (valid iff have)
+//   Wo   : weight matrix of this offset; !WT: [cin][cout] row-major;  WT: [cout][cin] row-major (used transposed)
+template <bool FAST, bool WT>
+__device__ __forceinline__ void tile_mac(f32x16& acc, const float* __restrict__ xrow, bool have, int cin,
+                                         const float* __restrict__ Wo, int cout, int n, bool n_ok, int h, bool relu_in) {
+    if (FAST) {   // cin % 8 == 0, rows 16-B aligned
+        for (int q = 0; q < cin; q += 8) {
+            const int k0 = q + 4 * h;
+            float4 a = have ? *(const float4*)(xrow + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (relu_in) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+            float4 b;
+            if (WT) {
+                b = n_ok ? *(const float4*)(Wo + (long long)n * cin + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const float* wp = Wo + (long long)k0 * cout + n;
+                b.x = n_ok ? wp[0] : 0.f;
+                b.y = n_ok ? wp[cout] : 0.f;
+                b.z = n_ok ? wp[2 * cout] : 0.f;
+                b.w = n_ok ? wp[3 * cout] : 0.f;
+            }
+            acc = MFMA(a.x, b.x, acc);
+            acc = MFMA(a.y, b.y, acc);
+            acc = MFMA(a.z, b.z, acc);
+            acc = MFMA(a.w, b.w, acc);
+        }
+    } else {      // any cin: guarded scalar loads
+        for (int q = 0; q < cin; q += 8) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = q + 4 * h + e;
+                const bool k_ok = k < cin;
+                float a = (have && k_ok) ? xrow[k] : 0.f;
+                if (relu_in) a = fmaxf(a, 0.f);
+                float b = 0.f;
+                if (k_ok && n_ok) b = WT ? Wo[(long long)n * cin + k] : Wo[(long long)k * cout + n];
+                acc = MFMA(a, b, acc);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_table
+// ------------------------------------------------------------------------------------------------
+template <bool FAST, bool WT>
+__global__ __launch_bounds__(256) void k_gemm_table(const float* __restrict__ X, int cin,
+                                                    const int* __restrict__ table, int n_off, long long n_out,
+                                                    const float* __restrict__ W, const float* __restrict__ bias,
+                                                    const float* __restrict__ residual,
+                                                    const float* __restrict__ relu_mask, float* __restrict__ Y, int cout,
+                                                    int flags) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    const long long r0 = ((long long)blockIdx.x * 4 + wave) * 32;
+    if (r0 >= n_out) return;                       // wave-uniform
+    const long long row = r0 + m;
+    const bool row_ok = row < n_out;
+    const int n0 = blockIdx.y * 32;
+    const int n = n0 + m;
+    const bool n_ok = n < cout;
+    const bool relu_in = flags & SCN_F_RELU_IN;
+    const bool rev = flags & SCN_F_OFF_REVERSE;
+    const long long wstride = (long long)cin * cout;
+
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+
+    int idx_next = row_ok ? (table ? table[row] : (int)row) : -1;
+    for (int o = 0; o < n_off; ++o) {
+        const int idx = idx_next;
+        if (o + 1 < n_off) idx_next = row_ok ? table[(long long)(o + 1) * n_out + row] : -1;
+        if (__ballot(idx >= 0) == 0ull) continue;  // no rule of this offset touches the tile
+        const float* Wo = W + (long long)(rev ? n_off - 1 - o : o) * wstride;
+        const float* xrow = X + (long long)(idx >= 0 ? idx : 0) * cin;
+        tile_mac<FAST, WT>(acc, xrow, idx >= 0, cin, Wo, cout, n, n_ok, h, relu_in);
+    }
+
+    const float bv = (bias && n_ok) ? bias[n] : 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const long long r = r0 + acc_row(v, h);
+        if (r < n_out && n_ok) {
+            const long long off = r * cout + n;
+            float y = acc[v] + bv;
+            if (residual) y += residual[off];
+            if (relu_mask && !(relu_mask[off] > 0.f)) y = 0.f;
+            Y[off] = y;
+        }
+    }
+}
+
+extern "C" int scn_gemm_table(const float* X, int64_t n_in, int cin, const int32_t* table, int n_off, int64_t n_out,
+                              const float* W, const float* bias, const float* residual, const float* relu_mask,
+                              float* Y, int cout, int flags, scn_stream_t stream) {
+    SCN_REQUIRE(n_in >= 0 && n_out >= 0 && cin >= 1 && cout >= 1 && n_off >= 1);
+    SCN_REQUIRE(table || (n_off == 1 && n_in == n_out));
+    if (n_out == 0) return SCN_OK;
+    SCN_REQUIRE(X && W && Y);
+    SCN_REQUIRE(n_out * (int64_t)cout < (1LL << 40) && cdiv(n_out, 128) < 2147483647LL);
+    const bool fast = (cin % 8 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0);
+    const bool wt = flags & SCN_F_W_TRANSPOSED;
+    dim3 grid((unsigned)cdiv(n_out, 128), (unsigned)cdiv(cout, 32));
+#define LAUNCH_T(F, T)                                                                                        \
+    hipLaunchKernelGGL((k_gemm_table<F, T>), grid, dim3(256), 0, S(stream), X, cin, table, n_off,             \
+                       (long long)n_out, W, bias, residual, relu_mask, Y, cout, flags)
+    if (fast && wt) LAUNCH_T(true, true);
+    else if (fast) LAUNCH_T(true, false);
+    else if (wt) LAUNCH_T(false, true);
+    else LAUNCH_T(false, false);
+#undef LAUNCH_T
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_rules: tiles of 32 rules inside one offset
+// ------------------------------------------------------------------------------------------------
+struct SegTiles {
+    long long rule_start[33];   // prefix of rules per offset (n_off <= 32)
+    long long tile_start[33];   // prefix of 32-rule tiles per offset
+    int n_off;
+};
+
+template <bool FAST, bool WT>
+__global__ __launch_bounds__(256) void k_gemm_rules(const float* __restrict__ X, int cin,
+                                                    const int* __restrict__ in_rows, const int* __restrict__ out_rows,
+                                                    SegTiles seg, const float* __restrict__ W,
+                                                    const float* __restrict__ bias, const float* __restrict__ relu_mask,
+                                                    float* __restrict__ Y, int cout, int flags) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    const long long tile = (long long)blockIdx.x * 4 + wave;
+    if (tile >= seg.tile_start[seg.n_off]) return;
+    int o = 0;
+    while (tile >= seg.tile_start[o + 1]) ++o;
+    const long long p0 = seg.rule_start[o] + (tile - seg.tile_start[o]) * 32;
+    const long long p_end = seg.rule_start[o + 1];
+    const long long p = p0 + m;
+    const bool p_ok = p < p_end;
+    const int idx = p_ok ? in_rows[p] : -1;
+    const int orow = p_ok ? out_rows[p] : -1;
+    const int n0 = blockIdx.y * 32;
+    const int n = n0 + m;
+    const bool n_ok = n < cout;
+
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    const float* Wo = W + (long long)o * cin * cout;
+    const float* xrow = X + (long long)(idx >= 0 ? idx : 0) * cin;
+    tile_mac<FAST, WT>(acc, xrow, idx >= 0, cin, Wo, cout, n, n_ok, h, flags & SCN_F_RELU_IN);
+
+    const float bv = (bias && n_ok) ? bias[n] : 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int r = __shfl(orow, acc_row(v, h));
+        if (r >= 0 && n_ok) {
+            const long long off = (long long)r * cout + n;
+            float y = acc[v] + bv;
+            if (relu_mask && !(relu_mask[off] > 0.f)) y = 0.f;
+            Y[off] = y;
+        }
+    }
+}
+
+static int make_seg_tiles(const int64_t* prefix_host, int n_off, int tile, SegTiles& seg) {
+    seg.n_off = n_off;
+    seg.rule_start[0] = prefix_host[0];
+    seg.tile_start[0] = 0;
+    for (int o = 0; o < n_off; ++o) {
+        int64_t cnt = prefix_host[o + 1] - prefix_host[o];
+        if (cnt < 0) return SCN_EINVAL;
+        seg.rule_start[o + 1] = prefix_host[o + 1];
+        seg.tile_start[o + 1] = seg.tile_start[o] + cdiv(cnt, tile);
+    }
+    return SCN_OK;
+}
+
+extern "C" int scn_gemm_rules(const float* X, int cin, const int32_t* in_rows, const int32_t* out_rows,
+                              const int64_t* prefix_host, int n_off, const float* W, const float* bias,
+                              const float* relu_mask, float* Y, int cout, int flags, scn_stream_t stream) {
+    SCN_REQUIRE(prefix_host && n_off >= 1 && n_off <= 32 && cin >= 1 && cout >= 1);
+    SegTiles seg;
+    SCN_REQUIRE(make_seg_tiles(prefix_host, n_off, 32, seg) == SCN_OK);
+    const long long tiles = seg.tile_start[n_off];
+    if (tiles == 0) return SCN_OK;
+    SCN_REQUIRE(X && in_rows && out_rows && W && Y);
+    const bool fast = (cin % 8 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0);
+    const bool wt = flags & SCN_F_W_TRANSPOSED;
+    dim3 grid((unsigned)cdiv(tiles, 4), (unsigned)cdiv(cout, 32));
+#define LAUNCH_R(F, T)                                                                                        \
+    hipLaunchKernelGGL((k_gemm_rules<F, T>), grid, dim3(256), 0, S(stream), X, cin, in_rows, out_rows, seg, W, \
+                       bias, relu_mask, Y, cout, flags)
+    if (fast && wt) LAUNCH_R(true, true);
+    else if (fast) LAUNCH_R(true, false);
+    else if (wt) LAUNCH_R(false, true);
+    else LAUNCH_R(false, false);
+#undef LAUNCH_R
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad_rules
+// ------------------------------------------------------------------------------------------------
+struct SegChunks {
+    long long rule_start[33];
+    long long chunk_start[33];
+    long long chunk;            // rules per chunk (multiple of 64)
+    int n_off;
+};
+
+static int make_seg_chunks(int cin, int cout, const int64_t* prefix_host, int n_off, SegChunks& sc) {
+    const int64_t tiles = cdiv(cin, 32) * cdiv(cout, 32);
+    const int64_t total = prefix_host[n_off] - prefix_host[0];
+    int64_t chunk = cdiv(total * tiles, 4096);
+    chunk = cdiv(chunk, 64) * 64;
+    if (chunk < 256) chunk = 256;
+    sc.chunk = chunk;
+    sc.n_off = n_off;
+    sc.rule_start[0] = prefix_host[0];
+    sc.chunk_start[0] = 0;
+    for (int o = 0; o < n_off; ++o) {
+        int64_t cnt = prefix_host[o + 1] - prefix_host[o];
+        if (cnt < 0) return SCN_EINVAL;
+        sc.rule_start[o + 1] = prefix_host[o + 1];
+        sc.chunk_start[o + 1] = sc.chunk_start[o] + cdiv(cnt, chunk);
+    }
+    return SCN_OK;
+}
+
+extern "C" int64_t scn_wgrad_scratch_bytes(int cin, int cout, const int64_t* prefix_host, int n_off) {
+    if (!prefix_host || n_off < 1 || n_off > 32 || cin < 1 || cout < 1) return -1;
+    SegChunks sc;
+    if (make_seg_chunks(cin, cout, prefix_host, n_off, sc) != SCN_OK) return -1;
+    const int64_t tiles = cdiv(cin, 32) * cdiv(cout, 32);
+    return sc.chunk_start[n_off] * tiles * 1024 * (int64_t)sizeof(float) + 256;
+}
+
+// slab layout: [chunk][tile][v 0..15][lane 0..63]
+__global__ __launch_bounds__(256) void k_wgrad_rules(const float* __restrict__ X, int cin, const float* __restrict__ dY,
+                                                     int cout, const int* __restrict__ in_rows,
+                                                     const int* __restrict__ out_rows, SegChunks sc,
+                                                     float* __restrict__ slabs, int tiles_n, int flags) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    const long long chunk = (long long)blockIdx.x * 4 + wave;
+    if (chunk >= sc.chunk_start[sc.n_off]) return;
+    int o = 0;
+    while (chunk >= sc.chunk_start[o + 1]) ++o;
+    const long long p0 = sc.rule_start[o] + (chunk - sc.chunk_start[o]) * sc.chunk;
+    long long p_end = p0 + sc.chunk;
+    if (p_end > sc.rule_start[o + 1]) p_end = sc.rule_start[o + 1];
+    const int tile = blockIdx.y;
+    const int ci = (tile / tiles_n) * 32 + m;     // A: tile row = input channel
+    const int co = (tile % tiles_n) * 32 + m;     // B: tile col = output channel
+    const bool ci_ok = ci < cin, co_ok = co < cout;
+    const bool relu_in = flags & SCN_F_RELU_IN;
+
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+
+    for (long long pb = p0; pb < p_end; pb += 64) {
+        const long long p = pb + lane;
+        int ri = -1, ro = -1;
+        if (p < p_end) {
+            ri = in_rows ? in_rows[p] : (int)p;
+            ro = out_rows ? out_rows[p] : (int)p;
+        }
+#pragma unroll 8
+        for (int s = 0; s < 32; ++s) {
+            const int src = 2 * s + h;
+            const int xi = __shfl(ri, src);
+            const int yo = __shfl(ro, src);
+            float a = (xi >= 0 && ci_ok) ? X[(long long)xi * cin + ci] : 0.f;
+            if (relu_in) a = fmaxf(a, 0.f);
+            const float b = (yo >= 0 && co_ok) ? dY[(long long)yo * cout + co] : 0.f;
+            acc = MFMA(a, b, acc);
+        }
+    }
+    float* slab = slabs + ((long long)chunk * gridDim.y + tile) * 1024;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) slab[v * 64 + lane] = acc[v];
+}
+
+// dW[o][ci][co] = sum over the offset's chunks, ascending
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slabs, SegChunks sc, int cin, int cout,
+                                                      int tiles_n, int tiles, float* __restrict__ dW) {
+    const long long total = (long long)sc.n_off * cin * cout;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(e % cout);
+        const int ci = (int)((e / cout) % cin);
+        const int o = (int)(e / ((long long)cin * cout));
+        const int tile = (ci / 32) * tiles_n + co / 32;
+        const int i = ci & 31, j = co & 31;
+        // acc_row(v,h) == i  <=>  h = (i>>2)&1, v = (i&3) + 4*(i>>3)
+        const int hh = (i >> 2) & 1, v = (i & 3) + 4 * (i >> 3);
+        const int slot = v * 64 + hh * 32 + j;
+        float s = 0.f;
+        for (long long c = sc.chunk_start[o]; c < sc.chunk_start[o + 1]; ++c)
+            s += slabs[(c * tiles + tile) * 1024 + slot];
+        dW[e] = s;
+    }
+}
+
+extern "C" int scn_wgrad_rules(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
+                               const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, void* scratch,
+                               int flags, scn_stream_t stream) {
+    SCN_REQUIRE(prefix_host && n_off >= 1 && n_off <= 32 && cin >= 1 && cout >= 1 && dW);
+    SCN_REQUIRE((in_rows == nullptr) == (out_rows == nullptr));
+    SCN_REQUIRE(in_rows || n_off == 1);
+    SegChunks sc;
+    SCN_REQUIRE(make_seg_chunks(cin, cout, prefix_host, n_off, sc) == SCN_OK);
+    const int tiles_n = (int)cdiv(cout, 32);
+    const int tiles = (int)cdiv(cin, 32) * tiles_n;
+    const long long chunks = sc.chunk_start[n_off];
+    if (chunks > 0) {
+        SCN_REQUIRE(X && dY && scratch);
+        hipLaunchKernelGGL(k_wgrad_rules, dim3((unsigned)cdiv(chunks, 4), (unsigned)tiles), dim3(256), 0, S(stream), X,
+                           cin, dY, cout, in_rows, out_rows, sc, (float*)scratch, tiles_n, flags);
+        SCN_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(scn::ew_grid((int64_t)n_off * cin * cout, 256)), dim3(256), 0, S(stream),
+                       (const float*)scratch, sc, cin, cout, tiles_n, tiles, dW);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// colsum (bias gradient): two-stage, fixed order
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ dY, long long n, int c,
+                                                        float* __restrict__ partial) {
+    // thread t owns column (t % cpad) of rows (t / cpad) + k*rows_per_pass inside this block's row range
+    const long long rows_per_block = (n + gridDim.x - 1) / gridDim.x;
+    const long long r_lo = blockIdx.x * rows_per_block;
+    long long r_hi = r_lo + rows_per_block;
+    if (r_hi > n) r_hi = n;
+    __shared__ float red[256];
+    for (int c0 = 0; c0 < c; c0 += 256) {
+        const int width = min(256, c - c0);          // columns handled this pass
+        const int lanes_per_row = width;             // one thread per column
+        const int rows_par = 256 / lanes_per_row > 0 ? 256 / lanes_per_row : 1;
+        const int col = threadIdx.x % lanes_per_row;
+        const int rsub = threadIdx.x / lanes_per_row;
+        float s = 0.f;
+        if (rsub < rows_par)
+            for (long long r = r_lo + rsub; r < r_hi; r += rows_par) s += dY[r * c + c0 + col];
+        red[threadIdx.x] = (rsub < rows_par) ? s : 0.f;
+        __syncthreads();
+        if (threadIdx.x < width) {
+            float t = 0.f;
+            for (int k = 0; k < rows_par; ++k) t += red[k * lanes_per_row + threadIdx.x];
+            partial[(long long)blockIdx.x * c + c0 + threadIdx.x] = t;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_colsum_final(const float* __restrict__ partial, int nblk, int c, float* __restrict__ db) {
+    int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(long long)b * c + col];
+    db[col] = s;
+}
+
+extern "C" int scn_colsum(const float* dY, int64_t n, int c, float* db, void* scratch, scn_stream_t stream) {
+    SCN_REQUIRE(n >= 0 && c >= 1 && db && scratch);
+    int nblk = (int)(n < SCN_COLSUM_BLOCKS * 8 ? cdiv(n, 8) : SCN_COLSUM_BLOCKS);
+    if (nblk < 1) nblk = 1;
+    if (n > 0) SCN_REQUIRE(dY);
+    hipLaunchKernelGGL(k_colsum_partial, dim3(nblk), dim3(256), 0, S(stream), dY, (long long)n, c, (float*)scratch);
+    SCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_colsum_final, dim3((c + 255) / 256), dim3(256), 0, S(stream), (const float*)scratch, nblk, c,
+                       db);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}

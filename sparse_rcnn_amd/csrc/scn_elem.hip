@@ -1,0 +1,418 @@
+// HBM-bound feature kernels of libscn_mi355x: ReLU / AddTable, BatchNorm(Leaky)ReLU, InputLayer / OutputLayer
+// feature movement, SparseToDense.  All are pure streaming or row-gather kernels (SURVEY.md §8d regime (i)):
+// 16-byte vector accesses where alignment allows, grid-stride loops, fp64 accumulation for reductions so results
+// do not depend on arrival order.
+#include "scn_common.h"
+
+using scn::S;
+using scn::cdiv;
+
+// ------------------------------------------------------------------------------------------------
+// ReLU / add
+// ------------------------------------------------------------------------------------------------
+template <int OP>   // 0 relu fwd (a), 1 relu bwd (a = x, b = dy), 2 add
+__global__ void k_ew(const float* __restrict__ a, const float* __restrict__ b, long long count, float* __restrict__ y,
+                     int vec) {
+    const long long tid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    if (vec) {
+        const long long n4 = count >> 2;
+        for (long long i = tid; i < n4; i += stride) {
+            float4 u = ((const float4*)a)[i], r;
+            if (OP == 0) {
+                r = make_float4(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f), fmaxf(u.w, 0.f));
+            } else {
+                float4 w = ((const float4*)b)[i];
+                if (OP == 1) r = make_float4(u.x > 0.f ? w.x : 0.f, u.y > 0.f ? w.y : 0.f, u.z > 0.f ? w.z : 0.f,
+                                             u.w > 0.f ? w.w : 0.f);
+                else r = make_float4(u.x + w.x, u.y + w.y, u.z + w.z, u.w + w.w);
+            }
+            ((float4*)y)[i] = r;
+        }
+        for (long long i = (n4 << 2) + tid; i < count; i += stride) {
+            float u = a[i];
+            y[i] = OP == 0 ? fmaxf(u, 0.f) : (OP == 1 ? (u > 0.f ? b[i] : 0.f) : u + b[i]);
+        }
+    } else {
+        for (long long i = tid; i < count; i += stride) {
+            float u = a[i];
+            y[i] = OP == 0 ? fmaxf(u, 0.f) : (OP == 1 ? (u > 0.f ? b[i] : 0.f) : u + b[i]);
+        }
+    }
+}
+
+template <int OP>
+static int ew_launch(const float* a, const float* b, int64_t count, float* y, scn_stream_t stream) {
+    SCN_REQUIRE(count >= 0);
+    if (count == 0) return SCN_OK;
+    SCN_REQUIRE(a && y && (OP == 0 || b));
+    int vec = (((uintptr_t)a | (uintptr_t)y | (uintptr_t)b) & 15) == 0;
+    hipLaunchKernelGGL(k_ew<OP>, dim3(scn::ew_grid(cdiv(count, 4), 256)), dim3(256), 0, S(stream), a, b,
+                       (long long)count, y, vec);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+extern "C" int scn_relu_fwd(const float* X, int64_t count, float* Y, scn_stream_t stream) {
+    return ew_launch<0>(X, nullptr, count, Y, stream);
+}
+extern "C" int scn_relu_bwd(const float* X, const float* dY, int64_t count, float* dX, scn_stream_t stream) {
+    return ew_launch<1>(X, dY, count, dX, stream);
+}
+extern "C" int scn_add(const float* A, const float* B, int64_t count, float* Y, scn_stream_t stream) {
+    return ew_launch<2>(A, B, count, Y, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// row gathers / scatters.  One thread per (row, 4-channel group) when c % 4 == 0, else per element.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_gather_rows(const float* __restrict__ X, const int* __restrict__ rows, long long m, int c,
+                              float* __restrict__ Y, int vec) {
+    const long long tid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    if (vec) {
+        const int c4 = c >> 2;
+        for (long long i = tid; i < m * c4; i += stride) {
+            long long r = i / c4;
+            int g = (int)(i - r * c4);
+            ((float4*)Y)[i] = ((const float4*)(X + (long long)rows[r] * c))[g];
+        }
+    } else {
+        for (long long i = tid; i < m * c; i += stride) {
+            long long r = i / c;
+            Y[i] = X[(long long)rows[r] * c + (i - r * c)];
+        }
+    }
+}
+
+extern "C" int scn_gather_rows(const float* X, const int32_t* rows, int64_t m, int c, float* Y, scn_stream_t stream) {
+    SCN_REQUIRE(m >= 0 && c >= 1);
+    if (m == 0) return SCN_OK;
+    SCN_REQUIRE(X && rows && Y);
+    int vec = (c % 4 == 0) && ((((uintptr_t)X | (uintptr_t)Y) & 15) == 0);
+    hipLaunchKernelGGL(k_gather_rows, dim3(scn::ew_grid(m * (vec ? c / 4 : c), 256)), dim3(256), 0, S(stream), X, rows,
+                       (long long)m, c, Y, vec);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+// acc64[row][ch] += v[item][ch]  (fp64 atomics: the sum of a handful of fp32 values is exact in fp64, so the
+// rounded result does not depend on arrival order)
+__global__ void k_scatter_add64(const float* __restrict__ V, const int* __restrict__ item_row, long long n_items, int c,
+                                double* __restrict__ acc) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n_items * c;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long it = i / c;
+        int ch = (int)(i - it * c);
+        atomicAdd(&acc[(long long)item_row[it] * c + ch], (double)V[i]);
+    }
+}
+
+__global__ void k_finish64(const double* __restrict__ acc, const int* __restrict__ row_count, long long n_rows, int c,
+                           int mean, float* __restrict__ Y) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n_rows * c;
+         i += (long long)gridDim.x * blockDim.x) {
+        double v = acc[i];
+        if (mean) {
+            int cnt = row_count[i / c];
+            v /= (double)(cnt > 0 ? cnt : 1);
+        }
+        Y[i] = (float)v;
+    }
+}
+
+__global__ void k_row_last(const int* __restrict__ item_row, long long n_items, int* __restrict__ row_last) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n_items;
+         i += (long long)gridDim.x * blockDim.x)
+        atomicMax(&row_last[item_row[i]], (int)i);
+}
+
+extern "C" int scn_segment_sum(const float* dY, const int32_t* item_row, int64_t n_items, int64_t n_rows, int c,
+                               float* dX, double* acc64, scn_stream_t stream) {
+    SCN_REQUIRE(n_items >= 0 && n_rows >= 0 && c >= 1);
+    if (n_rows == 0) return SCN_OK;
+    SCN_REQUIRE(dX && acc64);
+    SCN_HIP(hipMemsetAsync(acc64, 0, sizeof(double) * n_rows * c, S(stream)));
+    if (n_items) {
+        SCN_REQUIRE(dY && item_row);
+        hipLaunchKernelGGL(k_scatter_add64, dim3(scn::ew_grid(n_items * c, 256)), dim3(256), 0, S(stream), dY, item_row,
+                           (long long)n_items, c, acc64);
+        SCN_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_finish64, dim3(scn::ew_grid(n_rows * c, 256)), dim3(256), 0, S(stream), (const double*)acc64,
+                       (const int*)nullptr, (long long)n_rows, c, 0, dX);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+extern "C" int scn_input_fwd(const float* feats, const int32_t* item_row, const int32_t* row_count,
+                             const int32_t* row_first, int64_t n_items, int64_t n_rows, int c, int mode, float* Y,
+                             double* acc64, int32_t* row_last, scn_stream_t stream) {
+    SCN_REQUIRE(n_items >= 0 && n_rows >= 0 && c >= 1 && mode >= 0 && mode <= 4);
+    if (n_rows == 0) return SCN_OK;
+    SCN_REQUIRE(feats && item_row && Y);
+    hipStream_t st = S(stream);
+    if (mode == 3 || mode == 4) {
+        SCN_REQUIRE(acc64 && (mode == 3 || row_count));
+        SCN_HIP(hipMemsetAsync(acc64, 0, sizeof(double) * n_rows * c, st));
+        hipLaunchKernelGGL(k_scatter_add64, dim3(scn::ew_grid(n_items * c, 256)), dim3(256), 0, st, feats, item_row,
+                           (long long)n_items, c, acc64);
+        SCN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_finish64, dim3(scn::ew_grid(n_rows * c, 256)), dim3(256), 0, st, (const double*)acc64,
+                           row_count, (long long)n_rows, c, mode == 4, Y);
+        SCN_LAUNCH_CHECK();
+        return SCN_OK;
+    }
+    const int32_t* src = row_first;                 // modes 0 and 2: the first (for mode 0: only) item of each row
+    if (mode == 1) {
+        SCN_REQUIRE(row_last);
+        SCN_HIP(hipMemsetAsync(row_last, 0xFF, sizeof(int32_t) * n_rows, st));
+        hipLaunchKernelGGL(k_row_last, dim3(scn::ew_grid(n_items, 256)), dim3(256), 0, st, item_row, (long long)n_items,
+                           row_last);
+        SCN_LAUNCH_CHECK();
+        src = row_last;
+    }
+    SCN_REQUIRE(src);
+    return scn_gather_rows(feats, src, n_rows, c, Y, stream);
+}
+
+__global__ void k_input_bwd(const float* __restrict__ dY, const int* __restrict__ item_row,
+                            const int* __restrict__ row_count, const int* __restrict__ winner, long long n_items, int c,
+                            int mode, float* __restrict__ dF) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n_items * c;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long it = i / c;
+        int ch = (int)(i - it * c);
+        int r = item_row[it];
+        float g = dY[(long long)r * c + ch];
+        if (mode == 4) g /= (float)row_count[r];
+        else if (mode == 1 || mode == 2) g = (winner[r] == (int)it) ? g : 0.f;
+        dF[i] = g;
+    }
+}
+
+extern "C" int scn_input_bwd(const float* dY, const int32_t* item_row, const int32_t* row_count,
+                             const int32_t* row_first, const int32_t* row_last, int64_t n_items, int c, int mode,
+                             float* dfeats, scn_stream_t stream) {
+    SCN_REQUIRE(n_items >= 0 && c >= 1 && mode >= 0 && mode <= 4);
+    if (n_items == 0) return SCN_OK;
+    SCN_REQUIRE(dY && item_row && dfeats);
+    const int32_t* winner = mode == 1 ? row_last : row_first;
+    SCN_REQUIRE(mode != 4 || row_count);
+    SCN_REQUIRE((mode != 1 && mode != 2) || winner);
+    hipLaunchKernelGGL(k_input_bwd, dim3(scn::ew_grid(n_items * c, 256)), dim3(256), 0, S(stream), dY, item_row,
+                       row_count, winner, (long long)n_items, c, mode, dfeats);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SparseToDense: out[b][ch][x][y][z]
+// ------------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ void k_s2d(const float* __restrict__ src, const int4* __restrict__ coords, long long n, int c, long long sx,
+                      long long sy, long long sz, float* __restrict__ dst) {
+    const long long vol = sx * sy * sz;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n * c;
+         i += (long long)gridDim.x * blockDim.x) {
+        // channel-major inside a row so that, for a fixed channel, neighbouring rows hit nearby z
+        long long r = i % n;
+        int ch = (int)(i / n);
+        int4 p = coords[r];
+        long long d = ((long long)p.w * c + ch) * vol + ((long long)p.x * sy + p.y) * sz + p.z;
+        if (BWD) dst[r * c + ch] = src[d];
+        else dst[d] = src[r * c + ch];
+    }
+}
+
+extern "C" int scn_sparse_to_dense_fwd(const float* X, const int32_t* coords, int64_t n, int c,
+                                       const int64_t* size3_host, float* out, scn_stream_t stream) {
+    SCN_REQUIRE(n >= 0 && c >= 1 && size3_host);
+    if (n == 0) return SCN_OK;
+    SCN_REQUIRE(X && coords && out);
+    hipLaunchKernelGGL(k_s2d<false>, dim3(scn::ew_grid(n * c, 256)), dim3(256), 0, S(stream), X, (const int4*)coords,
+                       (long long)n, c, (long long)size3_host[0], (long long)size3_host[1], (long long)size3_host[2],
+                       out);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+extern "C" int scn_sparse_to_dense_bwd(const float* dOut, const int32_t* coords, int64_t n, int c,
+                                       const int64_t* size3_host, float* dX, scn_stream_t stream) {
+    SCN_REQUIRE(n >= 0 && c >= 1 && size3_host);
+    if (n == 0) return SCN_OK;
+    SCN_REQUIRE(dOut && coords && dX);
+    hipLaunchKernelGGL(k_s2d<true>, dim3(scn::ew_grid(n * c, 256)), dim3(256), 0, S(stream), dOut, (const int4*)coords,
+                       (long long)n, c, (long long)size3_host[0], (long long)size3_host[1], (long long)size3_host[2],
+                       dX);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm(Leaky)ReLU.  Statistics in fp64 (column sums of x and x^2), two-stage, fixed order.
+// ------------------------------------------------------------------------------------------------
+static constexpr int BN_BLOCKS = 256;
+
+// partial[blk][2][c] doubles: sum, sum of squares (or for bwd: sum g, sum g*xhat)
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ X, const float* __restrict__ dY,
+                                                    long long n, int c, const float* __restrict__ mean,
+                                                    const float* __restrict__ var, float eps,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float leak, double* __restrict__ partial) {
+    const long long rows_per_block = (n + gridDim.x - 1) / gridDim.x;
+    const long long r_lo = blockIdx.x * rows_per_block;
+    long long r_hi = r_lo + rows_per_block;
+    if (r_hi > n) r_hi = n;
+    __shared__ double red0[256], red1[256];
+    for (int c0 = 0; c0 < c; c0 += 256) {
+        const int width = min(256, c - c0);
+        const int rows_par = 256 / width;
+        const int col = threadIdx.x % width, rsub = threadIdx.x / width;
+        double s0 = 0.0, s1 = 0.0;
+        if (rsub < rows_par) {
+            float mu = 0.f, is = 0.f, ga = 0.f, be = 0.f;
+            if (BWD) {
+                mu = mean[c0 + col];
+                is = rsqrtf(var[c0 + col] + eps);
+                ga = gamma[c0 + col];
+                be = beta[c0 + col];
+            }
+            for (long long r = r_lo + rsub; r < r_hi; r += rows_par) {
+                float x = X[r * c + c0 + col];
+                if (BWD) {
+                    float xh = (x - mu) * is;
+                    float pre = xh * ga + be;
+                    float g = dY[r * c + c0 + col] * (pre > 0.f ? 1.f : leak);
+                    s0 += (double)g;
+                    s1 += (double)g * (double)xh;
+                } else {
+                    s0 += (double)x;
+                    s1 += (double)x * (double)x;
+                }
+            }
+        }
+        red0[threadIdx.x] = s0;
+        red1[threadIdx.x] = s1;
+        __syncthreads();
+        if (threadIdx.x < width) {
+            double t0 = 0.0, t1 = 0.0;
+            for (int k = 0; k < rows_par; ++k) {
+                t0 += red0[k * width + threadIdx.x];
+                t1 += red1[k * width + threadIdx.x];
+            }
+            partial[((long long)blockIdx.x * 2 + 0) * c + c0 + threadIdx.x] = t0;
+            partial[((long long)blockIdx.x * 2 + 1) * c + c0 + threadIdx.x] = t1;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_bn_stats_final(const double* __restrict__ partial, int nblk, int c, long long n,
+                                 float* __restrict__ mean, float* __restrict__ var) {
+    int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s0 += partial[((long long)b * 2 + 0) * c + col];
+        s1 += partial[((long long)b * 2 + 1) * c + col];
+    }
+    double mu = n > 0 ? s0 / (double)n : 0.0;
+    double v = n > 0 ? s1 / (double)n - mu * mu : 0.0;
+    mean[col] = (float)mu;
+    var[col] = (float)(v > 0.0 ? v : 0.0);
+}
+
+extern "C" int64_t scn_bn_scratch_bytes(int c) { return (int64_t)sizeof(double) * (BN_BLOCKS * 2 + 2) * c; }
+
+extern "C" int scn_bn_stats(const float* X, int64_t n, int c, float* mean, float* var_biased, void* scratch,
+                            scn_stream_t stream) {
+    SCN_REQUIRE(n >= 0 && c >= 1 && mean && var_biased && scratch);
+    SCN_REQUIRE(n == 0 || X);
+    hipLaunchKernelGGL(k_bn_partial<false>, dim3(BN_BLOCKS), dim3(256), 0, S(stream), X, (const float*)nullptr,
+                       (long long)n, c, (const float*)nullptr, (const float*)nullptr, 0.f, (const float*)nullptr,
+                       (const float*)nullptr, 0.f, (double*)scratch);
+    SCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_stats_final, dim3((c + 255) / 256), dim3(256), 0, S(stream), (const double*)scratch,
+                       BN_BLOCKS, c, (long long)n, mean, var_biased);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+__global__ void k_bn_fwd(const float* __restrict__ X, long long n, int c, const float* __restrict__ mean,
+                         const float* __restrict__ var, float eps, const float* __restrict__ gamma,
+                         const float* __restrict__ beta, float leak, float* __restrict__ Y) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n * c;
+         i += (long long)gridDim.x * blockDim.x) {
+        int ch = (int)(i % c);
+        float y = (X[i] - mean[ch]) * rsqrtf(var[ch] + eps) * gamma[ch] + beta[ch];
+        Y[i] = y > 0.f ? y : y * leak;
+    }
+}
+
+extern "C" int scn_bn_fwd(const float* X, int64_t n, int c, const float* mean, const float* var, float eps,
+                          const float* gamma, const float* beta, float leak, float* Y, scn_stream_t stream) {
+    SCN_REQUIRE(n >= 0 && c >= 1);
+    if (n == 0) return SCN_OK;
+    SCN_REQUIRE(X && mean && var && gamma && beta && Y);
+    hipLaunchKernelGGL(k_bn_fwd, dim3(scn::ew_grid(n * c, 256)), dim3(256), 0, S(stream), X, (long long)n, c, mean, var,
+                       eps, gamma, beta, leak, Y);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+__global__ void k_bn_bwd_final(const double* __restrict__ partial, int nblk, int c, float* __restrict__ dgamma,
+                               float* __restrict__ dbeta, double* __restrict__ sums /* [2][c] */) {
+    int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s0 += partial[((long long)b * 2 + 0) * c + col];
+        s1 += partial[((long long)b * 2 + 1) * c + col];
+    }
+    dbeta[col] = (float)s0;
+    dgamma[col] = (float)s1;
+    sums[col] = s0;
+    sums[c + col] = s1;
+}
+
+__global__ void k_bn_bwd_dx(const float* __restrict__ X, const float* __restrict__ dY, long long n, int c,
+                            const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                            const float* __restrict__ gamma, const float* __restrict__ beta, float leak, int training,
+                            const double* __restrict__ sums, float* __restrict__ dX) {
+    const double inv_n = n > 0 ? 1.0 / (double)n : 0.0;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n * c;
+         i += (long long)gridDim.x * blockDim.x) {
+        int ch = (int)(i % c);
+        float is = rsqrtf(var[ch] + eps);
+        float xh = (X[i] - mean[ch]) * is;
+        float pre = xh * gamma[ch] + beta[ch];
+        float g = dY[i] * (pre > 0.f ? 1.f : leak);
+        float dx;
+        if (training) dx = gamma[ch] * is * (g - (float)(sums[ch] * inv_n) - xh * (float)(sums[c + ch] * inv_n));
+        else dx = gamma[ch] * is * g;
+        dX[i] = dx;
+    }
+}
+
+extern "C" int scn_bn_bwd(const float* X, const float* dY, int64_t n, int c, const float* mean, const float* var,
+                          float eps, const float* gamma, const float* beta, float leak, int training, float* dX,
+                          float* dgamma, float* dbeta, void* scratch, scn_stream_t stream) {
+    SCN_REQUIRE(n >= 0 && c >= 1 && mean && var && gamma && beta && dgamma && dbeta && scratch);
+    SCN_REQUIRE(n == 0 || (X && dY && dX));
+    double* partial = (double*)scratch;                       // [BN_BLOCKS][2][c]
+    double* sums = partial + (long long)BN_BLOCKS * 2 * c;    // [2][c]
+    hipLaunchKernelGGL(k_bn_partial<true>, dim3(BN_BLOCKS), dim3(256), 0, S(stream), X, dY, (long long)n, c, mean, var,
+                       eps, gamma, beta, leak, partial);
+    SCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_bwd_final, dim3((c + 255) / 256), dim3(256), 0, S(stream), (const double*)partial, BN_BLOCKS,
+                       c, dgamma, dbeta, sums);
+    SCN_LAUNCH_CHECK();
+    if (n) {
+        hipLaunchKernelGGL(k_bn_bwd_dx, dim3(scn::ew_grid(n * c, 256)), dim3(256), 0, S(stream), X, dY, (long long)n, c,
+                           mean, var, eps, gamma, beta, leak, training, (const double*)sums, dX);
+        SCN_LAUNCH_CHECK();
+    }
+    return SCN_OK;
+}

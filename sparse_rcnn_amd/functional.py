@@ -1,0 +1,378 @@
+"""Autograd functions of the sparse operator set, each a thin host wrapper over the C ABI.
+
+Forward / backward definitions follow SURVEY.md Appendix B; each function names the reference call site it serves.
+No function here falls back to PyTorch arithmetic: feature math runs in libscn_mi355x kernels only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .metadata import Metadata, Rules
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError(f"sparse_rcnn_amd operators compute in fp32; got {t.dtype}")
+    if not t.is_cuda:
+        raise L.ScnError("feature tensors must live on the MI355X (no CPU fallback)")
+    return t.contiguous()
+
+
+def _new(shape, like, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# ------------------------------------------------------------------------------------------------------
+# raw kernels (no autograd)
+# ------------------------------------------------------------------------------------------------------
+
+def gemm_table(X, table, n_off, n_out, W, bias, cout, flags=0, residual=None, relu_mask=None):
+    lib = L.lib()
+    cin = X.shape[1]
+    Y = _new((n_out, cout), X)
+    L.check(lib.scn_gemm_table(L.ptr(X), X.shape[0], cin, L.ptr(table), n_off, n_out, L.ptr(W), L.ptr(bias),
+                               L.ptr(residual), L.ptr(relu_mask), L.ptr(Y), cout, flags, L.stream()))
+    return Y
+
+
+def gemm_rules(X, in_rows, out_rows, prefix_host, n_off, n_out, W, bias, cout, flags=0, relu_mask=None):
+    lib = L.lib()
+    Y = _new((n_out, cout), X)
+    L.check(lib.scn_gemm_rules(L.ptr(X), X.shape[1], L.ptr(in_rows), L.ptr(out_rows), prefix_host, n_off, L.ptr(W),
+                               L.ptr(bias), L.ptr(relu_mask), L.ptr(Y), cout, flags, L.stream()))
+    return Y
+
+
+def wgrad_rules(X, dY, in_rows, out_rows, prefix_host, n_off, flags=0):
+    lib = L.lib()
+    cin, cout = X.shape[1], dY.shape[1]
+    nbytes = lib.scn_wgrad_scratch_bytes(cin, cout, prefix_host, n_off)
+    if nbytes < 0:
+        raise L.ScnError("scn_wgrad_scratch_bytes: bad arguments")
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=X.device)
+    dW = _new((n_off, cin, cout), X)
+    L.check(lib.scn_wgrad_rules(L.ptr(X), cin, L.ptr(dY), cout, L.ptr(in_rows), L.ptr(out_rows), prefix_host, n_off,
+                                L.ptr(dW), L.ptr(scratch), flags, L.stream()))
+    return dW
+
+
+def colsum(dY):
+    lib = L.lib()
+    c = dY.shape[1]
+    scratch = _new((L.COLSUM_BLOCKS * c,), dY)
+    db = _new((c,), dY)
+    L.check(lib.scn_colsum(L.ptr(dY), dY.shape[0], c, L.ptr(db), L.ptr(scratch), L.stream()))
+    return db
+
+
+def _identity_prefix(n):
+    h = L.host_i64(2)
+    h[0], h[1] = 0, n
+    return h
+
+
+# ------------------------------------------------------------------------------------------------------
+# A5 SubmanifoldConvolution  (module_factory.py:383-385 k=1, 404-406 k=3)
+# ------------------------------------------------------------------------------------------------------
+class SubmanifoldConvolutionFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, weight, bias, metadata: Metadata, spatial_size, k, relu_in=False):
+        X, W = _f32(features), _f32(weight)
+        rb = metadata.subm_rulebook(spatial_size, k)
+        n_off = k ** 3
+        cout = W.shape[-1]
+        b = _f32(bias) if bias is not None else None
+        Y = gemm_table(X, rb.table, n_off, rb.n, W, b, cout, L.F_RELU_IN if relu_in else 0)
+        ctx.save_for_backward(X, W)
+        ctx.rb, ctx.has_bias, ctx.relu_in = rb, bias is not None, relu_in
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        X, W = ctx.saved_tensors
+        rb = ctx.rb
+        dY = _f32(dY)
+        n_off = rb.k ** 3
+        cin = X.shape[1]
+        fl = L.F_RELU_IN if ctx.relu_in else 0
+        dX = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dX = gemm_table(dY, rb.table, n_off, rb.n, W, None, cin, L.F_W_TRANSPOSED | L.F_OFF_REVERSE,
+                            relu_mask=X if ctx.relu_in else None)
+        if ctx.needs_input_grad[1]:
+            if rb.k == 1:
+                dW = wgrad_rules(X, dY, None, None, _identity_prefix(rb.n), 1, fl)
+            else:
+                r = rb.rules
+                dW = wgrad_rules(X, dY, r.in_rows, r.out_rows, r.prefix_host, n_off, fl)
+            dW = dW.view_as(W)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dY)
+        return dX, dW, db, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
+# A6 Convolution size=stride=2  (module_factory.py:232-234)
+# ------------------------------------------------------------------------------------------------------
+class ConvolutionFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, weight, bias, metadata: Metadata, in_size, relu_in=False):
+        X, W = _f32(features), _f32(weight)
+        rb = metadata.strided_rulebook(in_size)
+        b = _f32(bias) if bias is not None else None
+        Y = gemm_table(X, rb.child, 8, rb.n_coarse, W, b, W.shape[-1], L.F_RELU_IN if relu_in else 0)
+        ctx.save_for_backward(X, W)
+        ctx.rb, ctx.has_bias, ctx.relu_in = rb, bias is not None, relu_in
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        X, W = ctx.saved_tensors
+        rb, r = ctx.rb, ctx.rb.rules
+        dY = _f32(dY)
+        fl = L.F_RELU_IN if ctx.relu_in else 0
+        dX = dW = db = None
+        if ctx.needs_input_grad[0]:      # dX[f] = dY[parent f] . W[off f]^T : rule list with roles swapped
+            dX = gemm_rules(dY, r.out_rows, r.in_rows, r.prefix_host, 8, rb.n_fine, W, None, X.shape[1],
+                            L.F_W_TRANSPOSED, relu_mask=X if ctx.relu_in else None)
+        if ctx.needs_input_grad[1]:
+            dW = wgrad_rules(X, dY, r.in_rows, r.out_rows, r.prefix_host, 8, fl).view_as(W)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dY)
+        return dX, dW, db, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
+# A7 Deconvolution size=stride=2 back to the cached fine level  (module_factory.py:256-258)
+# ------------------------------------------------------------------------------------------------------
+class DeconvolutionFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, weight, bias, metadata: Metadata, out_size, relu_in=False):
+        X, W = _f32(features), _f32(weight)
+        out_size = tuple(int(s) for s in out_size)
+        rb = metadata.strided.get(out_size)
+        if rb is None:
+            raise L.ScnError(f"Deconvolution: no cached Convolution rulebook from spatial size {out_size}; the "
+                             "reference only deconvolves back to an encoder level (custom_container.py:70-83)")
+        r = rb.rules
+        b = _f32(bias) if bias is not None else None
+        Y = gemm_rules(X, r.out_rows, r.in_rows, r.prefix_host, 8, rb.n_fine, W, b, W.shape[-1],
+                       L.F_RELU_IN if relu_in else 0)
+        ctx.save_for_backward(X, W)
+        ctx.rb, ctx.has_bias, ctx.relu_in = rb, bias is not None, relu_in
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        X, W = ctx.saved_tensors
+        rb, r = ctx.rb, ctx.rb.rules
+        dY = _f32(dY)
+        fl = L.F_RELU_IN if ctx.relu_in else 0
+        dX = dW = db = None
+        if ctx.needs_input_grad[0]:      # dX[c] = sum_o dY[child[o][c]] . W[o]^T
+            dX = gemm_table(dY, rb.child, 8, rb.n_coarse, W, None, X.shape[1], L.F_W_TRANSPOSED,
+                            relu_mask=X if ctx.relu_in else None)
+        if ctx.needs_input_grad[1]:
+            dW = wgrad_rules(X, dY, r.out_rows, r.in_rows, r.prefix_host, 8, fl).view_as(W)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dY)
+        return dX, dW, db, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
+# A9 NetworkInNetwork (module_factory.py:366-367), ReLU (:88), AddTable (:52-54,308)
+# ------------------------------------------------------------------------------------------------------
+class NetworkInNetworkFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, weight, bias):
+        X, W = _f32(features), _f32(weight)
+        b = _f32(bias) if bias is not None else None
+        n = X.shape[0]
+        Y = gemm_table(X, None, 1, n, W, b, W.shape[-1])
+        ctx.save_for_backward(X, W)
+        ctx.has_bias = bias is not None
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        X, W = ctx.saved_tensors
+        dY = _f32(dY)
+        n = X.shape[0]
+        dX = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dX = gemm_table(dY, None, 1, n, W, None, X.shape[1], L.F_W_TRANSPOSED)
+        if ctx.needs_input_grad[1]:
+            dW = wgrad_rules(X, dY, None, None, _identity_prefix(n), 1).view_as(W)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dY)
+        return dX, dW, db
+
+
+class ReLUFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features):
+        X = _f32(features)
+        Y = torch.empty_like(X)
+        L.check(L.lib().scn_relu_fwd(L.ptr(X), X.numel(), L.ptr(Y), L.stream()))
+        ctx.save_for_backward(X)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        (X,) = ctx.saved_tensors
+        dY = _f32(dY)
+        dX = torch.empty_like(X)
+        L.check(L.lib().scn_relu_bwd(L.ptr(X), L.ptr(dY), X.numel(), L.ptr(dX), L.stream()))
+        return dX
+
+
+class AddFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        A, B = _f32(a), _f32(b)
+        if A.shape != B.shape:
+            raise ValueError("AddTable: shape mismatch")
+        Y = torch.empty_like(A)
+        L.check(L.lib().scn_add(L.ptr(A), L.ptr(B), A.numel(), L.ptr(Y), L.stream()))
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        return dY, dY
+
+
+# ------------------------------------------------------------------------------------------------------
+# A8 BatchNorm(Leaky)ReLU (module_factory.py:92-102)
+# ------------------------------------------------------------------------------------------------------
+class BatchNormReLUFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, weight, bias, running_mean, running_var, eps, momentum, leak, training):
+        lib = L.lib()
+        X = _f32(features)
+        n, c = X.shape
+        g, b = _f32(weight), _f32(bias)
+        scratch = torch.empty(lib.scn_bn_scratch_bytes(c), dtype=torch.uint8, device=X.device)
+        if training:
+            mean, var = _new((c,), X), _new((c,), X)
+            L.check(lib.scn_bn_stats(L.ptr(X), n, c, L.ptr(mean), L.ptr(var), L.ptr(scratch), L.stream()))
+            # momentum is the RETAIN fraction (SparseConvNet convention; SURVEY.md §4.1 caveat)
+            running_mean.mul_(momentum).add_(mean, alpha=1 - momentum)
+            running_var.mul_(momentum).add_(var, alpha=1 - momentum)
+        else:
+            mean, var = _f32(running_mean), _f32(running_var)
+        Y = torch.empty_like(X)
+        L.check(lib.scn_bn_fwd(L.ptr(X), n, c, L.ptr(mean), L.ptr(var), eps, L.ptr(g), L.ptr(b), leak, L.ptr(Y),
+                               L.stream()))
+        ctx.save_for_backward(X, g, b, mean, var)
+        ctx.cfg = (eps, leak, training)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        lib = L.lib()
+        X, g, b, mean, var = ctx.saved_tensors
+        eps, leak, training = ctx.cfg
+        dY = _f32(dY)
+        n, c = X.shape
+        scratch = torch.empty(lib.scn_bn_scratch_bytes(c), dtype=torch.uint8, device=X.device)
+        dX, dg, db = torch.empty_like(X), _new((c,), X), _new((c,), X)
+        L.check(lib.scn_bn_bwd(L.ptr(X), L.ptr(dY), n, c, L.ptr(mean), L.ptr(var), eps, L.ptr(g), L.ptr(b), leak,
+                               1 if training else 0, L.ptr(dX), L.ptr(dg), L.ptr(db), L.ptr(scratch), L.stream()))
+        return dX, dg, db, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
+# A3 / A10 ioLayers  (custom_operations.py:7-10, 67-86; roi_select_sparse.py:79-81,117-119)
+# ------------------------------------------------------------------------------------------------------
+class InputLayerFunction(torch.autograd.Function):
+    """``scn.ioLayers.InputLayerFunction.apply(dimension, metadata, spatial_size, coords, features, batch_size, mode)``"""
+
+    @staticmethod
+    def forward(ctx, dimension, metadata, spatial_size, coords, input_features, batch_size, mode):
+        lib = L.lib()
+        if int(dimension) != 3:
+            raise NotImplementedError("only dimension 3")
+        mode = int(mode)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        F = input_features.to(dev)
+        F = _f32(F)
+        if coords.shape[0] != F.shape[0]:
+            raise ValueError("coords / features row mismatch")
+        grid = metadata.set_input(spatial_size, coords, int(batch_size), mode)
+        n_items, c = F.shape
+        Y = _new((grid.n, c), F)
+        acc = torch.empty((grid.n, c), dtype=torch.float64, device=dev) if mode in (3, 4) else None
+        if mode == 1:
+            metadata.row_last = torch.empty(grid.n, dtype=torch.int32, device=dev)
+        L.check(lib.scn_input_fwd(L.ptr(F), L.ptr(metadata.item_row), L.ptr(metadata.row_count),
+                                  L.ptr(metadata.row_first), n_items, grid.n, c, mode, L.ptr(Y), L.ptr(acc),
+                                  L.ptr(metadata.row_last), L.stream()))
+        ctx.md, ctx.mode, ctx.shape, ctx.in_device = metadata, mode, (n_items, c), input_features.device
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        md = ctx.md
+        dY = _f32(dY)
+        n_items, c = ctx.shape
+        dF = _new((n_items, c), dY)
+        L.check(L.lib().scn_input_bwd(L.ptr(dY), L.ptr(md.item_row), L.ptr(md.row_count), L.ptr(md.row_first),
+                                      L.ptr(md.row_last), n_items, c, ctx.mode, L.ptr(dF), L.stream()))
+        return None, None, None, None, dF.to(ctx.in_device), None, None
+
+
+class OutputLayerFunction(torch.autograd.Function):
+    """``scn.ioLayers.OutputLayerFunction.apply(dimension, metadata, features)`` -> one row per ORIGINAL input point."""
+
+    @staticmethod
+    def forward(ctx, dimension, metadata, input_features):
+        X = _f32(input_features)
+        if metadata.item_row is None:
+            raise L.ScnError("OutputLayer: this Metadata has no InputLayer rules")
+        c = X.shape[1]
+        Y = _new((metadata.n_items, c), X)
+        L.check(L.lib().scn_gather_rows(L.ptr(X), L.ptr(metadata.item_row), metadata.n_items, c, L.ptr(Y), L.stream()))
+        ctx.md, ctx.n_rows = metadata, X.shape[0]
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        md = ctx.md
+        dY = _f32(dY)
+        c = dY.shape[1]
+        dX = _new((ctx.n_rows, c), dY)
+        acc = torch.empty((ctx.n_rows, c), dtype=torch.float64, device=dY.device)
+        L.check(L.lib().scn_segment_sum(L.ptr(dY), L.ptr(md.item_row), md.n_items, ctx.n_rows, c, L.ptr(dX),
+                                        L.ptr(acc), L.stream()))
+        return None, None, dX
+
+
+# ------------------------------------------------------------------------------------------------------
+# A13 SparseToDense (module_factory.py:429-435)
+# ------------------------------------------------------------------------------------------------------
+class SparseToDenseFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, metadata, spatial_size):
+        X = _f32(features)
+        size = tuple(int(s) for s in spatial_size)
+        g = metadata.grid(size)
+        n, c = X.shape
+        out = torch.zeros((metadata.n_samples, c) + size, dtype=torch.float32, device=X.device)
+        hs = L.host_i64(3)
+        hs[0], hs[1], hs[2] = size
+        L.check(L.lib().scn_sparse_to_dense_fwd(L.ptr(X), L.ptr(g.coords), n, c, hs, L.ptr(out), L.stream()))
+        ctx.g, ctx.size, ctx.shape = g, size, (n, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        dOut = _f32(dOut)
+        n, c = ctx.shape
+        dX = _new((n, c), dOut)
+        hs = L.host_i64(3)
+        hs[0], hs[1], hs[2] = ctx.size
+        L.check(L.lib().scn_sparse_to_dense_bwd(L.ptr(dOut), L.ptr(ctx.g.coords), n, c, hs, L.ptr(dX), L.stream()))
+        return dX, None, None

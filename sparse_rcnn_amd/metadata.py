@@ -1,0 +1,216 @@
+"""``scn.Metadata`` -- per-forward container of voxel grids and rulebooks, resident in HBM.
+
+Mirrors the object the reference creates once per InputLayer call and shares between every tensor and layer
+derived from it (ndsis/modules/custom_operations.py:15,70; roi_select_sparse.py:77,115).
+Upstream keeps host hash maps; here everything lives on the device:
+
+  grid of a spatial size  : int32 coords [N,4] + open-addressing hash (uint64 keys, int32 rows)
+  SubM rulebook (size, k) : neighbour table int32 [k^3, N]   (hot kernels read this, output-stationary)
+                            + compacted rules (in_rows, out_rows, prefix) in canonical order (weight grads, parity)
+  strided rulebook (size) : parent / child table / compacted rules, shared by Convolution and Deconvolution
+
+Buffers are torch tensors (caching allocator, stream ordered); the C library only fills them.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+def _empty(n, dtype, dev):
+    return torch.empty(int(n), dtype=dtype, device=dev)
+
+
+@dataclass
+class Grid:
+    coords: torch.Tensor            # int32 [N,4] device
+    table_keys: torch.Tensor        # int64 view of uint64 keys [cap]
+    table_rows: torch.Tensor        # int32 [cap]
+    cap: int
+    n: int
+
+
+@dataclass
+class Rules:
+    """Compacted rule list, offset-major, output row ascending inside an offset."""
+    in_rows: torch.Tensor           # int32 [P]
+    out_rows: torch.Tensor          # int32 [P]
+    prefix_host: "C.Array"          # int64[n_off+1] on the host
+    n_off: int
+
+    @property
+    def total(self):
+        return int(self.prefix_host[self.n_off])
+
+    def prefix_list(self):
+        return [int(self.prefix_host[i]) for i in range(self.n_off + 1)]
+
+
+@dataclass
+class SubmRulebook:
+    table: Optional[torch.Tensor]   # int32 [k^3, N]; None for k == 1 (identity)
+    rules: Optional[Rules]
+    k: int
+    n: int
+
+
+@dataclass
+class StridedRulebook:
+    parent: torch.Tensor            # int32 [Nf]  fine row -> coarse row
+    fine_off: torch.Tensor          # int32 [Nf]
+    child: torch.Tensor             # int32 [8, Nc]
+    rules: Rules                    # in = fine rows, out = coarse rows
+    n_fine: int
+    n_coarse: int
+    coarse_size: Tuple[int, ...]
+
+
+def compact_rules(table: torch.Tensor, n_off: int, n_out: int, want_seg=False):
+    """Rule table -> Rules (two-phase: scan, one host sync for the sizes, fill)."""
+    lib = L.lib()
+    dev = table.device
+    blocks = lib.scn_rules_blocks(n_off, n_out)
+    block_sums = _empty(blocks, torch.int32, dev)
+    prefix = _empty(n_off + 1, torch.int64, dev)
+    prefix_host = L.host_i64(n_off + 1)
+    L.check(lib.scn_rules_scan(L.ptr(table), n_off, n_out, L.ptr(block_sums), L.ptr(prefix), prefix_host, L.stream()))
+    total = int(prefix_host[n_off])
+    in_rows = _empty(total, torch.int32, dev)
+    out_rows = _empty(total, torch.int32, dev)
+    seg = _empty(total, torch.int32, dev) if want_seg else None
+    L.check(lib.scn_rules_fill(L.ptr(table), n_off, n_out, L.ptr(block_sums), L.ptr(in_rows), L.ptr(out_rows),
+                               L.ptr(seg), L.stream()))
+    rules = Rules(in_rows, out_rows, prefix_host, n_off)
+    return (rules, seg) if want_seg else rules
+
+
+def dedup(coords_i32: torch.Tensor, shift: int, want_counts: bool, want_first: bool):
+    """First-occurrence row numbering of (b, x>>shift, y>>shift, z>>shift).  One host sync."""
+    lib = L.lib()
+    dev = coords_i32.device
+    n = coords_i32.shape[0]
+    cap = lib.scn_hash_capacity(n)
+    keys = _empty(cap, torch.int64, dev)
+    rows = _empty(cap, torch.int32, dev)
+    item_row = _empty(n, torch.int32, dev)
+    row_count = _empty(n, torch.int32, dev) if want_counts else None
+    row_first = _empty(n, torch.int32, dev) if want_first else None
+    row_coords = torch.empty((n, 4), dtype=torch.int32, device=dev)
+    scratch = _empty(lib.scn_dedup_scratch_bytes(n), torch.uint8, dev)
+    n_rows = C.c_int64(0)
+    L.check(lib.scn_dedup_build(L.ptr(coords_i32), n, shift, L.ptr(keys), L.ptr(rows), cap, L.ptr(item_row),
+                                L.ptr(row_count), L.ptr(row_first), L.ptr(row_coords), L.ptr(scratch),
+                                C.byref(n_rows), L.stream()))
+    nr = int(n_rows.value)
+    grid = Grid(row_coords[:nr], keys, rows, cap, nr)
+    return grid, item_row, (row_count[:nr] if want_counts else None), (row_first[:nr] if want_first else None)
+
+
+class Metadata:
+    """``scn.Metadata(dimension)``.  Only dimension 3 is on the reference's path (model.py:31-114: 3D scenes)."""
+
+    def __init__(self, dimension=3):
+        if int(dimension) != 3:
+            raise NotImplementedError("sparse_rcnn_amd.Metadata: only dimension 3 (the reference's ScanNet path)")
+        self.dimension = 3
+        self.grids: Dict[Tuple[int, ...], Grid] = {}
+        self.subm: Dict[Tuple[Tuple[int, ...], int], SubmRulebook] = {}
+        self.strided: Dict[Tuple[int, ...], StridedRulebook] = {}
+        # InputLayer bookkeeping (kept for OutputLayer: custom_operations.py:7-10)
+        self.input_size: Optional[Tuple[int, ...]] = None
+        self.item_row: Optional[torch.Tensor] = None
+        self.row_count: Optional[torch.Tensor] = None
+        self.row_first: Optional[torch.Tensor] = None
+        self.row_last: Optional[torch.Tensor] = None
+        self.n_items = 0
+        self.n_samples = 0
+        self.device = None
+
+    # ---- InputLayer rules -------------------------------------------------------------------------
+    def set_input(self, spatial_size, coords: torch.Tensor, batch_size: int, mode: int):
+        """coords: int64 [Npts, 4] (x,y,z,batch), CPU (the reference's contract, data.py:95-98,207-210) or device."""
+        lib = L.lib()
+        size = tuple(int(s) for s in spatial_size)
+        if len(size) != 3:
+            raise ValueError("spatial_size must have 3 entries")
+        if coords.dim() != 2 or coords.shape[1] != 4:
+            raise ValueError("coords must be [N, 4] = (x, y, z, batch); single-sample [N,3] input is not used by the reference")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        c64 = coords.to(device=dev, dtype=torch.int64).contiguous()
+        n = c64.shape[0]
+        c32 = torch.empty((n, 4), dtype=torch.int32, device=dev)
+        bad = C.c_int64(0)
+        flag = _empty(1, torch.int32, dev)
+        L.check(lib.scn_coords_to_i32(L.ptr(c64), n, L.ptr(c32), L.ptr(flag), C.byref(bad), L.stream()))
+        grid, item_row, row_count, row_first = dedup(c32, 0, True, True)
+        self.grids[size] = grid
+        self.input_size = size
+        self.item_row, self.row_count, self.row_first = item_row, row_count, row_first
+        self.n_items = n
+        if mode == 0 and grid.n != n:
+            raise L.ScnError("InputLayer mode 0 requires unique coordinates")
+        if batch_size and batch_size > 0:
+            self.n_samples = int(batch_size)
+        else:
+            self.n_samples = int(c64[:, 3].max().item()) + 1 if n else 0
+        return grid
+
+    # ---- rulebooks ----------------------------------------------------------------------------------
+    def grid(self, size) -> Grid:
+        size = tuple(int(s) for s in size)
+        if size not in self.grids:
+            raise L.ScnError(f"Metadata holds no grid of spatial size {size}")
+        return self.grids[size]
+
+    def subm_rulebook(self, size, k: int) -> SubmRulebook:
+        size = tuple(int(s) for s in size)
+        key = (size, int(k))
+        rb = self.subm.get(key)
+        if rb is None:
+            g = self.grid(size)
+            if k == 1:
+                rb = SubmRulebook(None, None, 1, g.n)
+            else:
+                lib = L.lib()
+                table = torch.empty((k ** 3, g.n), dtype=torch.int32, device=g.coords.device)
+                L.check(lib.scn_subm_table(L.ptr(g.coords), g.n, L.ptr(g.table_keys), L.ptr(g.table_rows), g.cap, k,
+                                           L.ptr(table), L.stream()))
+                rb = SubmRulebook(table, compact_rules(table, k ** 3, g.n), k, g.n)
+            self.subm[key] = rb
+        return rb
+
+    def strided_rulebook(self, size) -> StridedRulebook:
+        """size=stride=2 Convolution from `size` to size/2; creates the coarse grid on first use."""
+        size = tuple(int(s) for s in size)
+        rb = self.strided.get(size)
+        if rb is None:
+            if any(s % 2 for s in size):
+                raise L.ScnError(f"Convolution size=stride=2 needs even spatial size, got {size} "
+                                 "((out-1)*stride+filter != in)")
+            coarse_size = tuple(s // 2 for s in size)
+            g = self.grid(size)
+            lib = L.lib()
+            dev = g.coords.device
+            cg, parent, _, _ = dedup(g.coords, 1, False, False)
+            if coarse_size in self.grids:
+                raise L.ScnError(f"Metadata already holds a grid of size {coarse_size}")
+            self.grids[coarse_size] = cg
+            child = torch.empty((8, cg.n), dtype=torch.int32, device=dev)
+            fine_off = _empty(g.n, torch.int32, dev)
+            L.check(lib.scn_child_table(L.ptr(g.coords), L.ptr(parent), g.n, cg.n, L.ptr(child), L.ptr(fine_off),
+                                        L.stream()))
+            rules = compact_rules(child, 8, cg.n)
+            rb = StridedRulebook(parent, fine_off, child, rules, g.n, cg.n, coarse_size)
+            self.strided[size] = rb
+        return rb
+
+    # ---- parity helpers (tests) -------------------------------------------------------------------
+    def get_spatial_locations(self, size) -> torch.Tensor:
+        """int64 CPU [N,4] in row order (roi_select_sparse.py:103)."""
+        return self.grid(size).coords.to(torch.int64).cpu()

@@ -1,0 +1,261 @@
+"""Module classes of the ``scn`` operator API the reference's ndsis.modules code calls.
+
+Constructor signatures, positional/keyword use and parameter attribute names (``weight``, ``bias``,
+``running_mean``, ``running_var``) follow the call sites in module_factory.py / model.py so that
+``sys.modules['sparseconvnet'] = sparse_rcnn_amd`` is a drop-in for that path.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch.nn import Module, Parameter
+
+from . import functional as F
+from .tensor import SparseConvNetTensor
+
+
+def _triple(v, what):
+    if isinstance(v, (int,)) or (hasattr(v, "ndim") and getattr(v, "ndim") == 0):
+        return (int(v),) * 3
+    t = tuple(int(x) for x in v)
+    if len(t) != 3:
+        raise ValueError(f"{what} must have 3 entries")
+    return t
+
+
+def _out(input, features, spatial_size=None):
+    return SparseConvNetTensor(features=features, metadata=input.metadata,
+                               spatial_size=input.spatial_size if spatial_size is None else spatial_size)
+
+
+class Sequential(torch.nn.Sequential):
+    """``scn.Sequential(*modules)`` with ``.append`` / ``.add`` (module_factory.py:52-56,421-424).
+    Peephole: ``ReLU`` directly followed by a conv-type layer runs as one kernel (ReLU fused into the gather)."""
+
+    def append(self, module):
+        self.add_module(str(len(self._modules)), module)
+        return self
+
+    def add(self, module):
+        return self.append(module)
+
+    def forward(self, input):
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if (FUSE_RELU and type(m) is ReLU and i + 1 < len(mods)
+                    and isinstance(mods[i + 1], (SubmanifoldConvolution, Convolution, Deconvolution))):
+                input = mods[i + 1](input, relu_in=True)
+                i += 2
+            else:
+                input = m(input)
+                i += 1
+        return input
+
+
+FUSE_RELU = True
+
+
+class ConcatTable(Sequential):
+    """Applies every child to the same input -> list (module_factory.py:52-54)."""
+
+    def forward(self, input):
+        return [m(input) for m in self._modules.values()]
+
+
+class AddTable(Module):
+    def forward(self, input):
+        feats = input[0].features
+        for t in input[1:]:
+            feats = F.AddFunction.apply(feats, t.features)
+        return _out(input[0], feats)
+
+
+class JoinTable(Module):
+    """Channel concat of tensors sharing Metadata / row order (module_factory.py:301)."""
+
+    def forward(self, input):
+        return _out(input[0], torch.cat([t.features for t in input], 1))
+
+
+class Identity(Module):
+    def forward(self, input):
+        return input
+
+
+class ReLU(Module):
+    def forward(self, input):
+        return _out(input, F.ReLUFunction.apply(input.features))
+
+
+class _BatchNorm(Module):
+    def __init__(self, nPlanes, eps=1e-4, momentum=0.9, affine=True, leakiness=0.0):
+        super().__init__()
+        self.nPlanes, self.eps, self.momentum, self.leakiness = nPlanes, eps, momentum, leakiness
+        self.register_buffer("running_mean", torch.zeros(nPlanes))
+        self.register_buffer("running_var", torch.ones(nPlanes))
+        self.weight = Parameter(torch.ones(nPlanes))
+        self.bias = Parameter(torch.zeros(nPlanes))
+
+    def forward(self, input):
+        y = F.BatchNormReLUFunction.apply(input.features, self.weight, self.bias, self.running_mean, self.running_var,
+                                          float(self.eps), float(self.momentum), float(self.leakiness), self.training)
+        return _out(input, y)
+
+    def extra_repr(self):
+        return f"{self.nPlanes}, eps={self.eps}, momentum={self.momentum}, leakiness={self.leakiness}"
+
+
+class BatchNormReLU(_BatchNorm):
+    """``scn.BatchNormReLU(nPlanes, eps, momentum)`` (module_factory.py:101-102)."""
+
+    def __init__(self, nPlanes, eps=1e-4, momentum=0.9):
+        super().__init__(nPlanes, eps, momentum, True, 0.0)
+
+
+class BatchNormLeakyReLU(_BatchNorm):
+    """``scn.BatchNormLeakyReLU(nPlanes, eps, momentum, leakiness)`` (module_factory.py:98-99)."""
+
+    def __init__(self, nPlanes, eps=1e-4, momentum=0.9, leakiness=0.333):
+        super().__init__(nPlanes, eps, momentum, True, leakiness)
+
+
+class _ConvBase(Module):
+    def _init(self, filter_volume, nIn, nOut, bias):
+        self.nIn, self.nOut = int(nIn), int(nOut)
+        std = math.sqrt(2.0 / self.nIn / filter_volume)
+        self.weight = Parameter(torch.empty(filter_volume, self.nIn, self.nOut).normal_(0, std))
+        if bias:
+            self.bias = Parameter(torch.zeros(self.nOut))
+        else:
+            self.register_parameter("bias", None)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # checkpoints written with SparseConvNet's grouped layout [fv, groups=1, nIn, nOut] load into [fv, nIn, nOut]
+        k = prefix + "weight"
+        if k in state_dict and state_dict[k].dim() == 4 and state_dict[k].shape[1] == 1:
+            state_dict[k] = state_dict[k].squeeze(1)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
+class SubmanifoldConvolution(_ConvBase):
+    """``scn.SubmanifoldConvolution(dimension, nIn, nOut, filter_size, bias, groups=1)`` (module_factory.py:383-385,404-406)."""
+
+    def __init__(self, dimension, nIn, nOut, filter_size, bias, groups=1):
+        super().__init__()
+        if int(dimension) != 3:
+            raise NotImplementedError("only dimension 3")
+        if groups != 1:
+            raise NotImplementedError("groups != 1 is never used by the reference (module_factory.py:152)")
+        fs = _triple(filter_size, "filter_size")
+        if len(set(fs)) != 1 or fs[0] % 2 == 0:
+            raise ValueError("SubmanifoldConvolution needs an odd cubic filter")
+        self.dimension, self.filter_size = 3, fs[0]
+        self._init(self.filter_size ** 3, nIn, nOut, bias)
+
+    def forward(self, input, relu_in=False):
+        y = F.SubmanifoldConvolutionFunction.apply(input.features, self.weight, self.bias, input.metadata,
+                                                   input.spatial_size, self.filter_size, relu_in)
+        return _out(input, y)
+
+    def extra_repr(self):
+        return f"{self.nIn}->{self.nOut} C{self.filter_size}"
+
+
+def _check_s2(filter_size, filter_stride):
+    fs, st = _triple(filter_size, "filter_size"), _triple(filter_stride, "filter_stride")
+    if fs != (2, 2, 2) or st != (2, 2, 2):
+        raise NotImplementedError(
+            f"only filter_size = filter_stride = 2 (the reference's down/up-samplers, module_factory.py:221-258); "
+            f"got size {fs} stride {st}")
+
+
+class Convolution(_ConvBase):
+    """``scn.Convolution(dimension, nIn, nOut, filter_size, filter_stride, bias)`` (module_factory.py:232-234)."""
+
+    def __init__(self, dimension, nIn, nOut, filter_size, filter_stride, bias):
+        super().__init__()
+        if int(dimension) != 3:
+            raise NotImplementedError("only dimension 3")
+        _check_s2(filter_size, filter_stride)
+        self._init(8, nIn, nOut, bias)
+
+    def forward(self, input, relu_in=False):
+        in_size = tuple(int(s) for s in input.spatial_size)
+        y = F.ConvolutionFunction.apply(input.features, self.weight, self.bias, input.metadata, in_size, relu_in)
+        out_size = torch.as_tensor([s // 2 for s in in_size], dtype=torch.long)
+        return _out(input, y, out_size)
+
+    def input_spatial_size(self, out_size):
+        return out_size * 2
+
+    def extra_repr(self):
+        return f"{self.nIn}->{self.nOut} C2/2"
+
+
+class Deconvolution(_ConvBase):
+    """``scn.Deconvolution(dimension, nIn, nOut, filter_size, filter_stride, bias)`` (module_factory.py:256-258)."""
+
+    def __init__(self, dimension, nIn, nOut, filter_size, filter_stride, bias):
+        super().__init__()
+        if int(dimension) != 3:
+            raise NotImplementedError("only dimension 3")
+        _check_s2(filter_size, filter_stride)
+        self._init(8, nIn, nOut, bias)
+
+    def forward(self, input, relu_in=False):
+        out_size = tuple(int(s) * 2 for s in input.spatial_size)
+        y = F.DeconvolutionFunction.apply(input.features, self.weight, self.bias, input.metadata, out_size, relu_in)
+        return _out(input, y, torch.as_tensor(out_size, dtype=torch.long))
+
+    def extra_repr(self):
+        return f"{self.nIn}->{self.nOut} D2/2"
+
+
+class NetworkInNetwork(Module):
+    """``scn.NetworkInNetwork(nIn, nOut, bias)`` (module_factory.py:366-367)."""
+
+    def __init__(self, nIn, nOut, bias):
+        super().__init__()
+        self.nIn, self.nOut = int(nIn), int(nOut)
+        self.weight = Parameter(torch.empty(self.nIn, self.nOut).normal_(0, math.sqrt(2.0 / self.nIn)))
+        if bias:
+            self.bias = Parameter(torch.zeros(self.nOut))
+        else:
+            self.register_parameter("bias", None)
+
+    def forward(self, input):
+        return _out(input, F.NetworkInNetworkFunction.apply(input.features, self.weight, self.bias))
+
+    def extra_repr(self):
+        return f"{self.nIn}->{self.nOut}"
+
+
+class SparseToDense(Module):
+    """``scn.SparseToDense(dimension, nPlanes)`` (module_factory.py:429-435) -> dense [B, C, X, Y, Z]."""
+
+    def __init__(self, dimension, nPlanes):
+        super().__init__()
+        self.dimension, self.nPlanes = dimension, nPlanes
+
+    def forward(self, input):
+        return F.SparseToDenseFunction.apply(input.features, input.metadata, input.spatial_size)
+
+
+class _PoolingNotBuilt(Module):
+    """scn.MaxPooling / scn.AveragePooling (module_factory.py:315-354) serve the sparse class network only --
+    SURVEY.md §8f row N1 ("next"); constructing one says so instead of silently computing something else."""
+
+    def __init__(self, dimension, pool_size, pool_stride, nFeaturesToDrop=0):
+        super().__init__()
+        raise NotImplementedError(f"{type(self).__name__}: next-tier component (SURVEY.md §8f N1), not on the hot path")
+
+
+class MaxPooling(_PoolingNotBuilt):
+    pass
+
+
+class AveragePooling(_PoolingNotBuilt):
+    pass

@@ -1,0 +1,104 @@
+"""Graph builder for the benchmark backbone: the topology the reference's factory code produces for its sparse
+U-Net, expressed with this package's scn-API modules.
+
+  encoder level l : {l = 0: SubM 1^3 Cin->C0 | l > 0: Convolution 2^3/2 C(l-1)->Cl}            (module_factory.py:438-486)
+                    + num_units x  [ x + SubM3(ReLU(SubM3(ReLU(x)))) ]                            (:127-183, relu_first)
+  decoder level l : ReLU -> Deconvolution 2^3/2 -> JoinTable([up, skip]) -> NetworkInNetwork(2C->C)
+                    -> num_units x residual                                                       (:533-578; custom_container.py:70-83)
+
+Flags reproduced: relu_first=True, main_path_relu=False, bottleneck_divisor=0, drop_input_relu=True, num_units=2,
+use_residuals=True, concat=True, batchnorm=False (scannet_config/run.py:516-519,609-623).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import modules as M
+from .ioLayers import InputLayer
+
+
+def residual_block(c, batchnorm=False):
+    """module_factory.py:51-57 sparse_residual(inner_block, Identity, None) with relu_first inner block."""
+    def act():
+        return M.BatchNormReLU(c) if batchnorm else M.ReLU()
+    inner = M.Sequential(act(), M.SubmanifoldConvolution(3, c, c, 3, not batchnorm),
+                         act(), M.SubmanifoldConvolution(3, c, c, 3, not batchnorm))
+    return M.Sequential(M.ConcatTable(M.Identity(), inner), M.AddTable())
+
+
+def units(c, num_units=2, batchnorm=False):
+    return M.Sequential(*[residual_block(c, batchnorm) for _ in range(num_units)])
+
+
+class SparseUNet(nn.Module):
+    """forward(SparseConvNetTensor with Cin channels) -> SparseConvNetTensor with channels[0] channels at full
+    resolution; ``.interims`` holds the encoder outputs (the reference's SequentialInterims, custom_container.py:5-12)."""
+
+    def __init__(self, cin=7, channels=(32, 64, 128, 256), num_units=2, batchnorm=False):
+        super().__init__()
+        self.channels = tuple(channels)
+        enc = []
+        for l, c in enumerate(self.channels):
+            head = (M.SubmanifoldConvolution(3, cin, c, 1, True) if l == 0
+                    else M.Convolution(3, self.channels[l - 1], c, (2, 2, 2), (2, 2, 2), True))
+            enc.append(M.Sequential(head, units(c, num_units, batchnorm)))
+        self.encoder = nn.ModuleList(enc)
+        dec = []
+        for l in range(len(self.channels) - 2, -1, -1):
+            c, cup = self.channels[l], self.channels[l + 1]
+            dec.append(nn.ModuleDict(dict(
+                up=M.Sequential(M.ReLU(), M.Deconvolution(3, cup, c, (2, 2, 2), (2, 2, 2), True)),
+                join=M.JoinTable(),
+                nin=M.NetworkInNetwork(2 * c, c, True),
+                units=units(c, num_units, batchnorm))))
+        self.decoder = nn.ModuleList(dec)
+
+    def forward(self, x):
+        interims = []
+        for level in self.encoder:
+            x = level(x)
+            interims.append(x)
+        self.interims = interims
+        for i, d in enumerate(self.decoder):
+            skip = interims[len(self.channels) - 2 - i]
+            x = d["units"](d["nin"](d["join"]([d["up"](x), skip])))
+        return x
+
+    # parameter naming shared with oracle.scn_oracle.unet_param_shapes (test infrastructure maps by these names)
+    def named_oracle_params(self):
+        out = {}
+        for l, level in enumerate(self.encoder):
+            out[f"enc{l}.in.weight"], out[f"enc{l}.in.bias"] = level[0].weight, level[0].bias
+            self._res(out, f"enc{l}", level[1])
+        for i, d in enumerate(self.decoder):
+            l = len(self.channels) - 2 - i
+            out[f"dec{l}.up.weight"], out[f"dec{l}.up.bias"] = d["up"][1].weight, d["up"][1].bias
+            out[f"dec{l}.nin.weight"], out[f"dec{l}.nin.bias"] = d["nin"].weight, d["nin"].bias
+            self._res(out, f"dec{l}", d["units"])
+        return out
+
+    @staticmethod
+    def _res(out, prefix, unit_seq):
+        for u, block in enumerate(unit_seq):
+            inner = block[0][1]
+            convs = [m for m in inner if isinstance(m, M.SubmanifoldConvolution)]
+            for v, cv in enumerate(convs):
+                out[f"{prefix}.res{u}.conv{v}.weight"], out[f"{prefix}.res{u}.conv{v}.bias"] = cv.weight, cv.bias
+
+    def load_oracle_params(self, params):
+        with torch.no_grad():
+            for k, p in self.named_oracle_params().items():
+                p.copy_(params[k].view_as(p))
+
+
+class Backbone(nn.Module):
+    """InputLayer(mode 4) + SparseUNet: what model.py:414-431 runs for sparse + include_unet."""
+
+    def __init__(self, cin=7, channels=(32, 64, 128, 256), num_units=2, batchnorm=False):
+        super().__init__()
+        self.unet = SparseUNet(cin, channels, num_units, batchnorm)
+
+    def forward(self, coords, feats, spatial_size, batch_size=0):
+        x = InputLayer(3, spatial_size, mode=4)((coords, feats, batch_size))
+        return self.unet(x)

@@ -1,0 +1,320 @@
+"""-m gpu parity tests: the HIP path (through the C ABI / Python operator mirror) against the CPU oracle on the same
+seeded inputs.  Index work must be BIT-EXACT; fp32 features within the north star's 1e-4 (relative to the output
+scale, stated per test)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import scn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FEAT_TOL = 1e-4          # BASELINE.json north_star: "features within 1e-4 fp32"
+
+
+def _scn():
+    import sparse_rcnn_amd as scn
+    return scn
+
+
+def _cloud(seed, grid=(24, 20, 16), n=1500, batch=2, dup=200):
+    rng = np.random.default_rng(seed)
+    cs = []
+    for b in range(batch):
+        lin = rng.choice(grid[0] * grid[1] * grid[2], size=n, replace=False)
+        p = np.stack(np.unravel_index(lin, grid), 1)
+        p = np.concatenate([p, p[rng.integers(0, n, size=dup)]]) if dup else p
+        rng.shuffle(p)
+        cs.append(np.concatenate([p, np.full((len(p), 1), b)], 1))
+    return torch.from_numpy(np.concatenate(cs).astype(np.int64)), torch.tensor(grid), batch
+
+
+def _close(a, b, tol=FEAT_TOL, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(1.0, b.abs().max().item())
+    err = (a - b).abs().max().item() / scale
+    assert err <= tol, f"{what}: max err {err:.3e} (scale {scale:.3g}) > {tol}"
+
+
+def _input(gpu, seed=0, cin=5, mode=4, **kw):
+    scn = _scn()
+    coords, size, batch = _cloud(seed, **kw)
+    feats = torch.randn(len(coords), cin, generator=torch.Generator().manual_seed(seed + 100))
+    fg = feats.to(gpu).requires_grad_()
+    x = scn.InputLayer(3, size, mode=mode)((coords, fg, batch))
+    scene = O.OracleScene(coords.numpy())
+    return scn, coords, feats, fg, x, scene, size
+
+
+# ---------------------------------------------------------------------------------------- index path
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+def test_input_output_layer_modes(gpu, mode):
+    dup = 0 if mode == 0 else 300
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=mode, cin=7, mode=mode, dup=dup)
+    assert np.array_equal(x.get_spatial_locations().numpy(), scene.coords0)            # first-occurrence order
+    assert np.array_equal(x.metadata.item_row.cpu().numpy(), scene.prow)
+    assert np.array_equal(x.metadata.row_count.cpu().numpy(), scene.counts)
+    assert x.batch_size() == 2
+    exp = O.input_layer_fwd(feats, scene.prow, scene.n(0), mode)
+    assert torch.equal(x.features.detach().cpu(), exp), "InputLayer features must be bit-exact (fp64 accumulate)"
+    g = torch.randn(exp.shape, generator=torch.Generator().manual_seed(9))
+    x.features.backward(g.to(gpu))
+    _close(fg.grad, O.input_layer_bwd(g, scene.prow, mode), 1e-6, "input bwd")
+    # OutputLayer: one row per original point, backward = segment sum
+    xf = x.features.detach().clone().requires_grad_()
+    y = scn.ioLayers.OutputLayerFunction.apply(3, x.metadata, xf)
+    assert torch.equal(y.detach().cpu(), O.output_layer_fwd(exp, scene.prow))
+    gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(10))
+    y.backward(gy.to(gpu))
+    _close(xf.grad, O.output_layer_bwd(gy, scene.prow, scene.n(0)), 1e-6, "output bwd")
+
+
+def test_empty_and_zero_row_samples(gpu):
+    scn = _scn()
+    # batch_size fixes the sample count even when a sample has no rows (ROI path, roi_select_sparse.py:49-50,74-81)
+    coords = torch.tensor([[1, 2, 3, 0], [1, 2, 3, 0], [4, 4, 4, 3]])
+    x = scn.InputLayer(3, torch.tensor([8, 8, 8]), mode=4)((coords, torch.ones(3, 2).to(gpu), 5))
+    assert x.batch_size() == 5 and x.features.shape == (2, 2)
+    e = scn.InputLayer(3, torch.tensor([8, 8, 8]), mode=4)((torch.zeros(0, 4, dtype=torch.long), torch.zeros(0, 2).to(gpu), 2))
+    assert e.features.shape == (0, 2) and e.batch_size() == 2
+
+
+@pytest.mark.parametrize("seed,kw", [(1, {}), (2, dict(grid=(64, 64, 32), n=20000, batch=1, dup=2000))])
+def test_rulebooks_bit_exact(gpu, seed, kw):
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=seed, **kw)
+    md = x.metadata
+    for k in (3,):
+        nbr, rules = O.subm_rulebook(scene.coords0, k)
+        rb = md.subm_rulebook(size, k)
+        assert np.array_equal(rb.table.cpu().numpy(), nbr)
+        pairs, prefix = O.rules_concat(rules)
+        assert rb.rules.prefix_list() == prefix.tolist()
+        assert np.array_equal(rb.rules.in_rows.cpu().numpy(), pairs[:, 0])
+        assert np.array_equal(rb.rules.out_rows.cpu().numpy(), pairs[:, 1])
+    level_size, level_coords = tuple(int(s) for s in size), scene.coords0
+    for level in range(2):                                                   # two strided transitions
+        ref = O.strided_rulebook(level_coords, 2)
+        rb = md.strided_rulebook(level_size)
+        coarse = tuple(s // 2 for s in level_size)
+        assert np.array_equal(md.get_spatial_locations(coarse).numpy(), ref["coords"])   # canonical coarse row order
+        assert np.array_equal(rb.parent.cpu().numpy(), ref["parent"])
+        assert np.array_equal(rb.fine_off.cpu().numpy(), ref["off"])
+        assert np.array_equal(rb.child.cpu().numpy(), ref["child"])
+        pairs, prefix = O.rules_concat(ref["rules"])
+        assert rb.rules.prefix_list() == prefix.tolist()
+        assert np.array_equal(rb.rules.in_rows.cpu().numpy(), pairs[:, 0])
+        assert np.array_equal(rb.rules.out_rows.cpu().numpy(), pairs[:, 1])
+        nbr, _ = O.subm_rulebook(ref["coords"], 3)                           # coarse grid's own hash works
+        assert np.array_equal(md.subm_rulebook(coarse, 3).table.cpu().numpy(), nbr)
+        level_size, level_coords = coarse, ref["coords"]
+
+
+def test_odd_size_strided_is_rejected(gpu):
+    scn = _scn()
+    x = scn.InputLayer(3, torch.tensor([9, 8, 8]), mode=4)((torch.tensor([[1, 2, 3, 0]]), torch.ones(1, 2).to(gpu), 1))
+    with pytest.raises(scn.ScnError):
+        scn.Convolution(3, 2, 4, (2, 2, 2), (2, 2, 2), True).to(gpu)(x)
+    with pytest.raises(NotImplementedError):
+        scn.Convolution(3, 2, 4, (3, 3, 3), (2, 2, 2), True)
+
+
+# ---------------------------------------------------------------------------------------- feature path
+CHANNELS = [(3, 16), (7, 32), (32, 32), (16, 23), (23, 20), (64, 48), (40, 8)]
+
+
+def _grads(y, params, g):
+    return torch.autograd.grad(y, params, g, allow_unused=False)
+
+
+@pytest.mark.parametrize("cin,cout", CHANNELS)
+@pytest.mark.parametrize("k", [1, 3])
+@pytest.mark.parametrize("relu_in", [False, True])
+def test_submanifold_conv(gpu, cin, cout, k, relu_in):
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=3, cin=cin)
+    conv = scn.SubmanifoldConvolution(3, cin, cout, k, True).to(gpu)
+    with torch.no_grad():
+        conv.bias.normal_(0, 0.5)
+    net = scn.Sequential(scn.ReLU(), conv) if relu_in else conv
+    y = net(x).features
+    rules = scene.subm_rules(0, k)
+    n = scene.n(0)
+    Xo = O.input_layer_fwd(feats, scene.prow, n, 4).requires_grad_()
+    W, b = conv.weight.detach().cpu().requires_grad_(), conv.bias.detach().cpu().requires_grad_()
+    yo = O.conv(torch.relu(Xo) if relu_in else Xo, W, b, rules, n)
+    _close(y, yo, what="fwd")
+    g = torch.randn(yo.shape, generator=torch.Generator().manual_seed(5))
+    gx, gw, gb = _grads(y, (x.features, conv.weight, conv.bias), g.to(gpu))
+    ox, ow, ob = _grads(yo, (Xo, W, b), g)
+    _close(gx, ox, what="dX"); _close(gw, ow, what="dW"); _close(gb, ob, what="db")
+
+
+@pytest.mark.parametrize("cin,cout", [(4, 6), (32, 64), (23, 32), (48, 64)])
+@pytest.mark.parametrize("relu_in", [False, True])
+def test_strided_conv_and_deconv(gpu, cin, cout, relu_in):
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=4, cin=cin)
+    down = scn.Convolution(3, cin, cout, (2, 2, 2), (2, 2, 2), True).to(gpu)
+    up = scn.Deconvolution(3, cout, cin, (2, 2, 2), (2, 2, 2), True).to(gpu)
+    with torch.no_grad():
+        down.bias.normal_(0, 0.5); up.bias.normal_(0, 0.5)
+    d = (scn.Sequential(scn.ReLU(), down) if relu_in else down)(x)
+    u = (scn.Sequential(scn.ReLU(), up) if relu_in else up)(d)
+    assert tuple(int(s) for s in d.spatial_size) == tuple(int(s) // 2 for s in size)
+    assert tuple(int(s) for s in u.spatial_size) == tuple(int(s) for s in size)
+    rules = scene.strided_rules(0)
+    n, nc = scene.n(0), scene.n(1)
+    act = torch.relu if relu_in else (lambda t: t)
+    Xo = O.input_layer_fwd(feats, scene.prow, n, 4).requires_grad_()
+    Wd, bd = down.weight.detach().cpu().requires_grad_(), down.bias.detach().cpu().requires_grad_()
+    Wu, bu = up.weight.detach().cpu().requires_grad_(), up.bias.detach().cpu().requires_grad_()
+    do = O.conv(act(Xo), Wd, bd, rules, nc)
+    uo = O.conv(act(do), Wu, bu, O.swap_rules(rules), n)
+    _close(d.features, do, what="conv fwd"); _close(u.features, uo, what="deconv fwd")
+    g = torch.randn(uo.shape, generator=torch.Generator().manual_seed(6))
+    got = _grads(u.features, (x.features, down.weight, down.bias, up.weight, up.bias), g.to(gpu))
+    exp = _grads(uo, (Xo, Wd, bd, Wu, bu), g)
+    for a, e, name in zip(got, exp, ("dX", "dWd", "dbd", "dWu", "dbu")):
+        _close(a, e, what=name)
+
+
+def test_deconvolution_needs_cached_level(gpu):
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=4, cin=4)
+    with pytest.raises(scn.ScnError):
+        scn.Deconvolution(3, 4, 4, (2, 2, 2), (2, 2, 2), True).to(gpu)(x)
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 32), (46, 23), (7, 5)])
+def test_nin_relu_add_join(gpu, cin, cout):
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=5, cin=cin)
+    nin = scn.NetworkInNetwork(cin, cout, True).to(gpu)
+    net = scn.Sequential(scn.ConcatTable(scn.Identity(), scn.ReLU()), scn.AddTable())      # x + relu(x)
+    y = nin(net(x)).features
+    j = scn.JoinTable()([x, x]).features
+    n = scene.n(0)
+    Xo = O.input_layer_fwd(feats, scene.prow, n, 4).requires_grad_()
+    W, b = nin.weight.detach().cpu().requires_grad_(), nin.bias.detach().cpu().requires_grad_()
+    yo = (Xo + torch.relu(Xo)) @ W + b
+    _close(y, yo, what="fwd")
+    assert torch.equal(j.detach().cpu(), torch.cat([Xo, Xo], 1).detach())
+    g = torch.randn(yo.shape, generator=torch.Generator().manual_seed(7))
+    for a, e, name in zip(_grads(y, (x.features, nin.weight, nin.bias), g.to(gpu)), _grads(yo, (Xo, W, b), g),
+                          ("dX", "dW", "db")):
+        _close(a, e, what=name)
+
+
+@pytest.mark.parametrize("leak", [0.0, 0.2])
+@pytest.mark.parametrize("training", [True, False])
+def test_batchnorm_relu(gpu, leak, training):
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=6, cin=24)
+    bn = (scn.BatchNormLeakyReLU(24, 1e-4, 0.9, leak) if leak else scn.BatchNormReLU(24, 1e-4, 0.9)).to(gpu)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5)
+    bn.train(training)
+    rm0, rv0 = bn.running_mean.detach().cpu().clone(), bn.running_var.detach().cpu().clone()
+    y = bn(x).features
+    n = scene.n(0)
+    Xo = O.input_layer_fwd(feats, scene.prow, n, 4).requires_grad_()
+    ga, be = bn.weight.detach().cpu().requires_grad_(), bn.bias.detach().cpu().requires_grad_()
+    yo = O.batchnorm_relu_fwd(Xo, ga, be, rm0, rv0, 1e-4, 0.9, leak, training)
+    _close(y, yo, what="fwd")
+    _close(bn.running_mean, rm0, 1e-6, "running_mean (retain-fraction momentum)")
+    _close(bn.running_var, rv0, 1e-6, "running_var")
+    g = torch.randn(yo.shape, generator=torch.Generator().manual_seed(8))
+    for a, e, name in zip(_grads(y, (x.features, bn.weight, bn.bias), g.to(gpu)), _grads(yo, (Xo, ga, be), g),
+                          ("dX", "dgamma", "dbeta")):
+        _close(a, e, what=name)
+
+
+def test_sparse_to_dense(gpu):
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=7, cin=6)
+    d = scn.SparseToDense(3, 6)(x)
+    Xo = O.input_layer_fwd(feats, scene.prow, scene.n(0), 4)
+    exp = O.sparse_to_dense(Xo, scene.coords0, size.tolist(), 2)
+    assert torch.equal(d.detach().cpu(), exp)
+    g = torch.randn(exp.shape, generator=torch.Generator().manual_seed(2))
+    (gx,) = torch.autograd.grad(d, x.features, g.to(gpu))
+    c = torch.from_numpy(scene.coords0)
+    assert torch.equal(gx.cpu(), g[c[:, 3], :, c[:, 0], c[:, 1], c[:, 2]])
+
+
+# ---------------------------------------------------------------------------------------- the U-Net (A12)
+def test_unet_forward_backward_matches_oracle(gpu):
+    from sparse_rcnn_amd.unet import Backbone
+    channels = (16, 24, 32)
+    coords, size, batch = _cloud(11, grid=(32, 32, 16), n=3000, batch=2, dup=300)
+    feats = torch.randn(len(coords), 7, generator=torch.Generator().manual_seed(3))
+    params = O.init_unet_params(7, channels, seed=4)
+    net = Backbone(7, channels).to(gpu)
+    net.unet.load_oracle_params(params)
+    out = net(coords, feats.to(gpu), size, batch)
+    scene = O.OracleScene(coords.numpy())
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    exp = O.unet_forward(scene, feats, po, channels)
+    _close(out.features, exp, what="unet fwd")
+    g = torch.randn(exp.shape, generator=torch.Generator().manual_seed(5))
+    out.features.backward(g.to(gpu))
+    exp.backward(g)
+    for k, p in net.unet.named_oracle_params().items():
+        _close(p.grad, po[k].grad.view_as(p), 2e-4, f"grad {k}")
+
+
+# ---------------------------------------------------------------------------------------- ROI crop (A11)
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "roi_crop_*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_roi_crop_matches_reference_golden(gpu, path):
+    from sparse_rcnn_amd import roi
+    z = np.load(path)
+    n_pts = int(z["n_pts"])
+    inside = np.unpackbits(z["is_inside"], axis=1)[:, :n_pts].astype(bool)
+    counts = z["box_counts"].tolist()
+    bbox_batch = [torch.from_numpy(b) for b in np.split(z["boxes"], np.cumsum(counts)[:-1])]
+    boxes, got_counts, assoc = roi.transform_boxes(bbox_batch, z["spatial_size"], bool(z["clip"]))
+    exp_boxes = np.concatenate([z["bbox_tensor"][:, 0], z["assoc"][:, None], z["bbox_tensor"][:, 1],
+                                z["assoc"][:, None] + 1], 1)
+    assert np.array_equal(boxes.cpu().numpy(), exp_boxes) and got_counts == counts
+    # reference-signature entry point
+    new_coords, new_feats, is_inside = roi.roi_cut(torch.from_numpy(z["coords"]), torch.from_numpy(z["feats"]).to(gpu),
+                                                   torch.from_numpy(z["bbox_tensor"]), torch.from_numpy(z["assoc"]))
+    assert new_coords.dtype == torch.int64 and not new_coords.is_cuda and is_inside.dtype == torch.bool
+    assert np.array_equal(new_coords.numpy(), z["out_coords"])
+    assert np.array_equal(new_feats.cpu().numpy(), z["out_feats"])
+    assert np.array_equal(is_inside.numpy(), inside)
+
+
+def test_roi_cut_module_revoxelises_like_oracle(gpu):
+    from sparse_rcnn_amd import roi
+    from sparse_rcnn_amd.synthetic import make_boxes
+    coords, size, batch = _cloud(21, grid=(48, 40, 24), n=4000, batch=2, dup=500)
+    feats = torch.randn(len(coords), 23, generator=torch.Generator().manual_seed(1))
+    bbox_batch = make_boxes(coords, n_boxes=9, seed=2, lo=3, hi=30)
+    fg = feats.to(gpu).requires_grad_()
+    cut = roi.SparseRoiCut(spatial_size_offset=32)
+    out, (is_inside, counts, splits) = cut((coords, fg, size, batch, [0]), bbox_batch)
+    bi, cnt, assoc = O.transform_boxes([b.numpy() for b in bbox_batch])
+    src, box_of, inside = O.roi_crop(coords.numpy(), bi, assoc)
+    assert np.array_equal(is_inside.numpy(), inside) and counts == cnt
+    new_coords = np.concatenate([coords.numpy()[src][:, :3], box_of[:, None]], 1)
+    ac, prow, _ = O.input_layer_rules(new_coords)
+    assert np.array_equal(out.get_spatial_locations().numpy(), ac)
+    assert out.batch_size() == 18 and tuple(out.spatial_size.tolist()) == tuple(s + 32 for s in size.tolist())
+    exp = O.input_layer_fwd(feats[torch.from_numpy(src)], prow, len(ac), 4)
+    assert torch.equal(out.features.detach().cpu(), exp)
+    g = torch.randn(exp.shape, generator=torch.Generator().manual_seed(3))
+    out.features.backward(g.to(gpu))
+    gsel = O.input_layer_bwd(g, prow, 4)
+    gexp = torch.zeros(len(coords), 23, dtype=torch.float64).index_add_(0, torch.from_numpy(src), gsel.double())
+    _close(fg.grad, gexp.float(), 1e-6, "roi crop backward")
+
+
+def test_roi_no_boxes(gpu):
+    from sparse_rcnn_amd import roi
+    coords, size, batch = _cloud(22, n=200, dup=0)
+    nc, nf, inside = roi.roi_cut(coords, torch.ones(len(coords), 3).to(gpu), torch.zeros(0, 2, 3, dtype=torch.long),
+                                 torch.zeros(0, dtype=torch.long))
+    assert nc.shape == (0, 4) and nf.shape == (0, 3) and inside.shape == (0, len(coords))

@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Headline benchmark: active-voxels/sec, forward + backward of the ScanNet U-Net backbone (BASELINE.json configs[1]):
+~150k active voxels per scene, 32->64->128->256 channels, 3^3 submanifold + 2^3/2 conv/deconv, fp32.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU)
+
+A step = InputLayer (voxel hash + first-occurrence rows + mean of duplicate points) + every rulebook build (they are
+rebuilt per forward, as in the reference) + U-Net forward + backward to all parameters and the input features + one
+all-reduce of the flat gradient bucket over RCCL (N > 1) + SGD update.  One scene per GPU (weak scaling); inputs are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+CHANNELS = (32, 64, 128, 256)
+GRID = (512, 512, 256)
+TARGET = 150_000
+PEAK_FP32_MATRIX_TFLOPS = 157.3          # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def cpu_baseline(coords, feats):
+    """The CPU restatement (oracle) of the same step -- SparseConvNet's CPU algorithm (hash -> rulebook; per offset
+    gather -> sgemm -> scatter-add) -- timed on this box's host cores.  It is NOT the SparseConvNet binary (unavailable:
+    SURVEY.md §8c).  Bounded sample: ONE full step (rulebooks + fwd + bwd) of the same 150k-voxel scene."""
+    from oracle import scn_oracle as O
+    params = {k: v.requires_grad_() for k, v in O.init_unet_params(7, CHANNELS, seed=0).items()}
+    c_np, f = coords.cpu().numpy(), feats.cpu()
+    t0 = time.perf_counter()
+    scene = O.OracleScene(c_np)
+    out = O.unet_forward(scene, f, params, CHANNELS)
+    out.backward(torch.ones_like(out))
+    dt = time.perf_counter() - t0
+    return dict(value=scene.n(0) / dt, unit="active-voxels/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 full step (rulebooks+fwd+bwd) of the {scene.n(0)}-voxel cfg-2 scene, torch-CPU fp32 "
+                       f"oracle port of the SparseConvNet CPU algorithm, {dt:.2f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--target", type=int, default=TARGET)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import sparse_rcnn_amd  # noqa: F401
+    from sparse_rcnn_amd import profiling
+    from sparse_rcnn_amd.dp import FlatParams, broadcast_params
+    from sparse_rcnn_amd.synthetic import make_batch
+    from sparse_rcnn_amd.unet import Backbone
+
+    # one balanced scene per rank (cfg 2: seed 1; cfg 4 style: seeds 10+rank)
+    seed = 1 if world == 1 else 10 + rank
+    coords, feats, size, bs, _ = make_batch(1, GRID, args.target, dup=1.15, seed=seed)
+    coords_d, feats_d = coords.to(dev), feats.to(dev)
+
+    torch.manual_seed(0)
+    model = Backbone(7, CHANNELS).to(dev)
+    flat = FlatParams(model)
+    broadcast_params(flat)
+    gen = torch.Generator(device="cpu").manual_seed(100 + rank)
+    gy = None
+    n_active = 0
+
+    def step():
+        nonlocal gy, n_active
+        flat.zero_grad()
+        fin = feats_d.detach().requires_grad_()
+        out = model(coords_d, fin, size, 1)
+        if gy is None or gy.shape != out.features.shape:
+            gy = torch.randn(out.features.shape, generator=gen).to(dev)          # upstream grad dY ~ N(0,1)
+            n_active = out.features.shape[0]
+        out.features.backward(gy)
+        flat.all_reduce_mean()
+        flat.sgd_step(1e-6)
+
+    for _ in range(args.warmup):
+        step()
+    timer = profiling.KernelTimer()
+    profiling.TIMER = timer
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    profiling.TIMER = None
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    vox = torch.tensor([float(n_active)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(vox, op=dist.ReduceOp.SUM)
+    dt, total_vox = tmax.item(), vox.item()
+
+    if rank == 0:
+        ks = timer.summary()
+        dom = max(ks, key=lambda k: ks[k]["ms"])
+        d = ks[dom]
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        out = {
+            "metric": "active-voxels/sec fwd+bwd, ScanNet U-Net backbone",
+            "value": total_vox * args.steps / dt,
+            "unit": "active-voxels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: one synthetic ScanNet-shaped scene per GPU, "
+                                   f"{n_active} active voxels (grid {GRID[0]}x{GRID[1]}x{GRID[2]}, 1.15 points/voxel), "
+                                   "U-Net 32-64-128-256, 2 pre-act residual blocks/level, 2^3/2 conv+deconv, "
+                                   "step = rulebooks + fwd + bwd (+ grad all-reduce + SGD)",
+                       "parallelism": f"dp{world} (1 scene/GPU, flat-bucket all-reduce)"},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                         "launches_per_step": d["launches"] / args.steps,
+                         "avg_launch_us": d["ms"] * 1e3 / d["launches"],
+                         "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9},
+            "kernels": {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
+                            "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else None}
+                        for k, v in ks.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(coords, feats)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -10,6 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
+from . import profiling
 from .metadata import Metadata, Rules
 
 
@@ -29,20 +30,35 @@ def _new(shape, like, dtype=torch.float32):
 # raw kernels (no autograd)
 # ------------------------------------------------------------------------------------------------------
 
-def gemm_table(X, table, n_off, n_out, W, bias, cout, flags=0, residual=None, relu_mask=None):
+def _conv_bytes(n_in, cin, n_out, cout, n_off, n_rules):
+    """Compulsory HBM bytes of one conv-type launch: X once, Y once, W, int32 rule pairs."""
+    return 4.0 * (n_in * cin + n_out * cout + n_off * cin * cout) + 8.0 * n_rules
+
+
+def gemm_table(X, table, n_off, n_out, W, bias, cout, flags=0, residual=None, relu_mask=None, n_rules=None):
+    """n_rules: number of (in,out) rules the table holds -- only used for the algorithmic-FLOP accounting."""
     lib = L.lib()
     cin = X.shape[1]
     Y = _new((n_out, cout), X)
-    L.check(lib.scn_gemm_table(L.ptr(X), X.shape[0], cin, L.ptr(table), n_off, n_out, L.ptr(W), L.ptr(bias),
-                               L.ptr(residual), L.ptr(relu_mask), L.ptr(Y), cout, flags, L.stream()))
+    P = n_out if n_rules is None else n_rules
+
+    def run():
+        L.check(lib.scn_gemm_table(L.ptr(X), X.shape[0], cin, L.ptr(table), n_off, n_out, L.ptr(W), L.ptr(bias),
+                                   L.ptr(residual), L.ptr(relu_mask), L.ptr(Y), cout, flags, L.stream()))
+    profiling.timed("k_gemm_table", 2.0 * P * cin * cout, _conv_bytes(X.shape[0], cin, n_out, cout, n_off, P), run)
     return Y
 
 
 def gemm_rules(X, in_rows, out_rows, prefix_host, n_off, n_out, W, bias, cout, flags=0, relu_mask=None):
     lib = L.lib()
     Y = _new((n_out, cout), X)
-    L.check(lib.scn_gemm_rules(L.ptr(X), X.shape[1], L.ptr(in_rows), L.ptr(out_rows), prefix_host, n_off, L.ptr(W),
-                               L.ptr(bias), L.ptr(relu_mask), L.ptr(Y), cout, flags, L.stream()))
+    cin = X.shape[1]
+    P = int(prefix_host[n_off] - prefix_host[0])
+
+    def run():
+        L.check(lib.scn_gemm_rules(L.ptr(X), cin, L.ptr(in_rows), L.ptr(out_rows), prefix_host, n_off, L.ptr(W),
+                                   L.ptr(bias), L.ptr(relu_mask), L.ptr(Y), cout, flags, L.stream()))
+    profiling.timed("k_gemm_rules", 2.0 * P * cin * cout, _conv_bytes(X.shape[0], cin, n_out, cout, n_off, P), run)
     return Y
 
 
@@ -54,8 +70,13 @@ def wgrad_rules(X, dY, in_rows, out_rows, prefix_host, n_off, flags=0):
         raise L.ScnError("scn_wgrad_scratch_bytes: bad arguments")
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=X.device)
     dW = _new((n_off, cin, cout), X)
-    L.check(lib.scn_wgrad_rules(L.ptr(X), cin, L.ptr(dY), cout, L.ptr(in_rows), L.ptr(out_rows), prefix_host, n_off,
-                                L.ptr(dW), L.ptr(scratch), flags, L.stream()))
+    P = int(prefix_host[n_off] - prefix_host[0])
+
+    def run():
+        L.check(lib.scn_wgrad_rules(L.ptr(X), cin, L.ptr(dY), cout, L.ptr(in_rows), L.ptr(out_rows), prefix_host,
+                                    n_off, L.ptr(dW), L.ptr(scratch), flags, L.stream()))
+    profiling.timed("k_wgrad_rules", 2.0 * P * cin * cout,
+                    4.0 * (X.shape[0] * cin + dY.shape[0] * cout + n_off * cin * cout) + 8.0 * P, run)
     return dW
 
 
@@ -85,7 +106,8 @@ class SubmanifoldConvolutionFunction(torch.autograd.Function):
         n_off = k ** 3
         cout = W.shape[-1]
         b = _f32(bias) if bias is not None else None
-        Y = gemm_table(X, rb.table, n_off, rb.n, W, b, cout, L.F_RELU_IN if relu_in else 0)
+        Y = gemm_table(X, rb.table, n_off, rb.n, W, b, cout, L.F_RELU_IN if relu_in else 0,
+                       n_rules=rb.rules.total if rb.rules is not None else rb.n)
         ctx.save_for_backward(X, W)
         ctx.rb, ctx.has_bias, ctx.relu_in = rb, bias is not None, relu_in
         return Y
@@ -101,7 +123,8 @@ class SubmanifoldConvolutionFunction(torch.autograd.Function):
         dX = dW = db = None
         if ctx.needs_input_grad[0]:
             dX = gemm_table(dY, rb.table, n_off, rb.n, W, None, cin, L.F_W_TRANSPOSED | L.F_OFF_REVERSE,
-                            relu_mask=X if ctx.relu_in else None)
+                            relu_mask=X if ctx.relu_in else None,
+                            n_rules=rb.rules.total if rb.rules is not None else rb.n)
         if ctx.needs_input_grad[1]:
             if rb.k == 1:
                 dW = wgrad_rules(X, dY, None, None, _identity_prefix(rb.n), 1, fl)
@@ -123,7 +146,8 @@ class ConvolutionFunction(torch.autograd.Function):
         X, W = _f32(features), _f32(weight)
         rb = metadata.strided_rulebook(in_size)
         b = _f32(bias) if bias is not None else None
-        Y = gemm_table(X, rb.child, 8, rb.n_coarse, W, b, W.shape[-1], L.F_RELU_IN if relu_in else 0)
+        Y = gemm_table(X, rb.child, 8, rb.n_coarse, W, b, W.shape[-1], L.F_RELU_IN if relu_in else 0,
+                       n_rules=rb.n_fine)
         ctx.save_for_backward(X, W)
         ctx.rb, ctx.has_bias, ctx.relu_in = rb, bias is not None, relu_in
         return Y
@@ -174,7 +198,7 @@ class DeconvolutionFunction(torch.autograd.Function):
         dX = dW = db = None
         if ctx.needs_input_grad[0]:      # dX[c] = sum_o dY[child[o][c]] . W[o]^T
             dX = gemm_table(dY, rb.child, 8, rb.n_coarse, W, None, X.shape[1], L.F_W_TRANSPOSED,
-                            relu_mask=X if ctx.relu_in else None)
+                            relu_mask=X if ctx.relu_in else None, n_rules=rb.n_fine)
         if ctx.needs_input_grad[1]:
             dW = wgrad_rules(X, dY, r.out_rows, r.in_rows, r.prefix_host, 8, fl).view_as(W)
         if ctx.has_bias and ctx.needs_input_grad[2]:

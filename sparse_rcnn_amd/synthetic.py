@@ -10,13 +10,16 @@ import numpy as np
 import torch
 
 
-def _surface_voxels(rng, grid, n_cuboids=20, n_planes=3):
+def _surface_voxels(rng, grid, n_cuboids=20, n_planes=3, scale=0.9):
+    """Room shell + furniture shells + tilted planes, 1 voxel thick with +-1 jitter.  `scale` = room extent as a
+    fraction of the grid (the room sits in the grid centre), chosen by the caller so that the raw surface has about
+    the target number of voxels -- surfaces stay dense (ScanNet-like ~9-10 rules per voxel), not thinned noise."""
     gx, gy, gz = grid
     pts = []
-    # room box: floor + 4 walls, inset from the grid border
-    x0, x1 = int(gx * 0.06), int(gx * 0.94)
-    y0, y1 = int(gy * 0.06), int(gy * 0.94)
-    z0, z1 = int(gz * 0.08), int(gz * 0.9)
+    x0, x1 = int(gx * (0.5 - scale / 2)), int(gx * (0.5 + scale / 2))
+    y0, y1 = int(gy * (0.5 - scale / 2)), int(gy * (0.5 + scale / 2))
+    z0, z1 = int(gz * (0.5 - scale / 2)), int(gz * (0.5 + scale / 2))
+    gx, gy, gz = max(x1 - x0, 8), max(y1 - y0, 8), max(z1 - z0, 8)        # furniture sizes relative to the room
     xs, ys = np.meshgrid(np.arange(x0, x1), np.arange(y0, y1), indexing="ij")
     pts.append(np.stack([xs.ravel(), ys.ravel(), np.full(xs.size, z0)], 1))
     xs, zs = np.meshgrid(np.arange(x0, x1), np.arange(z0, z1), indexing="ij")
@@ -51,7 +54,8 @@ def _surface_voxels(rng, grid, n_cuboids=20, n_planes=3):
     p = np.concatenate(pts).astype(np.int64)
     p += rng.integers(-1, 2, size=p.shape) * (rng.random(p.shape) < 0.15)                    # +-1 voxel jitter
     p = np.clip(p, 0, np.array(grid) - 1)
-    return np.unique(p, axis=0)
+    p = np.unique(p, axis=0)
+    return p[(p[:, 0] >= x0) & (p[:, 0] < x1) & (p[:, 1] >= y0) & (p[:, 1] < y1)]
 
 
 def make_scene(grid=(512, 512, 256), target_active=150_000, dup=1.15, seed=1, uniform=False):
@@ -62,10 +66,21 @@ def make_scene(grid=(512, 512, 256), target_active=150_000, dup=1.15, seed=1, un
         lin = rng.choice(grid[0] * grid[1] * grid[2], size=target_active, replace=False)
         vox = np.stack(np.unravel_index(lin, grid), 1).astype(np.int64)
     else:
-        vox = _surface_voxels(rng, grid)
+        lo, hi = 0.05, 0.98                                          # bisect the room scale for ~1.04 x target voxels
+        state = rng.bit_generator.state
+        for _ in range(14):
+            mid = 0.5 * (lo + hi)
+            rng.bit_generator.state = state
+            vox = _surface_voxels(rng, grid, scale=mid)
+            if len(vox) < 1.04 * target_active:
+                lo = mid
+            else:
+                hi = mid
+        rng.bit_generator.state = state
+        vox = _surface_voxels(rng, grid, scale=hi)
         tries = 0
-        while len(vox) < target_active and tries < 8:                                       # densify if short
-            extra = _surface_voxels(rng, grid, n_cuboids=40, n_planes=6)
+        while len(vox) < target_active and tries < 8:                                       # grid too small: densify
+            extra = _surface_voxels(rng, grid, n_cuboids=40, n_planes=6, scale=0.98)
             vox = np.unique(np.concatenate([vox, extra]), axis=0)
             tries += 1
         if len(vox) > target_active:

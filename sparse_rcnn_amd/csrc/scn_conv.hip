@@ -389,12 +389,18 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
     }
 }
 
-__global__ void k_colsum_final(const float* __restrict__ partial, int nblk, int c, float* __restrict__ db) {
-    int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= c) return;
+// one block per column: 256 threads sum the partial rows (fixed order), wave shuffle + LDS tree
+__global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ partial, int nblk, int c,
+                                                      float* __restrict__ db) {
+    const int col = blockIdx.x;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(long long)b * c + col];
-    db[col] = s;
+    for (int b = threadIdx.x; b < nblk; b += 256) s += partial[(long long)b * c + col];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d);
+    __shared__ float w[4];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) db[col] = (w[0] + w[1]) + (w[2] + w[3]);
 }
 
 extern "C" int scn_colsum(const float* dY, int64_t n, int c, float* db, void* scratch, scn_stream_t stream) {
@@ -404,8 +410,7 @@ extern "C" int scn_colsum(const float* dY, int64_t n, int c, float* db, void* sc
     if (n > 0) SCN_REQUIRE(dY);
     hipLaunchKernelGGL(k_colsum_partial, dim3(nblk), dim3(256), 0, S(stream), dY, (long long)n, c, (float*)scratch);
     SCN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_colsum_final, dim3((c + 255) / 256), dim3(256), 0, S(stream), (const float*)scratch, nblk, c,
-                       db);
+    hipLaunchKernelGGL(k_colsum_final, dim3(c), dim3(256), 0, S(stream), (const float*)scratch, nblk, c, db);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }

@@ -49,6 +49,24 @@ def gemm_table(X, table, n_off, n_out, W, bias, cout, flags=0, residual=None, re
     return Y
 
 
+def conv_rules(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu_mask=None, n_rules=0):
+    """The hot kernel: output-stationary convolution over mask-sorted tiles (scn_conv_tiles)."""
+    lib = L.lib()
+    cin = X.shape[1]
+    Y = _new((n_out, cout), X)
+    P = n_rules
+
+    def run():
+        L.check(lib.scn_conv_tiles(L.ptr(X), cin, L.ptr(tiles.tstab), L.ptr(tiles.tile_mask), L.ptr(tiles.perm),
+                                   tiles.n_off, n_out, L.ptr(W), L.ptr(bias), L.ptr(residual), L.ptr(relu_mask),
+                                   L.ptr(Y), cout, flags, L.stream()))
+    profiling.timed("k_conv_ts", 2.0 * P * cin * cout, _conv_bytes(X.shape[0], cin, n_out, cout, tiles.n_off, P), run)
+    return Y
+
+
+USE_CONV_OS = True
+
+
 def gemm_rules(X, in_rows, out_rows, prefix_host, n_off, n_out, W, bias, cout, flags=0, relu_mask=None):
     lib = L.lib()
     Y = _new((n_out, cout), X)
@@ -106,8 +124,11 @@ class SubmanifoldConvolutionFunction(torch.autograd.Function):
         n_off = k ** 3
         cout = W.shape[-1]
         b = _f32(bias) if bias is not None else None
-        Y = gemm_table(X, rb.table, n_off, rb.n, W, b, cout, L.F_RELU_IN if relu_in else 0,
-                       n_rules=rb.rules.total if rb.rules is not None else rb.n)
+        if USE_CONV_OS and rb.rules is not None:
+            Y = conv_rules(X, rb.tiles, rb.n, W, b, cout, L.F_RELU_IN if relu_in else 0, n_rules=rb.rules.total)
+        else:
+            Y = gemm_table(X, rb.table, n_off, rb.n, W, b, cout, L.F_RELU_IN if relu_in else 0,
+                           n_rules=rb.rules.total if rb.rules is not None else rb.n)
         ctx.save_for_backward(X, W)
         ctx.rb, ctx.has_bias, ctx.relu_in = rb, bias is not None, relu_in
         return Y
@@ -122,9 +143,13 @@ class SubmanifoldConvolutionFunction(torch.autograd.Function):
         fl = L.F_RELU_IN if ctx.relu_in else 0
         dX = dW = db = None
         if ctx.needs_input_grad[0]:
-            dX = gemm_table(dY, rb.table, n_off, rb.n, W, None, cin, L.F_W_TRANSPOSED | L.F_OFF_REVERSE,
-                            relu_mask=X if ctx.relu_in else None,
-                            n_rules=rb.rules.total if rb.rules is not None else rb.n)
+            if USE_CONV_OS and rb.rules is not None:
+                dX = conv_rules(dY, rb.tiles, rb.n, W, None, cin, L.F_W_TRANSPOSED | L.F_OFF_REVERSE,
+                                relu_mask=X if ctx.relu_in else None, n_rules=rb.rules.total)
+            else:
+                dX = gemm_table(dY, rb.table, n_off, rb.n, W, None, cin, L.F_W_TRANSPOSED | L.F_OFF_REVERSE,
+                                relu_mask=X if ctx.relu_in else None,
+                                n_rules=rb.rules.total if rb.rules is not None else rb.n)
         if ctx.needs_input_grad[1]:
             if rb.k == 1:
                 dW = wgrad_rules(X, dY, None, None, _identity_prefix(rb.n), 1, fl)
@@ -146,8 +171,12 @@ class ConvolutionFunction(torch.autograd.Function):
         X, W = _f32(features), _f32(weight)
         rb = metadata.strided_rulebook(in_size)
         b = _f32(bias) if bias is not None else None
-        Y = gemm_table(X, rb.child, 8, rb.n_coarse, W, b, W.shape[-1], L.F_RELU_IN if relu_in else 0,
-                       n_rules=rb.n_fine)
+        if USE_CONV_OS:
+            Y = conv_rules(X, rb.tiles, rb.n_coarse, W, b, W.shape[-1], L.F_RELU_IN if relu_in else 0,
+                           n_rules=rb.n_fine)
+        else:
+            Y = gemm_table(X, rb.child, 8, rb.n_coarse, W, b, W.shape[-1], L.F_RELU_IN if relu_in else 0,
+                           n_rules=rb.n_fine)
         ctx.save_for_backward(X, W)
         ctx.rb, ctx.has_bias, ctx.relu_in = rb, bias is not None, relu_in
         return Y
@@ -197,8 +226,12 @@ class DeconvolutionFunction(torch.autograd.Function):
         fl = L.F_RELU_IN if ctx.relu_in else 0
         dX = dW = db = None
         if ctx.needs_input_grad[0]:      # dX[c] = sum_o dY[child[o][c]] . W[o]^T
-            dX = gemm_table(dY, rb.child, 8, rb.n_coarse, W, None, X.shape[1], L.F_W_TRANSPOSED,
-                            relu_mask=X if ctx.relu_in else None, n_rules=rb.n_fine)
+            if USE_CONV_OS:
+                dX = conv_rules(dY, rb.tiles, rb.n_coarse, W, None, X.shape[1], L.F_W_TRANSPOSED,
+                                relu_mask=X if ctx.relu_in else None, n_rules=rb.n_fine)
+            else:
+                dX = gemm_table(dY, rb.child, 8, rb.n_coarse, W, None, X.shape[1], L.F_W_TRANSPOSED,
+                                relu_mask=X if ctx.relu_in else None, n_rules=rb.n_fine)
         if ctx.needs_input_grad[1]:
             dW = wgrad_rules(X, dY, r.out_rows, r.in_rows, r.prefix_host, 8, fl).view_as(W)
         if ctx.has_bias and ctx.needs_input_grad[2]:

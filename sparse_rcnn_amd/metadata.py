@@ -42,6 +42,9 @@ class Rules:
     out_rows: torch.Tensor          # int32 [P]
     prefix_host: "C.Array"          # int64[n_off+1] on the host
     n_off: int
+    prefix_dev: Optional[torch.Tensor] = None    # int64 [n_off+1] device
+    block_rows: int = 0             # output rows per conv_os workgroup
+    bstart: Optional[torch.Tensor] = None        # int32 [n_off, nb+1]
 
     @property
     def total(self):
@@ -52,11 +55,35 @@ class Rules:
 
 
 @dataclass
+class Tiles:
+    """Mask-sorted row tiles of a rule table (scn_tiles_build): what the hot kernel scn_conv_tiles walks."""
+    perm: torch.Tensor              # int32 [nt*16]
+    tstab: torch.Tensor             # int32 [nt, n_off, 16]
+    tile_mask: torch.Tensor         # int32 view of uint32 [nt]
+    n_off: int
+    n: int
+
+
+def build_tiles(table: torch.Tensor, n_off: int, n: int) -> Tiles:
+    lib = L.lib()
+    dev = table.device
+    nt = (n + 15) // 16
+    perm = _empty(nt * 16, torch.int32, dev)
+    tstab = torch.empty((nt, n_off, 16), dtype=torch.int32, device=dev)
+    tile_mask = _empty(nt, torch.int32, dev)
+    scratch = _empty(lib.scn_tiles_scratch_bytes(n_off, n), torch.uint8, dev)
+    L.check(lib.scn_tiles_build(L.ptr(table), n_off, n, L.ptr(perm), L.ptr(tstab), L.ptr(tile_mask), L.ptr(scratch),
+                                L.stream()))
+    return Tiles(perm, tstab, tile_mask, n_off, n)
+
+
+@dataclass
 class SubmRulebook:
     table: Optional[torch.Tensor]   # int32 [k^3, N]; None for k == 1 (identity)
     rules: Optional[Rules]
     k: int
     n: int
+    tiles: Optional[Tiles] = None
 
 
 @dataclass
@@ -68,6 +95,7 @@ class StridedRulebook:
     n_fine: int
     n_coarse: int
     coarse_size: Tuple[int, ...]
+    tiles: Optional[Tiles] = None
 
 
 def compact_rules(table: torch.Tensor, n_off: int, n_out: int, want_seg=False):
@@ -85,8 +113,31 @@ def compact_rules(table: torch.Tensor, n_off: int, n_out: int, want_seg=False):
     seg = _empty(total, torch.int32, dev) if want_seg else None
     L.check(lib.scn_rules_fill(L.ptr(table), n_off, n_out, L.ptr(block_sums), L.ptr(in_rows), L.ptr(out_rows),
                                L.ptr(seg), L.stream()))
-    rules = Rules(in_rows, out_rows, prefix_host, n_off)
+    rules = Rules(in_rows, out_rows, prefix_host, n_off, prefix)
     return (rules, seg) if want_seg else rules
+
+
+def pick_block_rows(n_out: int) -> int:
+    """Rows per conv_os workgroup: large blocks amortise the weight staging and tile quantisation, small ones keep
+    >= ~2 workgroups per CU on the coarse levels (conv_os)."""
+    if n_out >= 64 * 1024:
+        return 512
+    if n_out >= 32 * 1024:
+        return 256
+    if n_out >= 8 * 1024:
+        return 128
+    return 64
+
+
+def add_block_starts(rules: Rules, n_out: int, block_rows: int = 0):
+    lib = L.lib()
+    R = block_rows or pick_block_rows(n_out)
+    nb = (n_out + R - 1) // R
+    bstart = torch.empty((rules.n_off, nb + 1), dtype=torch.int32, device=rules.in_rows.device)
+    L.check(lib.scn_rules_block_starts(L.ptr(rules.out_rows), L.ptr(rules.prefix_dev), rules.n_off, n_out, R,
+                                       L.ptr(bstart), L.stream()))
+    rules.block_rows, rules.bstart = R, bstart
+    return rules
 
 
 def dedup(coords_i32: torch.Tensor, shift: int, want_counts: bool, want_first: bool):
@@ -181,7 +232,7 @@ class Metadata:
                 table = torch.empty((k ** 3, g.n), dtype=torch.int32, device=g.coords.device)
                 L.check(lib.scn_subm_table(L.ptr(g.coords), g.n, L.ptr(g.table_keys), L.ptr(g.table_rows), g.cap, k,
                                            L.ptr(table), L.stream()))
-                rb = SubmRulebook(table, compact_rules(table, k ** 3, g.n), k, g.n)
+                rb = SubmRulebook(table, compact_rules(table, k ** 3, g.n), k, g.n, build_tiles(table, k ** 3, g.n))
             self.subm[key] = rb
         return rb
 
@@ -206,7 +257,7 @@ class Metadata:
             L.check(lib.scn_child_table(L.ptr(g.coords), L.ptr(parent), g.n, cg.n, L.ptr(child), L.ptr(fine_off),
                                         L.stream()))
             rules = compact_rules(child, 8, cg.n)
-            rb = StridedRulebook(parent, fine_off, child, rules, g.n, cg.n, coarse_size)
+            rb = StridedRulebook(parent, fine_off, child, rules, g.n, cg.n, coarse_size, build_tiles(child, 8, cg.n))
             self.strided[size] = rb
         return rb
 

@@ -259,7 +259,7 @@ static int make_seg_chunks(int cin, int cout, const int64_t* prefix_host, int n_
     return SCN_OK;
 }
 
-extern "C" int64_t scn_wgrad_scratch_bytes(int cin, int cout, const int64_t* prefix_host, int n_off) {
+int64_t scn::wgrad_simple_scratch_bytes(int cin, int cout, const int64_t* prefix_host, int n_off) {
     if (!prefix_host || n_off < 1 || n_off > 32 || cin < 1 || cout < 1) return -1;
     SegChunks sc;
     if (make_seg_chunks(cin, cout, prefix_host, n_off, sc) != SCN_OK) return -1;
@@ -335,9 +335,10 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     }
 }
 
-extern "C" int scn_wgrad_rules(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
-                               const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, void* scratch,
-                               int flags, scn_stream_t stream) {
+// Generic (any channel count, scalar gathers) weight gradient; scn_wgrad.hip holds the fast path.
+int scn::wgrad_simple(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
+                      const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, void* scratch,
+                      int flags, scn_stream_t stream) {
     SCN_REQUIRE(prefix_host && n_off >= 1 && n_off <= 32 && cin >= 1 && cout >= 1 && dW);
     SCN_REQUIRE((in_rows == nullptr) == (out_rows == nullptr));
     SCN_REQUIRE(in_rows || n_off == 1);

@@ -55,11 +55,13 @@ def conv_rules(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu_mask
     cin = X.shape[1]
     Y = _new((n_out, cout), X)
     P = n_rules
+    nbytes = lib.scn_conv_tiles_scratch_bytes(cin, n_out, cout)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=X.device) if nbytes else None
 
     def run():
         L.check(lib.scn_conv_tiles(L.ptr(X), cin, L.ptr(tiles.tstab), L.ptr(tiles.tile_mask), L.ptr(tiles.perm),
                                    tiles.n_off, n_out, L.ptr(W), L.ptr(bias), L.ptr(residual), L.ptr(relu_mask),
-                                   L.ptr(Y), cout, flags, L.stream()))
+                                   L.ptr(Y), cout, flags, L.ptr(scratch), L.stream()))
     profiling.timed("k_conv_ts", 2.0 * P * cin * cout, _conv_bytes(X.shape[0], cin, n_out, cout, tiles.n_off, P), run)
     return Y
 

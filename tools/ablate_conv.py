@@ -20,22 +20,17 @@ n, P, t = rb.n, rb.rules.total, rb.tiles
 X = torch.randn(n, C, device="cuda"); W = torch.randn(27, C, C, device="cuda") * 0.05
 Y = torch.empty(n, C, device="cuda"); Y2 = torch.empty(n, C, device="cuda")
 lib = L.lib()
+SCR = torch.empty(max(1, lib.scn_conv_tiles_scratch_bytes(C, n, C)), dtype=torch.uint8, device='cuda')
 tm = t.tile_mask.cpu().numpy().view("uint32")
 import numpy as np
 execd = sum(bin(int(v)).count("1") for v in tm) * 16
 print(f"level {level} N={n} P={P} C={C} tiles={len(tm)} executed/useful={execd / P:.3f}")
 def run_ts(fl=0):
     L.check(lib.scn_conv_tiles(L.ptr(X), C, L.ptr(t.tstab), L.ptr(t.tile_mask), L.ptr(t.perm), 27, n, L.ptr(W), 0, 0, 0,
-                               L.ptr(Y), C, fl, L.stream()))
+                               L.ptr(Y), C, fl, L.ptr(SCR), L.stream()))
 def run_tab(fl=0):
     L.check(lib.scn_gemm_table(L.ptr(X), n, C, L.ptr(rb.table), 27, n, L.ptr(W), 0, 0, 0, L.ptr(Y2), C, fl, L.stream()))
-for name, fn in (("conv_tiles", run_ts), ("conv_tiles W^T", lambda: run_ts(6)), ("gemm_table (v1)", run_tab),
-                 ("ts no_gather", lambda: run_ts(256)), ("ts no_mfma", lambda: run_ts(512)),
-                 ("ts no_gather+no_mfma", lambda: run_ts(256 + 512)),
-                 ("ts no_gather+mfma+stage", lambda: run_ts(256 + 512 + 1024)),
-                 ("ts no_gather+mfma+stage+store", lambda: run_ts(256 + 512 + 1024 + 2048)),
-                 ("ts stage only (no tiles)", lambda: run_ts(4096)),
-                 ("ts empty (no stage, no tiles)", lambda: run_ts(4096 + 1024))):
+for name, fn in (("conv_tiles", run_ts), ("conv_tiles W^T", lambda: run_ts(6)), ("gemm_table (v1)", run_tab)):
     for _ in range(3): fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

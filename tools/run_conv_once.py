@@ -15,6 +15,7 @@ for l in range(level):
 rb = md.subm_rulebook(sz, 3); n, t = rb.n, rb.tiles
 X = torch.randn(n, C, device="cuda"); W = torch.randn(27, C, C, device="cuda") * 0.05; Y = torch.empty(n, C, device="cuda")
 lib = L.lib()
+SCR = torch.empty(max(1, lib.scn_conv_tiles_scratch_bytes(C, n, C)), dtype=torch.uint8, device='cuda')
 for _ in range(5):
-    L.check(lib.scn_conv_tiles(L.ptr(X), C, L.ptr(t.tstab), L.ptr(t.tile_mask), L.ptr(t.perm), 27, n, L.ptr(W), 0, 0, 0, L.ptr(Y), C, 0, L.stream()))
+    L.check(lib.scn_conv_tiles(L.ptr(X), C, L.ptr(t.tstab), L.ptr(t.tile_mask), L.ptr(t.perm), 27, n, L.ptr(W), 0, 0, 0, L.ptr(Y), C, 0, L.ptr(SCR), L.stream()))
 torch.cuda.synchronize()

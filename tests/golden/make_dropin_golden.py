@@ -1,0 +1,48 @@
+"""Drop-in boundary fixture (SURVEY.md §8c iii): in the build container only, register this package as
+``sparseconvnet``, import the REFERENCE's ndsis.modules.model and build its FeatureExtractor (sparse + U-Net) with the
+parameter dict restated from scannet_config/run.py:581-627.  Stores the state_dict key list + shapes and the scn layer
+census; tests/test_dropin_cpu.py checks this package's own graph builder against it without the reference present.
+
+    python tests/golden/make_dropin_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+import sparse_rcnn_amd                                     # noqa: E402
+sys.modules["sparseconvnet"] = sparse_rcnn_amd
+from ndsis.modules.model import FeatureExtractor, FeatureLevelDescriptor as FLD   # noqa: E402
+
+
+def build(channels, cin=7):
+    layer_descriptions = [FLD('B', channels[0], dict(stride=1, drop_input_relu=True)),
+                          *[FLD('B', c) for c in channels[1:]]]
+    unet_params = dict(use_residuals=True, num_units=2, bottleneck_divisor=0, groups=1, main_path_relu=False,
+                       relu_first=True, batchnorm=False, concat=True, min_channels=16)
+    params = dict(num_dims=3, sparse=True, input_channels=cin, network_description=layer_descriptions,
+                  class_output_anchor=False, class_output_upsampled=False, class_output_index=-1, num_dilations=5,
+                  num_units=2, bottleneck_divisor=0, stride=2, maxpool=False, relu_first=True, main_path_relu=False,
+                  bottleneck_groups=1, batchnorm=False, use_residuals=True, drop_input_relu=True, include_unet=True,
+                  unet_params=unet_params)
+    return FeatureExtractor(**params)
+
+
+if __name__ == "__main__":
+    out = {}
+    for name, ch in (("cfg2_32_256", [32, 64, 128, 256]), ("ref_32_112", [32, 48, 64, 80, 96, 112])):
+        fe = build(ch)
+        sd = fe.state_dict()
+        census = {}
+        for m in fe.modules():
+            if type(m).__module__.startswith("sparse_rcnn_amd"):
+                census[type(m).__name__] = census.get(type(m).__name__, 0) + 1
+        out[name] = dict(channels=ch, n_params=int(sum(v.numel() for v in sd.values())),
+                         keys={k: list(v.shape) for k, v in sd.items()}, census=census)
+        print(name, out[name]["n_params"], census)
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "dropin_feature_extractor.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)

@@ -1,0 +1,90 @@
+"""CPU: the scn operator surface the reference calls and the drop-in fixture (§8c iii)."""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import sparse_rcnn_amd as scn
+from sparse_rcnn_amd.unet import SparseUNet
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIX = json.load(open(os.path.join(HERE, "golden", "dropin_feature_extractor.json")))
+
+
+def test_surface_matches_the_reference_call_sites():
+    # every scn.* name at the 36 call-site lines
+    for name in ("Metadata", "SparseConvNetTensor", "ioLayers", "Sequential", "ConcatTable", "AddTable", "JoinTable",
+                 "Identity", "ReLU", "BatchNormReLU", "BatchNormLeakyReLU", "Convolution", "Deconvolution",
+                 "SubmanifoldConvolution", "NetworkInNetwork", "MaxPooling", "AveragePooling", "SparseToDense",
+                 "OutputLayer", "InputLayer"):
+        assert hasattr(scn, name), name
+    assert hasattr(scn.ioLayers, "InputLayerFunction") and hasattr(scn.ioLayers, "OutputLayerFunction")
+    # constructor call shapes used by module_factory.py (numpy-int tuples for size/stride: :225-234)
+    st = tuple(np.full(3, 2))
+    c = scn.Convolution(3, 32, 64, filter_size=st, filter_stride=st, bias=True)
+    d = scn.Deconvolution(3, 64, 32, filter_size=st, filter_stride=st, bias=True)
+    s = scn.SubmanifoldConvolution(3, 32, 32, filter_size=3, bias=True, groups=1)
+    s1 = scn.SubmanifoldConvolution(3, 7, 32, filter_size=1, bias=True)
+    n = scn.NetworkInNetwork(64, 32, True)
+    assert c.weight.shape == (8, 32, 64) and d.weight.shape == (8, 64, 32)
+    assert s.weight.shape == (27, 32, 32) and s1.weight.shape == (1, 7, 32) and n.weight.shape == (64, 32)
+    bn = scn.BatchNormLeakyReLU(16, 1e-4, 0.9, 0.2)
+    assert sorted(bn.state_dict()) == ["bias", "running_mean", "running_var", "weight"]
+    seq = scn.Sequential(scn.ConcatTable(scn.Identity(), s), scn.AddTable())
+    seq.append(scn.ReLU())
+    assert len(seq) == 3
+    with pytest.raises(NotImplementedError):
+        scn.Convolution(3, 4, 4, (3, 3, 3), (2, 2, 2), True)
+    with pytest.raises(NotImplementedError):
+        scn.MaxPooling(3, 2, 2)                       # next tier, says so loudly
+    with pytest.raises(NotImplementedError):
+        scn.SubmanifoldConvolution(3, 4, 4, 3, True, groups=2)
+
+
+def test_grouped_checkpoint_layout_loads():
+    s = scn.SubmanifoldConvolution(3, 4, 6, 3, True)
+    sd = {"weight": torch.randn(27, 1, 4, 6), "bias": torch.zeros(6)}      # SparseConvNet's [fv, groups, nIn, nOut]
+    s.load_state_dict(sd)
+    assert torch.equal(s.weight.data, sd["weight"].squeeze(1))
+
+
+@pytest.mark.parametrize("name", sorted(FIX))
+def test_own_graph_builder_reproduces_the_reference_feature_extractor(name):
+    """The fixture was produced by building the REFERENCE's FeatureExtractor on top of this package
+    (tests/golden/make_dropin_golden.py).  This package's own builder must hold the same parameters."""
+    fx = FIX[name]
+    net = SparseUNet(7, fx["channels"])
+    own = sorted(tuple(v.shape) for v in net.state_dict().values())
+    ref = sorted(tuple(v) for v in fx["keys"].values())
+    assert own == ref
+    assert sum(v.numel() for v in net.state_dict().values()) == fx["n_params"]
+    census = {}
+    for m in net.modules():
+        if type(m).__module__.startswith("sparse_rcnn_amd") and type(m).__name__ != "SparseUNet":
+            census[type(m).__name__] = census.get(type(m).__name__, 0) + 1
+    for k in ("SubmanifoldConvolution", "Convolution", "Deconvolution", "NetworkInNetwork", "ReLU", "AddTable",
+              "JoinTable", "ConcatTable"):
+        assert census[k] == fx["census"][k], (k, census[k], fx["census"][k])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/ndsis"), reason="reference checkout only exists in the build container")
+def test_reference_feature_extractor_constructs_on_this_package():
+    saved = sys.modules.get("sparseconvnet")
+    sys.modules["sparseconvnet"] = scn
+    sys.path.insert(0, "/root/reference")
+    try:
+        sys.path.insert(0, os.path.join(HERE, "golden"))
+        import make_dropin_golden as g
+        fe = g.build([32, 64, 128, 256])
+        assert sum(p.numel() for p in fe.parameters()) == 12_457_856
+        assert fe.calc_unet and list(fe.unet_channels) == [128, 64, 32]
+    finally:
+        sys.path.remove("/root/reference")
+        if saved is None:
+            sys.modules.pop("sparseconvnet", None)
+        else:
+            sys.modules["sparseconvnet"] = saved

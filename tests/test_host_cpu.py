@@ -1,0 +1,83 @@
+"""CPU: host-side logic -- synthetic generator, flat-bucket data parallelism over gloo (world_size 2)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import scn_oracle as O
+from sparse_rcnn_amd.dp import FlatParams, broadcast_params
+from sparse_rcnn_amd.synthetic import make_batch, make_boxes
+
+
+def test_synthetic_scene_is_deterministic_and_surface_like():
+    a = make_batch(1, (128, 128, 64), 12000, seed=5)
+    b = make_batch(1, (128, 128, 64), 12000, seed=5)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    coords, feats, size, bs, splits = a
+    assert coords.dtype == torch.int64 and coords.shape[1] == 4 and feats.shape[1] == 7 and feats.dtype == torch.float32
+    assert (coords[:, :3] >= 0).all() and (coords[:, :3] < size).all() and splits == [len(coords)]
+    ac, prow, cnt = O.input_layer_rules(coords.numpy())
+    assert len(ac) == 12000 and 1.1 < len(coords) / len(ac) < 1.2            # ~1.15 points per voxel
+    nbr, rules = O.subm_rulebook(ac, 3)
+    per_voxel = sum(len(i) for i, _ in rules) / len(ac)
+    assert 5.0 < per_voxel < 14.0                                             # 2-D surfaces, not noise (27) nor dust (1)
+    boxes = make_boxes(coords, 5)
+    assert len(boxes) == 1 and boxes[0].shape == (5, 2, 3) and (boxes[0][:, 1] > boxes[0][:, 0]).all()
+
+
+def test_batch_rows_are_sample_major():
+    coords, feats, size, bs, splits = make_batch(3, (64, 64, 32), 2000, seed=1)
+    b = coords[:, 3].numpy()
+    assert (np.diff(b) >= 0).all() and bs == 3 and sum(splits) == len(coords)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _dp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(rank)                                   # different init per rank: broadcast must fix it
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+    fp = FlatParams(net)
+    broadcast_params(fp)
+    x = torch.full((4, 6), float(rank + 1))                   # rank-dependent "scene"
+    fp.zero_grad()
+    net(x).sum().backward()
+    local = fp.flat_grad.clone()
+    fp.all_reduce_mean()
+    fp.sgd_step(0.1)
+    out.put((rank, fp.flat.clone(), local, fp.flat_grad.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_all_reduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps: p.start()
+    res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
+    for p in ps: p.join(60)
+    (_, w0, g0, m0), (_, w1, g1, m1) = res
+    assert torch.equal(w0, w1)                                 # ranks stay in lock-step
+    assert torch.allclose(m0, (g0 + g1) / 2) and torch.equal(m0, m1)
+
+
+def test_flat_params_views_survive_backward():
+    net = torch.nn.Linear(4, 3)
+    fp = FlatParams(net)
+    for _ in range(2):
+        fp.zero_grad()
+        net(torch.ones(2, 4)).sum().backward()
+        assert net.weight.grad.data_ptr() == fp.flat_grad.data_ptr()
+        assert torch.allclose(fp.flat_grad[:12], torch.full((12,), 2.0))
+    w = fp.flat.clone()
+    fp.sgd_step(0.5)
+    assert torch.allclose(fp.flat, w - 0.5 * fp.flat_grad) and net.weight.data_ptr() == fp.flat.data_ptr()

@@ -49,19 +49,43 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     const float* __restrict__ X, int cin, const int* __restrict__ tstab, const unsigned* __restrict__ tile_mask,
     const int* __restrict__ perm, int n_off, long long nt, const float* __restrict__ W, const float* __restrict__ bias,
     const float* __restrict__ residual, const float* __restrict__ relu_mask, float* __restrict__ Y,
-    float* __restrict__ slabs, long long n_out, int cout, int flags, int n_chunks, int n_kc) {
-    extern __shared__ __attribute__((aligned(16))) float Ws[];           // [n_off][32 k][32 n] swizzled, then counter
+    float* __restrict__ slabs, long long n_out, int cout, int flags, int n_chunks, int n_kc,
+    int* __restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) float Ws[];           // [n_off][32 k][32 n] swizzled
     constexpr int THREADS = TS_NW * 64;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int i = lane & 15, kq = lane >> 4;
     const int chunk = blockIdx.x % n_chunks;
     const int kci = (blockIdx.x / n_chunks) % n_kc;
-    const int tg = blockIdx.x / (n_chunks * n_kc), n_tg = gridDim.x / (n_chunks * n_kc);
     const int n0 = chunk * TS_CT, kc = kci * TS_KC;
     const bool relu_in = flags & SCN_F_RELU_IN;
     const bool rev = flags & SCN_F_OFF_REVERSE;
-    int* counter = (int*)(Ws + n_off * TS_KC * TS_CT);
+
+    // ---- tile queue: a workgroup owns every n_tg-th tile of its slice (interleaved: the mask sort orders tiles by
+    // offset set, contiguous ranges would be badly unbalanced) and its 16 waves pull them from an LDS counter, from the
+    // END of the sorted list: masks with more offsets sort later, so the expensive tiles start first and the cheap ones
+    // fill the tail.  (A chip-wide queue on global atomics was measured slower: returning global atomics cost more than
+    // the imbalance they remove -- DESIGN.md.)
+    const int tg = blockIdx.x / (n_chunks * n_kc), n_tg = gridDim.x / (n_chunks * n_kc);
     const int n_tiles = (int)((nt - tg + n_tg - 1) / n_tg);
+    int* counter = (int*)(Ws + n_off * TS_KC * TS_CT);
+    if (tid == 0) *counter = 0;
+    __syncthreads();
+    auto grab = [&]() -> long long {                    // -> tile id or -1
+        int tl = 0;
+        if (lane == 0) tl = atomicAdd(counter, 1);
+        tl = __builtin_amdgcn_readfirstlane(tl);
+        return tl < n_tiles ? tg + (long long)(n_tiles - 1 - tl) * n_tg : -1;
+    };
+    const int i = lane & 15, kq = lane >> 4;
+    // first tile: id, mask and output rows are requested before the weight slice is staged
+    long long tile_next = grab();
+    unsigned m_next = 0;
+    int orow_next[4] = {-1, -1, -1, -1};
+    if (tile_next >= 0) {
+        m_next = tile_mask[tile_next];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) orow_next[j] = perm[tile_next * TS_T + 4 * kq + j];
+    }
 
     // ---- stage the weight slice: 16-byte global reads, all in flight before the LDS writes ---------------------------
     {
@@ -120,7 +144,6 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
             }
         }
     }
-    if (tid == 0) *counter = 0;
     __syncthreads();
 
     const int ka = kc + 4 * kq;
@@ -164,23 +187,25 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         }                                                                                            \
     } while (0)
 
-    // one pipeline step: indices two offsets ahead, A rows of the next offset into (N0, N1), MFMAs on (C0, C1)
-#define TS_STEP(C0, C1, N0, N1)                                                                      \
+    // one pipeline step: index of the offset 4 ahead, A rows of the offset 3 ahead into (G0, G1), MFMAs on (C0, C1).
+    // Four named A register sets rotate (loop unrolled by 4): with ~2 us of gather latency and 512 MFMA cycles per
+    // offset a SIMD needs ~9 gathers in flight (4 waves x 3 here); one-ahead prefetch left the kernel latency-bound.
+#define TS_STEP(C0, C1, G0, G1)                                                                      \
     do {                                                                                             \
-        int onn_ = -1;                                                                               \
-        if (m) { onn_ = __builtin_ctz(m); m &= m - 1; olast = onn_; }                                \
-        const int idxnn_ = tb[olast * TS_T];                                                         \
-        TS_GATHER(idxn, N0, N1);                                                                     \
+        int o4_ = -1;                                                                                \
+        if (m) { o4_ = __builtin_ctz(m); m &= m - 1; olast = o4_; }                                  \
+        const int i4_ = tb[olast * TS_T];                                                            \
+        TS_GATHER(iq3, G0, G1);                                                                      \
         f32x4 a0_ = C0, a1_ = C1;                                                                    \
-        if (FULLK && idxc < 0) { a0_ = (f32x4){0.f, 0.f, 0.f, 0.f}; a1_ = a0_; }                     \
+        if (FULLK && iq0 < 0) { a0_ = (f32x4){0.f, 0.f, 0.f, 0.f}; a1_ = a0_; }                      \
         if (relu_in) {                                                                               \
             _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                       \
                 a0_[e_] = fmaxf(a0_[e_], 0.f);                                                       \
                 a1_[e_] = fmaxf(a1_[e_], 0.f);                                                       \
             }                                                                                        \
         }                                                                                            \
-        const float* wb_ = Ws + oc * (TS_KC * TS_CT) + bofs;                                         \
-        const float* wc_ = Ws + oc * (TS_KC * TS_CT) + (bofs ^ 16);                                  \
+        const float* wb_ = Ws + oq0 * (TS_KC * TS_CT) + bofs;                                        \
+        const float* wc_ = Ws + oq0 * (TS_KC * TS_CT) + (bofs ^ 16);                                 \
         float bl_[8], bh_[8];                                                                        \
         _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                           \
             bl_[e_] = wb_[e_ * TS_CT];                                                               \
@@ -196,42 +221,51 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
             c0 = MFMA16(a1_[e_], bl_[4 + e_], c0);                                                   \
             c1 = MFMA16(a1_[e_], bh_[4 + e_], c1);                                                   \
         }                                                                                            \
-        oc = on; idxc = idxn;                                                                        \
-        on = onn_; idxn = idxnn_;                                                                    \
+        oq0 = oq1; oq1 = oq2; oq2 = oq3; oq3 = o4_;                                                  \
+        iq0 = iq1; iq1 = iq2; iq2 = iq3; iq3 = i4_;                                                  \
     } while (0)
 
-    // ---- tiles of this workgroup, pulled dynamically ---------------------------------------------------------------
-    for (;;) {
-        int tl = 0;
-        if (lane == 0) tl = atomicAdd(counter, 1);
-        tl = __builtin_amdgcn_readfirstlane(tl);
-        if (tl >= n_tiles) break;
-        const long long tile = tg + (long long)tl * n_tg;
-        unsigned m = tile_mask[tile];
-        const int* tb = tstab + tile * n_off * TS_T + i;
-        const int rowbase = (int)(tile * TS_T) + 4 * kq;
+    // ---- tile loop: the id, mask and output rows of the NEXT tile are fetched while the current one computes --------
+    while (tile_next >= 0) {
+        const long long tile = tile_next;
+        unsigned m = m_next;
         int orow[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) orow[j] = perm[rowbase + j];
+        for (int j = 0; j < 4; ++j) orow[j] = orow_next[j];
+        const int* tb = tstab + tile * n_off * TS_T + i;
+        tile_next = grab();
+        if (tile_next >= 0) {
+            m_next = tile_mask[tile_next];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) orow_next[j] = perm[tile_next * TS_T + 4 * kq + j];
+        }
 
-        // 3-stage pipeline over the set bits of m:  indices 2 offsets ahead, A rows 1 offset ahead, MFMA now.
-        // All loads are unconditional (a finished list re-reads its last offset) -- see gather().  The A registers
-        // ping-pong between two named sets (loop unrolled by 2): a register move of a prefetched value would force
-        // its load to complete and serialise the pipeline.
-        int oc = -1, on = -1, idxc = -1, idxn = -1;
+        // queue of the next four offsets of this tile (-1 = none) and their row indices; loads are unconditional
+        // (a finished list re-reads its last offset)
+        int oq0 = -1, oq1 = -1, oq2 = -1, oq3 = -1, iq0, iq1, iq2, iq3;
         int olast = 0;
-        f32x4 p0, p1, q0, q1;
-        if (m) { oc = __builtin_ctz(m); m &= m - 1; olast = oc; }
-        idxc = tb[olast * TS_T];
-        if (m) { on = __builtin_ctz(m); m &= m - 1; olast = on; }
-        idxn = tb[olast * TS_T];
-        TS_GATHER(idxc, p0, p1);
+        if (m) { oq0 = __builtin_ctz(m); m &= m - 1; olast = oq0; }
+        iq0 = tb[olast * TS_T];
+        if (m) { oq1 = __builtin_ctz(m); m &= m - 1; olast = oq1; }
+        iq1 = tb[olast * TS_T];
+        if (m) { oq2 = __builtin_ctz(m); m &= m - 1; olast = oq2; }
+        iq2 = tb[olast * TS_T];
+        if (m) { oq3 = __builtin_ctz(m); m &= m - 1; olast = oq3; }
+        iq3 = tb[olast * TS_T];
+        f32x4 s00, s01, s10, s11, s20, s21, s30, s31;
+        TS_GATHER(iq0, s00, s01);
+        TS_GATHER(iq1, s10, s11);
+        TS_GATHER(iq2, s20, s21);
 
         f32x4 c0 = {bA, bA, bA, bA}, c1 = {bB, bB, bB, bB};
-        while (oc >= 0) {
-            TS_STEP(p0, p1, q0, q1);
-            if (oc < 0) break;
-            TS_STEP(q0, q1, p0, p1);
+        while (oq0 >= 0) {
+            TS_STEP(s00, s01, s30, s31);
+            if (oq0 < 0) break;
+            TS_STEP(s10, s11, s00, s01);
+            if (oq0 < 0) break;
+            TS_STEP(s20, s21, s10, s11);
+            if (oq0 < 0) break;
+            TS_STEP(s30, s31, s20, s21);
         }
 
         // ---- tile epilogue: 16 lanes write 64 contiguous bytes of a row -------------------------------------------
@@ -278,9 +312,12 @@ __global__ void k_conv_ts_sum(const float* __restrict__ slabs, int n_kc, long lo
 #undef TS_STEP
 #undef TS_GATHER
 
+// scratch = [256 reserved bytes] [slabs: n_kc * n_out * cout floats if n_kc > 1]
+static int64_t ts_counter_bytes(int, int) { return 256; }
+
 extern "C" int64_t scn_conv_tiles_scratch_bytes(int cin, int64_t n_out, int cout) {
     const int64_t n_kc = cdiv(cin, TS_KC);
-    return n_kc > 1 ? n_kc * n_out * cout * (int64_t)sizeof(float) : 0;
+    return ts_counter_bytes(cin, cout) + (n_kc > 1 ? n_kc * n_out * cout * (int64_t)sizeof(float) : 0);
 }
 
 extern "C" int scn_conv_tiles(const float* X, int cin, const int32_t* tstab, const uint32_t* tile_mask,
@@ -293,12 +330,14 @@ extern "C" int scn_conv_tiles(const float* X, int cin, const int32_t* tstab, con
     const int64_t nt = cdiv(n_out, TS_T);
     const int n_chunks = (int)cdiv(cout, TS_CT);
     const int n_kc = (int)cdiv(cin, TS_KC);
-    SCN_REQUIRE(n_kc == 1 || scratch);
+    SCN_REQUIRE(scratch);
+    int* counters = (int*)scratch;
+    float* slabs = (float*)((char*)scratch + ts_counter_bytes(cin, cout));
     const size_t lds = (size_t)n_off * TS_KC * TS_CT * sizeof(float) + 16;
     int wg_per_cu = (int)((160 * 1024) / lds);
     if (wg_per_cu > 2) wg_per_cu = 2;                  // 16 waves each: 2 workgroups fill a CU
     if (wg_per_cu < 1) wg_per_cu = 1;
-    // grid sized to the chip: tile groups x column chunks x K-chunks; a workgroup should see at least ~16 tiles
+    // grid sized to the chip: workgroups per (column chunk, K-chunk) slice; a workgroup should see at least ~16 tiles
     int64_t n_tg = (256 * wg_per_cu) / ((int64_t)n_chunks * n_kc);
     if (n_tg > cdiv(nt, TS_NW)) n_tg = cdiv(nt, TS_NW);
     if (n_tg < 1) n_tg = 1;
@@ -317,8 +356,8 @@ extern "C" int scn_conv_tiles(const float* X, int cin, const int32_t* tstab, con
             attr_set = true;                                                                                        \
         }                                                                                                           \
         hipLaunchKernelGGL((k_conv_ts<T, V, VN, FK>), grid, dim3(TS_NW * 64), lds, st, X, cin, tstab, tile_mask,    \
-                           perm, n_off, (long long)nt, W, bias, residual, relu_mask, Y, (float*)scratch,            \
-                           (long long)n_out, cout, flags, n_chunks, n_kc);                                          \
+                           perm, n_off, (long long)nt, W, bias, residual, relu_mask, Y, slabs,                      \
+                           (long long)n_out, cout, flags, n_chunks, n_kc, counters);                                \
     } while (0)
     if (fullk && wt) LAUNCH_TS(true, true, true, true);
     else if (fullk && vecn) LAUNCH_TS(false, true, true, true);
@@ -333,7 +372,7 @@ extern "C" int scn_conv_tiles(const float* X, int cin, const int32_t* tstab, con
     SCN_LAUNCH_CHECK();
     if (n_kc > 1) {
         hipLaunchKernelGGL(k_conv_ts_sum, dim3(scn::ew_grid(n_out * cout, 256)), dim3(256), 0, st,
-                           (const float*)scratch, n_kc, (long long)n_out, cout, bias, residual, relu_mask, Y);
+                           (const float*)slabs, n_kc, (long long)n_out, cout, bias, residual, relu_mask, Y);
         SCN_LAUNCH_CHECK();
     }
     return SCN_OK;

@@ -56,7 +56,7 @@ def conv_rules(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu_mask
     Y = _new((n_out, cout), X)
     P = n_rules
     nbytes = lib.scn_conv_tiles_scratch_bytes(cin, n_out, cout)
-    scratch = torch.empty(nbytes, dtype=torch.uint8, device=X.device) if nbytes else None
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=X.device)
 
     def run():
         L.check(lib.scn_conv_tiles(L.ptr(X), cin, L.ptr(tiles.tstab), L.ptr(tiles.tile_mask), L.ptr(tiles.perm),

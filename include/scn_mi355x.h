@@ -140,10 +140,11 @@ int scn_gemm_table(const float* X, int64_t n_in, int cin, const int32_t* table, 
  * (bit o set <=> table[o][r] >= 0) with a stable radix sort; nt = ceil(n/16) tiles of 16 sorted rows.
  *   perm      int32 [nt*16]          sorted position -> original row (-1 padding)
  *   tstab     int32 [nt][n_off][16]  tstab[t][o][i] = table[o][perm[16t+i]]
- *   tile_mask uint32 [nt]            OR of the row masks of the tile */
+ *   tile_mask uint32 [nt]            OR of the row masks of the tile
+ *   tile_order int32 [nt]            tile ids by offset count descending (hand-out order of scn_conv_tiles) */
 int64_t scn_tiles_scratch_bytes(int n_off, int64_t n);
 int scn_tiles_build(const int32_t* table, int n_off, int64_t n, int32_t* perm, int32_t* tstab, uint32_t* tile_mask,
-                    void* scratch, scn_stream_t stream);
+                    int32_t* tile_order, void* scratch, scn_stream_t stream);
 
 /* THE HOT KERNEL.  Output-stationary convolution over mask-sorted tiles, accumulators in registers, weights in LDS:
  *     Y[r] = residual[r] + bias + sum_o in(X[table[o][r]]) . W[o']          (same result as scn_gemm_table)
@@ -151,7 +152,7 @@ int scn_tiles_build(const int32_t* table, int n_off, int64_t n, int32_t* perm, i
  * Deconvolution backward-data (:256-258).  n_off <= 27.  Per-row accumulation order is fixed (offsets ascending). */
 int64_t scn_conv_tiles_scratch_bytes(int cin, int64_t n_out, int cout);   /* tile-queue counters + K-chunk slabs */
 int scn_conv_tiles(const float* X, int cin, const int32_t* tstab, const uint32_t* tile_mask, const int32_t* perm,
-                   int n_off, int64_t n_out, const float* W, const float* bias, const float* residual,
+                   const int32_t* tile_order, int n_off, int64_t n_out, const float* W, const float* bias, const float* residual,
                    const float* relu_mask, float* Y, int cout, int flags, void* scratch, scn_stream_t stream);
 
 /* Output-stationary rule-list convolution (an alternative to scn_conv_tiles kept for comparison; same result as scn_gemm_table on the table the rules were

@@ -47,7 +47,8 @@ __device__ __forceinline__ int ts_ws_off(int o, int k, int n) { return (o * TS_K
 template <bool WT, bool VEC, bool VECN, bool FULLK>
 __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     const float* __restrict__ X, int cin, const int* __restrict__ tstab, const unsigned* __restrict__ tile_mask,
-    const int* __restrict__ perm, int n_off, long long nt, const float* __restrict__ W, const float* __restrict__ bias,
+    const int* __restrict__ perm, const int* __restrict__ tile_order, int n_off, long long nt,
+    const float* __restrict__ W, const float* __restrict__ bias,
     const float* __restrict__ residual, const float* __restrict__ relu_mask, float* __restrict__ Y,
     float* __restrict__ slabs, long long n_out, int cout, int flags, int n_chunks, int n_kc,
     int* __restrict__ counters) {
@@ -60,10 +61,9 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     const bool relu_in = flags & SCN_F_RELU_IN;
     const bool rev = flags & SCN_F_OFF_REVERSE;
 
-    // ---- tile queue: a workgroup owns every n_tg-th tile of its slice (interleaved: the mask sort orders tiles by
-    // offset set, contiguous ranges would be badly unbalanced) and its 16 waves pull them from an LDS counter, from the
-    // END of the sorted list: masks with more offsets sort later, so the expensive tiles start first and the cheap ones
-    // fill the tail.  (A chip-wide queue on global atomics was measured slower: returning global atomics cost more than
+    // ---- tile queue: tile_order lists the tiles by offset count descending.  A workgroup owns every n_tg-th entry
+    // (an even sample of costs) and its 16 waves pull them from an LDS counter in that order: expensive tiles start
+    // first, cheap ones fill the tail (longest-processing-time scheduling).  (A chip-wide queue on global atomics was measured slower: returning global atomics cost more than
     // the imbalance they remove -- DESIGN.md.)
     const int tg = blockIdx.x / (n_chunks * n_kc), n_tg = gridDim.x / (n_chunks * n_kc);
     const int n_tiles = (int)((nt - tg + n_tg - 1) / n_tg);
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         int tl = 0;
         if (lane == 0) tl = atomicAdd(counter, 1);
         tl = __builtin_amdgcn_readfirstlane(tl);
-        return tl < n_tiles ? tg + (long long)(n_tiles - 1 - tl) * n_tg : -1;
+        return tl < n_tiles ? tile_order[tg + (long long)tl * n_tg] : -1;
     };
     const int i = lane & 15, kq = lane >> 4;
     // first tile: id, mask and output rows are requested before the weight slice is staged
@@ -321,12 +321,12 @@ extern "C" int64_t scn_conv_tiles_scratch_bytes(int cin, int64_t n_out, int cout
 }
 
 extern "C" int scn_conv_tiles(const float* X, int cin, const int32_t* tstab, const uint32_t* tile_mask,
-                              const int32_t* perm, int n_off, int64_t n_out, const float* W, const float* bias,
+                              const int32_t* perm, const int32_t* tile_order, int n_off, int64_t n_out, const float* W, const float* bias,
                               const float* residual, const float* relu_mask, float* Y, int cout, int flags,
                               void* scratch, scn_stream_t stream) {
     SCN_REQUIRE(n_off >= 1 && n_off <= 27 && n_out >= 0 && cin >= 1 && cout >= 1);
     if (n_out == 0) return SCN_OK;
-    SCN_REQUIRE(X && tstab && tile_mask && perm && W && Y);
+    SCN_REQUIRE(X && tstab && tile_mask && perm && tile_order && W && Y);
     const int64_t nt = cdiv(n_out, TS_T);
     const int n_chunks = (int)cdiv(cout, TS_CT);
     const int n_kc = (int)cdiv(cin, TS_KC);
@@ -356,7 +356,7 @@ extern "C" int scn_conv_tiles(const float* X, int cin, const int32_t* tstab, con
             attr_set = true;                                                                                        \
         }                                                                                                           \
         hipLaunchKernelGGL((k_conv_ts<T, V, VN, FK>), grid, dim3(TS_NW * 64), lds, st, X, cin, tstab, tile_mask,    \
-                           perm, n_off, (long long)nt, W, bias, residual, relu_mask, Y, slabs,                      \
+                           perm, tile_order, n_off, (long long)nt, W, bias, residual, relu_mask, Y, slabs,                      \
                            (long long)n_out, cout, flags, n_chunks, n_kc, counters);                                \
     } while (0)
     if (fullk && wt) LAUNCH_TS(true, true, true, true);

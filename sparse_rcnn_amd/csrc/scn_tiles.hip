@@ -13,6 +13,7 @@
 //   tstab     [NT][n_off][16]  tile-major table: tstab[t][o][i] = table[o][perm[16t+i]]  (one coalesced 64-B read
 //                              per (tile, offset) in the kernel)
 //   tile_mask [NT]             OR of the row masks of the tile: the offsets the kernel has to visit
+//   tile_order[NT]             tile ids by offset count descending (the kernel's hand-out order)
 //
 // The radix sort is rocPRIM's device_radix_sort (a plain library primitive on the index-building path); everything
 // else is hand-written.
@@ -59,6 +60,51 @@ __global__ void k_build_tiles(const int* __restrict__ table, int n_off, long lon
     }
 }
 
+// tile_order: tile ids sorted by offset count (popcount of tile_mask) DESCENDING -- the order in which the convolution
+// kernel hands tiles to its waves (longest-processing-time first).  Counting sort on 33 bins, one block.
+__global__ __launch_bounds__(1024) void k_tile_order(const unsigned* __restrict__ tile_mask, int nt,
+                                                     int* __restrict__ tile_order) {
+    __shared__ int hist[33], cursor[33];
+    if (threadIdx.x < 33) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < nt; t += 1024) atomicAdd(&hist[32 - __popc(tile_mask[t])], 1);   // bin 0 = 32 offsets
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int b = 0; b < 33; ++b) { cursor[b] = run; run += hist[b]; }
+    }
+    __syncthreads();
+    // position inside a bin = number of earlier tiles of the same bin: walk in tile order so the result is deterministic
+    for (int base = 0; base < nt; base += 1024) {
+        const int t = base + threadIdx.x;
+        const int bin = t < nt ? 32 - __popc(tile_mask[t]) : -1;
+        // rank among the threads of this pass with the same bin (wave ballot + per-wave counts through LDS)
+        __shared__ int wcnt[16][33];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        for (int b = lane; b < 33; b += 64) wcnt[w][b] = 0;
+        __syncthreads();
+        int my_rank = 0;
+        for (int b = 0; b < 33; ++b) {
+            const unsigned long long mb = __ballot(bin == b);
+            if (bin == b) my_rank = __popcll(mb & ((1ull << lane) - 1ull));
+            if (lane == 0) wcnt[w][b] = __popcll(mb);
+        }
+        __syncthreads();
+        if (bin >= 0) {
+            int before = 0;
+            for (int k = 0; k < w; ++k) before += wcnt[k][bin];
+            tile_order[cursor[bin] + before + my_rank] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < 33) {
+            int tot = 0;
+            for (int k = 0; k < 16; ++k) tot += wcnt[k][threadIdx.x];
+            cursor[threadIdx.x] += tot;
+        }
+        __syncthreads();
+    }
+}
+
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 static size_t sort_temp_bytes(int64_t n, int bits) {
@@ -74,10 +120,10 @@ extern "C" int64_t scn_tiles_scratch_bytes(int n_off, int64_t n) {
 }
 
 extern "C" int scn_tiles_build(const int32_t* table, int n_off, int64_t n, int32_t* perm, int32_t* tstab,
-                               uint32_t* tile_mask, void* scratch, scn_stream_t stream) {
+                               uint32_t* tile_mask, int32_t* tile_order, void* scratch, scn_stream_t stream) {
     SCN_REQUIRE(n_off >= 1 && n_off <= 32 && n >= 0);
     if (n == 0) return SCN_OK;
-    SCN_REQUIRE(table && perm && tstab && tile_mask && scratch);
+    SCN_REQUIRE(table && perm && tstab && tile_mask && tile_order && scratch);
     SCN_REQUIRE(n < 2147483647LL / 32);
     char* p = (char*)scratch;
     unsigned* mask = (unsigned*)p;          p += align256(4 * n);
@@ -93,6 +139,8 @@ extern "C" int scn_tiles_build(const int32_t* table, int n_off, int64_t n, int32
     const int64_t nt = cdiv(n, 16);
     hipLaunchKernelGGL(k_build_tiles, dim3(scn::ew_grid(nt * 16, 256)), dim3(256), 0, st, table, n_off, (long long)n,
                        (const int*)rows_sorted, (const unsigned*)mask_sorted, (long long)nt, perm, tstab, tile_mask);
+    SCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, (const unsigned*)tile_mask, (int)nt, tile_order);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }

@@ -62,6 +62,7 @@ class Tiles:
     tile_mask: torch.Tensor         # int32 view of uint32 [nt]
     n_off: int
     n: int
+    tile_order: Optional[torch.Tensor] = None    # int32 [nt], tiles by offset count descending
 
 
 def build_tiles(table: torch.Tensor, n_off: int, n: int) -> Tiles:
@@ -71,10 +72,11 @@ def build_tiles(table: torch.Tensor, n_off: int, n: int) -> Tiles:
     perm = _empty(nt * 16, torch.int32, dev)
     tstab = torch.empty((nt, n_off, 16), dtype=torch.int32, device=dev)
     tile_mask = _empty(nt, torch.int32, dev)
+    tile_order = _empty(nt, torch.int32, dev)
     scratch = _empty(lib.scn_tiles_scratch_bytes(n_off, n), torch.uint8, dev)
-    L.check(lib.scn_tiles_build(L.ptr(table), n_off, n, L.ptr(perm), L.ptr(tstab), L.ptr(tile_mask), L.ptr(scratch),
-                                L.stream()))
-    return Tiles(perm, tstab, tile_mask, n_off, n)
+    L.check(lib.scn_tiles_build(L.ptr(table), n_off, n, L.ptr(perm), L.ptr(tstab), L.ptr(tile_mask),
+                                L.ptr(tile_order), L.ptr(scratch), L.stream()))
+    return Tiles(perm, tstab, tile_mask, n_off, n, tile_order)
 
 
 @dataclass
@@ -260,6 +262,17 @@ class Metadata:
             rb = StridedRulebook(parent, fine_off, child, rules, g.n, cg.n, coarse_size, build_tiles(child, 8, cg.n))
             self.strided[size] = rb
         return rb
+
+    def build_pyramid(self, size, n_levels: int, k: int = 3):
+        """Build the rulebooks of an n_levels U-Net up front (SubM k^3 at every level, 2^3/2 between levels).
+        Same work as building them lazily; done before the first convolution is queued so that the host syncs of the
+        size queries do not wait behind (and then starve) the feature kernels."""
+        size = tuple(int(s) for s in size)
+        for level in range(n_levels):
+            self.subm_rulebook(size, k)
+            if level + 1 < n_levels:
+                self.strided_rulebook(size)
+                size = tuple(s // 2 for s in size)
 
     # ---- parity helpers (tests) -------------------------------------------------------------------
     def get_spatial_locations(self, size) -> torch.Tensor:

@@ -55,6 +55,7 @@ class SparseUNet(nn.Module):
         self.decoder = nn.ModuleList(dec)
 
     def forward(self, x):
+        x.metadata.build_pyramid(x.spatial_size, len(self.channels), 3)
         interims = []
         for level in self.encoder:
             x = level(x)

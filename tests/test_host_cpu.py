@@ -49,6 +49,7 @@ def _dp_worker(rank, world, port, out):
     x = torch.full((4, 6), float(rank + 1))                   # rank-dependent "scene"
     fp.zero_grad()
     net(x).sum().backward()
+    fp.gather_grads()
     local = fp.flat_grad.clone()
     fp.all_reduce_mean()
     fp.sgd_step(0.1)
@@ -76,8 +77,8 @@ def test_flat_params_views_survive_backward():
     for _ in range(2):
         fp.zero_grad()
         net(torch.ones(2, 4)).sum().backward()
-        assert net.weight.grad.data_ptr() == fp.flat_grad.data_ptr()
-        assert torch.allclose(fp.flat_grad[:12], torch.full((12,), 2.0))
+        fp.gather_grads()
+        assert torch.allclose(fp.flat_grad[:12], torch.full((12,), 2.0))        # no accumulation across steps
     w = fp.flat.clone()
     fp.sgd_step(0.5)
     assert torch.allclose(fp.flat, w - 0.5 * fp.flat_grad) and net.weight.data_ptr() == fp.flat.data_ptr()

@@ -12,7 +12,7 @@ torch.manual_seed(0)
 X = torch.randn(n, C, device="cuda"); W = torch.randn(27, C, C, device="cuda") * 0.05
 Y = torch.empty(n, C, device="cuda"); Y2 = torch.empty(n, C, device="cuda")
 lib = L.lib()
-L.check(lib.scn_conv_tiles(L.ptr(X), C, L.ptr(t.tstab), L.ptr(t.tile_mask), L.ptr(t.perm), 27, n, L.ptr(W), 0, 0, 0, L.ptr(Y), C, 0, 0, L.stream()))
+L.check(lib.scn_conv_tiles(L.ptr(X), C, L.ptr(t.tstab), L.ptr(t.tile_mask), L.ptr(t.perm), L.ptr(t.tile_order), 27, n, L.ptr(W), 0, 0, 0, L.ptr(Y), C, 0, 0, L.stream()))
 L.check(lib.scn_gemm_table(L.ptr(X), n, C, L.ptr(rb.table), 27, n, L.ptr(W), 0, 0, 0, L.ptr(Y2), C, 0, L.stream()))
 torch.cuda.synchronize()
 d = (Y - Y2).abs().cpu().numpy()
@@ -25,7 +25,7 @@ print("bad tiles:", sorted(set(pos[r] // 16 for r in bad))[:20], "of", len(perm)
 # single-offset test: W only offset 13
 for o in (0, 13, 26):
     W1 = torch.zeros_like(W); W1[o] = W[o]
-    L.check(lib.scn_conv_tiles(L.ptr(X), C, L.ptr(t.tstab), L.ptr(t.tile_mask), L.ptr(t.perm), 27, n, L.ptr(W1), 0, 0, 0, L.ptr(Y), C, 0, 0, L.stream()))
+    L.check(lib.scn_conv_tiles(L.ptr(X), C, L.ptr(t.tstab), L.ptr(t.tile_mask), L.ptr(t.perm), L.ptr(t.tile_order), 27, n, L.ptr(W1), 0, 0, 0, L.ptr(Y), C, 0, 0, L.stream()))
     L.check(lib.scn_gemm_table(L.ptr(X), n, C, L.ptr(rb.table), 27, n, L.ptr(W1), 0, 0, 0, L.ptr(Y2), C, 0, L.stream()))
     torch.cuda.synchronize()
     print("offset", o, "max diff", (Y - Y2).abs().max().item())

@@ -1,4 +1,4 @@
-"""GPU-box helper for counter collection: runs conv_tiles a few times on one level (see tools/ablate_conv.py)."""
+"""GPU-box helper for counter collection: runs scn_wgrad_rules a few times on one level."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,10 +12,11 @@ x = scn.InputLayer(3, size, mode=4)((coords, feats.cuda(), 1))
 md = x.metadata; sz = tuple(int(s) for s in size)
 for l in range(level):
     md.strided_rulebook(sz); sz = tuple(s // 2 for s in sz)
-rb = md.subm_rulebook(sz, 3); n, t = rb.n, rb.tiles
-X = torch.randn(n, C, device="cuda"); W = torch.randn(27, C, C, device="cuda") * 0.05; Y = torch.empty(n, C, device="cuda")
+rb = md.subm_rulebook(sz, 3); n, r = rb.n, rb.rules
+X = torch.randn(n, C, device="cuda"); dY = torch.randn(n, C, device="cuda"); dW = torch.empty(27, C, C, device="cuda")
 lib = L.lib()
-SCR = torch.empty(max(1, lib.scn_conv_tiles_scratch_bytes(C, n, C)), dtype=torch.uint8, device='cuda')
+scratch = torch.empty(lib.scn_wgrad_scratch_bytes(C, C, r.prefix_host, 27), dtype=torch.uint8, device="cuda")
 for _ in range(5):
-    L.check(lib.scn_conv_tiles(L.ptr(X), C, L.ptr(t.tstab), L.ptr(t.tile_mask), L.ptr(t.perm), L.ptr(t.tile_order), 27, n, L.ptr(W), 0, 0, 0, L.ptr(Y), C, 0, L.ptr(SCR), L.stream()))
+    L.check(lib.scn_wgrad_rules(L.ptr(X), C, L.ptr(dY), C, L.ptr(r.in_rows), L.ptr(r.out_rows), r.prefix_host, 27,
+                                L.ptr(dW), L.ptr(scratch), 0, L.stream()))
 torch.cuda.synchronize()

@@ -109,6 +109,50 @@ def colsum(dY):
     return db
 
 
+# ------------------------------------------------------------------------------------------------------
+# side stream for gradient leaves
+# ------------------------------------------------------------------------------------------------------
+# Weight and bias gradients are LEAVES of the backward graph: nothing downstream waits for them until the optimizer
+# step, while the backward-data GEMMs form the critical chain.  They are queued on a second HIP stream so their
+# workgroups fill the CUs the chain's kernels leave idle (tails, small coarse-level grids).  The main stream joins the
+# side stream once, in a callback at the end of the backward pass.
+LEAF_STREAM = False     # measured: no gain -- the chain kernels already fill the matrix pipes
+_side_streams = {}
+_join_pending = set()
+
+
+def _leaf_stream(device):
+    st = _side_streams.get(device)
+    if st is None:
+        st = _side_streams[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _on_leaf_stream(dY, fn):
+    """Run fn() (which launches the leaf-gradient kernels reading dY) on the side stream; returns its result."""
+    if not LEAF_STREAM:
+        return fn()
+    dev = dY.device
+    main = torch.cuda.current_stream(dev)
+    side = _leaf_stream(dev)
+    side.wait_stream(main)                       # dY (and everything before it) is ready
+    with torch.cuda.stream(side):
+        out = fn()
+    dY.record_stream(side)
+    for t in out:
+        if t is not None:
+            t.record_stream(main)
+    key = (dev, main.cuda_stream)
+    if key not in _join_pending:
+        _join_pending.add(key)
+
+        def _join():
+            _join_pending.discard(key)
+            main.wait_stream(side)
+        torch.autograd.Variable._execution_engine.queue_callback(_join)
+    return out
+
+
 def _identity_prefix(n):
     h = L.host_i64(2)
     h[0], h[1] = 0, n
@@ -152,15 +196,19 @@ class SubmanifoldConvolutionFunction(torch.autograd.Function):
                 dX = gemm_table(dY, rb.table, n_off, rb.n, W, None, cin, L.F_W_TRANSPOSED | L.F_OFF_REVERSE,
                                 relu_mask=X if ctx.relu_in else None,
                                 n_rules=rb.rules.total if rb.rules is not None else rb.n)
-        if ctx.needs_input_grad[1]:
-            if rb.k == 1:
-                dW = wgrad_rules(X, dY, None, None, _identity_prefix(rb.n), 1, fl)
-            else:
-                r = rb.rules
-                dW = wgrad_rules(X, dY, r.in_rows, r.out_rows, r.prefix_host, n_off, fl)
-            dW = dW.view_as(W)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dY)
+        def leaves():
+            dW = db = None
+            if ctx.needs_input_grad[1]:
+                if rb.k == 1:
+                    dW = wgrad_rules(X, dY, None, None, _identity_prefix(rb.n), 1, fl)
+                else:
+                    r = rb.rules
+                    dW = wgrad_rules(X, dY, r.in_rows, r.out_rows, r.prefix_host, n_off, fl)
+                dW = dW.view_as(W)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = colsum(dY)
+            return dW, db
+        dW, db = _on_leaf_stream(dY, leaves)
         return dX, dW, db, None, None, None, None
 
 
@@ -193,10 +241,14 @@ class ConvolutionFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:      # dX[f] = dY[parent f] . W[off f]^T : rule list with roles swapped
             dX = gemm_rules(dY, r.out_rows, r.in_rows, r.prefix_host, 8, rb.n_fine, W, None, X.shape[1],
                             L.F_W_TRANSPOSED, relu_mask=X if ctx.relu_in else None)
-        if ctx.needs_input_grad[1]:
-            dW = wgrad_rules(X, dY, r.in_rows, r.out_rows, r.prefix_host, 8, fl).view_as(W)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dY)
+        def leaves():
+            dW = db = None
+            if ctx.needs_input_grad[1]:
+                dW = wgrad_rules(X, dY, r.in_rows, r.out_rows, r.prefix_host, 8, fl).view_as(W)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = colsum(dY)
+            return dW, db
+        dW, db = _on_leaf_stream(dY, leaves)
         return dX, dW, db, None, None, None
 
 
@@ -234,10 +286,14 @@ class DeconvolutionFunction(torch.autograd.Function):
             else:
                 dX = gemm_table(dY, rb.child, 8, rb.n_coarse, W, None, X.shape[1], L.F_W_TRANSPOSED,
                                 relu_mask=X if ctx.relu_in else None, n_rules=rb.n_fine)
-        if ctx.needs_input_grad[1]:
-            dW = wgrad_rules(X, dY, r.out_rows, r.in_rows, r.prefix_host, 8, fl).view_as(W)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dY)
+        def leaves():
+            dW = db = None
+            if ctx.needs_input_grad[1]:
+                dW = wgrad_rules(X, dY, r.out_rows, r.in_rows, r.prefix_host, 8, fl).view_as(W)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = colsum(dY)
+            return dW, db
+        dW, db = _on_leaf_stream(dY, leaves)
         return dX, dW, db, None, None, None
 
 
@@ -263,10 +319,14 @@ class NetworkInNetworkFunction(torch.autograd.Function):
         dX = dW = db = None
         if ctx.needs_input_grad[0]:
             dX = gemm_table(dY, None, 1, n, W, None, X.shape[1], L.F_W_TRANSPOSED)
-        if ctx.needs_input_grad[1]:
-            dW = wgrad_rules(X, dY, None, None, _identity_prefix(n), 1).view_as(W)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dY)
+        def leaves():
+            dW = db = None
+            if ctx.needs_input_grad[1]:
+                dW = wgrad_rules(X, dY, None, None, _identity_prefix(n), 1).view_as(W)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = colsum(dY)
+            return dW, db
+        dW, db = _on_leaf_stream(dY, leaves)
         return dX, dW, db
 
 

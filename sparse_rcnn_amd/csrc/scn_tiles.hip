@@ -26,19 +26,39 @@
 using scn::S;
 using scn::cdiv;
 
-__global__ void k_row_masks(const int* __restrict__ table, int n_off, long long n, unsigned* __restrict__ mask,
+// Sort key = the offset mask with its bits PERMUTED: bit position of offset o is key_bit[o].  For 3^3 tables the rare
+// offsets (the 8 corners, then the 12 edges) take the most significant positions, faces and the centre the least: rows
+// that differ only in common offsets end up adjacent.  Measured executed/useful 1.31 vs 1.38 (natural bit order) at
+// 150k voxels.  Other table shapes keep the natural order.
+struct KeyBits { unsigned char pos[32]; };
+
+static KeyBits make_key_bits(int n_off) {
+    KeyBits kb;
+    for (int o = 0; o < 32; ++o) kb.pos[o] = (unsigned char)o;
+    if (n_off == 27) {
+        int next = 0;
+        for (int cls = 0; cls <= 3; ++cls)                 // centre (0), faces (1), edges (2), corners (3): LSB -> MSB
+            for (int o = 0; o < 27; ++o) {
+                const int dx = o / 9 - 1, dy = (o / 3) % 3 - 1, dz = o % 3 - 1;
+                if ((dx != 0) + (dy != 0) + (dz != 0) == cls) kb.pos[o] = (unsigned char)next++;
+            }
+    }
+    return kb;
+}
+
+__global__ void k_row_masks(const int* __restrict__ table, int n_off, long long n, KeyBits kb, unsigned* __restrict__ key,
                             int* __restrict__ iota) {
     for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < n;
          r += (long long)gridDim.x * blockDim.x) {
         unsigned m = 0;
-        for (int o = 0; o < n_off; ++o) m |= (table[(long long)o * n + r] >= 0 ? 1u : 0u) << o;
-        mask[r] = m;
+        for (int o = 0; o < n_off; ++o) m |= (table[(long long)o * n + r] >= 0 ? 1u : 0u) << kb.pos[o];
+        key[r] = m;
         iota[r] = (int)r;
     }
 }
 
 __global__ void k_build_tiles(const int* __restrict__ table, int n_off, long long n, const int* __restrict__ sorted_rows,
-                              const unsigned* __restrict__ sorted_mask, long long nt, int* __restrict__ perm,
+                              const unsigned* __restrict__ sorted_key, KeyBits kb, long long nt, int* __restrict__ perm,
                               int* __restrict__ tstab, unsigned* __restrict__ tile_mask) {
     // one thread per (tile, lane i); 16 threads of a tile are adjacent
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < nt * 16;
@@ -48,9 +68,13 @@ __global__ void k_build_tiles(const int* __restrict__ table, int n_off, long lon
         const bool ok = e < n;
         const int row = ok ? sorted_rows[e] : -1;
         perm[e] = row;
-        unsigned m = ok ? sorted_mask[e] : 0u;
-        for (int o = 0; o < n_off; ++o)
-            tstab[(t * n_off + o) * 16 + i] = (ok && ((m >> o) & 1u)) ? table[(long long)o * n + row] : -1;
+        const unsigned key = ok ? sorted_key[e] : 0u;
+        unsigned m = 0;                                     // the real offset mask: undo the key's bit permutation
+        for (int o = 0; o < n_off; ++o) {
+            const unsigned have = (key >> kb.pos[o]) & 1u;
+            m |= have << o;
+            tstab[(t * n_off + o) * 16 + i] = have ? table[(long long)o * n + row] : -1;
+        }
         // OR over the 16 lanes of the tile (they sit in one quarter of a wave)
         m |= __shfl_xor(m, 1);
         m |= __shfl_xor(m, 2);
@@ -133,12 +157,14 @@ extern "C" int scn_tiles_build(const int32_t* table, int n_off, int64_t n, int32
     void* temp = p;
     size_t temp_bytes = sort_temp_bytes(n, n_off);
     hipStream_t st = S(stream);
-    hipLaunchKernelGGL(k_row_masks, dim3(scn::ew_grid(n, 256)), dim3(256), 0, st, table, n_off, (long long)n, mask, iota);
+    const KeyBits kb = make_key_bits(n_off);
+    hipLaunchKernelGGL(k_row_masks, dim3(scn::ew_grid(n, 256)), dim3(256), 0, st, table, n_off, (long long)n, kb, mask,
+                       iota);
     SCN_LAUNCH_CHECK();
     SCN_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, mask, mask_sorted, iota, rows_sorted, (size_t)n, 0, n_off, st));
     const int64_t nt = cdiv(n, 16);
     hipLaunchKernelGGL(k_build_tiles, dim3(scn::ew_grid(nt * 16, 256)), dim3(256), 0, st, table, n_off, (long long)n,
-                       (const int*)rows_sorted, (const unsigned*)mask_sorted, (long long)nt, perm, tstab, tile_mask);
+                       (const int*)rows_sorted, (const unsigned*)mask_sorted, kb, (long long)nt, perm, tstab, tile_mask);
     SCN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, (const unsigned*)tile_mask, (int)nt, tile_order);
     SCN_LAUNCH_CHECK();

@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--target", type=int, default=TARGET)
+    ap.add_argument("--prefetch", action="store_true",
+                    help="build the next batch's index structures one batch ahead on the index stream "
+                         "(Metadata.prepare_async); measured slower from a single host thread, off by default")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -86,16 +89,21 @@ def main():
     gen = torch.Generator(device="cpu").manual_seed(100 + rank)
     gy = None
     n_active = 0
+    md_next = None
 
     def step():
-        nonlocal gy, n_active
+        nonlocal gy, n_active, md_next
         flat.zero_grad()
         fin = feats_d.detach().requires_grad_()
-        out = model(coords_d, fin, size, 1)
+        md, md_next = md_next, None
+        out = model(coords_d, fin, size, 1, metadata=md)
         if gy is None or gy.shape != out.features.shape:
             gy = torch.randn(out.features.shape, generator=gen).to(dev)          # upstream grad dY ~ N(0,1)
             n_active = out.features.shape[0]
         out.features.backward(gy)
+        # optional: index structures of the NEXT batch built on the index stream while this batch's backward runs
+        if args.prefetch:
+            md_next = model.prefetch(coords_d, size, 1)
         flat.all_reduce_mean()
         flat.sgd_step(1e-6)
 

@@ -420,7 +420,13 @@ class InputLayerFunction(torch.autograd.Function):
         F = _f32(F)
         if coords.shape[0] != F.shape[0]:
             raise ValueError("coords / features row mismatch")
-        grid = metadata.set_input(spatial_size, coords, int(batch_size), mode)
+        if metadata.input_size is None:
+            grid = metadata.set_input(spatial_size, coords, int(batch_size), mode)
+        else:                                   # prepared ahead of time (Metadata.prepare_async) for these coords
+            if metadata.n_items != coords.shape[0] or metadata.input_size != tuple(int(s) for s in spatial_size):
+                raise L.ScnError("InputLayer: this Metadata was prepared for different coordinates")
+            metadata.handover()
+            grid = metadata.grid(metadata.input_size)
         n_items, c = F.shape
         Y = _new((grid.n, c), F)
         acc = torch.empty((grid.n, c), dtype=torch.float64, device=dev) if mode in (3, 4) else None

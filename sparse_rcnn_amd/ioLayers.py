@@ -19,10 +19,10 @@ class InputLayer(Module):
             self.spatial_size = self.spatial_size.repeat(dimension)
         self.mode = mode
 
-    def forward(self, input):
+    def forward(self, input, metadata=None):
         coords, features = input[0], input[1]
         batch_size = input[2] if len(input) == 3 else 0
-        md = Metadata(self.dimension)
+        md = metadata if metadata is not None else Metadata(self.dimension)
         feats = InputLayerFunction.apply(self.dimension, md, self.spatial_size, coords.long(), features, batch_size,
                                          self.mode)
         return SparseConvNetTensor(features=feats, metadata=md, spatial_size=self.spatial_size)

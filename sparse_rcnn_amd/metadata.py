@@ -26,6 +26,16 @@ def _empty(n, dtype, dev):
     return torch.empty(int(n), dtype=dtype, device=dev)
 
 
+_index_streams = {}
+
+
+def index_stream(device) -> "torch.cuda.Stream":
+    st = _index_streams.get(device)
+    if st is None:
+        st = _index_streams[device] = torch.cuda.Stream(device=device)
+    return st
+
+
 @dataclass
 class Grid:
     coords: torch.Tensor            # int32 [N,4] device
@@ -183,6 +193,7 @@ class Metadata:
         self.n_items = 0
         self.n_samples = 0
         self.device = None
+        self.ready_event = None         # set by prepare_async: index structures were built on a side stream
 
     # ---- InputLayer rules -------------------------------------------------------------------------
     def set_input(self, spatial_size, coords: torch.Tensor, batch_size: int, mode: int):
@@ -262,6 +273,43 @@ class Metadata:
             rb = StridedRulebook(parent, fine_off, child, rules, g.n, cg.n, coarse_size, build_tiles(child, 8, cg.n))
             self.strided[size] = rb
         return rb
+
+    # ---- index prefetch on a side stream -----------------------------------------------------------
+    def prepare_async(self, spatial_size, coords, batch_size: int = 0, mode: int = 4, n_levels: int = 0, k: int = 3):
+        """Build the InputLayer rules (and optionally the rulebook pyramid of an n_levels U-Net) on the index stream.
+
+        All index structures depend only on the coordinates, so a training loop can build those of batch i+1 while the
+        matrix kernels of batch i still run: the index kernels are short and latency-bound and fit beside them, and
+        the host syncs of the size queries then wait on the index stream only.  `InputLayerFunction` adopts a prepared
+        Metadata (same coords) instead of rebuilding it; `handover()` orders the consumer stream behind the build."""
+        side = index_stream(torch.device("cuda", torch.cuda.current_device()))
+        side.wait_stream(torch.cuda.current_stream())          # coords may have been produced on the current stream
+        with torch.cuda.stream(side):
+            self.set_input(spatial_size, coords, batch_size, mode)
+            if n_levels:
+                self.build_pyramid(spatial_size, n_levels, k)
+            self.ready_event = torch.cuda.Event()
+            self.ready_event.record(side)
+        return self
+
+    def _all_tensors(self):
+        out = [self.item_row, self.row_count, self.row_first, self.row_last]
+        for g in self.grids.values():
+            out += [g.coords, g.table_keys, g.table_rows]
+        for rb in list(self.subm.values()) + list(self.strided.values()):
+            for obj in (rb, getattr(rb, "rules", None), getattr(rb, "tiles", None)):
+                if obj is not None:
+                    out += [v for v in vars(obj).values() if isinstance(v, torch.Tensor)]
+        return [t for t in out if t is not None]
+
+    def handover(self):
+        """Make the current stream wait for a side-stream build and tell the allocator the buffers are used here."""
+        if self.ready_event is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self.ready_event)
+            for t in self._all_tensors():
+                t.record_stream(cur)
+            self.ready_event = None
 
     def build_pyramid(self, size, n_levels: int, k: int = 3):
         """Build the rulebooks of an n_levels U-Net up front (SubM k^3 at every level, 2^3/2 between levels).

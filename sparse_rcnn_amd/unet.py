@@ -100,6 +100,12 @@ class Backbone(nn.Module):
         super().__init__()
         self.unet = SparseUNet(cin, channels, num_units, batchnorm)
 
-    def forward(self, coords, feats, spatial_size, batch_size=0):
-        x = InputLayer(3, spatial_size, mode=4)((coords, feats, batch_size))
+    def forward(self, coords, feats, spatial_size, batch_size=0, metadata=None):
+        """metadata: optional Metadata prepared with `prepare_async` for the same coords (index prefetch)."""
+        x = InputLayer(3, spatial_size, mode=4)((coords, feats, batch_size), metadata)
         return self.unet(x)
+
+    def prefetch(self, coords, spatial_size, batch_size=0):
+        """Build the index structures of a coming batch on the index stream (overlaps the current batch's kernels)."""
+        from .metadata import Metadata
+        return Metadata(3).prepare_async(spatial_size, coords, batch_size, 4, len(self.unet.channels), 3)

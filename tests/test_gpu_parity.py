@@ -318,3 +318,23 @@ def test_roi_no_boxes(gpu):
     nc, nf, inside = roi.roi_cut(coords, torch.ones(len(coords), 3).to(gpu), torch.zeros(0, 2, 3, dtype=torch.long),
                                  torch.zeros(0, dtype=torch.long))
     assert nc.shape == (0, 4) and nf.shape == (0, 3) and inside.shape == (0, len(coords))
+
+
+def test_index_prefetch_on_side_stream_is_equivalent(gpu):
+    """Metadata.prepare_async (index structures built one batch ahead on the index stream) gives the same tensors."""
+    from sparse_rcnn_amd.unet import Backbone
+    coords, size, batch = _cloud(31, grid=(32, 32, 16), n=2500, batch=2, dup=200)
+    feats = torch.randn(len(coords), 7, generator=torch.Generator().manual_seed(3)).to(gpu)
+    net = Backbone(7, (16, 24, 32)).to(gpu)
+    ref = net(coords, feats, size, batch).features
+    g = torch.randn_like(ref)
+    gr = torch.autograd.grad(ref, list(net.parameters()), g)
+    for _ in range(2):
+        md = net.prefetch(coords.to(gpu), size, batch)
+        out = net(coords.to(gpu), feats, size, batch, metadata=md).features
+        gp = torch.autograd.grad(out, list(net.parameters()), g)
+        assert torch.equal(out, ref)
+        for a, b in zip(gp, gr):
+            assert torch.equal(a, b)
+    with pytest.raises(_scn().ScnError):
+        net(coords[:-1].to(gpu), feats[:-1], size, batch, metadata=net.prefetch(coords.to(gpu), size, batch))

@@ -30,6 +30,15 @@ TARGET = 150_000
 PEAK_FP32_MATRIX_TFLOPS = 157.3          # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
 
+def _host_threads():
+    """Threads for the CPU baseline: the cores this process may use, capped at the 16-core share of a 1-GPU box."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
 def cpu_baseline(coords, feats):
     """The CPU restatement (oracle) of the same step -- SparseConvNet's CPU algorithm (hash -> rulebook; per offset
     gather -> sgemm -> scatter-add) -- timed on this box's host cores.  It is NOT the SparseConvNet binary (unavailable:
@@ -37,6 +46,7 @@ def cpu_baseline(coords, feats):
     from oracle import scn_oracle as O
     params = {k: v.requires_grad_() for k, v in O.init_unet_params(7, CHANNELS, seed=0).items()}
     c_np, f = coords.cpu().numpy(), feats.cpu()
+    torch.set_num_threads(_host_threads())
     t0 = time.perf_counter()
     scene = O.OracleScene(c_np)
     out = O.unet_forward(scene, f, params, CHANNELS)
@@ -64,11 +74,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    # one rank per GPU; SCN_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1 code path
+    backend = os.environ.get("SCN_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import sparse_rcnn_amd  # noqa: F401
@@ -135,6 +151,14 @@ def main():
         dom = max(ks, key=lambda k: ks[k]["ms"])
         d = ks[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        # HBM-side bytes per launch of the dominant kernel: rocprofv3 PMC passes cannot run inside this process; the
+        # figure comes from the committed separate passes (tools/collect_traffic.py -> profiles/r1_traffic.json)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+                traffic = json.load(f)["kernels"][dom]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "active-voxels/sec fwd+bwd, ScanNet U-Net backbone",
             "value": total_vox * args.steps / dt,
@@ -149,7 +173,9 @@ def main():
                                    "step = rulebooks + fwd + bwd (+ grad all-reduce + SGD)",
                        "parallelism": f"dp{world} (1 scene/GPU, flat-bucket all-reduce)"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_traffic.json)",
+                         "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                          "launches_per_step": d["launches"] / args.steps,
                          "avg_launch_us": d["ms"] * 1e3 / d["launches"],
                          "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9},

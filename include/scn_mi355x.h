@@ -185,6 +185,14 @@ int scn_wgrad_rules(const float* X, int cin, const float* dY, int cout, const in
                     const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, void* scratch,
                     int flags, scn_stream_t stream);
 
+/* Weight AND bias gradient in one pass: as scn_wgrad_rules, plus db[c] = sum over the rules of the offsets named in
+ * the bit mask db_offsets of dY[out_p][c].  The caller names offsets whose rule lists together contain every output row
+ * exactly once (centre offset of a submanifold conv: 1 << (k^3/2); all offsets of a Deconvolution; the identity list),
+ * so db equals the column sum of dY.  Channel counts must be multiples of 4 (otherwise SCN_EINVAL: use scn_colsum). */
+int scn_wgrad_bias_rules(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
+                         const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, float* db,
+                         uint32_t db_offsets, void* scratch, int flags, scn_stream_t stream);
+
 /* db[c] = sum_r dY[r][c]   (bias gradient of every conv-type layer).  scratch: SCN_COLSUM_BLOCKS*c floats. */
 #define SCN_COLSUM_BLOCKS 512
 int scn_colsum(const float* dY, int64_t n, int c, float* db, void* scratch, scn_stream_t stream);

@@ -42,7 +42,8 @@ template <int TW>
 __global__ __launch_bounds__(256) void k_wgrad_lds(const float* __restrict__ X, int cin, const float* __restrict__ dY,
                                                    int cout, const int* __restrict__ in_rows,
                                                    const int* __restrict__ out_rows, WgradPlan plan,
-                                                   float* __restrict__ slabs, int relu_in) {
+                                                   float* __restrict__ slabs, int relu_in,
+                                                   float* __restrict__ db_slabs, unsigned db_mask, int cout_pad) {
     constexpr int CB = 32 * TW;
     constexpr int NT = CB / 16;                      // tiles per block side
     constexpr int LD = CB + 4;                       // LDS row stride in floats
@@ -83,6 +84,12 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(const float* __restrict__ X, 
 
     int ri[PASSES], ro[PASSES], rin[PASSES], ron[PASSES];
     f32x4 vx[PASSES], vy[PASSES];
+    // Bias gradient for free: when the offsets in db_mask together name every output row exactly once (the centre
+    // offset of a submanifold conv, all 8 offsets of a Deconvolution, the identity list), db = sum of the dY rows this
+    // kernel stages anyway.  Workgroups of the first Cin-block add up the 16-byte pieces they write to LDS; the
+    // per-unit column sums go to db_slabs[unit][cout_pad] and k_wgrad_sum adds them in unit order.
+    const bool do_db = db_slabs != nullptr && ((db_mask >> o) & 1u) && bi == 0;
+    f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
 
 #define WG_LOAD_IDX(PC, RI, RO)                                                                      \
     _Pragma("unroll") for (int q = 0; q < PASSES; ++q) {                                             \
@@ -109,6 +116,7 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(const float* __restrict__ X, 
         if (RI[q] < 0) a_ = (f32x4){0.f, 0.f, 0.f, 0.f};                                             \
         if (RO[q] < 0) b_ = (f32x4){0.f, 0.f, 0.f, 0.f};                                             \
         if (relu_in) { _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) a_[e_] = fmaxf(a_[e_], 0.f); } \
+        if (do_db) dbacc += b_;                 /* bias gradient: column sums of dY, see below */      \
         float* xd_ = lds + (BUF) * 2 * OPND + (r_st + q * ROWS_PER_PASS) * LD + st_pos;              \
         float* yd_ = xd_ + OPND;                                                                     \
         _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                           \
@@ -158,6 +166,18 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(const float* __restrict__ X, 
 #undef WG_LOAD_ROWS
 #undef WG_STORE_ROWS
 
+    if (do_db) {        // reduce the per-thread pieces over the ROWS_PER_PASS threads that share a channel group (LDS reuse)
+        __syncthreads();
+        float* red = lds;
+        *(f32x4*)(red + r_st * CB + 4 * c4) = dbacc;
+        __syncthreads();
+        if (tid < CB) {
+            float t = 0.f;
+            for (int r = 0; r < ROWS_PER_PASS; ++r) t += red[r * CB + tid];
+            db_slabs[(long long)unit * cout_pad + co0 + tid] = t;
+        }
+    }
+
     // partial block -> slab [unit][block][CB][CB]  (row = channel of X, col = channel of dY)
     float* slab = slabs + ((long long)unit * (plan.nbi * plan.nbj) + blockIdx.z) * (CB * CB);
 #pragma unroll
@@ -175,12 +195,29 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(const float* __restrict__ X, 
 // dW[o][ci][co] = sum over the K-splits, fixed association: 4 interleaved partial sums (splits s, s+4, ...) per element
 // computed by 4 threads, combined through LDS in a fixed order.  64 elements x 4 split lanes per block.
 __global__ __launch_bounds__(256) void k_wgrad_sum(const float* __restrict__ slabs, WgradPlan plan, int cin, int cout,
-                                                   float* __restrict__ dW) {
+                                                   float* __restrict__ dW, const float* __restrict__ db_slabs,
+                                                   unsigned db_mask, int cout_pad, float* __restrict__ db, int main_blocks) {
+    if ((int)blockIdx.x >= main_blocks) {           // trailing blocks: bias gradient, one column each
+        const int co = blockIdx.x - main_blocks;
+        float s = 0.f;
+        for (int o = 0; o < plan.n_off; ++o) {
+            if (!((db_mask >> o) & 1u)) continue;
+            for (int u = plan.unit_start[o] + threadIdx.x; u < plan.unit_start[o + 1]; u += 256)
+                s += db_slabs[(long long)u * cout_pad + co];
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d);
+        __shared__ float w[4];
+        if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) db[co] = (w[0] + w[1]) + (w[2] + w[3]);
+        return;
+    }
     const long long total = (long long)plan.n_off * cin * cout;
     const int cb = plan.cb, nblk = plan.nbi * plan.nbj;
     const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
     __shared__ float part[4][64];
-    for (long long e0 = (long long)blockIdx.x * 64; e0 < total; e0 += (long long)gridDim.x * 64) {
+    for (long long e0 = (long long)blockIdx.x * 64; e0 < total; e0 += (long long)main_blocks * 64) {
         const long long e = e0 + el;
         float sum = 0.f;
         if (e < total) {
@@ -229,14 +266,33 @@ extern "C" int64_t scn_wgrad_scratch_bytes(int cin, int cout, const int64_t* pre
     if (!prefix_host || n_off < 1 || n_off > 32 || cin < 1 || cout < 1) return -1;
     WgradPlan pl;
     if (make_plan(cin, cout, prefix_host, n_off, pl) != SCN_OK) return -1;
-    const int64_t fast = (int64_t)pl.unit_start[n_off] * pl.nbi * pl.nbj * pl.cb * pl.cb * (int64_t)sizeof(float) + 256;
+    const int64_t fast = (int64_t)pl.unit_start[n_off] * ((int64_t)pl.nbi * pl.nbj * pl.cb * pl.cb + (int64_t)pl.nbj * pl.cb) *
+                             (int64_t)sizeof(float) + 512;
     const int64_t simple = scn::wgrad_simple_scratch_bytes(cin, cout, prefix_host, n_off);
     return fast > simple ? fast : simple;
 }
 
+static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
+                      const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, float* db,
+                      unsigned db_mask, void* scratch, int flags, scn_stream_t stream);
+
 extern "C" int scn_wgrad_rules(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
                                const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, void* scratch,
                                int flags, scn_stream_t stream) {
+    return wgrad_impl(X, cin, dY, cout, in_rows, out_rows, prefix_host, n_off, dW, nullptr, 0u, scratch, flags, stream);
+}
+
+extern "C" int scn_wgrad_bias_rules(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
+                                    const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, float* db,
+                                    uint32_t db_offsets, void* scratch, int flags, scn_stream_t stream) {
+    SCN_REQUIRE(db && db_offsets);
+    return wgrad_impl(X, cin, dY, cout, in_rows, out_rows, prefix_host, n_off, dW, db, db_offsets, scratch, flags,
+                      stream);
+}
+
+static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
+                      const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, float* db,
+                      unsigned db_mask, void* scratch, int flags, scn_stream_t stream) {
     SCN_REQUIRE(prefix_host && n_off >= 1 && n_off <= 32 && cin >= 1 && cout >= 1 && dW && scratch);
     SCN_REQUIRE((in_rows == nullptr) == (out_rows == nullptr));
     SCN_REQUIRE(in_rows || n_off == 1);
@@ -247,12 +303,20 @@ extern "C" int scn_wgrad_rules(const float* X, int cin, const float* dY, int cou
     // 16-byte row pieces need 16-byte aligned rows; otherwise fall back to a channel count the loads can take
     SCN_REQUIRE((((uintptr_t)X | (uintptr_t)dY) & 3) == 0);
     const bool aligned = (cin % 4 == 0) && (cout % 4 == 0) && ((((uintptr_t)X | (uintptr_t)dY) & 15) == 0);
-    if (!aligned)
-        return scn::wgrad_simple(X, cin, dY, cout, in_rows, out_rows, prefix_host, n_off, dW, scratch, flags, stream);
+    if (!aligned) {
+        int rc = scn::wgrad_simple(X, cin, dY, cout, in_rows, out_rows, prefix_host, n_off, dW, scratch, flags, stream);
+        if (rc == SCN_OK && db)
+            return scn::fail(SCN_EINVAL, "%sscn_wgrad_bias_rules needs channel counts that are multiples of 4 "
+                                         "(use scn_wgrad_rules + scn_colsum)", "");
+        return rc;
+    }
     if (pl.unit_start[n_off] == 0) {
         SCN_HIP(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)n_off * cin * cout, S(stream)));
+        if (db) SCN_HIP(hipMemsetAsync(db, 0, sizeof(float) * (size_t)cout, S(stream)));
         return SCN_OK;
     }
+    const int cout_pad = pl.nbj * pl.cb;
+    float* db_slabs = db ? (float*)scratch + (int64_t)pl.unit_start[n_off] * pl.nbi * pl.nbj * pl.cb * pl.cb : nullptr;
     dim3 grid((unsigned)pl.unit_start[n_off], 1, (unsigned)(pl.nbi * pl.nbj));
     const int relu_in = (flags & SCN_F_RELU_IN) ? 1 : 0;
 #define LAUNCH_WG(TW_)                                                                                      \
@@ -265,15 +329,17 @@ extern "C" int scn_wgrad_rules(const float* X, int cin, const float* dY, int cou
             attr_set = true;                                                                                    \
         }                                                                                                       \
         hipLaunchKernelGGL(k_wgrad_lds<TW_>, grid, dim3(256), lds_, S(stream), X, cin, dY, cout, in_rows, out_rows, \
-                           pl, (float*)scratch, relu_in);                                                       \
+                           pl, (float*)scratch, relu_in, db_slabs, db_mask, cout_pad);                          \
     } while (0)
     if (pl.cb == 128) LAUNCH_WG(4);
     else if (pl.cb == 64) LAUNCH_WG(2);
     else LAUNCH_WG(1);
 #undef LAUNCH_WG
     SCN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_wgrad_sum, dim3(scn::ew_grid((int64_t)n_off * cin * cout, 64)), dim3(256), 0, S(stream),
-                       (const float*)scratch, pl, cin, cout, dW);
+    const int main_blocks = scn::ew_grid((int64_t)n_off * cin * cout, 64);
+    hipLaunchKernelGGL(k_wgrad_sum, dim3(main_blocks + (db ? cout : 0)), dim3(256), 0, S(stream),
+                       (const float*)scratch, pl, cin, cout, dW, (const float*)db_slabs, db_mask, cout_pad, db,
+                       main_blocks);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }

@@ -100,6 +100,26 @@ def wgrad_rules(X, dY, in_rows, out_rows, prefix_host, n_off, flags=0):
     return dW
 
 
+def wgrad_bias_rules(X, dY, in_rows, out_rows, prefix_host, n_off, db_offsets, flags=0):
+    """dW and db in one pass (scn_wgrad_bias_rules); falls back to wgrad_rules + colsum for channel counts the fused
+    kernel cannot take."""
+    cin, cout = X.shape[1], dY.shape[1]
+    if cin % 4 or cout % 4 or (X.data_ptr() | dY.data_ptr()) & 15:
+        return wgrad_rules(X, dY, in_rows, out_rows, prefix_host, n_off, flags), colsum(dY)
+    lib = L.lib()
+    nbytes = lib.scn_wgrad_scratch_bytes(cin, cout, prefix_host, n_off)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=X.device)
+    dW, db = _new((n_off, cin, cout), X), _new((cout,), X)
+    P = int(prefix_host[n_off] - prefix_host[0])
+
+    def run():
+        L.check(lib.scn_wgrad_bias_rules(L.ptr(X), cin, L.ptr(dY), cout, L.ptr(in_rows), L.ptr(out_rows), prefix_host,
+                                         n_off, L.ptr(dW), L.ptr(db), db_offsets, L.ptr(scratch), flags, L.stream()))
+    profiling.timed("k_wgrad_rules", 2.0 * P * cin * cout,
+                    4.0 * (X.shape[0] * cin + dY.shape[0] * cout + n_off * cin * cout) + 8.0 * P, run)
+    return dW, db
+
+
 def colsum(dY):
     lib = L.lib()
     c = dY.shape[1]
@@ -198,14 +218,16 @@ class SubmanifoldConvolutionFunction(torch.autograd.Function):
                                 n_rules=rb.rules.total if rb.rules is not None else rb.n)
         def leaves():
             dW = db = None
+            want_b = ctx.has_bias and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
-                if rb.k == 1:
-                    dW = wgrad_rules(X, dY, None, None, _identity_prefix(rb.n), 1, fl)
+                ir, orr = (None, None) if rb.k == 1 else (rb.rules.in_rows, rb.rules.out_rows)
+                ph = _identity_prefix(rb.n) if rb.k == 1 else rb.rules.prefix_host
+                if want_b:      # the centre offset lists every row once: bias gradient from the same pass
+                    dW, db = wgrad_bias_rules(X, dY, ir, orr, ph, n_off, 1 << (n_off // 2), fl)
                 else:
-                    r = rb.rules
-                    dW = wgrad_rules(X, dY, r.in_rows, r.out_rows, r.prefix_host, n_off, fl)
+                    dW = wgrad_rules(X, dY, ir, orr, ph, n_off, fl)
                 dW = dW.view_as(W)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
+            elif want_b:
                 db = colsum(dY)
             return dW, db
         dW, db = _on_leaf_stream(dY, leaves)
@@ -288,9 +310,14 @@ class DeconvolutionFunction(torch.autograd.Function):
                                 relu_mask=X if ctx.relu_in else None, n_rules=rb.n_fine)
         def leaves():
             dW = db = None
+            want_b = ctx.has_bias and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
-                dW = wgrad_rules(X, dY, r.out_rows, r.in_rows, r.prefix_host, 8, fl).view_as(W)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
+                if want_b:      # every fine (output) row occurs in exactly one of the 8 rule lists
+                    dW, db = wgrad_bias_rules(X, dY, r.out_rows, r.in_rows, r.prefix_host, 8, 0xFF, fl)
+                else:
+                    dW = wgrad_rules(X, dY, r.out_rows, r.in_rows, r.prefix_host, 8, fl)
+                dW = dW.view_as(W)
+            elif want_b:
                 db = colsum(dY)
             return dW, db
         dW, db = _on_leaf_stream(dY, leaves)
@@ -321,9 +348,14 @@ class NetworkInNetworkFunction(torch.autograd.Function):
             dX = gemm_table(dY, None, 1, n, W, None, X.shape[1], L.F_W_TRANSPOSED)
         def leaves():
             dW = db = None
+            want_b = ctx.has_bias and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
-                dW = wgrad_rules(X, dY, None, None, _identity_prefix(n), 1).view_as(W)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
+                if want_b:
+                    dW, db = wgrad_bias_rules(X, dY, None, None, _identity_prefix(n), 1, 1)
+                else:
+                    dW = wgrad_rules(X, dY, None, None, _identity_prefix(n), 1)
+                dW = dW.view_as(W)
+            elif want_b:
                 db = colsum(dY)
             return dW, db
         dW, db = _on_leaf_stream(dY, leaves)

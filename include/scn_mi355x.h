@@ -235,6 +235,13 @@ int scn_sparse_to_dense_fwd(const float* X, const int32_t* coords, int64_t n, in
 int scn_sparse_to_dense_bwd(const float* dOut, const int32_t* coords, int64_t n, int c, const int64_t* size3_host,
                             float* dX, scn_stream_t stream);
 
+/* scn.MaxPooling / scn.AveragePooling with pool_size = pool_stride = 2 (module_factory.py:315-354), on the child /
+ * parent tables of the strided rulebook.  max: Y[c] = max(0, existing children); avg: Y[c] = sum(existing children) / 8. */
+int scn_pool_fwd(const float* X, const int32_t* child, int64_t n_coarse, int c, int average, float* Y,
+                 scn_stream_t stream);
+int scn_pool_bwd(const float* X, const float* Y, const float* dY, const int32_t* parent, int64_t n_fine, int c,
+                 int average, float* dX, scn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

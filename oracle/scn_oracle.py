@@ -280,6 +280,22 @@ def batchnorm_relu_fwd(X, gamma, beta, running_mean, running_var, eps=1e-4, mome
     return torch.where(y > 0, y, y * leak)
 
 
+def pool_fwd(X, child, average):
+    """MaxPooling / AveragePooling 2^3 stride 2 on the child table [8, Nc] ([UPSTREAM-SCN]):
+    max: zero-initialised output, max over existing children;  avg: sum over existing children / 8."""
+    nc = child.shape[1]
+    Y = torch.zeros(nc, X.shape[1], dtype=X.dtype)
+    for o in range(8):
+        rows = np.nonzero(child[o] >= 0)[0]
+        if len(rows):
+            src = X[_t(child[o][rows])]
+            if average:
+                Y.index_add_(0, _t(rows), src / 8.0)
+            else:
+                Y[_t(rows)] = torch.maximum(Y[_t(rows)], src)
+    return Y
+
+
 def sparse_to_dense(X, coords, spatial_size, batch_size):
     """A13: zeros [B,C,X,Y,Z]; out[b,:,x,y,z] = X[row]."""
     sx, sy, sz = (int(v) for v in spatial_size)

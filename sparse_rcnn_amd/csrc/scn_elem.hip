@@ -416,3 +416,60 @@ extern "C" int scn_bn_bwd(const float* X, const float* dY, int64_t n, int c, con
     }
     return SCN_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// MaxPooling / AveragePooling, pool_size = pool_stride = 2 (module_factory.py:315-354), on the strided rulebook.
+//   max: Y[c] = max(0, max over existing children)   (output zero-initialised, as the upstream CPU path does)
+//   avg: Y[c] = (sum over existing children) / 8     (inactive children count as zeros, like the dense twin)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pool_fwd(const float* __restrict__ X, const int* __restrict__ child, long long n_coarse, int c,
+                           int avg, float* __restrict__ Y) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n_coarse * c;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / c;
+        const int ch = (int)(i - r * c);
+        float acc = 0.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const int f = child[(long long)o * n_coarse + r];
+            if (f >= 0) {
+                const float v = X[(long long)f * c + ch];
+                acc = avg ? acc + v : fmaxf(acc, v);
+            }
+        }
+        Y[i] = avg ? acc * 0.125f : acc;
+    }
+}
+
+__global__ void k_pool_bwd(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ dY,
+                           const int* __restrict__ parent, long long n_fine, int c, int avg, float* __restrict__ dX) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n_fine * c;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long f = i / c;
+        const int ch = (int)(i - f * c);
+        const long long o = (long long)parent[f] * c + ch;
+        dX[i] = avg ? dY[o] * 0.125f : (X[i] == Y[o] ? dY[o] : 0.f);
+    }
+}
+
+extern "C" int scn_pool_fwd(const float* X, const int32_t* child, int64_t n_coarse, int c, int average, float* Y,
+                            scn_stream_t stream) {
+    SCN_REQUIRE(n_coarse >= 0 && c >= 1);
+    if (n_coarse == 0) return SCN_OK;
+    SCN_REQUIRE(X && child && Y);
+    hipLaunchKernelGGL(k_pool_fwd, dim3(scn::ew_grid(n_coarse * c, 256)), dim3(256), 0, S(stream), X, child,
+                       (long long)n_coarse, c, average, Y);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+extern "C" int scn_pool_bwd(const float* X, const float* Y, const float* dY, const int32_t* parent, int64_t n_fine, int c,
+                            int average, float* dX, scn_stream_t stream) {
+    SCN_REQUIRE(n_fine >= 0 && c >= 1);
+    if (n_fine == 0) return SCN_OK;
+    SCN_REQUIRE(X && Y && dY && parent && dX);
+    hipLaunchKernelGGL(k_pool_bwd, dim3(scn::ew_grid(n_fine * c, 256)), dim3(256), 0, S(stream), X, Y, dY, parent,
+                       (long long)n_fine, c, average, dX);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}

@@ -533,3 +533,28 @@ class SparseToDenseFunction(torch.autograd.Function):
         hs[0], hs[1], hs[2] = ctx.size
         L.check(L.lib().scn_sparse_to_dense_bwd(L.ptr(dOut), L.ptr(ctx.g.coords), n, c, hs, L.ptr(dX), L.stream()))
         return dX, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
+# MaxPooling / AveragePooling 2^3 stride 2 (module_factory.py:315-354)
+# ------------------------------------------------------------------------------------------------------
+class PoolingFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, metadata: Metadata, in_size, average):
+        X = _f32(features)
+        rb = metadata.strided_rulebook(in_size)
+        c = X.shape[1]
+        Y = _new((rb.n_coarse, c), X)
+        L.check(L.lib().scn_pool_fwd(L.ptr(X), L.ptr(rb.child), rb.n_coarse, c, int(average), L.ptr(Y), L.stream()))
+        ctx.save_for_backward(X, Y)
+        ctx.rb, ctx.average = rb, int(average)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        X, Y = ctx.saved_tensors
+        dY = _f32(dY)
+        dX = torch.empty_like(X)
+        L.check(L.lib().scn_pool_bwd(L.ptr(X), L.ptr(Y), L.ptr(dY), L.ptr(ctx.rb.parent), X.shape[0], X.shape[1],
+                                     ctx.average, L.ptr(dX), L.stream()))
+        return dX, None, None, None

@@ -244,18 +244,28 @@ class SparseToDense(Module):
         return F.SparseToDenseFunction.apply(input.features, input.metadata, input.spatial_size)
 
 
-class _PoolingNotBuilt(Module):
-    """scn.MaxPooling / scn.AveragePooling (module_factory.py:315-354) serve the sparse class network only --
-    SURVEY.md §8f row N1 ("next"); constructing one says so instead of silently computing something else."""
+class _Pooling(Module):
+    AVERAGE = False
 
     def __init__(self, dimension, pool_size, pool_stride, nFeaturesToDrop=0):
         super().__init__()
-        raise NotImplementedError(f"{type(self).__name__}: next-tier component (SURVEY.md §8f N1), not on the hot path")
+        if int(dimension) != 3:
+            raise NotImplementedError("only dimension 3")
+        ps, st = _triple(pool_size, "pool_size"), _triple(pool_stride, "pool_stride")
+        if ps != (2, 2, 2) or st != (2, 2, 2) or nFeaturesToDrop:
+            raise NotImplementedError("only pool_size = pool_stride = 2 (the reference's down-poolings, "
+                                      "module_factory.py:315-354)")
+
+    def forward(self, input):
+        in_size = tuple(int(s) for s in input.spatial_size)
+        y = F.PoolingFunction.apply(input.features, input.metadata, in_size, self.AVERAGE)
+        return _out(input, y, torch.as_tensor([s // 2 for s in in_size], dtype=torch.long))
 
 
-class MaxPooling(_PoolingNotBuilt):
-    pass
+class MaxPooling(_Pooling):
+    """``scn.MaxPooling(dimension, pool_size, pool_stride)`` (module_factory.py:326-327): max(0, active children)."""
 
 
-class AveragePooling(_PoolingNotBuilt):
-    pass
+class AveragePooling(_Pooling):
+    """``scn.AveragePooling(dimension, pool_size, pool_stride)`` (module_factory.py:347-348): sum(active children) / 8."""
+    AVERAGE = True

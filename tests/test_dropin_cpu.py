@@ -39,8 +39,9 @@ def test_surface_matches_the_reference_call_sites():
     assert len(seq) == 3
     with pytest.raises(NotImplementedError):
         scn.Convolution(3, 4, 4, (3, 3, 3), (2, 2, 2), True)
+    scn.MaxPooling(3, pool_size=st, pool_stride=st); scn.AveragePooling(3, pool_size=st, pool_stride=st)
     with pytest.raises(NotImplementedError):
-        scn.MaxPooling(3, 2, 2)                       # next tier, says so loudly
+        scn.MaxPooling(3, 3, 2)
     with pytest.raises(NotImplementedError):
         scn.SubmanifoldConvolution(3, 4, 4, 3, True, groups=2)
 

@@ -338,3 +338,72 @@ def test_index_prefetch_on_side_stream_is_equivalent(gpu):
             assert torch.equal(a, b)
     with pytest.raises(_scn().ScnError):
         net(coords[:-1].to(gpu), feats[:-1], size, batch, metadata=net.prefetch(coords.to(gpu), size, batch))
+
+
+@pytest.mark.parametrize("average", [False, True])
+def test_pooling(gpu, average):
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=8, cin=6)
+    pool = (scn.AveragePooling if average else scn.MaxPooling)(3, (2, 2, 2), (2, 2, 2))
+    y = pool(x)
+    assert tuple(int(s) for s in y.spatial_size) == tuple(int(s) // 2 for s in size)
+    scene.strided_rules(0)
+    child = scene.strided[0]["child"]
+    Xo = O.input_layer_fwd(feats, scene.prow, scene.n(0), 4).requires_grad_()
+    yo = O.pool_fwd(Xo, child, average)
+    _close(y.features, yo, 1e-6, "pool fwd")
+    # dense twin (module_factory.py:330-332,351-353) where it is defined the same way: average pooling of the zero-filled grid
+    if average:
+        import torch.nn.functional as Fn
+        dense = O.sparse_to_dense(Xo.detach(), scene.coords0, size.tolist(), 2)
+        dd = Fn.avg_pool3d(dense, 2, 2)
+        c = torch.from_numpy(scene.strided[0]["coords"])
+        _close(y.features, dd[c[:, 3], :, c[:, 0], c[:, 1], c[:, 2]], 1e-6, "dense avg twin")
+    g = torch.randn(yo.shape, generator=torch.Generator().manual_seed(4))
+    (gx,) = torch.autograd.grad(y.features, x.features, g.to(gpu))
+    (ox,) = torch.autograd.grad(yo, Xo, g)
+    _close(gx, ox, 1e-6, "pool bwd")
+
+
+def test_mask_head_path_matches_oracle(gpu):
+    """BASELINE config 3 shape in fp32: backbone features -> per-point features (OutputLayer) ++ raw point features ->
+    sparse ROI crop (mode-4 re-voxelisation, batch_size = #boxes, spatial size + 32) -> internal U-Net on the ROI batch
+    -> per-point logits (model.py:583-596,758-782; roi_select_sparse.py:38-52,74-84)."""
+    from sparse_rcnn_amd import roi
+    from sparse_rcnn_amd.synthetic import make_boxes
+    from sparse_rcnn_amd.unet import Backbone, SparseUNet
+    scn = _scn()
+    coords, size, batch = _cloud(41, grid=(32, 32, 16), n=2500, batch=2, dup=300)
+    raw = torch.randn(len(coords), 7, generator=torch.Generator().manual_seed(1))
+    bparams = O.init_unet_params(7, (16, 24), seed=2)
+    mparams = O.init_unet_params(16 + 7, (24, 32), seed=3)
+    backbone = Backbone(7, (16, 24)).to(gpu); backbone.unet.load_oracle_params(bparams)
+    mask_unet = SparseUNet(23, (24, 32)).to(gpu); mask_unet.load_oracle_params(mparams)
+    head = torch.nn.Linear(24, 5).to(gpu)
+    bbox_batch = make_boxes(coords, n_boxes=6, seed=5, lo=4, hi=24)
+    # --- HIP path
+    raw_g = raw.to(gpu).requires_grad_()
+    fmap = backbone(coords, raw_g, size, batch)
+    per_point = scn.OutputLayer(3)(fmap)                                     # [Npts, 16]
+    cat = torch.cat([per_point, raw_g], 1)                                   # [Npts, 23]
+    roi_tensor, (is_inside, counts, _) = roi.SparseRoiCut(spatial_size_offset=32)((coords, cat, size, batch, [0]), bbox_batch)
+    assert roi_tensor.batch_size() == 12
+    logits = head(scn.OutputLayer(3)(mask_unet(roi_tensor)))                 # one row per cropped point
+    # --- oracle
+    scene = O.OracleScene(coords.numpy())
+    raw_o = raw.clone().requires_grad_()
+    bp = {k: v.clone() for k, v in bparams.items()}
+    f_o = O.unet_forward(scene, raw_o, bp, (16, 24))
+    cat_o = torch.cat([O.output_layer_fwd(f_o, scene.prow), raw_o], 1)
+    boxes, cnt, assoc = O.transform_boxes([b.numpy() for b in bbox_batch])
+    src, box_of, inside = O.roi_crop(coords.numpy(), boxes, assoc)
+    assert np.array_equal(is_inside.numpy(), inside) and counts == cnt
+    new_coords = np.concatenate([coords.numpy()[src][:, :3], box_of[:, None]], 1)
+    rscene = O.OracleScene(new_coords)
+    mp = {k: v.clone() for k, v in mparams.items()}
+    m_o = O.unet_forward(rscene, cat_o[torch.from_numpy(src)], mp, (24, 32))
+    logits_o = O.output_layer_fwd(m_o, rscene.prow) @ head.weight.detach().cpu().t() + head.bias.detach().cpu()
+    _close(logits, logits_o, 2e-4, "mask logits")
+    g = torch.randn(logits_o.shape, generator=torch.Generator().manual_seed(7))
+    logits.backward(g.to(gpu))
+    logits_o.backward(g)
+    _close(raw_g.grad, raw_o.grad, 5e-4, "d raw features through ROI crop + both U-Nets")

@@ -123,21 +123,35 @@ def main():
         flat.all_reduce_mean()
         flat.sgd_step(1e-6)
 
-    for _ in range(args.warmup):
+    # Kernel timing: HIP events around the launches of the GEMM kernels on at most 4-5 steps spread over the timed
+    # region, from a pool of events created before it.  Timing every launch made the step host-bound (8.9 -> 9.8-12.5
+    # ms/step), and more than ~2k outstanding timing events slow the HIP runtime itself (profiling.py).
+    every = max(4, (args.steps + 3) // 4)
+    timer = profiling.KernelTimer(every=every)
+    for w in range(args.warmup):
+        if w == args.warmup - 1:                    # count the launches of one step to size the event pool
+            timer.count_only = True
+            profiling.TIMER = timer
         step()
-    timer = profiling.KernelTimer()
-    profiling.TIMER = timer
+    profiling.TIMER = None
+    timer.count_only = False
+    timer.reserve(2 * max(timer.count, 128) * ((args.steps + every - 1) // every))
+    use_timer = not os.environ.get("SCN_BENCH_NO_TIMER")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        if use_timer:
+            timer.begin_step()
+            profiling.TIMER = timer if timer.active else None
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     profiling.TIMER = None
+    sampled = max(1, timer.sampled_steps)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     vox = torch.tensor([float(n_active)], dtype=torch.float64, device=dev)
@@ -148,6 +162,11 @@ def main():
 
     if rank == 0:
         ks = timer.summary()
+        if not ks:                                   # SCN_BENCH_NO_TIMER (developer switch): wall clock only
+            print(json.dumps({"ms_per_step": dt / args.steps * 1e3, "value": total_vox * args.steps / dt}), flush=True)
+            if world > 1:
+                dist.destroy_process_group()
+            return
         dom = max(ks, key=lambda k: ks[k]["ms"])
         d = ks[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -176,10 +195,10 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
                          "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_traffic.json)",
                          "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
-                         "launches_per_step": d["launches"] / args.steps,
+                         "launches_per_step": d["launches"] / sampled, "sampled_steps": sampled,
                          "avg_launch_us": d["ms"] * 1e3 / d["launches"],
                          "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9},
-            "kernels": {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
+            "kernels": {k: {"ms_per_step": v["ms"] / sampled, "launches_per_step": v["launches"] / sampled,
                             "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else None}
                         for k, v in ks.items()},
         }

@@ -184,16 +184,20 @@ def _identity_prefix(n):
 # ------------------------------------------------------------------------------------------------------
 class SubmanifoldConvolutionFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, features, weight, bias, metadata: Metadata, spatial_size, k, relu_in=False):
+    def forward(ctx, features, weight, bias, metadata: Metadata, spatial_size, k, relu_in=False, residual=None):
+        """residual (optional, [N, Cout]): added in the kernel epilogue -- the AddTable of a residual block fused
+        (module_factory.py:51-57: Sequential(ConcatTable(Identity, inner), AddTable))."""
         X, W = _f32(features), _f32(weight)
         rb = metadata.subm_rulebook(spatial_size, k)
         n_off = k ** 3
         cout = W.shape[-1]
         b = _f32(bias) if bias is not None else None
+        R = _f32(residual) if residual is not None else None
         if USE_CONV_OS and rb.rules is not None:
-            Y = conv_rules(X, rb.tiles, rb.n, W, b, cout, L.F_RELU_IN if relu_in else 0, n_rules=rb.rules.total)
+            Y = conv_rules(X, rb.tiles, rb.n, W, b, cout, L.F_RELU_IN if relu_in else 0, residual=R,
+                           n_rules=rb.rules.total)
         else:
-            Y = gemm_table(X, rb.table, n_off, rb.n, W, b, cout, L.F_RELU_IN if relu_in else 0,
+            Y = gemm_table(X, rb.table, n_off, rb.n, W, b, cout, L.F_RELU_IN if relu_in else 0, residual=R,
                            n_rules=rb.rules.total if rb.rules is not None else rb.n)
         ctx.save_for_backward(X, W)
         ctx.rb, ctx.has_bias, ctx.relu_in = rb, bias is not None, relu_in
@@ -231,7 +235,8 @@ class SubmanifoldConvolutionFunction(torch.autograd.Function):
                 db = colsum(dY)
             return dW, db
         dW, db = _on_leaf_stream(dY, leaves)
-        return dX, dW, db, None, None, None, None
+        dR = dY if (len(ctx.needs_input_grad) > 7 and ctx.needs_input_grad[7]) else None
+        return dX, dW, db, None, None, None, None, dR
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -40,22 +40,47 @@ class Sequential(torch.nn.Sequential):
     def add(self, module):
         return self.append(module)
 
-    def forward(self, input):
+    def forward(self, input, residual=None):
+        """residual: features to add to the output of the LAST module when that is a SubmanifoldConvolution (used by
+        the residual-block peephole below)."""
         mods = list(self._modules.values())
         i = 0
         while i < len(mods):
             m = mods[i]
+            # residual block  Sequential(ConcatTable(Identity, inner), AddTable): the add runs in inner's last conv
+            if (FUSE_ADD and type(m) is ConcatTable and i + 1 < len(mods) and type(mods[i + 1]) is AddTable
+                    and len(m._modules) == 2):
+                a, inner = list(m._modules.values())
+                if type(a) is Identity and type(inner) is Sequential and inner._ends_with_subm():
+                    input = inner(input, residual=input.features)
+                    i += 2
+                    continue
+            last = residual is not None and (i == len(mods) - 1 or (i == len(mods) - 2 and type(m) is ReLU))
             if (FUSE_RELU and type(m) is ReLU and i + 1 < len(mods)
                     and isinstance(mods[i + 1], (SubmanifoldConvolution, Convolution, Deconvolution))):
-                input = mods[i + 1](input, relu_in=True)
+                nxt = mods[i + 1]
+                if last and isinstance(nxt, SubmanifoldConvolution):
+                    input = nxt(input, relu_in=True, residual=residual)
+                else:
+                    input = nxt(input, relu_in=True)
                 i += 2
             else:
-                input = m(input)
+                if last and isinstance(m, SubmanifoldConvolution):
+                    input = m(input, residual=residual)
+                else:
+                    input = m(input)
                 i += 1
         return input
 
+    def _ends_with_subm(self):
+        mods = list(self._modules.values())
+        return bool(mods) and isinstance(mods[-1], SubmanifoldConvolution)
+
+
+import os as _os
 
 FUSE_RELU = True
+FUSE_ADD = _os.environ.get("SCN_FUSE_ADD", "1") != "0"     # developer switch (tools/ab_bench.py)
 
 
 class ConcatTable(Sequential):
@@ -155,9 +180,9 @@ class SubmanifoldConvolution(_ConvBase):
         self.dimension, self.filter_size = 3, fs[0]
         self._init(self.filter_size ** 3, nIn, nOut, bias)
 
-    def forward(self, input, relu_in=False):
+    def forward(self, input, relu_in=False, residual=None):
         y = F.SubmanifoldConvolutionFunction.apply(input.features, self.weight, self.bias, input.metadata,
-                                                   input.spatial_size, self.filter_size, relu_in)
+                                                   input.spatial_size, self.filter_size, relu_in, residual)
         return _out(input, y)
 
     def extra_repr(self):

@@ -245,7 +245,7 @@ static int make_seg_chunks(int cin, int cout, const int64_t* prefix_host, int n_
     const int64_t total = prefix_host[n_off] - prefix_host[0];
     int64_t chunk = cdiv(total * tiles, 4096);
     chunk = cdiv(chunk, 64) * 64;
-    if (chunk < 256) chunk = 256;
+    if (chunk < 64) chunk = 64;
     sc.chunk = chunk;
     sc.n_off = n_off;
     sc.rule_start[0] = prefix_host[0];
@@ -314,12 +314,13 @@ __global__ __launch_bounds__(256) void k_wgrad_rules(const float* __restrict__ X
     for (int v = 0; v < 16; ++v) slab[v * 64 + lane] = acc[v];
 }
 
-// dW[o][ci][co] = sum over the offset's chunks, ascending
+// dW[o][ci][co] = sum over the offset's chunks.  One wave per element: lane l adds chunks l, l+64, ... in ascending
+// order, then a fixed butterfly over the lanes -- the summation tree depends only on the chunk count (deterministic).
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slabs, SegChunks sc, int cin, int cout,
                                                       int tiles_n, int tiles, float* __restrict__ dW) {
     const long long total = (long long)sc.n_off * cin * cout;
-    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
-         e += (long long)gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x & 63;
+    for (long long e = blockIdx.x * 4ll + (threadIdx.x >> 6); e < total; e += (long long)gridDim.x * 4) {
         const int co = (int)(e % cout);
         const int ci = (int)((e / cout) % cin);
         const int o = (int)(e / ((long long)cin * cout));
@@ -329,9 +330,11 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
         const int hh = (i >> 2) & 1, v = (i & 3) + 4 * (i >> 3);
         const int slot = v * 64 + hh * 32 + j;
         float s = 0.f;
-        for (long long c = sc.chunk_start[o]; c < sc.chunk_start[o + 1]; ++c)
+        for (long long c = sc.chunk_start[o] + lane; c < sc.chunk_start[o + 1]; c += 64)
             s += slabs[(c * tiles + tile) * 1024 + slot];
-        dW[e] = s;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+        if (lane == 0) dW[e] = s;
     }
 }
 
@@ -353,7 +356,7 @@ int scn::wgrad_simple(const float* X, int cin, const float* dY, int cout, const 
                            cin, dY, cout, in_rows, out_rows, sc, (float*)scratch, tiles_n, flags);
         SCN_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(scn::ew_grid((int64_t)n_off * cin * cout, 256)), dim3(256), 0, S(stream),
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(scn::ew_grid((int64_t)n_off * cin * cout, 4)), dim3(256), 0, S(stream),
                        (const float*)scratch, sc, cin, cout, tiles_n, tiles, dW);
     SCN_LAUNCH_CHECK();
     return SCN_OK;

@@ -66,7 +66,9 @@ int64_t scn_hash_capacity(int64_t n);
 
 /* int64 [n][4] coords (x,y,z,batch) as the reference hands them over (ndsis/data/data.py:95-98, consumed at
  * custom_operations.py:72-80) -> int32 [n][4].  *bad_host receives the number of rows with a field outside
- * [0,65535] (synchronises stream); such input is rejected with SCN_EHASH. */
+ * [0,65535] (synchronises stream); such input is rejected with SCN_EHASH.  bad_host == NULL: asynchronous form --
+ * nothing is copied back and the stream is not synchronised; *scratch1 (device) holds the count once the stream gets
+ * there and the caller checks it behind its own event. */
 int scn_coords_to_i32(const int64_t* coords, int64_t n, int32_t* out, int32_t* scratch1, int64_t* bad_host,
                       scn_stream_t stream);
 
@@ -86,6 +88,12 @@ int scn_dedup_build(const int32_t* coords, int64_t n, int shift, uint64_t* table
                     int64_t cap, int32_t* item_row, int32_t* row_count, int32_t* row_first, int32_t* row_coords,
                     void* scratch, int64_t* n_rows_host, scn_stream_t stream);
 
+/* scn_dedup_build without the host synchronisation: the row count goes to n_rows_dev (device int64[1]) in stream
+ * order; the caller copies it back behind its own event and may queue work that does not need it meanwhile. */
+int scn_dedup_launch(const int32_t* coords, int64_t n, int shift, uint64_t* table_keys, int32_t* table_rows,
+                    int64_t cap, int32_t* item_row, int32_t* row_count, int32_t* row_first, int32_t* row_coords,
+                    void* scratch, int64_t* n_rows_dev, scn_stream_t stream);
+
 /* Submanifold neighbour table for filter k (odd; reference uses 1 and 3: module_factory.py:383-385,404-406):
  * table[o][r] = row of coords[r] + delta_o or -1, o = ((dx+h)k + (dy+h))k + (dz+h). */
 int scn_subm_table(const int32_t* coords, int64_t n, const uint64_t* table_keys, const int32_t* table_rows,
@@ -98,7 +106,9 @@ int scn_child_table(const int32_t* fine_coords, const int32_t* parent, int64_t n
 
 /* Compaction of a rule table into (in,out) pairs -- wave ballot + prefix sum.
  * Phase 1: counts; block_sums must hold scn_rules_blocks(n_off, n_out) int32; writes prefix (device, int64[n_off+1])
- * and copies it to prefix_host (synchronises stream once). */
+ * and copies it to prefix_host (synchronises stream once).  prefix_host == NULL: asynchronous form -- no copy, no
+ * synchronisation; the caller reads `prefix` back when it needs the sizes (the forward pass never does: only
+ * scn_wgrad_rules / scn_gemm_rules take compacted rules). */
 int64_t scn_rules_blocks(int n_off, int64_t n_out);
 int scn_rules_scan(const int32_t* table, int n_off, int64_t n_out, int32_t* block_sums, int64_t* prefix,
                    int64_t* prefix_host, scn_stream_t stream);

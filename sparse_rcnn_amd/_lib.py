@@ -25,6 +25,7 @@ _SIGS = {
     "scn_coords_to_i32": (C.c_int, [p, i64, p, p, C.POINTER(i64), p]),
     "scn_dedup_scratch_bytes": (i64, [i64]),
     "scn_dedup_build": (C.c_int, [p, i64, i32, p, p, i64, p, p, p, p, p, C.POINTER(i64), p]),
+    "scn_dedup_launch": (C.c_int, [p, i64, i32, p, p, i64, p, p, p, p, p, p, p]),
     "scn_subm_table": (C.c_int, [p, i64, p, p, i64, i32, p, p]),
     "scn_child_table": (C.c_int, [p, p, i64, i64, p, p, p]),
     "scn_rules_blocks": (i64, [i32, i64]),
@@ -66,6 +67,7 @@ _SIGS = {
 EXPORTS = tuple(_SIGS)
 
 F_RELU_IN, F_W_TRANSPOSED, F_OFF_REVERSE = 1, 2, 4
+OK, EINVAL, ESIZE, EHASH, EHIP = 0, 1, 2, 3, 4
 COLSUM_BLOCKS = 512
 
 

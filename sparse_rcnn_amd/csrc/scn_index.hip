@@ -40,13 +40,14 @@ __global__ void k_coords_to_i32(const long long* __restrict__ in, long long n4, 
 
 extern "C" int scn_coords_to_i32(const int64_t* coords, int64_t n, int32_t* out, int32_t* scratch1,
                                  int64_t* bad_host, scn_stream_t stream) {
-    SCN_REQUIRE(n >= 0 && (n == 0 || (coords && out)) && scratch1 && bad_host);
+    SCN_REQUIRE(n >= 0 && (n == 0 || (coords && out)) && scratch1);
     SCN_HIP(hipMemsetAsync(scratch1, 0, sizeof(int32_t), S(stream)));
     if (n) {
         hipLaunchKernelGGL(k_coords_to_i32, dim3(scn::ew_grid(n * 4, 256)), dim3(256), 0, S(stream),
                            (const long long*)coords, (long long)n * 4, out, scratch1);
         SCN_LAUNCH_CHECK();
     }
+    if (!bad_host) return SCN_OK;          // asynchronous form: the caller reads *scratch1 behind its own event
     int32_t bad = 0;
     SCN_HIP(hipMemcpyAsync(&bad, scratch1, sizeof(bad), hipMemcpyDeviceToHost, S(stream)));
     SCN_HIP(hipStreamSynchronize(S(stream)));
@@ -183,10 +184,11 @@ static int scan_launch(const int32_t* table, int n_seg, int64_t n, int32_t* bloc
 
 extern "C" int scn_rules_scan(const int32_t* table, int n_off, int64_t n_out, int32_t* block_sums, int64_t* prefix,
                               int64_t* prefix_host, scn_stream_t stream) {
-    SCN_REQUIRE(n_off >= 1 && n_out >= 0 && block_sums && prefix && prefix_host && (n_out == 0 || table));
+    SCN_REQUIRE(n_off >= 1 && n_out >= 0 && block_sums && prefix && (n_out == 0 || table));
     SCN_REQUIRE((int64_t)n_off * n_out < 2147483647LL);
     int rc = scan_launch(table, n_off, n_out, block_sums, prefix, S(stream));
     if (rc) return rc;
+    if (!prefix_host) return SCN_OK;       // asynchronous form: the caller copies `prefix` back behind its own event
     SCN_HIP(hipMemcpyAsync(prefix_host, prefix, sizeof(int64_t) * (n_off + 1), hipMemcpyDeviceToHost, S(stream)));
     SCN_HIP(hipStreamSynchronize(S(stream)));
     return SCN_OK;
@@ -287,11 +289,12 @@ extern "C" int64_t scn_dedup_scratch_bytes(int64_t n) {
     return align256(4 * n) * 2 + align256(4 * blocks) + 256;
 }
 
-extern "C" int scn_dedup_build(const int32_t* coords, int64_t n, int shift, uint64_t* table_keys,
-                               int32_t* table_rows, int64_t cap, int32_t* item_row, int32_t* row_count,
-                               int32_t* row_first, int32_t* row_coords, void* scratch, int64_t* n_rows_host,
-                               scn_stream_t stream) {
-    SCN_REQUIRE(n >= 0 && shift >= 0 && shift < 16 && table_keys && table_rows && n_rows_host && scratch);
+static int dedup_impl(const int32_t* coords, int64_t n, int shift, uint64_t* table_keys,
+                      int32_t* table_rows, int64_t cap, int32_t* item_row, int32_t* row_count,
+                      int32_t* row_first, int32_t* row_coords, void* scratch, int64_t* n_rows_host,
+                      int64_t* n_rows_dev, scn_stream_t stream) {
+    SCN_REQUIRE(n >= 0 && shift >= 0 && shift < 16 && table_keys && table_rows && (n_rows_host || n_rows_dev) &&
+                scratch);
     SCN_REQUIRE(cap >= 2 * n && (cap & (cap - 1)) == 0);
     SCN_REQUIRE(n < 2147483647LL);
     hipStream_t st = S(stream);
@@ -299,7 +302,8 @@ extern "C" int scn_dedup_build(const int32_t* coords, int64_t n, int shift, uint
                        (unsigned long long*)table_keys, table_rows, (long long)cap);
     SCN_LAUNCH_CHECK();
     if (n == 0) {
-        *n_rows_host = 0;
+        if (n_rows_host) *n_rows_host = 0;
+        if (n_rows_dev) SCN_HIP(hipMemsetAsync(n_rows_dev, 0, sizeof(int64_t), st));
         return SCN_OK;
     }
     SCN_REQUIRE(coords && item_row && row_coords);
@@ -323,11 +327,33 @@ extern "C" int scn_dedup_build(const int32_t* coords, int64_t n, int shift, uint
     if (row_count) SCN_HIP(hipMemsetAsync(row_count, 0, sizeof(int32_t) * n, st));
     hipLaunchKernelGGL(k_item_rows, dim3(g), dim3(256), 0, st, slot_of, table_rows, (long long)n, item_row, row_count);
     SCN_LAUNCH_CHECK();
-    long long host_prefix[2] = {0, 0};
-    SCN_HIP(hipMemcpyAsync(host_prefix, prefix, sizeof(host_prefix), hipMemcpyDeviceToHost, st));
-    SCN_HIP(hipStreamSynchronize(st));
-    *n_rows_host = host_prefix[1];
+    if (n_rows_dev)
+        SCN_HIP(hipMemcpyAsync(n_rows_dev, prefix + 1, sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+    if (n_rows_host) {
+        long long host_prefix[2] = {0, 0};
+        SCN_HIP(hipMemcpyAsync(host_prefix, prefix, sizeof(host_prefix), hipMemcpyDeviceToHost, st));
+        SCN_HIP(hipStreamSynchronize(st));
+        *n_rows_host = host_prefix[1];
+    }
     return SCN_OK;
+}
+
+extern "C" int scn_dedup_build(const int32_t* coords, int64_t n, int shift, uint64_t* table_keys,
+                               int32_t* table_rows, int64_t cap, int32_t* item_row, int32_t* row_count,
+                               int32_t* row_first, int32_t* row_coords, void* scratch, int64_t* n_rows_host,
+                               scn_stream_t stream) {
+    SCN_REQUIRE(n_rows_host);
+    return dedup_impl(coords, n, shift, table_keys, table_rows, cap, item_row, row_count, row_first, row_coords,
+                      scratch, n_rows_host, nullptr, stream);
+}
+
+extern "C" int scn_dedup_launch(const int32_t* coords, int64_t n, int shift, uint64_t* table_keys,
+                                int32_t* table_rows, int64_t cap, int32_t* item_row, int32_t* row_count,
+                                int32_t* row_first, int32_t* row_coords, void* scratch, int64_t* n_rows_dev,
+                                scn_stream_t stream) {
+    SCN_REQUIRE(n_rows_dev);
+    return dedup_impl(coords, n, shift, table_keys, table_rows, cap, item_row, row_count, row_first, row_coords,
+                      scratch, nullptr, n_rows_dev, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -35,17 +35,25 @@ def _conv_bytes(n_in, cin, n_out, cout, n_off, n_rules):
     return 4.0 * (n_in * cin + n_out * cout + n_off * cin * cout) + 8.0 * n_rules
 
 
+def _count(n_rules):
+    """n_rules: an int or a metadata.RuleCount (whose total is read lazily; it holds no device buffers)."""
+    return n_rules if isinstance(n_rules, int) else n_rules.total
+
+
 def gemm_table(X, table, n_off, n_out, W, bias, cout, flags=0, residual=None, relu_mask=None, n_rules=None):
-    """n_rules: number of (in,out) rules the table holds -- only used for the algorithmic-FLOP accounting."""
+    """n_rules: number of (in,out) rules the table holds (int or RuleCount) -- only used for the algorithmic-FLOP
+    accounting, evaluated when a profile is summarised."""
     lib = L.lib()
     cin = X.shape[1]
     Y = _new((n_out, cout), X)
-    P = n_out if n_rules is None else n_rules
+    n_in = X.shape[0]
+    P = (lambda: n_out) if n_rules is None else (lambda: _count(n_rules))
 
     def run():
         L.check(lib.scn_gemm_table(L.ptr(X), X.shape[0], cin, L.ptr(table), n_off, n_out, L.ptr(W), L.ptr(bias),
                                    L.ptr(residual), L.ptr(relu_mask), L.ptr(Y), cout, flags, L.stream()))
-    profiling.timed("k_gemm_table", 2.0 * P * cin * cout, _conv_bytes(X.shape[0], cin, n_out, cout, n_off, P), run)
+    profiling.timed("k_gemm_table", lambda: 2.0 * P() * cin * cout,
+                    lambda: _conv_bytes(n_in, cin, n_out, cout, n_off, P()), run)
     return Y
 
 
@@ -54,7 +62,8 @@ def conv_rules(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu_mask
     lib = L.lib()
     cin = X.shape[1]
     Y = _new((n_out, cout), X)
-    P = n_rules
+    n_in, n_off = X.shape[0], tiles.n_off      # the profiling closures below must not keep device buffers alive
+    P = lambda: _count(n_rules)
     nbytes = lib.scn_conv_tiles_scratch_bytes(cin, n_out, cout)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=X.device)
 
@@ -62,7 +71,8 @@ def conv_rules(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu_mask
         L.check(lib.scn_conv_tiles(L.ptr(X), cin, L.ptr(tiles.tstab), L.ptr(tiles.tile_mask), L.ptr(tiles.perm),
                                    L.ptr(tiles.tile_order), tiles.n_off, n_out, L.ptr(W), L.ptr(bias), L.ptr(residual), L.ptr(relu_mask),
                                    L.ptr(Y), cout, flags, L.ptr(scratch), L.stream()))
-    profiling.timed("k_conv_ts", 2.0 * P * cin * cout, _conv_bytes(X.shape[0], cin, n_out, cout, tiles.n_off, P), run)
+    profiling.timed("k_conv_ts", lambda: 2.0 * P() * cin * cout,
+                    lambda: _conv_bytes(n_in, cin, n_out, cout, n_off, P()), run)
     return Y
 
 
@@ -195,10 +205,10 @@ class SubmanifoldConvolutionFunction(torch.autograd.Function):
         R = _f32(residual) if residual is not None else None
         if USE_CONV_OS and rb.rules is not None:
             Y = conv_rules(X, rb.tiles, rb.n, W, b, cout, L.F_RELU_IN if relu_in else 0, residual=R,
-                           n_rules=rb.rules.total)
+                           n_rules=rb.rules.count)
         else:
             Y = gemm_table(X, rb.table, n_off, rb.n, W, b, cout, L.F_RELU_IN if relu_in else 0, residual=R,
-                           n_rules=rb.rules.total if rb.rules is not None else rb.n)
+                           n_rules=rb.rules.count if rb.rules is not None else rb.n)
         ctx.save_for_backward(X, W)
         ctx.rb, ctx.has_bias, ctx.relu_in = rb, bias is not None, relu_in
         return Y
@@ -215,11 +225,11 @@ class SubmanifoldConvolutionFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if USE_CONV_OS and rb.rules is not None:
                 dX = conv_rules(dY, rb.tiles, rb.n, W, None, cin, L.F_W_TRANSPOSED | L.F_OFF_REVERSE,
-                                relu_mask=X if ctx.relu_in else None, n_rules=rb.rules.total)
+                                relu_mask=X if ctx.relu_in else None, n_rules=rb.rules.count)
             else:
                 dX = gemm_table(dY, rb.table, n_off, rb.n, W, None, cin, L.F_W_TRANSPOSED | L.F_OFF_REVERSE,
                                 relu_mask=X if ctx.relu_in else None,
-                                n_rules=rb.rules.total if rb.rules is not None else rb.n)
+                                n_rules=rb.rules.count if rb.rules is not None else rb.n)
         def leaves():
             dW = db = None
             want_b = ctx.has_bias and ctx.needs_input_grad[2]

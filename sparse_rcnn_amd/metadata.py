@@ -45,23 +45,104 @@ class Grid:
     n: int
 
 
-@dataclass
+class _Readback:
+    """A small device -> pinned-host copy queued on the current stream; `get()` waits for it (and only for it)."""
+
+    def __init__(self, *dev_tensors):
+        self.host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in dev_tensors]
+        for h, t in zip(self.host, dev_tensors):
+            h.copy_(t, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def get(self):
+        self.event.synchronize()
+        return self.host
+
+
+class RuleCount:
+    """Total rule count of a Rules, readable without keeping its device buffers alive (profiling closures)."""
+
+    def __init__(self, readback, n_off):
+        self._rb, self._n_off, self._total = readback, n_off, None
+
+    @property
+    def total(self):
+        if self._total is None:
+            self._total = int(self._rb.get()[0][self._n_off])
+        return self._total
+
+
 class Rules:
-    """Compacted rule list, offset-major, output row ascending inside an offset."""
-    in_rows: torch.Tensor           # int32 [P]
-    out_rows: torch.Tensor          # int32 [P]
-    prefix_host: "C.Array"          # int64[n_off+1] on the host
-    n_off: int
-    prefix_dev: Optional[torch.Tensor] = None    # int64 [n_off+1] device
-    block_rows: int = 0             # output rows per conv_os workgroup
-    bstart: Optional[torch.Tensor] = None        # int32 [n_off, nb+1]
+    """Compacted rule list, offset-major, output row ascending inside an offset (canonical order).
+
+    Built in two phases (scn_rules_scan -> sizes -> scn_rules_fill).  Only the weight-gradient kernels and the
+    rule-list GEMMs (Deconvolution forward, Convolution backward-data) read compacted rules; the forward hot kernel
+    walks tiles of the table.  So the scan is queued when the rulebook is built, its sizes travel back through a
+    pinned buffer behind an event, and the fill runs on first access -- by then (decoder / backward pass) the event
+    has long fired and the host never waits for the device."""
+
+    def __init__(self, table, n_off, n_out, want_seg=False):
+        lib = L.lib()
+        dev = table.device
+        self.n_off = int(n_off)
+        self._table, self._n_out, self._want_seg = table, int(n_out), want_seg
+        self._block_sums = _empty(lib.scn_rules_blocks(n_off, n_out), torch.int32, dev)
+        self.prefix_dev = _empty(n_off + 1, torch.int64, dev)
+        L.check(lib.scn_rules_scan(L.ptr(table), n_off, n_out, L.ptr(self._block_sums), L.ptr(self.prefix_dev), None,
+                                   L.stream()))
+        self._rb = _Readback(self.prefix_dev)
+        self.count = RuleCount(self._rb, self.n_off)
+        self._prefix_host = None
+        self._in = self._out = self._seg = None
+        self.block_rows = 0                     # conv_os (comparison kernel) bookkeeping
+        self.bstart = None
+
+    @property
+    def prefix_host(self):
+        """int64[n_off+1] on the host, usable as the `prefix_host` argument of the C calls."""
+        if self._prefix_host is None:
+            self._pinned = self._rb.get()[0]
+            self._prefix_host = C.cast(self._pinned.data_ptr(), C.POINTER(C.c_int64))
+        return self._prefix_host
 
     @property
     def total(self):
         return int(self.prefix_host[self.n_off])
 
     def prefix_list(self):
-        return [int(self.prefix_host[i]) for i in range(self.n_off + 1)]
+        ph = self.prefix_host
+        return [int(ph[i]) for i in range(self.n_off + 1)]
+
+    def _fill(self):
+        if self._in is None:
+            lib = L.lib()
+            total = self.total
+            dev = self._table.device
+            self._in = _empty(total, torch.int32, dev)
+            self._out = _empty(total, torch.int32, dev)
+            self._seg = _empty(total, torch.int32, dev) if self._want_seg else None
+            L.check(lib.scn_rules_fill(L.ptr(self._table), self.n_off, self._n_out, L.ptr(self._block_sums),
+                                       L.ptr(self._in), L.ptr(self._out), L.ptr(self._seg), L.stream()))
+
+    @property
+    def in_rows(self):
+        self._fill()
+        return self._in
+
+    @property
+    def out_rows(self):
+        self._fill()
+        return self._out
+
+    @property
+    def seg(self):
+        self._fill()
+        return self._seg
+
+    def tensors(self):
+        return [t for t in (self._table, self._block_sums, self.prefix_dev, self._in, self._out, self._seg)
+                if t is not None]
 
 
 @dataclass
@@ -111,22 +192,9 @@ class StridedRulebook:
 
 
 def compact_rules(table: torch.Tensor, n_off: int, n_out: int, want_seg=False):
-    """Rule table -> Rules (two-phase: scan, one host sync for the sizes, fill)."""
-    lib = L.lib()
-    dev = table.device
-    blocks = lib.scn_rules_blocks(n_off, n_out)
-    block_sums = _empty(blocks, torch.int32, dev)
-    prefix = _empty(n_off + 1, torch.int64, dev)
-    prefix_host = L.host_i64(n_off + 1)
-    L.check(lib.scn_rules_scan(L.ptr(table), n_off, n_out, L.ptr(block_sums), L.ptr(prefix), prefix_host, L.stream()))
-    total = int(prefix_host[n_off])
-    in_rows = _empty(total, torch.int32, dev)
-    out_rows = _empty(total, torch.int32, dev)
-    seg = _empty(total, torch.int32, dev) if want_seg else None
-    L.check(lib.scn_rules_fill(L.ptr(table), n_off, n_out, L.ptr(block_sums), L.ptr(in_rows), L.ptr(out_rows),
-                               L.ptr(seg), L.stream()))
-    rules = Rules(in_rows, out_rows, prefix_host, n_off, prefix)
-    return (rules, seg) if want_seg else rules
+    """Rule table -> Rules (lazy: the scan is queued now, sizes and fill on first access)."""
+    rules = Rules(table, n_off, n_out, want_seg)
+    return (rules, rules.seg) if want_seg else rules
 
 
 def pick_block_rows(n_out: int) -> int:
@@ -152,26 +220,39 @@ def add_block_starts(rules: Rules, n_out: int, block_rows: int = 0):
     return rules
 
 
+class _Dedup:
+    """A queued scn_dedup_launch; `finish()` waits for the row count and returns what `dedup` returns."""
+
+    def __init__(self, coords_i32, shift, want_counts, want_first, extra=()):
+        lib = L.lib()
+        dev = coords_i32.device
+        n = coords_i32.shape[0]
+        self.cap = lib.scn_hash_capacity(n)
+        self.keys = _empty(self.cap, torch.int64, dev)
+        self.rows = _empty(self.cap, torch.int32, dev)
+        self.item_row = _empty(n, torch.int32, dev)
+        self.row_count = _empty(n, torch.int32, dev) if want_counts else None
+        self.row_first = _empty(n, torch.int32, dev) if want_first else None
+        self.row_coords = torch.empty((n, 4), dtype=torch.int32, device=dev)
+        scratch = _empty(lib.scn_dedup_scratch_bytes(n), torch.uint8, dev)
+        n_rows = _empty(1, torch.int64, dev)
+        L.check(lib.scn_dedup_launch(L.ptr(coords_i32), n, shift, L.ptr(self.keys), L.ptr(self.rows), self.cap,
+                                     L.ptr(self.item_row), L.ptr(self.row_count), L.ptr(self.row_first),
+                                     L.ptr(self.row_coords), L.ptr(scratch), L.ptr(n_rows), L.stream()))
+        self._rb = _Readback(n_rows, *extra)
+
+    def finish(self):
+        host = self._rb.get()
+        nr = int(host[0][0])
+        self.extra = host[1:]
+        grid = Grid(self.row_coords[:nr], self.keys, self.rows, self.cap, nr)
+        return (grid, self.item_row, self.row_count[:nr] if self.row_count is not None else None,
+                self.row_first[:nr] if self.row_first is not None else None)
+
+
 def dedup(coords_i32: torch.Tensor, shift: int, want_counts: bool, want_first: bool):
-    """First-occurrence row numbering of (b, x>>shift, y>>shift, z>>shift).  One host sync."""
-    lib = L.lib()
-    dev = coords_i32.device
-    n = coords_i32.shape[0]
-    cap = lib.scn_hash_capacity(n)
-    keys = _empty(cap, torch.int64, dev)
-    rows = _empty(cap, torch.int32, dev)
-    item_row = _empty(n, torch.int32, dev)
-    row_count = _empty(n, torch.int32, dev) if want_counts else None
-    row_first = _empty(n, torch.int32, dev) if want_first else None
-    row_coords = torch.empty((n, 4), dtype=torch.int32, device=dev)
-    scratch = _empty(lib.scn_dedup_scratch_bytes(n), torch.uint8, dev)
-    n_rows = C.c_int64(0)
-    L.check(lib.scn_dedup_build(L.ptr(coords_i32), n, shift, L.ptr(keys), L.ptr(rows), cap, L.ptr(item_row),
-                                L.ptr(row_count), L.ptr(row_first), L.ptr(row_coords), L.ptr(scratch),
-                                C.byref(n_rows), L.stream()))
-    nr = int(n_rows.value)
-    grid = Grid(row_coords[:nr], keys, rows, cap, nr)
-    return grid, item_row, (row_count[:nr] if want_counts else None), (row_first[:nr] if want_first else None)
+    """First-occurrence row numbering of (b, x>>shift, y>>shift, z>>shift).  One host wait (for the row count)."""
+    return _Dedup(coords_i32, shift, want_counts, want_first).finish()
 
 
 class Metadata:
@@ -209,10 +290,13 @@ class Metadata:
         c64 = coords.to(device=dev, dtype=torch.int64).contiguous()
         n = c64.shape[0]
         c32 = torch.empty((n, 4), dtype=torch.int32, device=dev)
-        bad = C.c_int64(0)
         flag = _empty(1, torch.int32, dev)
-        L.check(lib.scn_coords_to_i32(L.ptr(c64), n, L.ptr(c32), L.ptr(flag), C.byref(bad), L.stream()))
-        grid, item_row, row_count, row_first = dedup(c32, 0, True, True)
+        L.check(lib.scn_coords_to_i32(L.ptr(c64), n, L.ptr(c32), L.ptr(flag), None, L.stream()))
+        dd = _Dedup(c32, 0, True, True, extra=(flag,))           # range flag and row count come back together
+        grid, item_row, row_count, row_first = dd.finish()
+        if int(dd.extra[0][0]):
+            raise L.ScnError(f"libscn_mi355x error {L.EHASH}: coordinates outside [0,65535] "
+                             f"in {int(dd.extra[0][0])} wave(s)")
         self.grids[size] = grid
         self.input_size = size
         self.item_row, self.row_count, self.row_first = item_row, row_count, row_first
@@ -249,29 +333,38 @@ class Metadata:
             self.subm[key] = rb
         return rb
 
+    def _strided_launch(self, size):
+        """Queue the coarse-site numbering of a size=stride=2 Convolution; `_strided_finish` needs its row count."""
+        if any(s % 2 for s in size):
+            raise L.ScnError(f"Convolution size=stride=2 needs even spatial size, got {size} "
+                             "((out-1)*stride+filter != in)")
+        coarse_size = tuple(s // 2 for s in size)
+        if coarse_size in self.grids:
+            raise L.ScnError(f"Metadata already holds a grid of size {coarse_size}")
+        return _Dedup(self.grid(size).coords, 1, False, False)
+
+    def _strided_finish(self, size, pending) -> StridedRulebook:
+        coarse_size = tuple(s // 2 for s in size)
+        g = self.grid(size)
+        lib = L.lib()
+        dev = g.coords.device
+        cg, parent, _, _ = pending.finish()
+        self.grids[coarse_size] = cg
+        child = torch.empty((8, cg.n), dtype=torch.int32, device=dev)
+        fine_off = _empty(g.n, torch.int32, dev)
+        L.check(lib.scn_child_table(L.ptr(g.coords), L.ptr(parent), g.n, cg.n, L.ptr(child), L.ptr(fine_off),
+                                    L.stream()))
+        rules = compact_rules(child, 8, cg.n)
+        rb = StridedRulebook(parent, fine_off, child, rules, g.n, cg.n, coarse_size, build_tiles(child, 8, cg.n))
+        self.strided[size] = rb
+        return rb
+
     def strided_rulebook(self, size) -> StridedRulebook:
         """size=stride=2 Convolution from `size` to size/2; creates the coarse grid on first use."""
         size = tuple(int(s) for s in size)
         rb = self.strided.get(size)
         if rb is None:
-            if any(s % 2 for s in size):
-                raise L.ScnError(f"Convolution size=stride=2 needs even spatial size, got {size} "
-                                 "((out-1)*stride+filter != in)")
-            coarse_size = tuple(s // 2 for s in size)
-            g = self.grid(size)
-            lib = L.lib()
-            dev = g.coords.device
-            cg, parent, _, _ = dedup(g.coords, 1, False, False)
-            if coarse_size in self.grids:
-                raise L.ScnError(f"Metadata already holds a grid of size {coarse_size}")
-            self.grids[coarse_size] = cg
-            child = torch.empty((8, cg.n), dtype=torch.int32, device=dev)
-            fine_off = _empty(g.n, torch.int32, dev)
-            L.check(lib.scn_child_table(L.ptr(g.coords), L.ptr(parent), g.n, cg.n, L.ptr(child), L.ptr(fine_off),
-                                        L.stream()))
-            rules = compact_rules(child, 8, cg.n)
-            rb = StridedRulebook(parent, fine_off, child, rules, g.n, cg.n, coarse_size, build_tiles(child, 8, cg.n))
-            self.strided[size] = rb
+            rb = self._strided_finish(size, self._strided_launch(size))
         return rb
 
     # ---- index prefetch on a side stream -----------------------------------------------------------
@@ -297,9 +390,11 @@ class Metadata:
         for g in self.grids.values():
             out += [g.coords, g.table_keys, g.table_rows]
         for rb in list(self.subm.values()) + list(self.strided.values()):
-            for obj in (rb, getattr(rb, "rules", None), getattr(rb, "tiles", None)):
+            for obj in (rb, getattr(rb, "tiles", None)):
                 if obj is not None:
                     out += [v for v in vars(obj).values() if isinstance(v, torch.Tensor)]
+            if getattr(rb, "rules", None) is not None:
+                out += rb.rules.tensors()
         return [t for t in out if t is not None]
 
     def handover(self):
@@ -313,13 +408,18 @@ class Metadata:
 
     def build_pyramid(self, size, n_levels: int, k: int = 3):
         """Build the rulebooks of an n_levels U-Net up front (SubM k^3 at every level, 2^3/2 between levels).
-        Same work as building them lazily; done before the first convolution is queued so that the host syncs of the
-        size queries do not wait behind (and then starve) the feature kernels."""
+        Same work as building them lazily, ordered so that the host never idles the device: the coarse-site numbering
+        of level l+1 is queued first, then the SubM table / scan / tiles of level l (which do not need its row
+        count), and only then the count is awaited."""
         size = tuple(int(s) for s in size)
         for level in range(n_levels):
+            pending = None
+            if level + 1 < n_levels and size not in self.strided:
+                pending = self._strided_launch(size)
             self.subm_rulebook(size, k)
             if level + 1 < n_levels:
-                self.strided_rulebook(size)
+                if pending is not None:
+                    self._strided_finish(size, pending)
                 size = tuple(s // 2 for s in size)
 
     # ---- parity helpers (tests) -------------------------------------------------------------------

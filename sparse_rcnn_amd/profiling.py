@@ -56,8 +56,8 @@ class KernelTimer:
             d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
-            d["flops"] += flops
-            d["bytes"] += nbytes
+            d["flops"] += flops() if callable(flops) else flops
+            d["bytes"] += nbytes() if callable(nbytes) else nbytes
         return out
 
     @property
@@ -69,6 +69,8 @@ TIMER: KernelTimer | None = None
 
 
 def timed(name, flops, nbytes, fn):
+    """flops / nbytes may be callables: they are evaluated in summary(), not on the launch path (rule counts come back
+    from the device asynchronously -- metadata.Rules)."""
     if TIMER is None:
         return fn()
     return TIMER.launch(name, flops, nbytes, fn)

@@ -189,7 +189,8 @@ int scn_gemm_rules(const float* X, int cin, const int32_t* in_rows, const int32_
 
 /* Weight gradient:  dW[o] = sum_{p in R_o} in(X[in_rows[p]])^T . dY[out_rows[p]]     (dW fully overwritten)
  * in_rows == out_rows == NULL means the identity rule list of length prefix_host[1] (NetworkInNetwork).
- * scratch: scn_wgrad_scratch_bytes(...) bytes. */
+ * One kernel streams the rules (MFMA operands straight from the gathered rows, no LDS staging) into per-unit partial
+ * blocks, a second adds them in a fixed order: bitwise reproducible.  scratch: scn_wgrad_scratch_bytes(...) bytes. */
 int64_t scn_wgrad_scratch_bytes(int cin, int cout, const int64_t* prefix_host, int n_off);
 int scn_wgrad_rules(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
                     const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, void* scratch,
@@ -198,7 +199,7 @@ int scn_wgrad_rules(const float* X, int cin, const float* dY, int cout, const in
 /* Weight AND bias gradient in one pass: as scn_wgrad_rules, plus db[c] = sum over the rules of the offsets named in
  * the bit mask db_offsets of dY[out_p][c].  The caller names offsets whose rule lists together contain every output row
  * exactly once (centre offset of a submanifold conv: 1 << (k^3/2); all offsets of a Deconvolution; the identity list),
- * so db equals the column sum of dY.  Channel counts must be multiples of 4 (otherwise SCN_EINVAL: use scn_colsum). */
+ * so db equals the column sum of dY.  Any channel count (rows that are not 16-byte aligned take element-wise loads). */
 int scn_wgrad_bias_rules(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
                          const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, float* db,
                          uint32_t db_offsets, void* scratch, int flags, scn_stream_t stream);

@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscn_mi355x.so")
+LIB_PATH = os.environ.get("SCN_MI355X_LIB") or os.path.join(_HERE, "libscn_mi355x.so")   # env: developer builds
 
 _lib = None
 

@@ -56,11 +56,6 @@ inline int ew_grid(int64_t work_items, int block) {
     return (int)g;
 }
 
-// generic weight-gradient path (scn_conv.hip), used by scn_wgrad.hip for channel counts its 16-byte gathers cannot take
-int64_t wgrad_simple_scratch_bytes(int cin, int cout, const int64_t* prefix_host, int n_off);
-int wgrad_simple(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows, const int32_t* out_rows,
-                 const int64_t* prefix_host, int n_off, float* dW, void* scratch, int flags, scn_stream_t stream);
-
 }  // namespace scn
 
 // ---- device-side key packing / hashing (shared by index kernels) ----

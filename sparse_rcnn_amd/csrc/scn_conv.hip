@@ -231,138 +231,6 @@ extern "C" int scn_gemm_rules(const float* X, int cin, const int32_t* in_rows, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// wgrad_rules
-// ------------------------------------------------------------------------------------------------
-struct SegChunks {
-    long long rule_start[33];
-    long long chunk_start[33];
-    long long chunk;            // rules per chunk (multiple of 64)
-    int n_off;
-};
-
-static int make_seg_chunks(int cin, int cout, const int64_t* prefix_host, int n_off, SegChunks& sc) {
-    const int64_t tiles = cdiv(cin, 32) * cdiv(cout, 32);
-    const int64_t total = prefix_host[n_off] - prefix_host[0];
-    int64_t chunk = cdiv(total * tiles, 4096);
-    chunk = cdiv(chunk, 64) * 64;
-    if (chunk < 64) chunk = 64;
-    sc.chunk = chunk;
-    sc.n_off = n_off;
-    sc.rule_start[0] = prefix_host[0];
-    sc.chunk_start[0] = 0;
-    for (int o = 0; o < n_off; ++o) {
-        int64_t cnt = prefix_host[o + 1] - prefix_host[o];
-        if (cnt < 0) return SCN_EINVAL;
-        sc.rule_start[o + 1] = prefix_host[o + 1];
-        sc.chunk_start[o + 1] = sc.chunk_start[o] + cdiv(cnt, chunk);
-    }
-    return SCN_OK;
-}
-
-int64_t scn::wgrad_simple_scratch_bytes(int cin, int cout, const int64_t* prefix_host, int n_off) {
-    if (!prefix_host || n_off < 1 || n_off > 32 || cin < 1 || cout < 1) return -1;
-    SegChunks sc;
-    if (make_seg_chunks(cin, cout, prefix_host, n_off, sc) != SCN_OK) return -1;
-    const int64_t tiles = cdiv(cin, 32) * cdiv(cout, 32);
-    return sc.chunk_start[n_off] * tiles * 1024 * (int64_t)sizeof(float) + 256;
-}
-
-// slab layout: [chunk][tile][v 0..15][lane 0..63]
-__global__ __launch_bounds__(256) void k_wgrad_rules(const float* __restrict__ X, int cin, const float* __restrict__ dY,
-                                                     int cout, const int* __restrict__ in_rows,
-                                                     const int* __restrict__ out_rows, SegChunks sc,
-                                                     float* __restrict__ slabs, int tiles_n, int flags) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m = lane & 31, h = lane >> 5;
-    const long long chunk = (long long)blockIdx.x * 4 + wave;
-    if (chunk >= sc.chunk_start[sc.n_off]) return;
-    int o = 0;
-    while (chunk >= sc.chunk_start[o + 1]) ++o;
-    const long long p0 = sc.rule_start[o] + (chunk - sc.chunk_start[o]) * sc.chunk;
-    long long p_end = p0 + sc.chunk;
-    if (p_end > sc.rule_start[o + 1]) p_end = sc.rule_start[o + 1];
-    const int tile = blockIdx.y;
-    const int ci = (tile / tiles_n) * 32 + m;     // A: tile row = input channel
-    const int co = (tile % tiles_n) * 32 + m;     // B: tile col = output channel
-    const bool ci_ok = ci < cin, co_ok = co < cout;
-    const bool relu_in = flags & SCN_F_RELU_IN;
-
-    f32x16 acc;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-
-    for (long long pb = p0; pb < p_end; pb += 64) {
-        const long long p = pb + lane;
-        int ri = -1, ro = -1;
-        if (p < p_end) {
-            ri = in_rows ? in_rows[p] : (int)p;
-            ro = out_rows ? out_rows[p] : (int)p;
-        }
-#pragma unroll 8
-        for (int s = 0; s < 32; ++s) {
-            const int src = 2 * s + h;
-            const int xi = __shfl(ri, src);
-            const int yo = __shfl(ro, src);
-            float a = (xi >= 0 && ci_ok) ? X[(long long)xi * cin + ci] : 0.f;
-            if (relu_in) a = fmaxf(a, 0.f);
-            const float b = (yo >= 0 && co_ok) ? dY[(long long)yo * cout + co] : 0.f;
-            acc = MFMA(a, b, acc);
-        }
-    }
-    float* slab = slabs + ((long long)chunk * gridDim.y + tile) * 1024;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) slab[v * 64 + lane] = acc[v];
-}
-
-// dW[o][ci][co] = sum over the offset's chunks.  One wave per element: lane l adds chunks l, l+64, ... in ascending
-// order, then a fixed butterfly over the lanes -- the summation tree depends only on the chunk count (deterministic).
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slabs, SegChunks sc, int cin, int cout,
-                                                      int tiles_n, int tiles, float* __restrict__ dW) {
-    const long long total = (long long)sc.n_off * cin * cout;
-    const int lane = threadIdx.x & 63;
-    for (long long e = blockIdx.x * 4ll + (threadIdx.x >> 6); e < total; e += (long long)gridDim.x * 4) {
-        const int co = (int)(e % cout);
-        const int ci = (int)((e / cout) % cin);
-        const int o = (int)(e / ((long long)cin * cout));
-        const int tile = (ci / 32) * tiles_n + co / 32;
-        const int i = ci & 31, j = co & 31;
-        // acc_row(v,h) == i  <=>  h = (i>>2)&1, v = (i&3) + 4*(i>>3)
-        const int hh = (i >> 2) & 1, v = (i & 3) + 4 * (i >> 3);
-        const int slot = v * 64 + hh * 32 + j;
-        float s = 0.f;
-        for (long long c = sc.chunk_start[o] + lane; c < sc.chunk_start[o + 1]; c += 64)
-            s += slabs[(c * tiles + tile) * 1024 + slot];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-        if (lane == 0) dW[e] = s;
-    }
-}
-
-// Generic (any channel count, scalar gathers) weight gradient; scn_wgrad.hip holds the fast path.
-int scn::wgrad_simple(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
-                      const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, void* scratch,
-                      int flags, scn_stream_t stream) {
-    SCN_REQUIRE(prefix_host && n_off >= 1 && n_off <= 32 && cin >= 1 && cout >= 1 && dW);
-    SCN_REQUIRE((in_rows == nullptr) == (out_rows == nullptr));
-    SCN_REQUIRE(in_rows || n_off == 1);
-    SegChunks sc;
-    SCN_REQUIRE(make_seg_chunks(cin, cout, prefix_host, n_off, sc) == SCN_OK);
-    const int tiles_n = (int)cdiv(cout, 32);
-    const int tiles = (int)cdiv(cin, 32) * tiles_n;
-    const long long chunks = sc.chunk_start[n_off];
-    if (chunks > 0) {
-        SCN_REQUIRE(X && dY && scratch);
-        hipLaunchKernelGGL(k_wgrad_rules, dim3((unsigned)cdiv(chunks, 4), (unsigned)tiles), dim3(256), 0, S(stream), X,
-                           cin, dY, cout, in_rows, out_rows, sc, (float*)scratch, tiles_n, flags);
-        SCN_LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(scn::ew_grid((int64_t)n_off * cin * cout, 4)), dim3(256), 0, S(stream),
-                       (const float*)scratch, sc, cin, cout, tiles_n, tiles, dW);
-    SCN_LAUNCH_CHECK();
-    return SCN_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
 // colsum (bias gradient): two-stage, fixed order
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ dY, long long n, int c,

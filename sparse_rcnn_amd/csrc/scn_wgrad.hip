@@ -1,22 +1,32 @@
-// wgrad: weight gradient of every conv-type layer,   dW[o] = sum_{p in R_o} in(X[in_p])^T . dY[out_p]
+// wgrad: weight (and bias) gradient of every conv-type layer,   dW[o] = sum_{p in R_o} in(X[in_p])^T . dY[out_p]
 //
-// A tall-skinny reduction: M x N = Cin x Cout is small, K = number of rules is long and GATHERED on both operands.
-// At 32-64 channels it is bound by the row gathers (8-16 FLOP per gathered byte), from 128 channels on by the fp32
-// matrix cores.
+// Both MFMA operands of this product are "rule-major": A[i = channel of X][k = rule] and B[k = rule][j = channel of dY]
+// mean that lane (i, kq) of v_mfma_f32_16x16x4_f32 needs ONE element of the gathered row of rule kq -- element i.  So a
+// 16-lane group can read its fragment straight from the row in global memory: with the channel <-> (tile, i) mapping
+// channel = T*i + t, the T fragment values a lane needs for its T tiles are T CONSECUTIVE floats of the row, i.e. one
+// global_load_dwordx2/x4 per lane, and the 16 lanes of a group read one contiguous 64*T/4-byte piece of the row.
+// No LDS staging, no transposition, no workgroup barrier: every wave streams its own rule range with its own software
+// pipeline (row indices 2-3 blocks ahead, rows 2 blocks ahead, three named register sets rotating), which is what a
+// latency-bound gather wants -- the first, LDS-staged kernel met at a barrier every 32 rules and needed 2-4x the
+// instructions per MFMA (measured 35-60 TFLOP/s; this one 50-72, the small rectangular layers 2x faster).
 //
-// Workgroup (4 waves) = (offset o, K-split s, CB x CB block of dW[o]).  It walks its rule range in chunks of 32 rules:
-//   * the 32 X rows (CB channels) and 32 dY rows (CB channels) of the NEXT chunk are gathered with 16-byte loads into
-//     registers while the current chunk is multiplied -- all loads are unconditional (out-of-range rules read row 0 and
-//     are zeroed before the LDS write) so they stay in flight across the MFMAs;
-//   * they are written to the other LDS buffer ([rule][channel], row stride 80 floats: the 4 rules x 16 channels of an
-//     MFMA fragment hit 64 distinct banks), one barrier per chunk;
-//   * MFMA v_mfma_f32_16x16x4_f32: A[i = channel of X][k = rule], B[k = rule][j = channel of dY]; a wave owns a
-//     (CB/2) x (CB/2) sub-block (2 x 2 tiles at CB = 64) so each fragment read feeds two MFMAs.
-// Every workgroup writes its CB x CB partial to a slab; a second kernel sums the K-splits in fixed order
-// (bitwise reproducible, no float atomics).
+// Workgroup = 4 waves.  Wave block = (16 TA) x (16 TB) channels of dW[o].
+//   K mode   : the 4 waves take the 4 quarters of the unit's rule range on the SAME block and add their partial blocks
+//              through LDS in wave order at the end (channels <= 64).
+//   QUAD mode: the 4 waves take the 2 x 2 quadrants of a (32 TA) x (32 TB) block over the whole rule range (the two waves
+//              that share an operand read the same rows at about the same time: second reader hits in L1/L2).
+// Every workgroup writes its block to a slab; k_wgradd_sum adds the units of an offset in fixed order (bitwise
+// reproducible, no float atomics).  Bias gradient: column sums of the dY fragments of the offsets in db_mask, same route.
 #include <stdlib.h>
 
 #include "scn_common.h"
+
+#ifndef WD_DEEP_ALL
+#define WD_DEEP_ALL 1
+#endif
+#ifndef WD_EXP
+#define WD_EXP 0            // developer experiments (tools/exp): 1 = no MFMA, 2 = no row loads
+#endif
 
 using scn::S;
 using scn::cdiv;
@@ -24,180 +34,303 @@ using scn::cdiv;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-static constexpr int WG_PK = 32;        // rules per chunk
-
-struct WgradPlan {
+struct DPlan {
     long long rule_start[33];           // prefix of rules per offset
-    int unit_start[33];                 // prefix of work units per offset: a unit = `per` consecutive rules of ONE offset
-    long long per;                      // rules per unit (multiple of 32): units are equal-sized, so offsets with many
-                                        // rules (the centre offset has N, a corner a tenth of that) get many units
-    int n_off, cb, nbi, nbj;            // block size, blocks along Cin / Cout
+    int unit_start[33];                 // prefix of work units per offset; a unit = `per` consecutive rules of one offset
+    long long per;                      // rules per unit (multiple of 64)
+    int n_off, cbi, cbj, nbi, nbj;      // workgroup block (channels of X x channels of dY), blocks along Cin / Cout
 };
 
-// TW = tiles per wave along each side of its sub-block (1, 2 or 4); block CB = 32*TW channels on both sides, 4 waves in
-// a 2 x 2 arrangement.  LDS image of a chunk: [rule][i][t] with channel = 16*t + i stored at i*(CB/16) + t, so the TW
-// fragment values a lane needs for its TW tiles (same i, consecutive t) are ONE ds_read of TW floats (b32 / b64 / b128):
-// TW^2 MFMAs per 2 LDS reads -- at TW = 1..2 the kernel was bound by LDS fragment reads (128 B/clk/CU of ds_read_b32).
-template <int TW>
-__global__ __launch_bounds__(256) void k_wgrad_lds(const float* __restrict__ X, int cin, const float* __restrict__ dY,
-                                                   int cout, const int* __restrict__ in_rows,
-                                                   const int* __restrict__ out_rows, WgradPlan plan,
-                                                   float* __restrict__ slabs, int relu_in,
-                                                   float* __restrict__ db_slabs, unsigned db_mask, int cout_pad) {
-    constexpr int CB = 32 * TW;
-    constexpr int NT = CB / 16;                      // tiles per block side
-    constexpr int LD = CB + 4;                       // LDS row stride in floats
-    constexpr int F4_PER_ROW = CB / 4;               // 16-byte pieces per staged row
-    constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;  // rows staged per pass of the 256 threads
-    constexpr int PASSES = WG_PK / ROWS_PER_PASS;    // 1, 2 or 4
-    typedef float fragT __attribute__((ext_vector_type(TW)));
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [buffer 2][X | dY][rule][LD]
-    constexpr int OPND = WG_PK * LD;                 // floats per operand image
+template <int T>
+struct Frag { typedef float type __attribute__((ext_vector_type(T))); };
+
+template <int TA, int TB, bool QUAD, bool EDGE, bool IDENT>
+__global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ X, int cin, const float* __restrict__ dY,
+                                                      int cout, const int* __restrict__ in_rows,
+                                                      const int* __restrict__ out_rows, DPlan plan,
+                                                      float* __restrict__ slabs, int relu_in,
+                                                      float* __restrict__ db_slabs, unsigned db_mask, int cout_pad) {
+    typedef typename Frag<TA>::type fa_t;
+    typedef typename Frag<TB>::type fb_t;
+    constexpr int WI = 16 * TA, WJ = 16 * TB;                   // wave block
+    constexpr int CBI = QUAD ? 2 * WI : WI, CBJ = QUAD ? 2 * WJ : WJ;
+    constexpr int NACC = TA * TB;
+    extern __shared__ __attribute__((aligned(16))) float red[];     // K mode: 4 partial blocks + 4 x 64 bias sums
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, kq = lane >> 4;
     const int unit = blockIdx.x;
-    int o = 0;
-    while (unit >= plan.unit_start[o + 1]) ++o;      // <= 27 scalar compares
-    const int s = unit - plan.unit_start[o];
+    // offset of this unit: unit_start is non-decreasing, so o = #{o' : unit >= unit_start[o'+1]} -- one ballot instead
+    // of a serial scalar search (every workgroup pays its prologue; with ~1000 short workgroups it adds up)
+    const bool past = lane < plan.n_off && unit >= plan.unit_start[lane + 1];
+    const int o = __builtin_amdgcn_readfirstlane(__popcll(__ballot(past)));
+    const int s_unit = unit - plan.unit_start[o];
     const int bi = blockIdx.z / plan.nbj, bj = blockIdx.z % plan.nbj;
-    const int ci0 = bi * CB, co0 = bj * CB;
-    const int wi = wave >> 1, wj = wave & 1;         // wave's sub-block inside the CB x CB block
+    const int wi = QUAD ? (wave >> 1) : 0, wj = QUAD ? (wave & 1) : 0;
+    const int ci0 = bi * CBI + wi * WI, co0 = bj * CBJ + wj * WJ;       // first channel of the wave block
 
     const long long p_lo = plan.rule_start[o], p_hi = plan.rule_start[o + 1];
-    const long long per = plan.per;
-    const long long p0 = p_lo + (long long)s * per;
-    const long long p1 = p0 + per < p_hi ? p0 + per : p_hi;
-
-    f32x4 acc[TW][TW];
-#pragma unroll
-    for (int a = 0; a < TW; ++a)
-#pragma unroll
-        for (int b = 0; b < TW; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // staging role of this thread: row r_st (+ ROWS_PER_PASS per pass), 16-byte piece c4 = channels 4*c4 .. 4*c4+3
-    const int c4 = tid % F4_PER_ROW, r_st = tid / F4_PER_ROW;
-    const bool x_ok = ci0 + 4 * c4 + 3 < cin, y_ok = co0 + 4 * c4 + 3 < cout;     // channel counts are multiples of 4
-    // LDS position of channel c = 4*c4 + j: tile t = c / 16, i = c % 16 -> i * NT + t
-    const int st_pos = ((4 * c4) & 15) * NT + (4 * c4) / 16;
-
-    int ri[PASSES], ro[PASSES], rin[PASSES], ron[PASSES];
-    f32x4 vx[PASSES], vy[PASSES];
-    // Bias gradient for free: when the offsets in db_mask together name every output row exactly once (the centre
-    // offset of a submanifold conv, all 8 offsets of a Deconvolution, the identity list), db = sum of the dY rows this
-    // kernel stages anyway.  Workgroups of the first Cin-block add up the 16-byte pieces they write to LDS; the
-    // per-unit column sums go to db_slabs[unit][cout_pad] and k_wgrad_sum adds them in unit order.
-    const bool do_db = db_slabs != nullptr && ((db_mask >> o) & 1u) && bi == 0;
-    f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
-
-#define WG_LOAD_IDX(PC, RI, RO)                                                                      \
-    _Pragma("unroll") for (int q = 0; q < PASSES; ++q) {                                             \
-        const long long p_ = (PC) + r_st + q * ROWS_PER_PASS;                                        \
-        long long pl_ = p_ < p1 ? p_ : p1 - 1;              /* clamp: the load stays unconditional */ \
-        if (pl_ < p_lo) pl_ = p_lo < p_hi ? p_lo : 0;                                                \
-        const int vi_ = in_rows ? in_rows[pl_] : (int)pl_;                                           \
-        const int vo_ = out_rows ? out_rows[pl_] : (int)pl_;                                         \
-        RI[q] = p_ < p1 ? vi_ : -1;                                                                  \
-        RO[q] = p_ < p1 ? vo_ : -1;                                                                  \
+    const long long p0 = p_lo + (long long)s_unit * plan.per;
+    const long long p1 = p0 + plan.per < p_hi ? p0 + plan.per : p_hi;
+    // this wave's rule range [q0, q1): K mode = a quarter of the unit (multiple of 16 rules), QUAD = the whole unit
+    long long q0 = p0, q1 = p1;
+    if (!QUAD) {
+        const long long quarter = ((p1 - p0 + 63) / 64) * 16;
+        q0 = p0 + wave * quarter;
+        q1 = q0 + quarter < p1 ? q0 + quarter : p1;
     }
-#define WG_LOAD_ROWS(RI, RO)                                                                         \
-    _Pragma("unroll") for (int q = 0; q < PASSES; ++q) {                                             \
-        const float* xp_ = X + (long long)(RI[q] < 0 ? 0 : RI[q]) * cin + ci0 + 4 * c4;              \
-        const float* yp_ = dY + (long long)(RO[q] < 0 ? 0 : RO[q]) * cout + co0 + 4 * c4;            \
-        vx[q] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                         \
-        vy[q] = vx[q];                                                                               \
-        if (x_ok) vx[q] = *(const f32x4*)xp_;               /* loop-invariant per thread */          \
-        if (y_ok) vy[q] = *(const f32x4*)yp_;                                                        \
-    }
-#define WG_STORE_ROWS(BUF, RI, RO)                                                                   \
-    _Pragma("unroll") for (int q = 0; q < PASSES; ++q) {                                             \
-        f32x4 a_ = vx[q], b_ = vy[q];                                                                \
-        if (RI[q] < 0) a_ = (f32x4){0.f, 0.f, 0.f, 0.f};                                             \
-        if (RO[q] < 0) b_ = (f32x4){0.f, 0.f, 0.f, 0.f};                                             \
-        if (relu_in) { _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) a_[e_] = fmaxf(a_[e_], 0.f); } \
-        if (do_db) dbacc += b_;                 /* bias gradient: column sums of dY, see below */      \
-        float* xd_ = lds + (BUF) * 2 * OPND + (r_st + q * ROWS_PER_PASS) * LD + st_pos;              \
-        float* yd_ = xd_ + OPND;                                                                     \
-        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                           \
-            xd_[e_ * NT] = a_[e_];                                                                   \
-            yd_[e_ * NT] = b_[e_];                                                                   \
+    // rules of this wave, relative to q0: nfull whole blocks of 16 (pipelined, unmasked) + one masked tail block
+    const int nrel = __builtin_amdgcn_readfirstlane(q1 > q0 ? (int)(q1 - q0) : 0);
+    const int nfull = nrel / 16;
+    const int* inq = IDENT ? nullptr : in_rows + q0;
+    const int* outq = IDENT ? nullptr : out_rows + q0;
+    const int lane_r = 4 * kq;
+    const int q0i = (int)q0;                                   // identity list: rule index == row index (< 2^31)
+
+    // channel offsets of this lane inside a row: T consecutive floats starting at ci0 + TA*i (resp. co0 + TB*i)
+    const int ca = ci0 + TA * i, cbn = co0 + TB * i;
+    bool a_ok[TA], b_ok[TB];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) a_ok[t] = !EDGE || ca + t < cin;
+#pragma unroll
+    for (int t = 0; t < TB; ++t) b_ok[t] = !EDGE || cbn + t < cout;
+    const bool do_db = db_slabs != nullptr && ((db_mask >> o) & 1u) && bi == 0 && wi == 0;
+
+    f32x4 acc[TA][TB];
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float dbacc[TB];
+#pragma unroll
+    for (int t = 0; t < TB; ++t) dbacc[t] = 0.f;
+
+    // A block = 16 rules = 4 MFMA steps; lane group kq owns rules qb + 4*kq + s, s = step.
+    // Three named register sets (0,1,2) rotate through: indices of block b+3.., rows of block b+2.., MFMAs of block b.
+    // The instruction budget matters as much as the latency: a 16x16x4 fp32 MFMA is 32 cycles = 8 VALU slots, and at
+    // TA = TB = 2 a block has only 16 of them.  So: the block offset of the index loads is SCALAR (saddr + lane offset +
+    // immediate, zero VALU), a row address is ONE v_mad_i64_i32 (row * stride + per-lane base), ReLU is one v_max
+    // against 0 or -inf, and rule masking exists only in the peeled tail block.  (First version: ~110 VALU per block,
+    // VALU-issue-bound at 1/3 of the MFMA rate.)
+    const char* xlane = (const char*)(X + ca);
+    const char* ylane = (const char*)(dY + cbn);
+    const int xstride = 4 * cin, ystride = 4 * cout;           // int: row * stride is one v_mad_i64_i32
+    const int relu_lo = relu_in ? 0 : (int)0x80000000;
+    const int last_full = nfull > 0 ? (nfull - 1) * 16 : 0;        // prefetches past the end re-read the last whole block
+#define WD_IDX(IN, OUT, QB)                                                                          \
+    {                                                                                                \
+        const int qs_ = (QB) < last_full ? (QB) : last_full;           /* scalar */                  \
+        _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                           \
+            IN[s_] = IDENT ? q0i + qs_ + lane_r + s_ : inq[qs_ + lane_r + s_];                       \
+            OUT[s_] = IDENT ? q0i + qs_ + lane_r + s_ : outq[qs_ + lane_r + s_];                     \
         }                                                                                            \
     }
-
-    if (p0 < p1) {
-        WG_LOAD_IDX(p0, ri, ro);
-        WG_LOAD_ROWS(ri, ro);
-        WG_LOAD_IDX(p0 + WG_PK, rin, ron);
-        WG_STORE_ROWS(0, ri, ro);
-        __syncthreads();
-        int buf = 0;
-        for (long long pc = p0; pc < p1; pc += WG_PK, buf ^= 1) {
-            const bool more = pc + WG_PK < p1;
-            // next chunk's rows -> registers (indices were fetched one chunk earlier), indices of the chunk after
-            int ri2[PASSES], ro2[PASSES];
-            if (more) {
-                WG_LOAD_ROWS(rin, ron);
-                WG_LOAD_IDX(pc + 2 * WG_PK, ri2, ro2);
-            }
-            // multiply the current chunk: 8 steps of 4 rules; fragments of the wave's TW tiles in one LDS read each
-            const float* xs = lds + buf * 2 * OPND + i * NT + wi * TW;
-            const float* ys = lds + buf * 2 * OPND + OPND + i * NT + wj * TW;
-#pragma unroll
-            for (int st = 0; st < WG_PK / 4; ++st) {
-                const fragT a = *(const fragT*)(xs + (4 * st + kq) * LD);
-                const fragT b = *(const fragT*)(ys + (4 * st + kq) * LD);
-#pragma unroll
-                for (int ta = 0; ta < TW; ++ta)
-#pragma unroll
-                    for (int tb = 0; tb < TW; ++tb) {
-                        acc[ta][tb] = MFMA16(a[ta], b[tb], acc[ta][tb]);
-                    }
-            }
-            if (more) {
-                WG_STORE_ROWS(buf ^ 1, rin, ron);
-#pragma unroll
-                for (int q = 0; q < PASSES; ++q) { rin[q] = ri2[q]; ron[q] = ro2[q]; }
-            }
-            __syncthreads();
-        }
+#define WD_ROWS(A, B, IN, OUT)                                                                       \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                               \
+        if (EDGE) {                  /* element loads; channels past the end read channel 0 (zeroed at use) */ \
+            const float* xr_ = X + (long long)IN[s_] * cin;                                          \
+            const float* yr_ = dY + (long long)OUT[s_] * cout;                                       \
+            _Pragma("unroll") for (int t_ = 0; t_ < TA; ++t_) A[s_][t_] = xr_[a_ok[t_] ? ca + t_ : 0]; \
+            _Pragma("unroll") for (int t_ = 0; t_ < TB; ++t_) B[s_][t_] = yr_[b_ok[t_] ? cbn + t_ : 0]; \
+        } else if (WD_EXP == 2) {    /* experiment: no row loads */                                   \
+            _Pragma("unroll") for (int t_ = 0; t_ < TA; ++t_) A[s_][t_] = __int_as_float(IN[s_] + t_); \
+            _Pragma("unroll") for (int t_ = 0; t_ < TB; ++t_) B[s_][t_] = __int_as_float(OUT[s_] + t_); \
+        } else {                                                                                     \
+            A[s_] = *(const fa_t*)(xlane + (long long)IN[s_] * xstride);                             \
+            B[s_] = *(const fb_t*)(ylane + (long long)OUT[s_] * ystride);                            \
+        }                                                                                            \
     }
-#undef WG_LOAD_IDX
-#undef WG_LOAD_ROWS
-#undef WG_STORE_ROWS
-
-    if (do_db) {        // reduce the per-thread pieces over the ROWS_PER_PASS threads that share a channel group (LDS reuse)
-        __syncthreads();
-        float* red = lds;
-        *(f32x4*)(red + r_st * CB + 4 * c4) = dbacc;
-        __syncthreads();
-        if (tid < CB) {
-            float t = 0.f;
-            for (int r = 0; r < ROWS_PER_PASS; ++r) t += red[r * CB + tid];
-            db_slabs[(long long)unit * cout_pad + co0 + tid] = t;
-        }
+    // MASK: rules at or past `nrel` contribute nothing (tail block only)
+#define WD_MFMA(A, B, QB, MASK)                                                                      \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                               \
+        const bool v_ = !(MASK) || (QB) + lane_r + s_ < nrel;                                        \
+        fa_t a_ = A[s_];                                                                             \
+        fb_t b_ = B[s_];                                                                             \
+        _Pragma("unroll") for (int t_ = 0; t_ < TA; ++t_) {                                          \
+            /* ReLU as ONE integer max on the bit pattern (fmaxf costs a canonicalising v_max x,x more; inline asm \
+               hides the VALU->MFMA hazard from the compiler): negative floats are negative ints */  \
+            float x_ = __int_as_float(max(__float_as_int(a_[t_]), relu_lo));                         \
+            if ((MASK) || EDGE) x_ = (v_ && a_ok[t_]) ? x_ : 0.f;                                    \
+            a_[t_] = x_;                                                                             \
+        }                                                                                            \
+        if ((MASK) || EDGE) {                                                                        \
+            _Pragma("unroll") for (int t_ = 0; t_ < TB; ++t_) b_[t_] = (v_ && b_ok[t_]) ? b_[t_] : 0.f; \
+        }                                                                                            \
+        if (do_db) { _Pragma("unroll") for (int t_ = 0; t_ < TB; ++t_) dbacc[t_] += b_[t_]; }         \
+        _Pragma("unroll") for (int ta_ = 0; ta_ < TA; ++ta_)                                         \
+            _Pragma("unroll") for (int tb_ = 0; tb_ < TB; ++tb_)                                     \
+                if (WD_EXP == 1) acc[ta_][tb_][0] += a_[ta_] * b_[tb_];   /* experiment: no MFMA */   \
+                else acc[ta_][tb_] = MFMA16(a_[ta_], b_[tb_], acc[ta_][tb_]);                        \
     }
 
-    // partial block -> slab [unit][block][CB][CB]  (row = channel of X, col = channel of dY)
-    float* slab = slabs + ((long long)unit * (plan.nbi * plan.nbj) + blockIdx.z) * (CB * CB);
+    int in0[4], out0[4], in1[4], out1[4], in2[4], out2[4];
+    fa_t a0[4], a1[4], a2[4];
+    fb_t b0[4], b1[4], b2[4];
+    // Ring depth: 3 sets (rows two blocks ahead) for the small wave blocks; 2 sets (one block ahead) at TA = TB = 4,
+    // where a block is 64 MFMAs = 2048 cycles and the third set would cost the second resident wave per SIMD
+    // (64 accumulators + 3 x 32 row registers + indices > 256 registers).
+    constexpr bool DEEP = WD_DEEP_ALL || TA * TB < 16;
+    if (DEEP && nfull > 0) {
+        // (the prologue's issue order is pinned too: the loop header's wait counts are the merge of both ways in)
+        WD_IDX(in0, out0, 0);
+        WD_IDX(in1, out1, 16);
+        __builtin_amdgcn_sched_barrier(0);
+        WD_IDX(in2, out2, 32);
+        __builtin_amdgcn_sched_barrier(0);
+        WD_ROWS(a0, b0, in0, out0);
+        WD_IDX(in0, out0, 48);
+        __builtin_amdgcn_sched_barrier(0);
+        WD_ROWS(a1, b1, in1, out1);
+        WD_IDX(in1, out1, 64);
+        // steady state, block b (set b%3 holds its rows): queue rows of b+2 (indices arrived), indices of b+5, multiply b.
+        // The scheduling barriers keep each phase's address arithmetic in its phase: hoisted to the loop top it made
+        // every iteration wait for the newest index loads (s_waitcnt vmcnt(0)) and serialised the pipeline.
+        int qb = 0, b = 0;
+        for (; b + 3 <= nfull; b += 3, qb += 48) {
+            __builtin_amdgcn_sched_barrier(0);
+            WD_ROWS(a2, b2, in2, out2);
+            WD_IDX(in2, out2, qb + 80);
+            WD_MFMA(a0, b0, qb, false);
+            __builtin_amdgcn_sched_barrier(0);
+            WD_ROWS(a0, b0, in0, out0);
+            WD_IDX(in0, out0, qb + 96);
+            WD_MFMA(a1, b1, qb + 16, false);
+            __builtin_amdgcn_sched_barrier(0);
+            WD_ROWS(a1, b1, in1, out1);
+            WD_IDX(in1, out1, qb + 112);
+            WD_MFMA(a2, b2, qb + 32, false);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // remainder: 0, 1 or 2 whole blocks; their rows are already queued (sets 0 and 1)
+        if (b < nfull) { WD_MFMA(a0, b0, qb, false); }
+        if (b + 1 < nfull) { WD_MFMA(a1, b1, qb + 16, false); }
+    }
+    if (!DEEP && nfull > 0) {
+        WD_IDX(in0, out0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        WD_IDX(in1, out1, 16);
+        __builtin_amdgcn_sched_barrier(0);
+        WD_ROWS(a0, b0, in0, out0);
+        WD_IDX(in0, out0, 32);
+        // block b: set b%2 holds its rows; queue rows of b+1, indices of b+3, multiply b
+        int qb = 0, b = 0;
+        for (; b + 2 <= nfull; b += 2, qb += 32) {
+            __builtin_amdgcn_sched_barrier(0);
+            WD_ROWS(a1, b1, in1, out1);
+            WD_IDX(in1, out1, qb + 48);
+            WD_MFMA(a0, b0, qb, false);
+            __builtin_amdgcn_sched_barrier(0);
+            WD_ROWS(a0, b0, in0, out0);
+            WD_IDX(in0, out0, qb + 64);
+            WD_MFMA(a1, b1, qb + 16, false);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (b < nfull) { WD_MFMA(a0, b0, qb, false); }
+    }
+    if (nrel > nfull * 16) {        // tail block: clamped indices, masked values, no pipelining (once per wave)
+        const int qt = nfull * 16;
 #pragma unroll
-    for (int ta = 0; ta < TW; ++ta)
+        for (int s_ = 0; s_ < 4; ++s_) {
+            int r_ = qt + lane_r + s_;
+            r_ = r_ < nrel ? r_ : nrel - 1;
+            in2[s_] = IDENT ? q0i + r_ : inq[r_];
+            out2[s_] = IDENT ? q0i + r_ : outq[r_];
+        }
+        WD_ROWS(a2, b2, in2, out2);
+        WD_MFMA(a2, b2, qt, true);
+    }
+#undef WD_IDX
+#undef WD_ROWS
+#undef WD_MFMA
+
+    float* slab = slabs + ((long long)unit * (plan.nbi * plan.nbj) + blockIdx.z) * (CBI * CBJ);
+    float* dbr = red + (QUAD ? 0 : 4 * NACC * 4 * 64);                  // [4 waves][64 columns]
+
+    // ---- K mode: add the four waves' partial blocks in wave order.  Every wave stores its whole block to LDS
+    // ([wave][element][lane], conflict-free) and then OWNS a quarter of the elements: it adds the four copies of its
+    // quarter in wave order and writes those rows of the slab -- the epilogue is spread over the 4 waves and never holds
+    // more than one quarter in registers (a first version had wave 0 add everything: 200+ VGPRs, one wave per SIMD).
+    // acc[a][b][j] is row TA*(4kq+j)+a, column TB*i+b of the wave block; owner of (a, j): a (TA = 4), 2a + j/2 (TA = 2).
+    if (!QUAD) {
+        float* mine = red + wave * (NACC * 4 * 64);
 #pragma unroll
-        for (int tb = 0; tb < TW; ++tb)
+        for (int a = 0; a < TA; ++a)
+#pragma unroll
+            for (int b = 0; b < TB; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mine[((a * TB + b) * 4 + j) * 64 + lane] = acc[a][b][j];
+        __syncthreads();
+        constexpr int NJ = TA == 4 ? 4 : 2;                              // (a, j) pairs per owner
+        const int a_own = TA == 4 ? wave : (wave >> 1);
+        const int j_own = TA == 4 ? 0 : 2 * (wave & 1);
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int jx = j_own + jj;
+            fb_t v;
+#pragma unroll
+            for (int b = 0; b < TB; ++b) {
+                const float* src = red + ((a_own * TB + b) * 4 + jx) * 64 + lane;
+                v[b] = ((src[0] + src[NACC * 4 * 64]) + src[2 * NACC * 4 * 64]) + src[3 * NACC * 4 * 64];
+            }
+            const int r = TA * (4 * kq + jx) + a_own;
+            *(fb_t*)(slab + r * CBJ + TB * i) = v;
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < TA; ++a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int r = (wi * TW + ta) * 16 + 4 * kq + j;
-                const int c = (wj * TW + tb) * 16 + i;
-                slab[r * CB + c] = acc[ta][tb][j];
+                const int r = wi * WI + TA * (4 * kq + j) + a;
+                fb_t v;
+#pragma unroll
+                for (int b = 0; b < TB; ++b) v[b] = acc[a][b][j];
+                *(fb_t*)(slab + r * CBJ + wj * WJ + TB * i) = v;
             }
+    }
+
+    // ---- bias gradient: lanes (i, kq) hold column sums of their own rules -> add the 4 kq groups, then the waves ------
+    if (db_slabs != nullptr && ((db_mask >> o) & 1u) && bi == 0) {
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            float v = dbacc[t];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            dbacc[t] = v;
+        }
+        if (!QUAD) {
+            if (kq == 0) {
+#pragma unroll
+                for (int t = 0; t < TB; ++t) dbr[wave * 64 + TB * i + t] = dbacc[t];
+            }
+            __syncthreads();
+            if (wave == 0 && kq == 0) {
+#pragma unroll
+                for (int t = 0; t < TB; ++t) {
+                    const int c = TB * i + t;
+                    const float v = ((dbr[c] + dbr[64 + c]) + dbr[128 + c]) + dbr[192 + c];
+                    if (co0 + c < cout_pad) db_slabs[(long long)unit * cout_pad + co0 + c] = v;
+                }
+            }
+        } else if (wi == 0 && kq == 0) {
+#pragma unroll
+            for (int t = 0; t < TB; ++t)
+                if (cbn + t < cout_pad) db_slabs[(long long)unit * cout_pad + cbn + t] = dbacc[t];
+        }
+    }
 }
 
-// dW[o][ci][co] = sum over the K-splits, fixed association: 4 interleaved partial sums (splits s, s+4, ...) per element
-// computed by 4 threads, combined through LDS in a fixed order.  64 elements x 4 split lanes per block.
-__global__ __launch_bounds__(256) void k_wgrad_sum(const float* __restrict__ slabs, WgradPlan plan, int cin, int cout,
-                                                   float* __restrict__ dW, const float* __restrict__ db_slabs,
-                                                   unsigned db_mask, int cout_pad, float* __restrict__ db, int main_blocks) {
-    if ((int)blockIdx.x >= main_blocks) {           // trailing blocks: bias gradient, one column each
+// dW[o][ci][co] = sum over the units of offset o.  A thread owns V consecutive output channels (one 16-byte slab read
+// per unit at V = 4) and every G-th unit; the G partial sums of an element meet in LDS and are added in ascending g --
+// a fixed association for a given plan (bitwise reproducible).  G is chosen on the host so that small dW (many units,
+// few elements) still fill the chip.  Trailing blocks: bias gradient, one column each.
+template <int V>
+__global__ __launch_bounds__(256) void k_wgradd_sum(const float* __restrict__ slabs, DPlan plan, int cin, int cout,
+                                                    float* __restrict__ dW, const float* __restrict__ db_slabs,
+                                                    unsigned db_mask, int cout_pad, float* __restrict__ db,
+                                                    int main_blocks, int G) {
+    typedef typename Frag<V>::type vec_t;
+    if ((int)blockIdx.x >= main_blocks) {
         const int co = blockIdx.x - main_blocks;
         float s = 0.f;
         for (int o = 0; o < plan.n_off; ++o) {
@@ -213,68 +346,164 @@ __global__ __launch_bounds__(256) void k_wgrad_sum(const float* __restrict__ sla
         if (threadIdx.x == 0) db[co] = (w[0] + w[1]) + (w[2] + w[3]);
         return;
     }
-    const long long total = (long long)plan.n_off * cin * cout;
-    const int cb = plan.cb, nblk = plan.nbi * plan.nbj;
-    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    __shared__ float part[4][64];
-    for (long long e0 = (long long)blockIdx.x * 64; e0 < total; e0 += (long long)main_blocks * 64) {
-        const long long e = e0 + el;
-        float sum = 0.f;
-        if (e < total) {
-            const int co = (int)(e % cout);
-            const int ci = (int)((e / cout) % cin);
-            const int o = (int)(e / ((long long)cin * cout));
-            const int blk = (ci / cb) * plan.nbj + co / cb;
-            const int u0 = plan.unit_start[o], nu = plan.unit_start[o + 1] - u0;
-            const long long base = ((long long)u0 * nblk + blk) * (cb * cb) + (ci % cb) * cb + co % cb;
-            for (int s = sl; s < nu; s += 4) sum += slabs[base + (long long)s * nblk * cb * cb];
+    __shared__ __attribute__((aligned(16))) float part[256 * V];
+    const int per_block = 256 / G;                                   // element groups per block
+    const int el = threadIdx.x % per_block, g = threadIdx.x / per_block;
+    const long long total = (long long)plan.n_off * cin * (cout / V);    // element groups (cout % V == 0)
+    const int cbi = plan.cbi, cbj = plan.cbj, nblk = plan.nbi * plan.nbj;
+    const long long eg = (long long)blockIdx.x * per_block + el;
+    vec_t sum;
+#pragma unroll
+    for (int v = 0; v < V; ++v) sum[v] = 0.f;
+    long long e = 0;
+    if (eg < total) {
+        e = eg * V;
+        const int co = (int)(e % cout);
+        const int ci = (int)((e / cout) % cin);
+        const int o = (int)(e / ((long long)cin * cout));
+        const int blk = (ci / cbi) * plan.nbj + co / cbj;
+        const int u0 = plan.unit_start[o], nu = plan.unit_start[o + 1] - u0;
+        const long long stride = (long long)nblk * cbi * cbj;
+        const float* p = slabs + ((long long)u0 * nblk + blk) * (cbi * cbj) + (ci % cbi) * cbj + co % cbj;
+        for (int s = g; s < nu; s += G) {
+            const vec_t x = *(const vec_t*)(p + s * stride);
+#pragma unroll
+            for (int v = 0; v < V; ++v) sum[v] += x[v];
         }
-        part[sl][el] = sum;
-        __syncthreads();
-        if (sl == 0 && e < total) dW[e] = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
-        __syncthreads();
     }
+    if (G > 1) {
+        *(vec_t*)(part + (g * per_block + el) * V) = sum;
+        __syncthreads();
+        if (g == 0) {
+            for (int k = 1; k < G; ++k) {
+                const vec_t x = *(const vec_t*)(part + (k * per_block + el) * V);
+#pragma unroll
+                for (int v = 0; v < V; ++v) sum[v] += x[v];
+            }
+        }
+    }
+    if (g == 0 && eg < total) *(vec_t*)(dW + e) = sum;
 }
 
-static int make_plan(int cin, int cout, const int64_t* prefix_host, int n_off, WgradPlan& pl) {
+namespace {
+struct Shape { int ta, tb; bool quad; };
+
+Shape pick_shape(int cin, int cout) {
+    Shape s;
+    s.ta = cin > 32 ? 4 : 2;
+    s.tb = cout > 32 ? 4 : 2;
+    s.quad = cin > 64 && cout > 64;
+    return s;
+}
+
+int make_dplan(int cin, int cout, const int64_t* prefix_host, int n_off, DPlan& pl) {
+    const Shape sh = pick_shape(cin, cout);
     pl.n_off = n_off;
-    pl.cb = (cin > 64 || cout > 64) ? 128 : ((cin > 32 || cout > 32) ? 64 : 32);
-    if (const char* e = getenv("SCN_WGRAD_CB")) pl.cb = atoi(e);             // developer override (tools/ablate_wgrad.py)
-    pl.nbi = (int)cdiv(cin, pl.cb);
-    pl.nbj = (int)cdiv(cout, pl.cb);
+    pl.cbi = 16 * sh.ta * (sh.quad ? 2 : 1);
+    pl.cbj = 16 * sh.tb * (sh.quad ? 2 : 1);
+    pl.nbi = (int)cdiv(cin, pl.cbi);
+    pl.nbj = (int)cdiv(cout, pl.cbj);
     pl.rule_start[0] = prefix_host[0];
     for (int o = 0; o < n_off; ++o) {
         if (prefix_host[o + 1] < prefix_host[o]) return SCN_EINVAL;
         pl.rule_start[o + 1] = prefix_host[o + 1];
     }
-    // work units: ~4 per CU (2 at CB = 128) over all offsets together, at least 4 chunks of rules each
     const int64_t total = prefix_host[n_off] - prefix_host[0];
     const int64_t nblk = (int64_t)pl.nbi * pl.nbj;
-    int64_t target = (pl.cb == 128 && nblk == 1) ? 512 : 1024 / nblk;      // measured: tools/ablate_wgrad.py
+    // Unit count: the grid should fill the resident workgroup slots of the chip a whole number of times (R rounds) --
+    // 1.05 rounds costs as much as 2.  Slots = 256 CUs x workgroups per CU (registers / LDS of the instantiation).
+    // Every offset rounds its unit count up, hence the n_off margin.  R and the slot counts: tools/sweep_wgrad_splits.py.
+    const int occ = sh.quad ? 2 : (sh.ta == 4 && sh.tb == 4 ? 2 : (sh.ta == 2 && sh.tb == 2 ? 4 : 3));
+    const int rounds = (sh.quad ? nblk > 1 : (sh.ta == 4 && sh.tb == 4)) ? 2 : 1;
+    int64_t target = (256 * occ * rounds) / nblk - n_off;
     if (const char* e = getenv("SCN_WGRAD_SPLITS")) target = atoi(e);       // developer override
     if (target < 1) target = 1;
-    int64_t per = cdiv(cdiv(total, target), WG_PK) * WG_PK;
-    if (per < 4 * WG_PK) per = 4 * WG_PK;
+    const int64_t gran = sh.quad ? 16 : 64;
+    int64_t per = cdiv(cdiv(total, target), gran) * gran;
+    const int64_t min_per = sh.quad ? 128 : 512;                           // >= 8 blocks of 16 rules per wave
+    if (per < min_per) per = min_per;
     pl.per = per;
     pl.unit_start[0] = 0;
     for (int o = 0; o < n_off; ++o)
         pl.unit_start[o + 1] = pl.unit_start[o] + (int)cdiv(prefix_host[o + 1] - prefix_host[o], per);
     return SCN_OK;
 }
+}  // namespace
 
 extern "C" int64_t scn_wgrad_scratch_bytes(int cin, int cout, const int64_t* prefix_host, int n_off) {
     if (!prefix_host || n_off < 1 || n_off > 32 || cin < 1 || cout < 1) return -1;
-    WgradPlan pl;
-    if (make_plan(cin, cout, prefix_host, n_off, pl) != SCN_OK) return -1;
-    const int64_t fast = (int64_t)pl.unit_start[n_off] * ((int64_t)pl.nbi * pl.nbj * pl.cb * pl.cb + (int64_t)pl.nbj * pl.cb) *
-                             (int64_t)sizeof(float) + 512;
-    const int64_t simple = scn::wgrad_simple_scratch_bytes(cin, cout, prefix_host, n_off);
-    return fast > simple ? fast : simple;
+    DPlan pl;
+    if (make_dplan(cin, cout, prefix_host, n_off, pl) != SCN_OK) return -1;
+    return (int64_t)pl.unit_start[n_off] * ((int64_t)pl.nbi * pl.nbj * pl.cbi * pl.cbj + (int64_t)pl.nbj * pl.cbj) *
+               (int64_t)sizeof(float) + 512;
 }
 
 static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
                       const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, float* db,
-                      unsigned db_mask, void* scratch, int flags, scn_stream_t stream);
+                      unsigned db_mask, void* scratch, int flags, scn_stream_t stream) {
+    SCN_REQUIRE(prefix_host && n_off >= 1 && n_off <= 32 && cin >= 1 && cout >= 1 && dW && scratch);
+    SCN_REQUIRE((in_rows == nullptr) == (out_rows == nullptr));
+    SCN_REQUIRE(in_rows || n_off == 1);
+    DPlan pl;
+    SCN_REQUIRE(make_dplan(cin, cout, prefix_host, n_off, pl) == SCN_OK);
+    SCN_REQUIRE(prefix_host[n_off] == prefix_host[0] || (X && dY));
+    SCN_REQUIRE((((uintptr_t)X | (uintptr_t)dY) & 3) == 0);
+    if (pl.unit_start[n_off] == 0) {
+        SCN_HIP(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)n_off * cin * cout, S(stream)));
+        if (db) SCN_HIP(hipMemsetAsync(db, 0, sizeof(float) * (size_t)cout, S(stream)));
+        return SCN_OK;
+    }
+    const Shape sh = pick_shape(cin, cout);
+    // vector row pieces need aligned rows and whole blocks; anything else takes the element-wise (EDGE) instantiation
+    const bool edge = (cin % (16 * sh.ta) != 0) || (cout % (16 * sh.tb) != 0) ||
+                      ((((uintptr_t)X | (uintptr_t)dY) & 15) != 0);
+    const bool ident = in_rows == nullptr;
+    const int cout_pad = pl.nbj * pl.cbj;
+    float* db_slabs = db ? (float*)scratch + (int64_t)pl.unit_start[n_off] * pl.nbi * pl.nbj * pl.cbi * pl.cbj : nullptr;
+    dim3 grid((unsigned)pl.unit_start[n_off], 1, (unsigned)(pl.nbi * pl.nbj));
+    const int relu_in = (flags & SCN_F_RELU_IN) ? 1 : 0;
+#define LAUNCH_WD(TA_, TB_, Q_, E_, I_)                                                                          \
+    do {                                                                                                         \
+        const size_t lds_ = ((Q_) ? 4 * 64 : 4 * (TA_) * (TB_) * 4 * 64 + 4 * 64) * sizeof(float);               \
+        static bool attr_set = false;                                                                            \
+        if (!attr_set) {                                                                                         \
+            SCN_HIP(hipFuncSetAttribute((const void*)k_wgrad_direct<TA_, TB_, Q_, E_, I_>,                       \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                \
+            attr_set = true;                                                                                     \
+        }                                                                                                        \
+        hipLaunchKernelGGL((k_wgrad_direct<TA_, TB_, Q_, E_, I_>), grid, dim3(256), lds_, S(stream), X, cin, dY, \
+                           cout, in_rows, out_rows, pl, (float*)scratch, relu_in, db_slabs, db_mask, cout_pad);  \
+    } while (0)
+#define PICK_EI(TA_, TB_, Q_)                                                                                    \
+    do {                                                                                                         \
+        if (edge) { if (ident) LAUNCH_WD(TA_, TB_, Q_, true, true); else LAUNCH_WD(TA_, TB_, Q_, true, false); } \
+        else { if (ident) LAUNCH_WD(TA_, TB_, Q_, false, true); else LAUNCH_WD(TA_, TB_, Q_, false, false); }    \
+    } while (0)
+    if (sh.quad) PICK_EI(4, 4, true);
+    else if (sh.ta == 4 && sh.tb == 4) PICK_EI(4, 4, false);
+    else if (sh.ta == 4) PICK_EI(4, 2, false);
+    else if (sh.tb == 4) PICK_EI(2, 4, false);
+    else PICK_EI(2, 2, false);
+#undef PICK_EI
+#undef LAUNCH_WD
+    SCN_LAUNCH_CHECK();
+    // sum of the units: V output channels per thread, G threads per element group so that ~>= 128k threads run
+    const int V = (cout % 4 == 0 && (((uintptr_t)dW | (uintptr_t)scratch) & 15) == 0) ? 4 : 1;
+    const int64_t groups = (int64_t)n_off * cin * (cout / V);
+    int G = 1;
+    while (G < 16 && groups * G < 128 * 1024) G *= 2;
+    const int main_blocks = (int)cdiv(groups, 256 / G);
+    if (V == 4)
+        hipLaunchKernelGGL(k_wgradd_sum<4>, dim3(main_blocks + (db ? cout : 0)), dim3(256), 0, S(stream),
+                           (const float*)scratch, pl, cin, cout, dW, (const float*)db_slabs, db_mask, cout_pad, db,
+                           main_blocks, G);
+    else
+        hipLaunchKernelGGL(k_wgradd_sum<1>, dim3(main_blocks + (db ? cout : 0)), dim3(256), 0, S(stream),
+                           (const float*)scratch, pl, cin, cout, dW, (const float*)db_slabs, db_mask, cout_pad, db,
+                           main_blocks, G);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
 
 extern "C" int scn_wgrad_rules(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
                                const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, void* scratch,
@@ -288,58 +517,4 @@ extern "C" int scn_wgrad_bias_rules(const float* X, int cin, const float* dY, in
     SCN_REQUIRE(db && db_offsets);
     return wgrad_impl(X, cin, dY, cout, in_rows, out_rows, prefix_host, n_off, dW, db, db_offsets, scratch, flags,
                       stream);
-}
-
-static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
-                      const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, float* db,
-                      unsigned db_mask, void* scratch, int flags, scn_stream_t stream) {
-    SCN_REQUIRE(prefix_host && n_off >= 1 && n_off <= 32 && cin >= 1 && cout >= 1 && dW && scratch);
-    SCN_REQUIRE((in_rows == nullptr) == (out_rows == nullptr));
-    SCN_REQUIRE(in_rows || n_off == 1);
-    WgradPlan pl;
-    SCN_REQUIRE(make_plan(cin, cout, prefix_host, n_off, pl) == SCN_OK);
-    const int64_t total = prefix_host[n_off] - prefix_host[0];
-    SCN_REQUIRE(total == 0 || (X && dY));
-    // 16-byte row pieces need 16-byte aligned rows; otherwise fall back to a channel count the loads can take
-    SCN_REQUIRE((((uintptr_t)X | (uintptr_t)dY) & 3) == 0);
-    const bool aligned = (cin % 4 == 0) && (cout % 4 == 0) && ((((uintptr_t)X | (uintptr_t)dY) & 15) == 0);
-    if (!aligned) {
-        int rc = scn::wgrad_simple(X, cin, dY, cout, in_rows, out_rows, prefix_host, n_off, dW, scratch, flags, stream);
-        if (rc == SCN_OK && db)
-            return scn::fail(SCN_EINVAL, "%sscn_wgrad_bias_rules needs channel counts that are multiples of 4 "
-                                         "(use scn_wgrad_rules + scn_colsum)", "");
-        return rc;
-    }
-    if (pl.unit_start[n_off] == 0) {
-        SCN_HIP(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)n_off * cin * cout, S(stream)));
-        if (db) SCN_HIP(hipMemsetAsync(db, 0, sizeof(float) * (size_t)cout, S(stream)));
-        return SCN_OK;
-    }
-    const int cout_pad = pl.nbj * pl.cb;
-    float* db_slabs = db ? (float*)scratch + (int64_t)pl.unit_start[n_off] * pl.nbi * pl.nbj * pl.cb * pl.cb : nullptr;
-    dim3 grid((unsigned)pl.unit_start[n_off], 1, (unsigned)(pl.nbi * pl.nbj));
-    const int relu_in = (flags & SCN_F_RELU_IN) ? 1 : 0;
-#define LAUNCH_WG(TW_)                                                                                      \
-    do {                                                                                                        \
-        const size_t lds_ = (size_t)2 * 2 * WG_PK * (32 * TW_ + 4) * sizeof(float);                             \
-        static bool attr_set = false;                                                                           \
-        if (!attr_set) {                                                                                        \
-            SCN_HIP(hipFuncSetAttribute((const void*)k_wgrad_lds<TW_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                        160 * 1024));                                                           \
-            attr_set = true;                                                                                    \
-        }                                                                                                       \
-        hipLaunchKernelGGL(k_wgrad_lds<TW_>, grid, dim3(256), lds_, S(stream), X, cin, dY, cout, in_rows, out_rows, \
-                           pl, (float*)scratch, relu_in, db_slabs, db_mask, cout_pad);                          \
-    } while (0)
-    if (pl.cb == 128) LAUNCH_WG(4);
-    else if (pl.cb == 64) LAUNCH_WG(2);
-    else LAUNCH_WG(1);
-#undef LAUNCH_WG
-    SCN_LAUNCH_CHECK();
-    const int main_blocks = scn::ew_grid((int64_t)n_off * cin * cout, 64);
-    hipLaunchKernelGGL(k_wgrad_sum, dim3(main_blocks + (db ? cout : 0)), dim3(256), 0, S(stream),
-                       (const float*)scratch, pl, cin, cout, dW, (const float*)db_slabs, db_mask, cout_pad, db,
-                       main_blocks);
-    SCN_LAUNCH_CHECK();
-    return SCN_OK;
 }

@@ -111,11 +111,8 @@ def wgrad_rules(X, dY, in_rows, out_rows, prefix_host, n_off, flags=0):
 
 
 def wgrad_bias_rules(X, dY, in_rows, out_rows, prefix_host, n_off, db_offsets, flags=0):
-    """dW and db in one pass (scn_wgrad_bias_rules); falls back to wgrad_rules + colsum for channel counts the fused
-    kernel cannot take."""
+    """dW and db in one pass (scn_wgrad_bias_rules)."""
     cin, cout = X.shape[1], dY.shape[1]
-    if cin % 4 or cout % 4 or (X.data_ptr() | dY.data_ptr()) & 15:
-        return wgrad_rules(X, dY, in_rows, out_rows, prefix_host, n_off, flags), colsum(dY)
     lib = L.lib()
     nbytes = lib.scn_wgrad_scratch_bytes(cin, cout, prefix_host, n_off)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=X.device)

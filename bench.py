@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--target", type=int, default=TARGET)
+    ap.add_argument("--profile-all", action="store_true",
+                    help="time every GEMM kernel launch of the sampled steps, not only the dominant kernel")
     ap.add_argument("--prefetch", action="store_true",
                     help="build the next batch's index structures one batch ahead on the index stream "
                          "(Metadata.prepare_async); measured slower from a single host thread, off by default")
@@ -124,11 +126,12 @@ def main():
         flat.all_reduce_mean()
         flat.sgd_step(1e-6)
 
-    # Kernel timing: HIP events around the launches of the GEMM kernels on at most 4-5 steps spread over the timed
-    # region, from a pool of events created before it.  Timing every launch made the step host-bound (8.9 -> 9.8-12.5
-    # ms/step), and more than ~2k outstanding timing events slow the HIP runtime itself (profiling.py).
-    every = max(4, (args.steps + 3) // 4)
-    timer = profiling.KernelTimer(every=every)
+    # Kernel timing: HIP events around the launches of the dominant kernel (scn_conv_tiles: 62 launches per step) on 3-4
+    # steps spread over the timed region, from a pool of events created before it.  Timing events are not free: every
+    # launch of every step timed cost 1-3.5 ms/step (host-bound, and each event pair fences the queue), all four GEMM
+    # kernels on every 5th step still ~0.5 ms/step.  --profile-all times all GEMM kernels (the "kernels" table).
+    every = max(5, (args.steps + 2) // 3)
+    timer = profiling.KernelTimer(every=every, names=None if args.profile_all else {"k_conv_ts"})
     for w in range(args.warmup):
         if w == args.warmup - 1:                    # count the launches of one step to size the event pool
             timer.count_only = True

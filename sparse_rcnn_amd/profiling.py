@@ -11,8 +11,9 @@ import torch
 
 
 class KernelTimer:
-    def __init__(self, every: int = 1):
+    def __init__(self, every: int = 1, names=None):
         self.every = max(1, int(every))
+        self.names = set(names) if names else None      # only these launch names are timed (None = all)
         self.step = -1
         self.active = True
         self.count_only = False
@@ -38,9 +39,9 @@ class KernelTimer:
 
     def launch(self, name, flops, nbytes, fn):
         if self.count_only:
-            self.count += 1
+            self.count += self.names is None or name in self.names
             return fn()
-        if not self.active:
+        if not self.active or (self.names is not None and name not in self.names):
             return fn()
         s, e = self._event(), self._event()
         s.record()

@@ -1,7 +1,7 @@
 """Developer tool (GPU box): A/B bench.py variants through environment switches in one gpurun call."""
 import subprocess, sys, json, os
 os.chdir(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-runs = [({"SCN_BENCH_NO_TIMER": "1"}, 20), ({}, 10), ({}, 20), ({}, 40), ({}, 100)]
+runs = [({"SCN_BENCH_NO_TIMER": "1"}, 20), ({}, 10), ({}, 20), ({}, 20), ({}, 40), ({}, 100)]
 for env, steps in runs:
     e = dict(os.environ); e.update(env)
     r = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--steps", str(steps), "--warmup", "5"], env=e,

@@ -161,7 +161,7 @@ int scn_tiles_build(const int32_t* table, int n_off, int64_t n, int32_t* perm, i
  * Serves SubmanifoldConvolution fwd / backward-data (module_factory.py:404-406), Convolution fwd (:232-234) and
  * Deconvolution backward-data (:256-258).  n_off <= 27.  Per-row accumulation order is fixed (offsets ascending). */
 int64_t scn_conv_tiles_scratch_bytes(int cin, int64_t n_out, int cout);   /* tile-queue counters + K-chunk slabs */
-int scn_conv_tiles(const float* X, int cin, const int32_t* tstab, const uint32_t* tile_mask, const int32_t* perm,
+int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32_t* tstab, const uint32_t* tile_mask, const int32_t* perm,
                    const int32_t* tile_order, int n_off, int64_t n_out, const float* W, const float* bias, const float* residual,
                    const float* relu_mask, float* Y, int cout, int flags, void* scratch, scn_stream_t stream);
 

@@ -46,7 +46,8 @@ __device__ __forceinline__ int ts_ws_off(int o, int k, int n) { return (o * TS_K
 //   K-chunk's workgroups write their partial sums to slab[kc] and k_conv_ts_sum adds the slabs in fixed order.
 template <bool WT, bool VEC, bool VECN, bool FULLK>
 __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
-    const float* __restrict__ X, int cin, const int* __restrict__ tstab, const unsigned* __restrict__ tile_mask,
+    const float* __restrict__ X, long long n_in, int cin, const int* __restrict__ tstab,
+    const unsigned* __restrict__ tile_mask,
     const int* __restrict__ perm, const int* __restrict__ tile_order, int n_off, long long nt,
     const float* __restrict__ W, const float* __restrict__ bias,
     const float* __restrict__ residual, const float* __restrict__ relu_mask, float* __restrict__ Y,
@@ -157,14 +158,21 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     const int bofs = (4 * kq) * TS_CT + (i ^ ((kq & 1) << 4));
 
     // A-row gather of one offset into two named registers (macro, not a lambda: the ping-pong below must keep the
-    // two register sets apart by NAME).  FULLK: branch-free -- rows without a rule read row 0 and are zeroed when used,
-    // so the loads stay outside divergent control flow and the compiler keeps them in flight across the MFMAs.
+    // two register sets apart by NAME).
+    // FULLK: RAW BUFFER loads.  The buffer descriptor covers X exactly, so a row index of -1 (no rule) turns into a byte
+    // offset past num_records and the hardware returns zeros: no select on the eight A values, no clamp of the index,
+    // and the address is ONE v_mad_i32_i24 (row * row_bytes + lane offset) instead of a 64-bit multiply-add chain.
+    // Every VALU instruction counts here: on this chip a VALU op takes ~4 cycles away from the MFMA pipe of the same
+    // SIMD (tools/micro/step_skeleton.hip: 137 TFLOP/s with 0, 119 with 16, 99 with 64 dependent VALU ops per step).
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(unsigned)(n_in * cin * 4), 0x00020000);
+    const int row_bytes = cin * 4, lane_boff = ka * 4;
 #define TS_GATHER(IDX, A0, A1)                                                                       \
     do {                                                                                             \
         if constexpr (FULLK) {                                                                       \
-            const float* xp_ = X + (long long)((IDX) < 0 ? 0 : (IDX)) * cin + ka;                    \
-            A0 = *(const f32x4*)xp_;                                                                 \
-            A1 = *(const f32x4*)(xp_ + 16);                                                          \
+            const int off_ = __mul24((IDX), row_bytes) + lane_boff;      /* -1 -> out of range -> 0 */ \
+            A0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off_, 0, 0));  \
+            A1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off_ + 64, 0, 0)); \
         } else {                                                                                     \
             A0 = (f32x4){0.f, 0.f, 0.f, 0.f};                                                        \
             A1 = A0;                                                                                 \
@@ -187,25 +195,27 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         }                                                                                            \
     } while (0)
 
-    // one pipeline step: index of the offset 4 ahead, A rows of the offset 3 ahead into (G0, G1), MFMAs on (C0, C1).
-    // Four named A register sets rotate (loop unrolled by 4): with ~2 us of gather latency and 512 MFMA cycles per
-    // offset a SIMD needs ~9 gathers in flight (4 waves x 3 here); one-ahead prefetch left the kernel latency-bound.
-#define TS_STEP(C0, C1, G0, G1)                                                                      \
+    // one pipeline step: index of the offset 4 ahead (into INEW), A rows of the offset 3 ahead into (G0, G1) from the
+    // index loaded one step earlier (IOLD), MFMAs on (C0, C1).  Four named A register sets and two named index registers
+    // rotate with the unrolled loop -- no register moves (a move of a value still in flight forces a wait, and every VALU
+    // op costs MFMA time).  With ~2 us of gather latency and 512 MFMA cycles per offset a SIMD needs ~9 gathers in
+    // flight (4 waves x 3 here); one-ahead prefetch left the kernel latency-bound.
+    // ZERO0: (non-FULLK only) the item multiplied now has rows without a rule -> handled in TS_GATHER (zero-filled).
+#define TS_STEP(C0, C1, G0, G1, IOLD, INEW)                                                          \
     do {                                                                                             \
         int o4_ = -1;                                                                                \
         if (m) { o4_ = __builtin_ctz(m); m &= m - 1; olast = o4_; }                                  \
-        const int i4_ = tb[olast * TS_T];                                                            \
-        TS_GATHER(iq3, G0, G1);                                                                      \
+        INEW = tb_s[olast * TS_T + i];                  /* scalar base + lane offset: no VALU */     \
+        TS_GATHER(IOLD, G0, G1);                                                                     \
         f32x4 a0_ = C0, a1_ = C1;                                                                    \
-        if (FULLK && iq0 < 0) { a0_ = (f32x4){0.f, 0.f, 0.f, 0.f}; a1_ = a0_; }                      \
-        if (relu_in) {                                                                               \
+        if (relu_in) {                                  /* ReLU as one integer max per value */      \
             _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                       \
-                a0_[e_] = fmaxf(a0_[e_], 0.f);                                                       \
-                a1_[e_] = fmaxf(a1_[e_], 0.f);                                                       \
+                a0_[e_] = __int_as_float(max(__float_as_int(a0_[e_]), 0));                           \
+                a1_[e_] = __int_as_float(max(__float_as_int(a1_[e_]), 0));                           \
             }                                                                                        \
         }                                                                                            \
-        const float* wb_ = Ws + oq0 * (TS_KC * TS_CT) + bofs;                                        \
-        const float* wc_ = Ws + oq0 * (TS_KC * TS_CT) + (bofs ^ 16);                                 \
+        const float* wb_ = Ws + (oq0 * (TS_KC * TS_CT) + bofs);                                      \
+        const float* wc_ = Ws + (oq0 * (TS_KC * TS_CT) + (bofs ^ 16));                               \
         float bl_[8], bh_[8];                                                                        \
         _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                           \
             bl_[e_] = wb_[e_ * TS_CT];                                                               \
@@ -222,7 +232,6 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
             c1 = MFMA16(a1_[e_], bh_[4 + e_], c1);                                                   \
         }                                                                                            \
         oq0 = oq1; oq1 = oq2; oq2 = oq3; oq3 = o4_;                                                  \
-        iq0 = iq1; iq1 = iq2; iq2 = iq3; iq3 = i4_;                                                  \
     } while (0)
 
     // ---- tile loop: the id, mask and output rows of the NEXT tile are fetched while the current one computes --------
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         int orow[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) orow[j] = orow_next[j];
-        const int* tb = tstab + tile * n_off * TS_T + i;
+        const int* tb_s = tstab + tile * n_off * TS_T;              // wave-uniform base; the lane adds i
         tile_next = grab();
         if (tile_next >= 0) {
             m_next = tile_mask[tile_next];
@@ -242,16 +251,16 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
 
         // queue of the next four offsets of this tile (-1 = none) and their row indices; loads are unconditional
         // (a finished list re-reads its last offset)
-        int oq0 = -1, oq1 = -1, oq2 = -1, oq3 = -1, iq0, iq1, iq2, iq3;
+        int oq0 = -1, oq1 = -1, oq2 = -1, oq3 = -1, iq0, iq1, iq2, iqa, iqb;
         int olast = 0;
         if (m) { oq0 = __builtin_ctz(m); m &= m - 1; olast = oq0; }
-        iq0 = tb[olast * TS_T];
+        iq0 = tb_s[olast * TS_T + i];
         if (m) { oq1 = __builtin_ctz(m); m &= m - 1; olast = oq1; }
-        iq1 = tb[olast * TS_T];
+        iq1 = tb_s[olast * TS_T + i];
         if (m) { oq2 = __builtin_ctz(m); m &= m - 1; olast = oq2; }
-        iq2 = tb[olast * TS_T];
+        iq2 = tb_s[olast * TS_T + i];
         if (m) { oq3 = __builtin_ctz(m); m &= m - 1; olast = oq3; }
-        iq3 = tb[olast * TS_T];
+        iqa = tb_s[olast * TS_T + i];
         f32x4 s00, s01, s10, s11, s20, s21, s30, s31;
         TS_GATHER(iq0, s00, s01);
         TS_GATHER(iq1, s10, s11);
@@ -259,35 +268,46 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
 
         f32x4 c0 = {bA, bA, bA, bA}, c1 = {bB, bB, bB, bB};
         while (oq0 >= 0) {
-            TS_STEP(s00, s01, s30, s31);
+            TS_STEP(s00, s01, s30, s31, iqa, iqb);
             if (oq0 < 0) break;
-            TS_STEP(s10, s11, s00, s01);
+            TS_STEP(s10, s11, s00, s01, iqb, iqa);
             if (oq0 < 0) break;
-            TS_STEP(s20, s21, s10, s11);
+            TS_STEP(s20, s21, s10, s11, iqa, iqb);
             if (oq0 < 0) break;
-            TS_STEP(s30, s31, s20, s21);
+            TS_STEP(s30, s31, s20, s21, iqb, iqa);
         }
 
-        // ---- tile epilogue: 16 lanes write 64 contiguous bytes of a row -------------------------------------------
+        // ---- tile epilogue: 16 lanes write 64 contiguous bytes of a row.  The residual / ReLU-mask operands of all
+        // eight outputs are requested first and consumed afterwards (one wait, not eight round trips).
+        float rs[4][2], mk[4][2];
+        const bool use_res = single && residual != nullptr, use_mask = single && relu_mask != nullptr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long off = (long long)(orow[j] < 0 ? 0 : orow[j]) * cout;
+            rs[j][0] = rs[j][1] = 0.f;
+            mk[j][0] = mk[j][1] = 1.f;
+            if (use_res) {
+                if (nA < cout) rs[j][0] = residual[off + nA];
+                if (nB < cout) rs[j][1] = residual[off + nB];
+            }
+            if (use_mask) {
+                if (nA < cout) mk[j][0] = relu_mask[off + nA];
+                if (nB < cout) mk[j][1] = relu_mask[off + nB];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = orow[j];
             if (row < 0) continue;
             const long long off = (long long)row * cout;
             if (nA < cout) {
-                float y = c0[j];
-                if (single) {
-                    if (residual) y += residual[off + nA];
-                    if (relu_mask && !(relu_mask[off + nA] > 0.f)) y = 0.f;
-                }
+                float y = c0[j] + rs[j][0];
+                if (!(mk[j][0] > 0.f)) y = 0.f;
                 out[off + nA] = y;
             }
             if (nB < cout) {
-                float y = c1[j];
-                if (single) {
-                    if (residual) y += residual[off + nB];
-                    if (relu_mask && !(relu_mask[off + nB] > 0.f)) y = 0.f;
-                }
+                float y = c1[j] + rs[j][1];
+                if (!(mk[j][1] > 0.f)) y = 0.f;
                 out[off + nB] = y;
             }
         }
@@ -320,11 +340,11 @@ extern "C" int64_t scn_conv_tiles_scratch_bytes(int cin, int64_t n_out, int cout
     return ts_counter_bytes(cin, cout) + (n_kc > 1 ? n_kc * n_out * cout * (int64_t)sizeof(float) : 0);
 }
 
-extern "C" int scn_conv_tiles(const float* X, int cin, const int32_t* tstab, const uint32_t* tile_mask,
+extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32_t* tstab, const uint32_t* tile_mask,
                               const int32_t* perm, const int32_t* tile_order, int n_off, int64_t n_out, const float* W, const float* bias,
                               const float* residual, const float* relu_mask, float* Y, int cout, int flags,
                               void* scratch, scn_stream_t stream) {
-    SCN_REQUIRE(n_off >= 1 && n_off <= 27 && n_out >= 0 && cin >= 1 && cout >= 1);
+    SCN_REQUIRE(n_off >= 1 && n_off <= 27 && n_out >= 0 && n_in >= 0 && cin >= 1 && cout >= 1);
     if (n_out == 0) return SCN_OK;
     SCN_REQUIRE(X && tstab && tile_mask && perm && tile_order && W && Y);
     const int64_t nt = cdiv(n_out, TS_T);
@@ -344,7 +364,8 @@ extern "C" int scn_conv_tiles(const float* X, int cin, const int32_t* tstab, con
     const bool wt = flags & SCN_F_W_TRANSPOSED;
     const bool vec = (cin % 4 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0);
     const bool vecn = (cout % 4 == 0) && (((uintptr_t)W & 15) == 0);
-    const bool fullk = vec && (cin % TS_KC == 0);
+    // the fast path addresses X through a raw buffer descriptor: 32-bit byte offsets, 24-bit row indices
+    const bool fullk = vec && (cin % TS_KC == 0) && n_in < (1ll << 23) && n_in * cin * 4 < (1ll << 32) - (1ll << 24);
     dim3 grid((unsigned)(n_tg * n_chunks * n_kc));
     hipStream_t st = S(stream);
 #define LAUNCH_TS(T, V, VN, FK)                                                                                     \
@@ -355,7 +376,7 @@ extern "C" int scn_conv_tiles(const float* X, int cin, const int32_t* tstab, con
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((k_conv_ts<T, V, VN, FK>), grid, dim3(TS_NW * 64), lds, st, X, cin, tstab, tile_mask,    \
+        hipLaunchKernelGGL((k_conv_ts<T, V, VN, FK>), grid, dim3(TS_NW * 64), lds, st, X, (long long)n_in, cin, tstab, tile_mask, \
                            perm, tile_order, n_off, (long long)nt, W, bias, residual, relu_mask, Y, slabs,                      \
                            (long long)n_out, cout, flags, n_chunks, n_kc, counters);                                \
     } while (0)

@@ -68,7 +68,7 @@ def conv_rules(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu_mask
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=X.device)
 
     def run():
-        L.check(lib.scn_conv_tiles(L.ptr(X), cin, L.ptr(tiles.tstab), L.ptr(tiles.tile_mask), L.ptr(tiles.perm),
+        L.check(lib.scn_conv_tiles(L.ptr(X), n_in, cin, L.ptr(tiles.tstab), L.ptr(tiles.tile_mask), L.ptr(tiles.perm),
                                    L.ptr(tiles.tile_order), tiles.n_off, n_out, L.ptr(W), L.ptr(bias), L.ptr(residual), L.ptr(relu_mask),
                                    L.ptr(Y), cout, flags, L.ptr(scratch), L.stream()))
     profiling.timed("k_conv_ts", lambda: 2.0 * P() * cin * cout,

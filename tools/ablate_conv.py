@@ -26,7 +26,7 @@ import numpy as np
 execd = sum(bin(int(v)).count("1") for v in tm) * 16
 print(f"level {level} N={n} P={P} C={C} tiles={len(tm)} executed/useful={execd / P:.3f}")
 def run_ts(fl=0):
-    L.check(lib.scn_conv_tiles(L.ptr(X), C, L.ptr(t.tstab), L.ptr(t.tile_mask), L.ptr(t.perm), L.ptr(t.tile_order), 27, n, L.ptr(W), 0, 0, 0,
+    L.check(lib.scn_conv_tiles(L.ptr(X), n, C, L.ptr(t.tstab), L.ptr(t.tile_mask), L.ptr(t.perm), L.ptr(t.tile_order), 27, n, L.ptr(W), 0, 0, 0,
                                L.ptr(Y), C, fl, L.ptr(SCR), L.stream()))
 def run_tab(fl=0):
     L.check(lib.scn_gemm_table(L.ptr(X), n, C, L.ptr(rb.table), 27, n, L.ptr(W), 0, 0, 0, L.ptr(Y2), C, fl, L.stream()))

@@ -1,0 +1,43 @@
+"""Developer tool (GPU box): per-wave timeline of k_conv_ts built with -DTS_EXP=9 (wall_clock64 stamps, 100 MHz)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, numpy as np
+import sparse_rcnn_amd as scn
+from sparse_rcnn_amd import _lib as L
+from sparse_rcnn_amd.synthetic import make_batch
+level = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+C = [32, 64, 128, 256][level]
+coords, feats, size, bs, _ = make_batch(1, (512, 512, 256), 150000, seed=1)
+x = scn.InputLayer(3, size, mode=4)((coords, feats.cuda(), 1))
+md = x.metadata; sz = tuple(int(s) for s in size)
+for l in range(level):
+    md.strided_rulebook(sz); sz = tuple(s // 2 for s in sz)
+rb = md.subm_rulebook(sz, 3); n, t = rb.n, rb.tiles
+X = torch.randn(n, C, device="cuda"); W = torch.randn(27, C, C, device="cuda") * 0.05
+Y = torch.empty(n, C, device="cuda")
+lib = L.lib()
+SCR = torch.zeros(lib.scn_conv_tiles_scratch_bytes(C, n, C) + (4 << 20), dtype=torch.uint8, device="cuda")
+def run():
+    L.check(lib.scn_conv_tiles(L.ptr(X), n, C, L.ptr(t.tstab), L.ptr(t.tile_mask), L.ptr(t.perm), L.ptr(t.tile_order), 27, n, L.ptr(W), 0, 0, 0,
+                               L.ptr(Y), C, 0, L.ptr(SCR), L.stream()))
+for _ in range(3): run()
+torch.cuda.synchronize()
+base = lib.scn_conv_tiles_scratch_bytes(C, n, C)
+d = SCR[base:base + 8192 * 64].view(torch.int64).cpu().numpy().reshape(-1, 8)
+d = d[d[:, 2] > 0]
+t0 = d[:, 0].min()
+us = lambda v: v / 100.0
+print(f"waves {len(d)}  kernel span {us(d[:,2].max() - t0):.1f} us")
+print(f"start  (first..last wave)     : {us(d[:,0].min()-t0):.1f} .. {us(d[:,0].max()-t0):.1f} us")
+print(f"staged (t1 - t0) mean / max    : {us((d[:,1]-d[:,0]).mean()):.1f} / {us((d[:,1]-d[:,0]).max()):.1f} us")
+work = d[:, 2] - d[:, 1]
+print(f"tile phase (end - staged) mean / min / max : {us(work.mean()):.1f} / {us(work.min()):.1f} / {us(work.max()):.1f} us")
+print(f"wave end (first..last)        : {us(d[:,2].min()-t0):.1f} .. {us(d[:,2].max()-t0):.1f} us")
+print(f"tiles per wave mean {d[:,3].mean():.2f}  steps per wave mean {d[:,4].mean():.1f} max {d[:,4].max()}  epilogue per wave mean {us(d[:,5].mean()):.2f} us")
+steps = d[:, 4].astype(float)
+ok = steps > 0
+print(f"us per step (tile phase / steps): mean {us((work[ok]/steps[ok]).mean()):.2f}   corr(steps, time) = {np.corrcoef(steps[ok], work[ok])[0,1]:.2f}")
+# least squares: time = a * steps + b * tiles + c
+A = np.stack([steps[ok], d[ok, 3].astype(float), np.ones(ok.sum())], 1)
+coef, *_ = np.linalg.lstsq(A, work[ok].astype(float), rcond=None)
+print(f"fit: time = {us(coef[0]):.3f} us/step + {us(coef[1]):.2f} us/tile + {us(coef[2]):.2f} us")

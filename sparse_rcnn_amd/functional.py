@@ -57,6 +57,19 @@ def gemm_table(X, table, n_off, n_out, W, bias, cout, flags=0, residual=None, re
     return Y
 
 
+_ts_scratch_cache = {}
+
+
+def _conv_tiles_scratch_bytes(cin, n_out, cout):
+    key = (cin, n_out, cout)
+    v = _ts_scratch_cache.get(key)
+    if v is None:
+        if len(_ts_scratch_cache) > 4096:
+            _ts_scratch_cache.clear()
+        v = _ts_scratch_cache[key] = L.lib().scn_conv_tiles_scratch_bytes(cin, n_out, cout)
+    return v
+
+
 def conv_rules(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu_mask=None, n_rules=0):
     """The hot kernel: output-stationary convolution over mask-sorted tiles (scn_conv_tiles)."""
     lib = L.lib()
@@ -64,8 +77,7 @@ def conv_rules(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu_mask
     Y = _new((n_out, cout), X)
     n_in, n_off = X.shape[0], tiles.n_off      # the profiling closures below must not keep device buffers alive
     P = lambda: _count(n_rules)
-    nbytes = lib.scn_conv_tiles_scratch_bytes(cin, n_out, cout)
-    scratch = torch.empty(nbytes, dtype=torch.uint8, device=X.device)
+    scratch = L.scratch(_conv_tiles_scratch_bytes(cin, n_out, cout), X.device)
 
     def run():
         L.check(lib.scn_conv_tiles(L.ptr(X), n_in, cin, L.ptr(tiles.tstab), L.ptr(tiles.tile_mask), L.ptr(tiles.perm),
@@ -98,7 +110,7 @@ def wgrad_rules(X, dY, in_rows, out_rows, prefix_host, n_off, flags=0):
     nbytes = lib.scn_wgrad_scratch_bytes(cin, cout, prefix_host, n_off)
     if nbytes < 0:
         raise L.ScnError("scn_wgrad_scratch_bytes: bad arguments")
-    scratch = torch.empty(nbytes, dtype=torch.uint8, device=X.device)
+    scratch = L.scratch(nbytes, X.device)
     dW = _new((n_off, cin, cout), X)
     P = int(prefix_host[n_off] - prefix_host[0])
 
@@ -115,7 +127,7 @@ def wgrad_bias_rules(X, dY, in_rows, out_rows, prefix_host, n_off, db_offsets, f
     cin, cout = X.shape[1], dY.shape[1]
     lib = L.lib()
     nbytes = lib.scn_wgrad_scratch_bytes(cin, cout, prefix_host, n_off)
-    scratch = torch.empty(nbytes, dtype=torch.uint8, device=X.device)
+    scratch = L.scratch(nbytes, X.device)
     dW, db = _new((n_off, cin, cout), X), _new((cout,), X)
     P = int(prefix_host[n_off] - prefix_host[0])
 

@@ -114,15 +114,17 @@ def main():
         nonlocal gy, n_active, md_next
         flat.zero_grad()
         fin = feats_d.detach().requires_grad_()
-        md, md_next = md_next, None
+        md = md_next.result() if md_next is not None else None
+        md_next = None
+        # optional: the index structures of the NEXT batch are built by a helper thread on the (high-priority) index
+        # stream while this batch's forward and backward run
+        if args.prefetch:
+            md_next = model.prefetch_in_thread(coords_d, size, 1)
         out = model(coords_d, fin, size, 1, metadata=md)
         if gy is None or gy.shape != out.features.shape:
             gy = torch.randn(out.features.shape, generator=gen).to(dev)          # upstream grad dY ~ N(0,1)
             n_active = out.features.shape[0]
         out.features.backward(gy)
-        # optional: index structures of the NEXT batch built on the index stream while this batch's backward runs
-        if args.prefetch:
-            md_next = model.prefetch(coords_d, size, 1)
         flat.all_reduce_mean()
         flat.sgd_step(1e-6)
 

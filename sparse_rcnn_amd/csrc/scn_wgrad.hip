@@ -22,10 +22,7 @@
 #include "scn_common.h"
 
 #ifndef WD_DEEP_ALL
-#define WD_DEEP_ALL 1
-#endif
-#ifndef WD_EXP
-#define WD_EXP 0            // developer experiments (tools/exp): 1 = no MFMA, 2 = no row loads
+#define WD_DEEP_ALL 1       // 1: three register sets (rows two blocks ahead) for every wave block size
 #endif
 
 using scn::S;
@@ -133,9 +130,6 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ 
             const float* yr_ = dY + (long long)OUT[s_] * cout;                                       \
             _Pragma("unroll") for (int t_ = 0; t_ < TA; ++t_) A[s_][t_] = xr_[a_ok[t_] ? ca + t_ : 0]; \
             _Pragma("unroll") for (int t_ = 0; t_ < TB; ++t_) B[s_][t_] = yr_[b_ok[t_] ? cbn + t_ : 0]; \
-        } else if (WD_EXP == 2) {    /* experiment: no row loads */                                   \
-            _Pragma("unroll") for (int t_ = 0; t_ < TA; ++t_) A[s_][t_] = __int_as_float(IN[s_] + t_); \
-            _Pragma("unroll") for (int t_ = 0; t_ < TB; ++t_) B[s_][t_] = __int_as_float(OUT[s_] + t_); \
         } else {                                                                                     \
             A[s_] = *(const fa_t*)(xlane + (long long)IN[s_] * xstride);                             \
             B[s_] = *(const fb_t*)(ylane + (long long)OUT[s_] * ystride);                            \
@@ -160,8 +154,7 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ 
         if (do_db) { _Pragma("unroll") for (int t_ = 0; t_ < TB; ++t_) dbacc[t_] += b_[t_]; }         \
         _Pragma("unroll") for (int ta_ = 0; ta_ < TA; ++ta_)                                         \
             _Pragma("unroll") for (int tb_ = 0; tb_ < TB; ++tb_)                                     \
-                if (WD_EXP == 1) acc[ta_][tb_][0] += a_[ta_] * b_[tb_];   /* experiment: no MFMA */   \
-                else acc[ta_][tb_] = MFMA16(a_[ta_], b_[tb_], acc[ta_][tb_]);                        \
+                acc[ta_][tb_] = MFMA16(a_[ta_], b_[tb_], acc[ta_][tb_]);                             \
     }
 
     int in0[4], out0[4], in1[4], out1[4], in2[4], out2[4];

@@ -32,8 +32,32 @@ _index_streams = {}
 def index_stream(device) -> "torch.cuda.Stream":
     st = _index_streams.get(device)
     if st is None:
-        st = _index_streams[device] = torch.cuda.Stream(device=device)
+        # high priority: the index kernels are tiny and latency-bound; next to the matrix kernels of another batch they
+        # should be dispatched as soon as a slot frees up
+        st = _index_streams[device] = torch.cuda.Stream(device=device, priority=-1)
     return st
+
+
+class PendingMetadata:
+    """A Metadata being built by a helper thread on the index stream (Metadata.prepare_in_thread)."""
+
+    def __init__(self, fn):
+        import threading
+        self._md, self._err = None, None
+
+        def run():
+            try:
+                self._md = fn()
+            except BaseException as e:          # re-raised in result()
+                self._err = e
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def result(self) -> "Metadata":
+        self._thread.join()
+        if self._err is not None:
+            raise self._err
+        return self._md
 
 
 @dataclass
@@ -384,6 +408,18 @@ class Metadata:
             self.ready_event = torch.cuda.Event()
             self.ready_event.record(side)
         return self
+
+    def prepare_in_thread(self, spatial_size, coords, batch_size: int = 0, mode: int = 4, n_levels: int = 0,
+                          k: int = 3) -> "PendingMetadata":
+        """prepare_async on a helper thread.  The build waits four times for a row count; on the caller's thread those
+        waits would keep it from queueing the matrix kernels of the current batch (measured: slower than no prefetch).
+        The helper spends its time inside C calls and event waits, which release the GIL."""
+        dev = torch.cuda.current_device()
+
+        def fn():
+            torch.cuda.set_device(dev)
+            return self.prepare_async(spatial_size, coords, batch_size, mode, n_levels, k)
+        return PendingMetadata(fn)
 
     def _all_tensors(self):
         out = [self.item_row, self.row_count, self.row_first, self.row_last]

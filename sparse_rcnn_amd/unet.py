@@ -105,6 +105,11 @@ class Backbone(nn.Module):
         x = InputLayer(3, spatial_size, mode=4)((coords, feats, batch_size), metadata)
         return self.unet(x)
 
+    def prefetch_in_thread(self, coords, spatial_size, batch_size=0):
+        """As `prefetch`, on a helper thread: returns a PendingMetadata whose `.result()` is passed as `metadata=`."""
+        from .metadata import Metadata
+        return Metadata(3).prepare_in_thread(spatial_size, coords, batch_size, 4, len(self.unet.channels), 3)
+
     def prefetch(self, coords, spatial_size, batch_size=0):
         """Build the index structures of a coming batch on the index stream (overlaps the current batch's kernels)."""
         from .metadata import Metadata

@@ -338,6 +338,30 @@ def test_index_prefetch_on_side_stream_is_equivalent(gpu):
             assert torch.equal(a, b)
     with pytest.raises(_scn().ScnError):
         net(coords[:-1].to(gpu), feats[:-1], size, batch, metadata=net.prefetch(coords.to(gpu), size, batch))
+    # the same build driven by a helper thread (bench.py --prefetch)
+    pending = net.prefetch_in_thread(coords.to(gpu), size, batch)
+    out = net(coords.to(gpu), feats, size, batch, metadata=pending.result()).features
+    assert torch.equal(out, ref)
+
+
+def test_async_row_count_equals_synchronous_dedup(gpu):
+    """scn_dedup_launch (row count left on the device, no host sync) numbers rows exactly like scn_dedup_build."""
+    from sparse_rcnn_amd import metadata as M
+    coords, size, batch = _cloud(5, grid=(32, 32, 16), n=3000, batch=2, dup=400)
+    c32 = coords.to(gpu).to(torch.int32).contiguous()
+    for shift in (0, 1):
+        pend = M._Dedup(c32, shift, True, True)
+        # unrelated work may be queued before the count is awaited
+        _ = torch.ones(1024, device=gpu).sum()
+        grid, item_row, cnt, first = pend.finish()
+        keys = O.pack_keys(np.concatenate([coords[:, :3].numpy() >> shift, coords[:, 3:].numpy()], 1))
+        _, first_idx, inv = np.unique(keys, return_index=True, return_inverse=True)
+        order = np.argsort(first_idx)                       # rows numbered by first occurrence
+        rank = np.empty_like(order); rank[order] = np.arange(len(order))
+        assert grid.n == len(first_idx)
+        assert np.array_equal(item_row.cpu().numpy(), rank[inv])
+        assert np.array_equal(first.cpu().numpy(), np.sort(first_idx))
+        assert np.array_equal(cnt.cpu().numpy(), np.bincount(rank[inv]))
 
 
 @pytest.mark.parametrize("average", [False, True])

@@ -195,10 +195,12 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         }                                                                                            \
     } while (0)
 
-    // one pipeline step: index of the offset 4 ahead (into INEW), A rows of the offset 3 ahead into (G0, G1) from the
-    // index loaded one step earlier (IOLD), MFMAs on (C0, C1).  Four named A register sets and two named index registers
-    // rotate with the unrolled loop -- no register moves (a move of a value still in flight forces a wait, and every VALU
-    // op costs MFMA time).  With ~2 us of gather latency and 512 MFMA cycles per offset a SIMD needs ~9 gathers in
+    // one pipeline step: index of the offset 5 ahead (into INEW), A rows of the offset 3 ahead into (G0, G1) from the
+    // index loaded TWO steps earlier (IOLD), MFMAs on (C0, C1).  Four named A register sets and four named index
+    // registers rotate with the unrolled loop -- no register moves (a move of a value still in flight forces a wait, and
+    // every VALU op costs MFMA time).  The index must not be consumed in the step after its load: loads retire in order,
+    // so waiting for a one-step-old index also waited for the row gathers issued right after it (`s_waitcnt vmcnt(0)`
+    // in every step: the 3-deep gather pipeline was only one deep).  With ~2 us of gather latency and 512 MFMA cycles per offset a SIMD needs ~9 gathers in
     // flight (4 waves x 3 here); one-ahead prefetch left the kernel latency-bound.
     // ZERO0: (non-FULLK only) the item multiplied now has rows without a rule -> handled in TS_GATHER (zero-filled).
 #define TS_STEP(C0, C1, G0, G1, IOLD, INEW)                                                          \
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
             c0 = MFMA16(a1_[e_], bl_[4 + e_], c0);                                                   \
             c1 = MFMA16(a1_[e_], bh_[4 + e_], c1);                                                   \
         }                                                                                            \
-        oq0 = oq1; oq1 = oq2; oq2 = oq3; oq3 = o4_;                                                  \
+        oq0 = oq1; oq1 = oq2; oq2 = oq3; oq3 = oq4; oq4 = o4_;                                       \
     } while (0)
 
     // ---- tile loop: the id, mask and output rows of the NEXT tile are fetched while the current one computes --------
@@ -242,6 +244,7 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
 #pragma unroll
         for (int j = 0; j < 4; ++j) orow[j] = orow_next[j];
         const int* tb_s = tstab + tile * n_off * TS_T;              // wave-uniform base; the lane adds i
+        const int n_steps = __popc(m);
         tile_next = grab();
         if (tile_next >= 0) {
             m_next = tile_mask[tile_next];
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
 
         // queue of the next four offsets of this tile (-1 = none) and their row indices; loads are unconditional
         // (a finished list re-reads its last offset)
-        int oq0 = -1, oq1 = -1, oq2 = -1, oq3 = -1, iq0, iq1, iq2, iqa, iqb;
+        int oq0 = -1, oq1 = -1, oq2 = -1, oq3 = -1, oq4 = -1, iq0, iq1, iq2, iqa, iqb, iqc, iqd;
         int olast = 0;
         if (m) { oq0 = __builtin_ctz(m); m &= m - 1; olast = oq0; }
         iq0 = tb_s[olast * TS_T + i];
@@ -261,21 +264,29 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         iq2 = tb_s[olast * TS_T + i];
         if (m) { oq3 = __builtin_ctz(m); m &= m - 1; olast = oq3; }
         iqa = tb_s[olast * TS_T + i];
+        if (m) { oq4 = __builtin_ctz(m); m &= m - 1; olast = oq4; }
+        iqb = tb_s[olast * TS_T + i];
+        // (issue order pinned: if the compiler sinks the last two index loads below the gathers they become the newest
+        // loads and the first step of the loop waits for everything)
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 s00, s01, s10, s11, s20, s21, s30, s31;
         TS_GATHER(iq0, s00, s01);
         TS_GATHER(iq1, s10, s11);
         TS_GATHER(iq2, s20, s21);
+        __builtin_amdgcn_sched_barrier(0);
 
         f32x4 c0 = {bA, bA, bA, bA}, c1 = {bB, bB, bB, bB};
-        while (oq0 >= 0) {
-            TS_STEP(s00, s01, s30, s31, iqa, iqb);
-            if (oq0 < 0) break;
-            TS_STEP(s10, s11, s00, s01, iqb, iqa);
-            if (oq0 < 0) break;
-            TS_STEP(s20, s21, s10, s11, iqa, iqb);
-            if (oq0 < 0) break;
-            TS_STEP(s30, s31, s20, s21, iqb, iqa);
+        // n_steps offsets: whole rounds of four steps without a per-step exit test, then the 0-3 left over
+        int n_left = n_steps;
+        for (; n_left >= 4; n_left -= 4) {
+            TS_STEP(s00, s01, s30, s31, iqa, iqc);
+            TS_STEP(s10, s11, s00, s01, iqb, iqd);
+            TS_STEP(s20, s21, s10, s11, iqc, iqa);
+            TS_STEP(s30, s31, s20, s21, iqd, iqb);
         }
+        if (n_left >= 1) { TS_STEP(s00, s01, s30, s31, iqa, iqc); }
+        if (n_left >= 2) { TS_STEP(s10, s11, s00, s01, iqb, iqd); }
+        if (n_left >= 3) { TS_STEP(s20, s21, s10, s11, iqc, iqa); }
 
         // ---- tile epilogue: 16 lanes write 64 contiguous bytes of a row.  The residual / ReLU-mask operands of all
         // eight outputs are requested first and consumed afterwards (one wait, not eight round trips).

@@ -103,7 +103,7 @@ def main():
 
     torch.manual_seed(0)
     model = Backbone(7, CHANNELS).to(dev)
-    flat = FlatParams(model)
+    flat = FlatParams(model, n_buckets=4)      # N > 1: gradient slices are all-reduced while backward still runs
     broadcast_params(flat)
     gen = torch.Generator(device="cpu").manual_seed(100 + rank)
     gy = None

@@ -39,21 +39,28 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _dp_worker(rank, world, port, out):
+def _dp_worker(rank, world, port, out, n_buckets=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(rank)                                   # different init per rank: broadcast must fix it
     net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
-    fp = FlatParams(net)
+    if n_buckets:                                             # a parameter that never receives a gradient
+        net.unused = torch.nn.Parameter(torch.ones(7))
+    fp = FlatParams(net, n_buckets=n_buckets)
     broadcast_params(fp)
     x = torch.full((4, 6), float(rank + 1))                   # rank-dependent "scene"
     fp.zero_grad()
     net(x).sum().backward()
-    fp.gather_grads()
-    local = fp.flat_grad.clone()
+    if n_buckets:                                             # overlapped path: slices were reduced during backward
+        assert len(fp.buckets) >= 2
+        local = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in fp.params])
+    else:
+        fp.gather_grads()
+        local = fp.flat_grad.clone()
     fp.all_reduce_mean()
     fp.sgd_step(0.1)
-    out.put((rank, fp.flat.clone(), local, fp.flat_grad.clone()))
+    # by value (numpy): a tensor would travel as a shared-memory handle that dies with this process
+    out.put((rank, fp.flat.detach().numpy().copy(), local.detach().numpy().copy(), fp.flat_grad.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -66,9 +73,25 @@ def test_flat_bucket_all_reduce_world2():
     for p in ps: p.start()
     res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
     for p in ps: p.join(60)
-    (_, w0, g0, m0), (_, w1, g1, m1) = res
+    (_, w0, g0, m0), (_, w1, g1, m1) = [(r, *map(torch.from_numpy, t)) for r, *t in res]
     assert torch.equal(w0, w1)                                 # ranks stay in lock-step
     assert torch.allclose(m0, (g0 + g1) / 2) and torch.equal(m0, m1)
+
+
+def test_bucketed_overlapped_all_reduce_world2():
+    """n_buckets > 0: slices of the flat gradient are all-reduced from post-accumulate hooks while backward runs; same
+    result as the single all-reduce, also with a parameter that receives no gradient, and over two steps."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, 3)) for r in range(2)]
+    for p in ps: p.start()
+    res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
+    for p in ps: p.join(60)
+    (_, w0, g0, m0), (_, w1, g1, m1) = [(r, *map(torch.from_numpy, t)) for r, *t in res]
+    assert torch.equal(w0, w1)
+    assert torch.allclose(m0, (g0 + g1) / 2) and torch.equal(m0, m1)
+    assert torch.equal(m0[:7], torch.zeros(7))                # the unused parameter (first in parameters()) stays zero
 
 
 def test_flat_params_views_survive_backward():

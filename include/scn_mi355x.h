@@ -165,21 +165,6 @@ int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32_t* tstab, 
                    const int32_t* tile_order, int n_off, int64_t n_out, const float* W, const float* bias, const float* residual,
                    const float* relu_mask, float* Y, int cout, int flags, void* scratch, scn_stream_t stream);
 
-/* Output-stationary rule-list convolution (an alternative to scn_conv_tiles kept for comparison; same result as scn_gemm_table on the table the rules were
- * compacted from, without its wasted matrix work):
- *     Y[r] = residual[r] + bias + sum_o sum_{(i,r) in R_o} in(X[i]) . W[o']
- * Rules must be in canonical order (output row ascending inside an offset).  A workgroup owns `block_rows` consecutive
- * output rows; bstart[o][b] (int32 [n_off][nb+1], nb = ceil(n_out/block_rows), from scn_rules_block_starts) is the first
- * rule of offset o with output row >= b*block_rows.  block_rows in {16..256}; n_off <= 27.
- * Serves SubmanifoldConvolution fwd / backward-data (module_factory.py:404-406), Convolution fwd (:232-234) and
- * Deconvolution backward-data (:256-258).  Accumulation order across offsets is not fixed (LDS float atomics). */
-int scn_rules_block_starts(const int32_t* out_rows, const int64_t* prefix /* device, [n_off+1] */, int n_off,
-                           int64_t n_out, int block_rows, int32_t* bstart, scn_stream_t stream);
-int64_t scn_conv_os_lds_bytes(int n_off, int block_rows);
-int scn_conv_rules(const float* X, int cin, const int32_t* in_rows, const int32_t* out_rows, const int32_t* bstart,
-                   int n_off, int64_t n_out, int block_rows, const float* W, const float* bias, const float* residual,
-                   const float* relu_mask, float* Y, int cout, int flags, scn_stream_t stream);
-
 /* Rule-list gather GEMM with row scatter:  Y[out_rows[p]] = bias + in(X[in_rows[p]]) . W[o(p)]
  * where every output row occurs in exactly one pair (Deconvolution fwd, module_factory.py:256-258; backward-data
  * of Convolution).  prefix_host = int64[n_off+1] on the HOST. */

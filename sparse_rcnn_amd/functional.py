@@ -88,7 +88,9 @@ def conv_rules(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu_mask
     return Y
 
 
-USE_CONV_OS = True
+# The 3^3 / 2^3 table convolutions run on the tile kernel (scn_conv_tiles); USE_TILES = False routes them through the
+# plain table GEMM (scn_gemm_table: no mask sorting, 2-3x wasted matrix work) -- kept as a cross-check of the two kernels.
+USE_TILES = True
 
 
 def gemm_rules(X, in_rows, out_rows, prefix_host, n_off, n_out, W, bias, cout, flags=0, relu_mask=None):
@@ -212,7 +214,7 @@ class SubmanifoldConvolutionFunction(torch.autograd.Function):
         cout = W.shape[-1]
         b = _f32(bias) if bias is not None else None
         R = _f32(residual) if residual is not None else None
-        if USE_CONV_OS and rb.rules is not None:
+        if USE_TILES and rb.rules is not None:
             Y = conv_rules(X, rb.tiles, rb.n, W, b, cout, L.F_RELU_IN if relu_in else 0, residual=R,
                            n_rules=rb.rules.count)
         else:
@@ -232,7 +234,7 @@ class SubmanifoldConvolutionFunction(torch.autograd.Function):
         fl = L.F_RELU_IN if ctx.relu_in else 0
         dX = dW = db = None
         if ctx.needs_input_grad[0]:
-            if USE_CONV_OS and rb.rules is not None:
+            if USE_TILES and rb.rules is not None:
                 dX = conv_rules(dY, rb.tiles, rb.n, W, None, cin, L.F_W_TRANSPOSED | L.F_OFF_REVERSE,
                                 relu_mask=X if ctx.relu_in else None, n_rules=rb.rules.count)
             else:
@@ -267,7 +269,7 @@ class ConvolutionFunction(torch.autograd.Function):
         X, W = _f32(features), _f32(weight)
         rb = metadata.strided_rulebook(in_size)
         b = _f32(bias) if bias is not None else None
-        if USE_CONV_OS:
+        if USE_TILES:
             Y = conv_rules(X, rb.tiles, rb.n_coarse, W, b, W.shape[-1], L.F_RELU_IN if relu_in else 0,
                            n_rules=rb.n_fine)
         else:
@@ -326,7 +328,7 @@ class DeconvolutionFunction(torch.autograd.Function):
         fl = L.F_RELU_IN if ctx.relu_in else 0
         dX = dW = db = None
         if ctx.needs_input_grad[0]:      # dX[c] = sum_o dY[child[o][c]] . W[o]^T
-            if USE_CONV_OS:
+            if USE_TILES:
                 dX = conv_rules(dY, rb.tiles, rb.n_coarse, W, None, X.shape[1], L.F_W_TRANSPOSED,
                                 relu_mask=X if ctx.relu_in else None, n_rules=rb.n_fine)
             else:

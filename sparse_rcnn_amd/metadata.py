@@ -119,8 +119,6 @@ class Rules:
         self.count = RuleCount(self._rb, self.n_off)
         self._prefix_host = None
         self._in = self._out = self._seg = None
-        self.block_rows = 0                     # conv_os (comparison kernel) bookkeeping
-        self.bstart = None
 
     @property
     def prefix_host(self):
@@ -219,29 +217,6 @@ def compact_rules(table: torch.Tensor, n_off: int, n_out: int, want_seg=False):
     """Rule table -> Rules (lazy: the scan is queued now, sizes and fill on first access)."""
     rules = Rules(table, n_off, n_out, want_seg)
     return (rules, rules.seg) if want_seg else rules
-
-
-def pick_block_rows(n_out: int) -> int:
-    """Rows per conv_os workgroup: large blocks amortise the weight staging and tile quantisation, small ones keep
-    >= ~2 workgroups per CU on the coarse levels (conv_os)."""
-    if n_out >= 64 * 1024:
-        return 512
-    if n_out >= 32 * 1024:
-        return 256
-    if n_out >= 8 * 1024:
-        return 128
-    return 64
-
-
-def add_block_starts(rules: Rules, n_out: int, block_rows: int = 0):
-    lib = L.lib()
-    R = block_rows or pick_block_rows(n_out)
-    nb = (n_out + R - 1) // R
-    bstart = torch.empty((rules.n_off, nb + 1), dtype=torch.int32, device=rules.in_rows.device)
-    L.check(lib.scn_rules_block_starts(L.ptr(rules.out_rows), L.ptr(rules.prefix_dev), rules.n_off, n_out, R,
-                                       L.ptr(bstart), L.stream()))
-    rules.block_rows, rules.bstart = R, bstart
-    return rules
 
 
 class _Dedup:

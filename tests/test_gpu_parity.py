@@ -40,6 +40,10 @@ def _close(a, b, tol=FEAT_TOL, what=""):
     assert err <= tol, f"{what}: max err {err:.3e} (scale {scale:.3g}) > {tol}"
 
 
+def _grads(y, params, g):
+    return torch.autograd.grad(y, params, g, allow_unused=False)
+
+
 def _input(gpu, seed=0, cin=5, mode=4, **kw):
     scn = _scn()
     coords, size, batch = _cloud(seed, **kw)
@@ -122,12 +126,68 @@ def test_odd_size_strided_is_rejected(gpu):
         scn.Convolution(3, 2, 4, (3, 3, 3), (2, 2, 2), True)
 
 
+def test_coordinate_range_limits(gpu):
+    """16 bits per coordinate field: 65535 is accepted (and neighbours across the limit simply do not exist), 65536 and
+    negative values are rejected with ScnError -- never a silent wrap."""
+    scn = _scn()
+    size = torch.tensor([65536, 65536, 65536])
+    coords = torch.tensor([[65535, 65535, 65535, 0], [65534, 65535, 65535, 0], [0, 0, 0, 0]])
+    x = scn.InputLayer(3, size, mode=4)((coords, torch.ones(3, 4).to(gpu), 1))
+    rb = x.metadata.subm_rulebook(tuple(int(v) for v in size), 3)
+    nbr, _ = O.subm_rulebook(coords.numpy(), 3)
+    assert np.array_equal(rb.table.cpu().numpy(), nbr)
+    for bad in ([65536, 0, 0, 0], [0, -1, 0, 0]):
+        with pytest.raises(scn.ScnError):
+            scn.InputLayer(3, size, mode=4)((torch.tensor([bad]), torch.ones(1, 4).to(gpu), 1))
+
+
 # ---------------------------------------------------------------------------------------- feature path
 CHANNELS = [(3, 16), (7, 32), (32, 32), (16, 23), (23, 20), (64, 48), (40, 8)]
 
 
-def _grads(y, params, g):
-    return torch.autograd.grad(y, params, g, allow_unused=False)
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 33])
+@pytest.mark.parametrize("cin,cout", [(32, 32), (5, 7)])
+def test_tiny_scenes_and_tile_boundaries(gpu, n, cin, cout):
+    """Row counts around the 16-row tile size, down to a single voxel, and a batch whose middle sample is empty."""
+    scn = _scn()
+    rng = np.random.default_rng(n)
+    lin = rng.choice(6 * 6 * 6, size=n, replace=False)
+    p = np.stack(np.unravel_index(lin, (6, 6, 6)), 1)
+    b = np.where(np.arange(n) < (n + 1) // 2, 0, 2)[:, None]                 # samples 0 and 2 of 3; sample 1 is empty
+    coords = torch.from_numpy(np.concatenate([p, b], 1).astype(np.int64))
+    feats = torch.randn(n, cin, generator=torch.Generator().manual_seed(n))
+    fg = feats.to(gpu).requires_grad_()
+    x = scn.InputLayer(3, torch.tensor([8, 8, 8]), mode=4)((coords, fg, 3))
+    assert x.batch_size() == 3
+    conv = scn.SubmanifoldConvolution(3, cin, cout, 3, True).to(gpu)
+    y = scn.Sequential(scn.ReLU(), conv)(x).features
+    scene = O.OracleScene(coords.numpy())
+    Xo = O.input_layer_fwd(feats, scene.prow, scene.n(0), 4).requires_grad_()
+    W, bb = conv.weight.detach().cpu().requires_grad_(), conv.bias.detach().cpu().requires_grad_()
+    yo = O.conv(torch.relu(Xo), W, bb, scene.subm_rules(0, 3), scene.n(0))
+    _close(y, yo, what="fwd")
+    g = torch.randn(yo.shape, generator=torch.Generator().manual_seed(1))
+    gx, gw, gb = _grads(y, (x.features, conv.weight, conv.bias), g.to(gpu))
+    ox, ow, ob = _grads(yo, (Xo, W, bb), g)
+    _close(gx, ox, what="dX"); _close(gw, ow, what="dW"); _close(gb, ob, what="db")
+
+
+@pytest.mark.parametrize("cin,cout", [(128, 128), (256, 128), (64, 128), (128, 32)])
+def test_wide_layers_take_the_quad_and_k_paths(gpu, cin, cout):
+    """Channel counts of the deep U-Net levels: K-split slabs in scn_conv_tiles, the 128x128 (QUAD) and 64x64 (K mode)
+    wave blocks of the weight gradient, rectangular blocks -- against the oracle, not only against each other."""
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=11, cin=cin, n=900, dup=100)
+    conv = scn.SubmanifoldConvolution(3, cin, cout, 3, True).to(gpu)
+    y = conv(x).features
+    n = scene.n(0)
+    Xo = O.input_layer_fwd(feats, scene.prow, n, 4).requires_grad_()
+    W, b = conv.weight.detach().cpu().requires_grad_(), conv.bias.detach().cpu().requires_grad_()
+    yo = O.conv(Xo, W, b, scene.subm_rules(0, 3), n)
+    _close(y, yo, what="fwd")
+    g = torch.randn(yo.shape, generator=torch.Generator().manual_seed(5))
+    gx, gw, gb = _grads(y, (x.features, conv.weight, conv.bias), g.to(gpu))
+    ox, ow, ob = _grads(yo, (Xo, W, b), g)
+    _close(gx, ox, what="dX"); _close(gw, ow, what="dW"); _close(gb, ob, what="db")
 
 
 @pytest.mark.parametrize("cin,cout", CHANNELS)

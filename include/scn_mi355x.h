@@ -51,6 +51,8 @@ extern "C" {
 #define SCN_F_RELU_IN 1      /* use max(X,0) as the input slab (fuses scn.ReLU before a conv, module_factory.py:88,173-176) */
 #define SCN_F_W_TRANSPOSED 2 /* use W[o]^T: W is [n_off][cout][cin] seen from this call (backward-data) */
 #define SCN_F_OFF_REVERSE 4  /* weight index n_off-1-o for table row o (SubM backward-data: R_o^T = R_{k^3-1-o}) */
+#define SCN_F_RESIDUAL_LAST 8 /* scn_conv_tiles: add `residual` AFTER the ReLU-backward mask (gradient of a residual block:
+                                dX = mask(conv^T dY1) + dY), default is before */
 
 typedef void* scn_stream_t;
 

@@ -63,7 +63,7 @@ _SIGS = {
 
 EXPORTS = tuple(_SIGS)
 
-F_RELU_IN, F_W_TRANSPOSED, F_OFF_REVERSE = 1, 2, 4
+F_RELU_IN, F_W_TRANSPOSED, F_OFF_REVERSE, F_RESIDUAL_LAST = 1, 2, 4, 8
 OK, EINVAL, ESIZE, EHASH, EHIP = 0, 1, 2, 3, 4
 COLSUM_BLOCKS = 512
 

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     const int n0 = chunk * TS_CT, kc = kci * TS_KC;
     const bool relu_in = flags & SCN_F_RELU_IN;
     const bool rev = flags & SCN_F_OFF_REVERSE;
+    const bool res_last = flags & SCN_F_RESIDUAL_LAST;
 
     // ---- tile queue: tile_order lists the tiles by offset count descending.  A workgroup owns every n_tg-th entry
     // (an even sample of costs) and its 16 waves pull them from an LDS counter in that order: expensive tiles start
@@ -312,13 +313,15 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
             if (row < 0) continue;
             const long long off = (long long)row * cout;
             if (nA < cout) {
-                float y = c0[j] + rs[j][0];
+                float y = c0[j] + (res_last ? 0.f : rs[j][0]);
                 if (!(mk[j][0] > 0.f)) y = 0.f;
+                if (res_last) y += rs[j][0];
                 out[off + nA] = y;
             }
             if (nB < cout) {
-                float y = c1[j] + rs[j][1];
+                float y = c1[j] + (res_last ? 0.f : rs[j][1]);
                 if (!(mk[j][1] > 0.f)) y = 0.f;
+                if (res_last) y += rs[j][1];
                 out[off + nB] = y;
             }
         }
@@ -328,14 +331,15 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
 // Y = bias + sum_kc slab[kc] (+ residual, ReLU-backward mask); K-chunks added in ascending order.
 __global__ void k_conv_ts_sum(const float* __restrict__ slabs, int n_kc, long long n_out, int cout,
                               const float* __restrict__ bias, const float* __restrict__ residual,
-                              const float* __restrict__ relu_mask, float* __restrict__ Y) {
+                              const float* __restrict__ relu_mask, float* __restrict__ Y, int res_last) {
     const long long total = n_out * cout;
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
          e += (long long)gridDim.x * blockDim.x) {
         float y = bias ? bias[e % cout] : 0.f;
         for (int k = 0; k < n_kc; ++k) y += slabs[(long long)k * total + e];
-        if (residual) y += residual[e];
+        if (residual && !res_last) y += residual[e];
         if (relu_mask && !(relu_mask[e] > 0.f)) y = 0.f;
+        if (residual && res_last) y += residual[e];
         Y[e] = y;
     }
 }
@@ -404,7 +408,8 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     SCN_LAUNCH_CHECK();
     if (n_kc > 1) {
         hipLaunchKernelGGL(k_conv_ts_sum, dim3(scn::ew_grid(n_out * cout, 256)), dim3(256), 0, st,
-                           (const float*)slabs, n_kc, (long long)n_out, cout, bias, residual, relu_mask, Y);
+                           (const float*)slabs, n_kc, (long long)n_out, cout, bias, residual, relu_mask, Y,
+                           (flags & SCN_F_RESIDUAL_LAST) ? 1 : 0);
         SCN_LAUNCH_CHECK();
     }
     return SCN_OK;

@@ -261,6 +261,54 @@ class SubmanifoldConvolutionFunction(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------------
+# Residual block  x + SubM3(ReLU(SubM3(ReLU(x))))  as ONE autograd node  (module_factory.py:127-183 get_residual_block
+# with relu_first, two units; custom_container.py: Sequential(ConcatTable(Identity, inner), AddTable))
+# ------------------------------------------------------------------------------------------------------
+class ResidualBlockFunction(torch.autograd.Function):
+    """Same kernels as the layer-by-layer path; what the fusion removes is the glue: the AddTable runs in the epilogue
+    of the second convolution (forward) and the sum of the two gradient paths of x in the epilogue of the first
+    convolution's backward-data kernel (SCN_F_RESIDUAL_LAST: dX = mask(conv1^T dY1) + dY) -- no elementwise launches, one
+    autograd node instead of two."""
+
+    @staticmethod
+    def forward(ctx, features, w1, b1, w2, b2, metadata: Metadata, spatial_size):
+        X, W1, W2 = _f32(features), _f32(w1), _f32(w2)
+        rb = metadata.subm_rulebook(spatial_size, 3)
+        B1 = _f32(b1) if b1 is not None else None
+        B2 = _f32(b2) if b2 is not None else None
+        Y1 = conv_rules(X, rb.tiles, rb.n, W1, B1, W1.shape[-1], L.F_RELU_IN, n_rules=rb.rules.count)
+        Y = conv_rules(Y1, rb.tiles, rb.n, W2, B2, W2.shape[-1], L.F_RELU_IN, residual=X, n_rules=rb.rules.count)
+        ctx.save_for_backward(X, Y1, W1, W2)
+        ctx.rb, ctx.has_b1, ctx.has_b2 = rb, b1 is not None, b2 is not None
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        X, Y1, W1, W2 = ctx.saved_tensors
+        rb, r = ctx.rb, ctx.rb.rules
+        dY = _f32(dY)
+        need = ctx.needs_input_grad
+        back = L.F_W_TRANSPOSED | L.F_OFF_REVERSE
+        dY1 = conv_rules(dY, rb.tiles, rb.n, W2, None, W2.shape[1], back, relu_mask=Y1, n_rules=r.count)
+        dX = None
+        if need[0]:
+            dX = conv_rules(dY1, rb.tiles, rb.n, W1, None, W1.shape[1], back | L.F_RESIDUAL_LAST, relu_mask=X,
+                            residual=dY, n_rules=r.count)
+        centre = 1 << 13
+
+        def wgrad(Xin, G, W, want_w, want_b):
+            if want_w and want_b:
+                dW, db = wgrad_bias_rules(Xin, G, r.in_rows, r.out_rows, r.prefix_host, 27, centre, L.F_RELU_IN)
+                return dW.view_as(W), db
+            if want_w:
+                return wgrad_rules(Xin, G, r.in_rows, r.out_rows, r.prefix_host, 27, L.F_RELU_IN).view_as(W), None
+            return None, (colsum(G) if want_b else None)
+        dW2, db2 = wgrad(Y1, dY, W2, need[3], ctx.has_b2 and need[4])
+        dW1, db1 = wgrad(X, dY1, W1, need[1], ctx.has_b1 and need[2])
+        return dX, dW1, db1, dW2, db2, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
 # A6 Convolution size=stride=2  (module_factory.py:232-234)
 # ------------------------------------------------------------------------------------------------------
 class ConvolutionFunction(torch.autograd.Function):

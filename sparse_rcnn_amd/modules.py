@@ -51,6 +51,13 @@ class Sequential(torch.nn.Sequential):
             if (FUSE_ADD and type(m) is ConcatTable and i + 1 < len(mods) and type(mods[i + 1]) is AddTable
                     and len(m._modules) == 2):
                 a, inner = list(m._modules.values())
+                if type(a) is Identity and type(inner) is Sequential and inner._is_plain_residual_branch(input):
+                    c1, c2 = inner._modules["1"], inner._modules["3"]          # ReLU, SubM3, ReLU, SubM3
+                    y = F.ResidualBlockFunction.apply(input.features, c1.weight, c1.bias, c2.weight, c2.bias,
+                                                      input.metadata, input.spatial_size)
+                    input = _out(input, y)
+                    i += 2
+                    continue
                 if type(a) is Identity and type(inner) is Sequential and inner._ends_with_subm():
                     input = inner(input, residual=input.features)
                     i += 2
@@ -72,6 +79,16 @@ class Sequential(torch.nn.Sequential):
                 i += 1
         return input
 
+    def _is_plain_residual_branch(self, input):
+        """ReLU, SubM 3^3, ReLU, SubM 3^3 with the block's channel count kept (the reference's residual unit,
+        module_factory.py:127-183 with relu_first=True, two convolutions): runs as one fused autograd node."""
+        mods = list(self._modules.values())
+        return (FUSE_BLOCK and len(mods) == 4 and list(self._modules.keys()) == ["0", "1", "2", "3"]
+                and type(mods[0]) is ReLU and type(mods[2]) is ReLU
+                and type(mods[1]) is SubmanifoldConvolution and type(mods[3]) is SubmanifoldConvolution
+                and mods[1].filter_size == 3 and mods[3].filter_size == 3
+                and mods[1].nIn == mods[3].nOut == input.features.shape[1] and mods[1].nOut == mods[3].nIn)
+
     def _ends_with_subm(self):
         mods = list(self._modules.values())
         return bool(mods) and isinstance(mods[-1], SubmanifoldConvolution)
@@ -81,6 +98,7 @@ import os as _os
 
 FUSE_RELU = True
 FUSE_ADD = _os.environ.get("SCN_FUSE_ADD", "1") != "0"     # developer switch (tools/ab_bench.py)
+FUSE_BLOCK = _os.environ.get("SCN_FUSE_BLOCK", "1") != "0"
 
 
 class ConcatTable(Sequential):

@@ -157,7 +157,8 @@ def colsum(dY):
 # step, while the backward-data GEMMs form the critical chain.  They are queued on a second HIP stream so their
 # workgroups fill the CUs the chain's kernels leave idle (tails, small coarse-level grids).  The main stream joins the
 # side stream once, in a callback at the end of the backward pass.
-LEAF_STREAM = False     # measured: no gain -- the chain kernels already fill the matrix pipes
+import os as _os
+LEAF_STREAM = _os.environ.get("SCN_LEAF_STREAM", "0") == "1"     # developer switch; measured: see DESIGN.md
 _side_streams = {}
 _join_pending = set()
 
@@ -290,10 +291,6 @@ class ResidualBlockFunction(torch.autograd.Function):
         need = ctx.needs_input_grad
         back = L.F_W_TRANSPOSED | L.F_OFF_REVERSE
         dY1 = conv_rules(dY, rb.tiles, rb.n, W2, None, W2.shape[1], back, relu_mask=Y1, n_rules=r.count)
-        dX = None
-        if need[0]:
-            dX = conv_rules(dY1, rb.tiles, rb.n, W1, None, W1.shape[1], back | L.F_RESIDUAL_LAST, relu_mask=X,
-                            residual=dY, n_rules=r.count)
         centre = 1 << 13
 
         def wgrad(Xin, G, W, want_w, want_b):
@@ -303,8 +300,12 @@ class ResidualBlockFunction(torch.autograd.Function):
             if want_w:
                 return wgrad_rules(Xin, G, r.in_rows, r.out_rows, r.prefix_host, 27, L.F_RELU_IN).view_as(W), None
             return None, (colsum(G) if want_b else None)
-        dW2, db2 = wgrad(Y1, dY, W2, need[3], ctx.has_b2 and need[4])
-        dW1, db1 = wgrad(X, dY1, W1, need[1], ctx.has_b1 and need[2])
+        dW2, db2 = _on_leaf_stream(dY, lambda: wgrad(Y1, dY, W2, need[3], ctx.has_b2 and need[4]))
+        dX = None
+        if need[0]:
+            dX = conv_rules(dY1, rb.tiles, rb.n, W1, None, W1.shape[1], back | L.F_RESIDUAL_LAST, relu_mask=X,
+                            residual=dY, n_rules=r.count)
+        dW1, db1 = _on_leaf_stream(dY1, lambda: wgrad(X, dY1, W1, need[1], ctx.has_b1 and need[2]))
         return dX, dW1, db1, dW2, db2, None, None
 
 

@@ -240,6 +240,28 @@ int scn_pool_fwd(const float* X, const int32_t* child, int64_t n_coarse, int c, 
 int scn_pool_bwd(const float* X, const float* Y, const float* dY, const int32_t* parent, int64_t n_fine, int c,
                  int average, float* dX, scn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Mask-head epilogue on the device: consumers of the ROI selection in CSR form
+ * (rows of the crop are box-major; box_of[r] = box, src_point[r] = point row in the batch).
+ * ---------------------------------------------------------------------------------------- */
+
+/* SparseMaskPredictor.forward (model.py:859-882): out (pre-zeroed, the per-sample dense [boxes][points] masks back to
+ * back) gets sigmoid(scores[r][class_of_box[box]]) at row_base[box] + src_point[r]; classes < 0, >= num_valid
+ * (num_valid > 0) or >= k leave zeros.  row_base[box] = offset of the box's row in out - first point row of its sample. */
+int scn_mask_scatter(const float* scores, int64_t m, int k, const int32_t* src_point, const int32_t* box_of,
+                     const int64_t* class_of_box, int num_valid, const int64_t* row_base, float* out,
+                     scn_stream_t stream);
+
+/* SparseMaskLossSelector gathers (model.py:1157-1227): pred[r] = scores[r][label_of_box[box]],
+ * gt[r] = gt_flat[gt_base[box] + src_point[r]] (gt_base[box] = offset of the associated ground-truth mask row in
+ * gt_flat - first point row of the sample; < 0 or label < 0: box not kept, rows get 0 and keep_row[r] = 0).
+ * keep_row may be NULL.  _bwd: dscores[r][c] = dpred[r] at c = label of a kept box, 0 elsewhere. */
+int scn_mask_gather(const float* scores, int64_t m, int k, const int32_t* src_point, const int32_t* box_of,
+                    const int64_t* label_of_box, const int64_t* gt_base, const float* gt_flat, float* pred, float* gt,
+                    uint8_t* keep_row, scn_stream_t stream);
+int scn_mask_gather_bwd(const float* dpred, int64_t m, int k, const int32_t* box_of, const int64_t* label_of_box,
+                        const int64_t* gt_base, float* dscores, scn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

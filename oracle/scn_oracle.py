@@ -461,3 +461,57 @@ class _InputFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dY):
         return input_layer_bwd(dY, ctx.scene.prow, 4), None
+
+
+# --------------------------------------------------------------------------
+# N2: mask-head epilogue over the ROI selection
+# (ndsis/modules/model.py:824-882 SparseMaskPredictor, :1150-1227 SparseMaskLossSelector;
+#  ndsis/utils/basic_functions.py:177-216 split_select_nd)
+# --------------------------------------------------------------------------
+
+def mask_predict(mask_output, is_inside, box_sample_count, batch_splits, class_indices, num_valid=0):
+    """is_inside bool [BB, N]; mask_output fp32 [M, K] with rows box-major / ascending point.
+    -> list per sample of fp32 [boxes_s, points_s] (model.py:859-882)."""
+    mo = np.asarray(mask_output, dtype=np.float32)
+    ins = np.asarray(is_inside, dtype=bool)
+    out, r, b0, p0 = [], 0, 0, 0
+    for nb, npts in zip(box_sample_count, batch_splits):
+        blk = np.zeros((nb, npts), np.float32)
+        for j in range(nb):
+            pts = np.nonzero(ins[b0 + j])[0]
+            c = int(class_indices[b0 + j])
+            valid = c >= 0 and (num_valid == 0 or c < num_valid)
+            if valid:
+                x = mo[r:r + len(pts), c].astype(np.float64)
+                blk[j, pts - p0] = (1.0 / (1.0 + np.exp(-x))).astype(np.float32)
+            r += len(pts)
+        out.append(blk)
+        b0 += nb
+        p0 += npts
+    return out
+
+
+def mask_loss_select(mask_scores, is_inside, box_sample_count, batch_splits, keep_list, gt_associations_list,
+                     gt_labels_list, gt_masks_list):
+    """-> (pred flat, gt flat, rows per kept box, labels) in crop order over the kept boxes (model.py:1157-1227)."""
+    ms = np.asarray(mask_scores, dtype=np.float32)
+    ins = np.asarray(is_inside, dtype=bool)
+    pred, gt, rows, labels = [], [], [], []
+    r, b0, p0 = 0, 0, 0
+    for s, (nb, npts) in enumerate(zip(box_sample_count, batch_splits)):
+        keep = np.asarray(keep_list[s], dtype=bool)
+        assoc = np.asarray(gt_associations_list[s], dtype=np.int64)
+        a = 0
+        for j in range(nb):
+            pts = np.nonzero(ins[b0 + j])[0]
+            if keep[j]:
+                g = int(assoc[a]); a += 1
+                lab = int(np.asarray(gt_labels_list[s])[g])
+                pred.append(ms[r:r + len(pts), lab])
+                gt.append(np.asarray(gt_masks_list[s], dtype=np.float32)[g, pts - p0])
+                rows.append(len(pts)); labels.append(lab)
+            r += len(pts)
+        b0 += nb
+        p0 += npts
+    cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.float32)
+    return cat(pred), cat(gt), rows, np.asarray(labels, np.int64)

@@ -55,6 +55,9 @@ _SIGS = {
     "scn_input_bwd": (C.c_int, [p, p, p, p, p, i64, i32, i32, p, p]),
     "scn_gather_rows": (C.c_int, [p, p, i64, i32, p, p]),
     "scn_segment_sum": (C.c_int, [p, p, i64, i64, i32, p, p, p]),
+    "scn_mask_scatter": (C.c_int, [p, i64, i32, p, p, p, i32, p, p, p]),
+    "scn_mask_gather": (C.c_int, [p, i64, i32, p, p, p, p, p, p, p, p, p]),
+    "scn_mask_gather_bwd": (C.c_int, [p, i64, i32, p, p, p, p, p]),
     "scn_pool_fwd": (C.c_int, [p, p, i64, i32, i32, p, p]),
     "scn_pool_bwd": (C.c_int, [p, p, p, p, i64, i32, i32, p, p]),
     "scn_sparse_to_dense_fwd": (C.c_int, [p, p, i64, i32, C.POINTER(i64), p, p]),

@@ -473,3 +473,90 @@ extern "C" int scn_pool_bwd(const float* X, const float* Y, const float* dY, con
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Mask-head epilogue on the device: consumers of the ROI selection in CSR form.
+//   rows m = 0..M-1 of the crop are box-major; box_of[m] = box, src_point[m] = point row in the batch.
+// ------------------------------------------------------------------------------------------------
+// SparseMaskPredictor.forward (model.py:859-882): per sample a dense [boxes, points] mask, sigmoid of the score of the
+// box's class at the points inside the box, 0 elsewhere and for invalid classes.  out is pre-zeroed; row_base[box] =
+// offset of the box's row in `out` minus the first point row of its sample.
+__global__ void k_mask_scatter(const float* __restrict__ scores, long long m, int k, const int* __restrict__ src_point,
+                               const int* __restrict__ box_of, const long long* __restrict__ class_of_box,
+                               int num_valid, const long long* __restrict__ row_base, float* __restrict__ out) {
+    for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < m; r += (long long)gridDim.x * blockDim.x) {
+        const int box = box_of[r];
+        const long long cls = class_of_box[box];
+        const bool valid = cls >= 0 && (num_valid == 0 || cls < num_valid) && cls < k;
+        if (!valid) continue;
+        const float x = scores[r * k + cls];
+        out[row_base[box] + src_point[r]] = 1.f / (1.f + __expf(-x));
+    }
+}
+
+extern "C" int scn_mask_scatter(const float* scores, int64_t m, int k, const int32_t* src_point, const int32_t* box_of,
+                                const int64_t* class_of_box, int num_valid, const int64_t* row_base, float* out,
+                                scn_stream_t stream) {
+    SCN_REQUIRE(m >= 0 && k >= 1 && num_valid >= 0);
+    if (m == 0) return SCN_OK;
+    SCN_REQUIRE(scores && src_point && box_of && class_of_box && row_base && out);
+    hipLaunchKernelGGL(k_mask_scatter, dim3(scn::ew_grid(m, 256)), dim3(256), 0, S(stream), scores, (long long)m, k,
+                       src_point, box_of, (const long long*)class_of_box, num_valid, (const long long*)row_base, out);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+// SparseMaskLossSelector (model.py:1157-1227): pred[r] = scores[r][label[box]]; gt[r] = gt_flat[gt_base[box] + point]
+// (gt_base[box] = offset of the associated ground-truth mask row minus the sample's first point row).  Boxes with
+// label < 0 or gt_base < 0 are not kept: their rows get pred = gt = 0 and keep_row = 0.
+__global__ void k_mask_gather(const float* __restrict__ scores, long long m, int k, const int* __restrict__ src_point,
+                              const int* __restrict__ box_of, const long long* __restrict__ label_of_box,
+                              const long long* __restrict__ gt_base, const float* __restrict__ gt_flat,
+                              float* __restrict__ pred, float* __restrict__ gt, unsigned char* __restrict__ keep_row) {
+    for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < m; r += (long long)gridDim.x * blockDim.x) {
+        const int box = box_of[r];
+        const long long lab = label_of_box[box], gb = gt_base[box];
+        const bool keep = lab >= 0 && lab < k && gb >= 0;
+        pred[r] = keep ? scores[r * k + lab] : 0.f;
+        gt[r] = keep ? gt_flat[gb + src_point[r]] : 0.f;
+        if (keep_row) keep_row[r] = keep ? 1 : 0;
+    }
+}
+
+extern "C" int scn_mask_gather(const float* scores, int64_t m, int k, const int32_t* src_point, const int32_t* box_of,
+                               const int64_t* label_of_box, const int64_t* gt_base, const float* gt_flat, float* pred,
+                               float* gt, uint8_t* keep_row, scn_stream_t stream) {
+    SCN_REQUIRE(m >= 0 && k >= 1);
+    if (m == 0) return SCN_OK;
+    SCN_REQUIRE(scores && src_point && box_of && label_of_box && gt_base && gt_flat && pred && gt);
+    hipLaunchKernelGGL(k_mask_gather, dim3(scn::ew_grid(m, 256)), dim3(256), 0, S(stream), scores, (long long)m, k,
+                       src_point, box_of, (const long long*)label_of_box, (const long long*)gt_base, gt_flat, pred, gt,
+                       keep_row);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+// backward of pred w.r.t. scores: dscores[r][c] = (c == label[box]) ? dpred[r] : 0   (whole rows written)
+__global__ void k_mask_gather_bwd(const float* __restrict__ dpred, long long m, int k, const int* __restrict__ box_of,
+                                  const long long* __restrict__ label_of_box, const long long* __restrict__ gt_base,
+                                  float* __restrict__ dscores) {
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < m * k; e += (long long)gridDim.x * blockDim.x) {
+        const long long r = e / k;
+        const int c = (int)(e - r * k);
+        const int box = box_of[r];
+        const long long lab = label_of_box[box];
+        dscores[e] = (lab == c && gt_base[box] >= 0) ? dpred[r] : 0.f;
+    }
+}
+
+extern "C" int scn_mask_gather_bwd(const float* dpred, int64_t m, int k, const int32_t* box_of,
+                                   const int64_t* label_of_box, const int64_t* gt_base, float* dscores,
+                                   scn_stream_t stream) {
+    SCN_REQUIRE(m >= 0 && k >= 1);
+    if (m == 0) return SCN_OK;
+    SCN_REQUIRE(dpred && box_of && label_of_box && gt_base && dscores);
+    hipLaunchKernelGGL(k_mask_gather_bwd, dim3(scn::ew_grid(m * k, 256)), dim3(256), 0, S(stream), dpred, (long long)m, k,
+                       box_of, (const long long*)label_of_box, (const long long*)gt_base, dscores);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}

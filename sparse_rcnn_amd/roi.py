@@ -140,3 +140,116 @@ class SparseRoiCut(torch.nn.Module):
         feats = InputLayerFunction.apply(3, md, size, new_coords, new_features, boxes.shape[0], self.mode)
         out = SparseConvNetTensor(features=feats, metadata=md, spatial_size=size)
         return out, (sel.is_inside() if self.dense_inside else sel, counts, batch_splits)
+
+
+# ------------------------------------------------------------------------------------------------------
+# Mask-head epilogue on the device: what the reference does with the dense BB x N `is_inside` matrix
+# after the mask network -- SparseMaskPredictor (model.py:824-882) and SparseMaskLossSelector (model.py:1150-1227) --
+# from the CSR selection, without bringing the indicator to the host.
+# ------------------------------------------------------------------------------------------------------
+def _box_layout(sel: RoiSelection, box_sample_count, batch_splits):
+    """Per-box (sample, first box of the sample, first point row of the sample, points of the sample) on the host."""
+    import numpy as np
+    counts = np.asarray([int(c) for c in box_sample_count], dtype=np.int64)
+    splits = np.asarray([int(c) for c in batch_splits], dtype=np.int64)
+    if counts.sum() != sel.n_boxes or splits.sum() != sel.n_points or len(counts) != len(splits):
+        raise L.ScnError("box_sample_count / batch_splits do not match the selection")
+    sample = np.repeat(np.arange(len(counts)), counts)
+    box_start = np.concatenate([[0], np.cumsum(counts)])[:-1]
+    point_start = np.concatenate([[0], np.cumsum(splits)])[:-1]
+    return counts, splits, sample, box_start, point_start
+
+
+def mask_predict(mask_output, sel: RoiSelection, box_sample_count, batch_splits, class_indices, num_valid=0):
+    """SparseMaskPredictor.forward: list (one per sample) of fp32 device tensors [boxes_s, points_s] holding
+    sigmoid(score of the box's class) at the points inside each box and 0 elsewhere / for invalid classes."""
+    import numpy as np
+    lib = L.lib()
+    S = _f32(mask_output.detach())
+    dev = S.device
+    counts, splits, sample, box_start, point_start = _box_layout(sel, box_sample_count, batch_splits)
+    sizes = counts * splits
+    out_off = np.concatenate([[0], np.cumsum(sizes)])
+    out = torch.zeros(int(out_off[-1]), dtype=torch.float32, device=dev)
+    box = np.arange(sel.n_boxes)
+    row_base = out_off[sample] + (box - box_start[sample]) * splits[sample] - point_start[sample]
+    m = sel.src_row.shape[0]
+    if m:
+        if S.shape[0] != m:
+            raise L.ScnError(f"mask_output has {S.shape[0]} rows, the selection {m}")
+        cls = torch.as_tensor(class_indices, dtype=torch.int64).to(dev).contiguous()
+        rb = torch.from_numpy(row_base.astype(np.int64)).to(dev)
+        L.check(lib.scn_mask_scatter(L.ptr(S), m, S.shape[1], L.ptr(sel.src_row), L.ptr(sel.box_of), L.ptr(cls),
+                                     int(num_valid), L.ptr(rb), L.ptr(out), L.stream()))
+    return [out[out_off[s]:out_off[s + 1]].view(int(counts[s]), int(splits[s])) for s in range(len(counts))]
+
+
+class _MaskGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scores, src_point, box_of, label_of_box, gt_base, gt_flat):
+        S = _f32(scores)
+        m, k = S.shape
+        pred = torch.empty(m, dtype=torch.float32, device=S.device)
+        gt = torch.empty(m, dtype=torch.float32, device=S.device)
+        keep = torch.empty(m, dtype=torch.uint8, device=S.device)
+        L.check(L.lib().scn_mask_gather(L.ptr(S), m, k, L.ptr(src_point), L.ptr(box_of), L.ptr(label_of_box),
+                                        L.ptr(gt_base), L.ptr(gt_flat), L.ptr(pred), L.ptr(gt), L.ptr(keep),
+                                        L.stream()))
+        ctx.k, ctx.idx = k, (box_of, label_of_box, gt_base)
+        ctx.mark_non_differentiable(gt, keep)
+        return pred, gt, keep
+
+    @staticmethod
+    def backward(ctx, dpred, _dgt, _dkeep):
+        box_of, label_of_box, gt_base = ctx.idx
+        dpred = _f32(dpred)
+        m = dpred.shape[0]
+        dS = torch.empty((m, ctx.k), dtype=torch.float32, device=dpred.device)
+        L.check(L.lib().scn_mask_gather_bwd(L.ptr(dpred), m, ctx.k, L.ptr(box_of), L.ptr(label_of_box), L.ptr(gt_base),
+                                            L.ptr(dS), L.stream()))
+        return dS, None, None, None, None, None
+
+
+def mask_loss_select(mask_scores, sel: RoiSelection, box_sample_count, batch_splits, keep_list, gt_associations_list,
+                     gt_labels_list, gt_masks_list):
+    """SparseMaskLossSelector.forward on the device.
+
+    keep_list[s]: bool [boxes_s] (LossFilter keep); gt_associations_list[s]: int64 [kept boxes of s] (ground-truth index
+    of every kept box); gt_labels_list[s]: int64 [G_s]; gt_masks_list[s]: [G_s, points_s] (bool or float).
+    Returns (pred, gt, rows_per_kept_box, labels): pred / gt are flat fp32 device tensors over the rows of the KEPT
+    boxes in crop order (pred differentiable w.r.t. mask_scores), i.e. the concatenation of the reference's nested
+    lists `pred_masks` / `gt_masks`; labels = torch.cat(selected_labels)."""
+    import numpy as np
+    dev = mask_scores.device
+    counts, splits, sample, box_start, point_start = _box_layout(sel, box_sample_count, batch_splits)
+    n_s = len(counts)
+    label = np.full(sel.n_boxes, -1, dtype=np.int64)
+    gt_base = np.full(sel.n_boxes, -1, dtype=np.int64)
+    gt_sizes = np.asarray([int(g.shape[0]) * int(splits[s]) for s, g in enumerate(gt_masks_list)], dtype=np.int64)
+    gt_off = np.concatenate([[0], np.cumsum(gt_sizes)])
+    labels_out = []
+    for s in range(n_s):
+        keep = np.asarray(torch.as_tensor(keep_list[s]).cpu().numpy(), dtype=bool)
+        assoc = torch.as_tensor(gt_associations_list[s]).cpu().numpy().astype(np.int64)
+        boxes = box_start[s] + np.nonzero(keep)[0]
+        if len(boxes) != len(assoc):
+            raise L.ScnError("gt_associations_list must have one entry per kept box")
+        lab = torch.as_tensor(gt_labels_list[s]).cpu().numpy().astype(np.int64)[assoc]
+        label[boxes] = lab
+        gt_base[boxes] = gt_off[s] + assoc * splits[s] - point_start[s]
+        labels_out.append(torch.from_numpy(lab))
+    gt_flat = torch.cat([torch.as_tensor(g).reshape(-1).to(torch.float32) for g in gt_masks_list]).to(dev) \
+        if gt_off[-1] else torch.zeros(1, dtype=torch.float32, device=dev)
+    lab_d = torch.from_numpy(label).to(dev)
+    base_d = torch.from_numpy(gt_base).to(dev)
+    m = sel.src_row.shape[0]
+    if m == 0:
+        e = torch.zeros(0, dtype=torch.float32, device=dev)
+        return e, e, [], torch.cat(labels_out) if labels_out else torch.zeros(0, dtype=torch.long)
+    pred, gt, keep_row = _MaskGather.apply(mask_scores, sel.src_row, sel.box_of, lab_d, base_d, gt_flat)
+    rows = np.diff(np.asarray(sel.prefix, dtype=np.int64))
+    kept = label >= 0
+    if kept.all():
+        return pred, gt, rows.tolist(), torch.cat(labels_out)
+    kr = keep_row.bool()
+    return pred[kr], gt[kr], rows[kept].tolist(), torch.cat(labels_out)

@@ -347,6 +347,46 @@ def test_roi_crop_matches_reference_golden(gpu, path):
     assert np.array_equal(is_inside.numpy(), inside)
 
 
+MASK_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mask_epilogue_*.npz")))
+
+
+@pytest.mark.parametrize("path", MASK_GOLDEN, ids=[os.path.basename(p) for p in MASK_GOLDEN])
+def test_mask_epilogue_matches_reference_golden(gpu, path):
+    """SparseMaskPredictor / SparseMaskLossSelector from the CSR selection on the device, against the
+    outputs of the reference's own classes (tests/golden/make_mask_golden.py) and the oracle."""
+    from sparse_rcnn_amd import roi
+    from test_oracle_golden import load_mask
+    d = load_mask(path)
+    z = np.load(os.path.join(os.path.dirname(path), f"roi_crop_{str(d['roi_case'])}.npz"))
+    counts, splits = d["box_counts"].tolist(), d["batch_splits"].tolist()
+    bt = torch.from_numpy(z["bbox_tensor"]).to(gpu).to(torch.int32)
+    sa = torch.from_numpy(z["assoc"]).to(gpu).to(torch.int32).reshape(-1, 1)
+    boxes = torch.cat([bt[:, 0], sa, bt[:, 1], sa + 1], 1).contiguous()
+    _, _, sel = roi.roi_cut_device(torch.from_numpy(z["coords"]), torch.from_numpy(z["feats"]).to(gpu), boxes)
+    scores = torch.from_numpy(d["scores"]).to(gpu).requires_grad_()
+    pred = roi.mask_predict(scores, sel, counts, splits, torch.from_numpy(d["classes"]), int(d["num_valid"]))
+    got = torch.cat([p.reshape(-1) for p in pred]).cpu().numpy()
+    assert [tuple(p.shape) for p in pred] == [(c, s) for c, s in zip(counts, splits)]
+    assert np.allclose(got, d["pred_masks"], rtol=0, atol=1e-6)
+    assert np.array_equal(got == 0, d["pred_masks"] == 0)                     # zeros exactly where the reference has them
+    p, g, rows, labels = roi.mask_loss_select(scores, sel, counts, splits, d["keep_list"], d["assoc_list"],
+                                              d["labels_list"], d["masks_list"])
+    assert np.array_equal(p.detach().cpu().numpy(), d["loss_pred"]) and np.array_equal(g.cpu().numpy(), d["loss_gt"])
+    assert rows == d["loss_rows"].tolist() and np.array_equal(labels.numpy(), d["loss_labels"])
+    # gradient of the selected scores: one-hot of the box label on the rows of kept boxes
+    w = torch.randn(p.shape, generator=torch.Generator().manual_seed(2)).to(gpu)
+    (ds,) = torch.autograd.grad(p, scores, w)
+    exp = np.zeros(d["scores"].shape, np.float32)
+    kept_boxes = np.nonzero(np.concatenate(d["keep_list"]))[0]
+    starts = np.asarray(sel.prefix)
+    r = 0
+    for b, lab in zip(kept_boxes, d["loss_labels"]):
+        n = starts[b + 1] - starts[b]
+        exp[starts[b]:starts[b + 1], lab] = w.cpu().numpy()[r:r + n]
+        r += n
+    assert np.array_equal(ds.cpu().numpy(), exp)
+
+
 def test_roi_cut_module_revoxelises_like_oracle(gpu):
     from sparse_rcnn_amd import roi
     from sparse_rcnn_amd.synthetic import make_boxes

@@ -35,3 +35,41 @@ def test_oracle_roi_crop_matches_reference(path):
 
 def test_golden_present():
     assert len(GOLDEN) >= 4
+
+
+# ---- N2: mask-head epilogue, pinned by the reference's SparseMaskPredictor / SparseMaskLossSelector ------------------
+MASK_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mask_epilogue_*.npz")))
+
+
+def load_mask(path):
+    z = np.load(path)
+    d = {k: z[k] for k in z.files}
+    roi = load(os.path.join(os.path.dirname(path), f"roi_crop_{str(d['roi_case'])}.npz"))
+    d["is_inside"] = roi["is_inside"]
+    counts, splits = d["box_counts"].tolist(), d["batch_splits"].tolist()
+    thr = float(d["thr"])
+    mo = np.split(d["max_overlap"], np.cumsum(counts)[:-1])
+    ao = np.split(d["argmax_overlap"], np.cumsum(counts)[:-1])
+    d["keep_list"] = [m >= thr for m in mo]                                   # LossFilter (model.py:1017-1032)
+    d["assoc_list"] = [a[k] for a, k in zip(ao, d["keep_list"])]
+    g = d["gt_counts"].tolist()
+    d["labels_list"] = np.split(d["gt_labels"], np.cumsum(g)[:-1])
+    sizes = [gi * s for gi, s in zip(g, splits)]
+    d["masks_list"] = [m.reshape(gi, s) for m, gi, s in zip(np.split(d["gt_masks"], np.cumsum(sizes)[:-1]), g, splits)]
+    return d
+
+
+@pytest.mark.parametrize("path", MASK_GOLDEN, ids=[os.path.basename(p) for p in MASK_GOLDEN])
+def test_oracle_mask_epilogue_matches_reference(path):
+    d = load_mask(path)
+    counts, splits = d["box_counts"].tolist(), d["batch_splits"].tolist()
+    pred = O.mask_predict(d["scores"], d["is_inside"], counts, splits, d["classes"], int(d["num_valid"]))
+    assert np.allclose(np.concatenate([p.reshape(-1) for p in pred]), d["pred_masks"], rtol=0, atol=1e-6)
+    p, g, rows, labels = O.mask_loss_select(d["scores"], d["is_inside"], counts, splits, d["keep_list"], d["assoc_list"],
+                                            d["labels_list"], d["masks_list"])
+    assert np.array_equal(p, d["loss_pred"]) and np.array_equal(g, d["loss_gt"])
+    assert rows == d["loss_rows"].tolist() and np.array_equal(labels, d["loss_labels"])
+
+
+def test_mask_golden_present():
+    assert len(MASK_GOLDEN) >= 3

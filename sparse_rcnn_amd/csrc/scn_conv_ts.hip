@@ -19,6 +19,10 @@
 //     C/D: acc[j] = D[4*kq + j][lane & 15].
 #include "scn_common.h"
 
+#ifndef TS_TIMELINE
+#define TS_TIMELINE 0       // 1: per-wave wall_clock64 stamps appended to the scratch buffer (tools/ts_timeline.py)
+#endif
+
 using scn::S;
 using scn::cdiv;
 
@@ -67,6 +71,8 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     // (an even sample of costs) and its 16 waves pull them from an LDS counter in that order: expensive tiles start
     // first, cheap ones fill the tail (longest-processing-time scheduling).  (A chip-wide queue on global atomics was measured slower: returning global atomics cost more than
     // the imbalance they remove -- DESIGN.md.)
+    long long tl_t0 = 0, tl_t1 = 0, tl_steps = 0, tl_tiles = 0;
+    if (TS_TIMELINE) tl_t0 = wall_clock64();
     const int tg = blockIdx.x / (n_chunks * n_kc), n_tg = gridDim.x / (n_chunks * n_kc);
     const int n_tiles = (int)((nt - tg + n_tg - 1) / n_tg);
     int* counter = (int*)(Ws + n_off * TS_KC * TS_CT);
@@ -147,6 +153,7 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         }
     }
     __syncthreads();
+    if (TS_TIMELINE) tl_t1 = wall_clock64();
 
     const int ka = kc + 4 * kq;
     const bool k0_ok = ka + 3 < cin, k1_ok = ka + 16 + 3 < cin;
@@ -246,6 +253,7 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         for (int j = 0; j < 4; ++j) orow[j] = orow_next[j];
         const int* tb_s = tstab + tile * n_off * TS_T;              // wave-uniform base; the lane adds i
         const int n_steps = __popc(m);
+        if (TS_TIMELINE) { tl_tiles += 1; tl_steps += n_steps; }
         tile_next = grab();
         if (tile_next >= 0) {
             m_next = tile_mask[tile_next];
@@ -325,6 +333,11 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
                 out[off + nB] = y;
             }
         }
+    }
+    if (TS_TIMELINE && lane == 0) {         // [t0, staged, end, tiles, steps] per wave, after the K-chunk slabs
+        long long* d = (long long*)(slabs + (n_kc > 1 ? (long long)n_kc * n_out * cout : 0)) +
+                       ((long long)blockIdx.x * TS_NW + (tid >> 6)) * 8;
+        d[0] = tl_t0; d[1] = tl_t1; d[2] = wall_clock64(); d[3] = tl_tiles; d[4] = tl_steps; d[5] = 0;
     }
 }
 

@@ -262,6 +262,13 @@ int scn_mask_gather(const float* scores, int64_t m, int k, const int32_t* src_po
 int scn_mask_gather_bwd(const float* dpred, int64_t m, int k, const int32_t* box_of, const int64_t* label_of_box,
                         const int64_t* gt_base, float* dscores, scn_stream_t stream);
 
+/* Greedy non-maximum suppression of score-sorted 3-D boxes (ndsis/utils/bbox.py:713-759 non_maximum_supression as
+ * called by ProposalSelector, proposal_selector.py:60-89): boxes fp32 [batch][n][2][3] = (start xyz, stop xyz), sorted
+ * by descending score inside a scene; keep[batch][n] = 1 for boxes that survive.  A box is suppressed by an earlier
+ * surviving box whose IoU with it is > overlap_threshold (fp32, the reference's operation order: bit-exact decisions).
+ * n <= 8192.  One workgroup per scene, one launch instead of n. */
+int scn_nms(const float* boxes, int batch, int n, float overlap_threshold, uint8_t* keep, scn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -515,3 +515,29 @@ def mask_loss_select(mask_scores, is_inside, box_sample_count, batch_splits, kee
         p0 += npts
     cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.float32)
     return cat(pred), cat(gt), rows, np.asarray(labels, np.int64)
+
+
+# --------------------------------------------------------------------------
+# N3: greedy NMS of score-sorted boxes (ndsis/utils/bbox.py:713-759, IoU :205-242, :598-620)
+# --------------------------------------------------------------------------
+
+def nms(boxes, thr):
+    """boxes fp32 [N, 2, 3] sorted by descending confidence -> bool [N].  fp32 arithmetic in the reference's order."""
+    b = np.asarray(boxes, dtype=np.float32).reshape(-1, 2, 3)
+    n = len(b)
+    size = b[:, 1] - b[:, 0]
+    vol = (size[:, 0] * size[:, 1]) * size[:, 2]
+    keep = np.ones(n, dtype=bool)
+    thr = np.float32(thr)
+    for j in range(n):
+        if not keep[j]:
+            continue
+        lo = np.maximum(b[j, 0], b[j + 1:, 0])
+        hi = np.minimum(b[j, 1], b[j + 1:, 1])
+        e = np.maximum(hi - lo, np.float32(0))
+        inter = (e[:, 0] * e[:, 1]) * e[:, 2]
+        union = (vol[j] + vol[j + 1:]) - inter
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ov = inter / union
+        keep[j + 1:] &= ~(ov > thr)
+    return keep

@@ -560,3 +560,77 @@ extern "C" int scn_mask_gather_bwd(const float* dpred, int64_t m, int k, const i
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Greedy non-maximum suppression of score-sorted 3-D boxes (ndsis/utils/bbox.py:713-759
+// non_maximum_supression, IoU as bbox.py:205-242 / 598-620).  The reference sweeps the columns of an N x N threshold
+// matrix with N tiny kernels; here one workgroup owns a scene: thread i keeps box i in registers, step j broadcasts
+// box j and -- if j is still alive -- every later box tests its IoU against it.  keep[j] is final when step j starts
+// (only earlier boxes can clear it), so one barrier per step is enough.  Arithmetic uses the non-contracted
+// round-to-nearest intrinsics in the reference's operation order: the comparison `overlap > threshold` is bit-exact.
+// ------------------------------------------------------------------------------------------------
+static constexpr int NMS_THREADS = 1024;
+static constexpr int NMS_MAX_PER_THREAD = 8;
+
+__device__ __forceinline__ float nms_volume(const float* b) {          // size.prod(-1), left to right
+    return __fmul_rn(__fmul_rn(__fsub_rn(b[3], b[0]), __fsub_rn(b[4], b[1])), __fsub_rn(b[5], b[2]));
+}
+
+__global__ __launch_bounds__(NMS_THREADS) void k_nms(const float* __restrict__ boxes, int n, float thr,
+                                                     unsigned char* __restrict__ keep_out) {
+    __shared__ float cur[8];             // box j: start xyz, stop xyz, volume, alive
+    extern __shared__ unsigned char alive[];                 // [n]
+    const float* B = boxes + (long long)blockIdx.x * n * 6;
+    unsigned char* K = keep_out + (long long)blockIdx.x * n;
+    float mine[NMS_MAX_PER_THREAD][7];
+    for (int q = 0; q < NMS_MAX_PER_THREAD; ++q) {
+        const int i = threadIdx.x + q * NMS_THREADS;
+        if (i < n) {
+            for (int d = 0; d < 6; ++d) mine[q][d] = B[i * 6 + d];
+            mine[q][6] = nms_volume(mine[q]);
+            alive[i] = 1;
+        }
+    }
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        const int owner = j % NMS_THREADS, oq = j / NMS_THREADS;
+        if ((int)threadIdx.x == owner) {
+#pragma unroll
+            for (int q = 0; q < NMS_MAX_PER_THREAD; ++q)
+                if (q == oq) {
+                    for (int d = 0; d < 7; ++d) cur[d] = mine[q][d];
+                    cur[7] = alive[j] ? 1.f : 0.f;
+                }
+        }
+        __syncthreads();
+        if (cur[7] != 0.f) {
+#pragma unroll
+            for (int q = 0; q < NMS_MAX_PER_THREAD; ++q) {
+                const int i = threadIdx.x + q * NMS_THREADS;
+                if (i > j && i < n && alive[i]) {
+                    float inter = 1.f;                       // prod over the dims of clamp(min_end - max_start, 0)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        const float lo = fmaxf(cur[d], mine[q][d]), hi = fminf(cur[3 + d], mine[q][3 + d]);
+                        const float e = fmaxf(__fsub_rn(hi, lo), 0.f);
+                        inter = d == 0 ? e : __fmul_rn(inter, e);
+                    }
+                    const float uni = __fsub_rn(__fadd_rn(cur[6], mine[q][6]), inter);
+                    if (__fdiv_rn(inter, uni) > thr) alive[i] = 0;       // NaN (0/0) compares false, as in torch
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n; i += NMS_THREADS) K[i] = alive[i];
+}
+
+extern "C" int scn_nms(const float* boxes, int batch, int n, float overlap_threshold, uint8_t* keep,
+                       scn_stream_t stream) {
+    SCN_REQUIRE(batch >= 0 && n >= 0 && n <= NMS_THREADS * NMS_MAX_PER_THREAD);
+    if (batch == 0 || n == 0) return SCN_OK;
+    SCN_REQUIRE(boxes && keep);
+    hipLaunchKernelGGL(k_nms, dim3(batch), dim3(NMS_THREADS), (size_t)n, S(stream), boxes, n, overlap_threshold, keep);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}

@@ -387,6 +387,40 @@ def test_mask_epilogue_matches_reference_golden(gpu, path):
     assert np.array_equal(ds.cpu().numpy(), exp)
 
 
+NMS_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "nms_*.npz")))
+
+
+@pytest.mark.parametrize("path", NMS_GOLDEN, ids=[os.path.basename(p) for p in NMS_GOLDEN])
+def test_nms_and_proposal_selector_match_reference_golden(gpu, path):
+    """one-launch greedy NMS (scn_nms) and the ProposalSelector mirror against the outputs of the
+    reference's own non_maximum_supression / ProposalSelector -- keep decisions bit-exact."""
+    from sparse_rcnn_amd.proposals import ProposalSelector, non_maximum_suppression
+    z = np.load(path)
+    thr = float(z["thr"])
+    keep = non_maximum_suppression(torch.from_numpy(z["sorted_boxes"]).to(gpu), thr)
+    assert keep.dtype == torch.bool and np.array_equal(keep.cpu().numpy(), z["keep"])
+    s, b, i = ProposalSelector(int(z["pre"]), int(z["post"]), thr)(torch.from_numpy(z["score"]).to(gpu),
+                                                                  torch.from_numpy(z["boxes"]).to(gpu))
+    assert [len(x) for x in s] == z["out_counts"].tolist()
+    assert np.array_equal(torch.cat(s).cpu().numpy(), z["out_scores"])
+    assert np.array_equal(torch.cat(b).cpu().numpy(), z["out_boxes"])
+    assert np.array_equal(torch.cat(i).numpy(), z["out_index"])
+
+
+def test_nms_edge_cases(gpu):
+    from sparse_rcnn_amd.proposals import non_maximum_suppression
+    e = non_maximum_suppression(torch.zeros(2, 0, 2, 3, device=gpu), 0.5)
+    assert e.shape == (2, 0)
+    one = non_maximum_suppression(torch.tensor([[[[0., 0, 0], [1, 1, 1]]]], device=gpu), 0.5)
+    assert one.tolist() == [[True]]
+    rng = np.random.default_rng(0)
+    n = 2500                                                          # more boxes than threads: several per thread
+    c = rng.uniform(0, 30, size=(n, 3)); sz = rng.uniform(1, 6, size=(n, 3))
+    boxes = np.stack([c - sz, c + sz], 1).astype(np.float32)
+    got = non_maximum_suppression(torch.from_numpy(boxes).to(gpu)[None], 0.25)[0].cpu().numpy()
+    assert np.array_equal(got, O.nms(boxes, 0.25))
+
+
 def test_roi_cut_module_revoxelises_like_oracle(gpu):
     from sparse_rcnn_amd import roi
     from sparse_rcnn_amd.synthetic import make_boxes

@@ -73,3 +73,18 @@ def test_oracle_mask_epilogue_matches_reference(path):
 
 def test_mask_golden_present():
     assert len(MASK_GOLDEN) >= 3
+
+
+# ---- N3: greedy NMS, pinned by the reference's non_maximum_supression / ProposalSelector ------------------------------
+NMS_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "nms_*.npz")))
+
+
+@pytest.mark.parametrize("path", NMS_GOLDEN, ids=[os.path.basename(p) for p in NMS_GOLDEN])
+def test_oracle_nms_matches_reference(path):
+    z = np.load(path)
+    for boxes, keep in zip(z["sorted_boxes"], z["keep"]):
+        assert np.array_equal(O.nms(boxes, float(z["thr"])), keep)
+
+
+def test_nms_golden_present():
+    assert len(NMS_GOLDEN) >= 3

@@ -48,7 +48,9 @@ __device__ __forceinline__ int ts_ws_off(int o, int k, int n) { return (o * TS_K
 //   tail of half-empty waves and no restaging.
 //   With one K-chunk the tile epilogue writes Y (bias, residual, ReLU-backward mask fused).  With several, each
 //   K-chunk's workgroups write their partial sums to slab[kc] and k_conv_ts_sum adds the slabs in fixed order.
-template <bool WT, bool VEC, bool VECN, bool FULLK>
+// FULLK: the fast path (rows gathered through a buffer descriptor, Cin % 4 == 0); PART: Cin is not a multiple of the
+// 32-channel K-chunk, the lanes of the last chunk whose channels lie past Cin gather from an out-of-range offset (zeros)
+template <bool WT, bool VEC, bool VECN, bool FULLK, bool PART>
 __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     const float* __restrict__ X, long long n_in, int cin, const int* __restrict__ tstab,
     const unsigned* __restrict__ tile_mask,
@@ -179,8 +181,13 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     do {                                                                                             \
         if constexpr (FULLK) {                                                                       \
             const int off_ = __mul24((IDX), row_bytes) + lane_boff;      /* -1 -> out of range -> 0 */ \
-            A0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off_, 0, 0));  \
-            A1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off_ + 64, 0, 0)); \
+            int off0_ = off_, off1_ = off_ + 64;                                                     \
+            if constexpr (PART) {                                                                    \
+                off0_ = k0_ok ? off0_ : (int)0xFFFFFFF0;                                             \
+                off1_ = k1_ok ? off1_ : (int)0xFFFFFFF0;                                             \
+            }                                                                                        \
+            A0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off0_, 0, 0)); \
+            A1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off1_, 0, 0)); \
         } else {                                                                                     \
             A0 = (f32x4){0.f, 0.f, 0.f, 0.f};                                                        \
             A1 = A0;                                                                                 \
@@ -393,30 +400,31 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     const bool vec = (cin % 4 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0);
     const bool vecn = (cout % 4 == 0) && (((uintptr_t)W & 15) == 0);
     // the fast path addresses X through a raw buffer descriptor: 32-bit byte offsets, 24-bit row indices
-    const bool fullk = vec && (cin % TS_KC == 0) && n_in < (1ll << 23) && n_in * cin * 4 < (1ll << 32) - (1ll << 24);
+    const bool fullk = vec && n_in < (1ll << 23) && n_in * cin * 4 < (1ll << 32) - (1ll << 24);
+    const bool part = cin % TS_KC != 0;
     dim3 grid((unsigned)(n_tg * n_chunks * n_kc));
     hipStream_t st = S(stream);
-#define LAUNCH_TS(T, V, VN, FK)                                                                                     \
+#define LAUNCH_TS(T, V, VN, FK, PT)                                                                                 \
     do {                                                                                                            \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
-            SCN_HIP(hipFuncSetAttribute((const void*)k_conv_ts<T, V, VN, FK>,                                       \
+            SCN_HIP(hipFuncSetAttribute((const void*)k_conv_ts<T, V, VN, FK, PT>,                                       \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((k_conv_ts<T, V, VN, FK>), grid, dim3(TS_NW * 64), lds, st, X, (long long)n_in, cin, tstab, tile_mask, \
+        hipLaunchKernelGGL((k_conv_ts<T, V, VN, FK, PT>), grid, dim3(TS_NW * 64), lds, st, X, (long long)n_in, cin, tstab, tile_mask, \
                            perm, tile_order, n_off, (long long)nt, W, bias, residual, relu_mask, Y, slabs,                      \
                            (long long)n_out, cout, flags, n_chunks, n_kc, counters);                                \
     } while (0)
-    if (fullk && wt) LAUNCH_TS(true, true, true, true);
-    else if (fullk && vecn) LAUNCH_TS(false, true, true, true);
-    else if (fullk) LAUNCH_TS(false, true, false, true);
-    else if (wt && vec) LAUNCH_TS(true, true, true, false);
-    else if (wt) LAUNCH_TS(true, false, true, false);
-    else if (vec && vecn) LAUNCH_TS(false, true, true, false);
-    else if (vec) LAUNCH_TS(false, true, false, false);
-    else if (vecn) LAUNCH_TS(false, false, true, false);
-    else LAUNCH_TS(false, false, false, false);
+    if (fullk && wt && part) LAUNCH_TS(true, true, true, true, true);
+    else if (fullk && wt) LAUNCH_TS(true, true, true, true, false);
+    else if (fullk && vecn && part) LAUNCH_TS(false, true, true, true, true);
+    else if (fullk && vecn) LAUNCH_TS(false, true, true, true, false);
+    else if (fullk && part) LAUNCH_TS(false, true, false, true, true);
+    else if (fullk) LAUNCH_TS(false, true, false, true, false);
+    else if (wt) LAUNCH_TS(true, false, true, false, false);
+    else if (vecn) LAUNCH_TS(false, false, true, false, false);
+    else LAUNCH_TS(false, false, false, false, false);
 #undef LAUNCH_TS
     SCN_LAUNCH_CHECK();
     if (n_kc > 1) {

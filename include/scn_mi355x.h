@@ -269,6 +269,31 @@ int scn_mask_gather_bwd(const float* dpred, int64_t m, int k, const int32_t* box
  * n <= 8192.  One workgroup per scene, one launch instead of n. */
 int scn_nms(const float* boxes, int batch, int n, float overlap_threshold, uint8_t* keep, scn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Voxelisation front-end: the deterministic core of augment_coords
+ * (ndsis/data/sparse_augmentation.py:81-126) and the batch column of collate_fn (data.py:95-98).
+ * The reference's random draws (distortion matrix, sub-pixel offset, cut-out start) are inputs.
+ * ---------------------------------------------------------------------------------------- */
+
+/* aug[n][3] = points[n][3] @ rot_and_scale (3x3 row-major, HOST), each element as fma(z, R2j, fma(y, R1j, x*R0j)) -- the
+ * association of torch's CPU matmul for K = 3, so the truncation below sees the reference's fp32 values;
+ * shift_max[0..2] = -min(aug) + offset (complete_shift, sparse_augmentation.py:95-99), shift_max[3..5] = max(aug).
+ * No host synchronisation.  scratch: scn_vox_scratch_bytes(n). */
+int64_t scn_vox_scratch_bytes(int64_t n);
+int scn_vox_project(const float* points, int64_t n, const float* rot_and_scale_host, const float* offset_host,
+                    float* aug, float* shift_max, void* scratch, scn_stream_t stream);
+
+/* discrete[n][3] = trunc(aug + shift)  (`.long()`, :100);  table[i] = i if 0 <= discrete - test_start < size on every axis
+ * else -1 (both HOST int32[3]; NULL: no cut-out, every row is kept).  fix_cut_out (:42-47) tests the UNMOVED coordinates
+ * (test_start = 0); random_cut_out (:50-78) tests against its start positions.  Feed `table` (one segment) to
+ * scn_rules_scan/_fill to obtain the kept rows in ascending order. */
+int scn_vox_discretize(const float* aug, int64_t n, const float* shift, const int32_t* test_start_host,
+                       const int32_t* size_host, int32_t* discrete, int32_t* table, scn_stream_t stream);
+
+/* out int64 [m][4] = (discrete[rows[j]] - start, batch_index): the rows of one sample of collate_fn's coords_batch. */
+int scn_vox_gather(const int32_t* discrete, const int32_t* rows, int64_t m, const int32_t* start_host,
+                   int64_t batch_index, int64_t* out, scn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

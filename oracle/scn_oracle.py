@@ -541,3 +541,44 @@ def nms(boxes, thr):
             ov = inter / union
         keep[j + 1:] &= ~(ov > thr)
     return keep
+
+
+# --------------------------------------------------------------------------
+# N4: voxelisation (ndsis/data/sparse_augmentation.py:81-126 augment_coords, :42-47 fix_cut_out,
+#     :50-78 random_cut_out given its drawn start positions)
+# --------------------------------------------------------------------------
+
+def augment_coords(coords, rot_and_scale, sub_pixel_offset, spatial_size=None, shift=None, start_positions=None):
+    """-> (resulting int64 [M,3], is_inside bool [N], spatial_size int64 [3], complete_shift fp32 [3]).
+    points @ R in fp32 as fma(z, R2j, fma(y, R1j, x*R0j)) (torch's CPU association for K = 3; the fused multiply-adds are
+    emulated in float64: the product of two fp32 values is exact there)."""
+    p = np.asarray(coords, dtype=np.float32)
+    r = np.asarray(rot_and_scale, dtype=np.float32).reshape(3, 3)
+    aug = np.empty_like(p)
+    for j in range(3):
+        acc = (p[:, 0] * r[0, j]).astype(np.float32)
+        for k in (1, 2):
+            acc = (p[:, k].astype(np.float64) * np.float64(r[k, j]) + acc.astype(np.float64)).astype(np.float32)
+        aug[:, j] = acc
+    complete_shift = (-aug.min(0) + np.asarray(sub_pixel_offset, dtype=np.float32)).astype(np.float32)
+    discrete = (aug + complete_shift).astype(np.float32).astype(np.int64)          # .long(): truncation
+    if spatial_size is not None:
+        size = np.broadcast_to(np.asarray(spatial_size, dtype=np.int64), (3,))
+        if shift is not None:
+            start = np.broadcast_to(-np.asarray(shift, dtype=np.int64), (3,))
+            inside = ((0 <= discrete) & (discrete < size)).all(1)
+        else:
+            start = np.broadcast_to(np.asarray(start_positions, dtype=np.int64), (3,))
+            moved = discrete - start
+            inside = ((0 <= moved) & (moved < size)).all(1)
+        res = (discrete - start)[inside]
+        complete_shift = complete_shift - start.astype(np.float32)
+        return res, inside, size.copy(), complete_shift
+    size = discrete.max(0)
+    res = discrete
+    if shift is not None:
+        sh = np.broadcast_to(np.asarray(shift, dtype=np.int64), (3,))
+        res = discrete + sh
+        size = size + 2 * sh
+        complete_shift = complete_shift + sh.astype(np.float32)
+    return res, np.ones(len(p), bool), size, complete_shift

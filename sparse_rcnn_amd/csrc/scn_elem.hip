@@ -634,3 +634,129 @@ extern "C" int scn_nms(const float* boxes, int batch, int n, float overlap_thres
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Voxelisation front-end on the device (ndsis/data/sparse_augmentation.py:81-126 augment_coords,
+// :42-47 fix_cut_out, :50-78 random_cut_out; ndsis/data/data.py:95-98 collate).  The random numbers of the reference
+// (distortion matrix, sub-pixel offset, cut-out start) are inputs; the deterministic core is:
+//   aug = points @ R;  shift = -min(aug) + offset;  discrete = trunc(aug + shift);  keep rows inside the cut-out.
+// `points @ R` is evaluated as fma(z, R2j, fma(y, R1j, x * R0j)) -- the association torch's CPU matmul uses for K = 3
+// (checked on 10^6 points: identical bits), so the truncation sees the same fp32 values as the reference.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_vox_project(const float* __restrict__ P, long long n, float r00, float r01,
+                                                     float r02, float r10, float r11, float r12, float r20, float r21,
+                                                     float r22, float* __restrict__ aug, float* __restrict__ part) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float x = P[3 * i], y = P[3 * i + 1], z = P[3 * i + 2];
+        const float a[3] = {fmaf(z, r20, fmaf(y, r10, __fmul_rn(x, r00))), fmaf(z, r21, fmaf(y, r11, __fmul_rn(x, r01))),
+                            fmaf(z, r22, fmaf(y, r12, __fmul_rn(x, r02)))};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            aug[3 * i + d] = a[d];
+            mn[d] = fminf(mn[d], a[d]);
+            mx[d] = fmaxf(mx[d], a[d]);
+        }
+    }
+    __shared__ float red[4][6];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            mn[d] = fminf(mn[d], __shfl_xor(mn[d], o));
+            mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o));
+        }
+    }
+    if ((threadIdx.x & 63) == 0)
+        for (int d = 0; d < 3; ++d) { red[threadIdx.x >> 6][d] = mn[d]; red[threadIdx.x >> 6][3 + d] = mx[d]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int d = threadIdx.x;
+        float v = red[0][d];
+        for (int w = 1; w < 4; ++w) v = d < 3 ? fminf(v, red[w][d]) : fmaxf(v, red[w][d]);
+        part[blockIdx.x * 6 + d] = v;
+    }
+}
+
+// shift[d] = -min[d] + offset[d];  out[3..5] = max(aug)[d]  (one block)
+__global__ void k_vox_shift(const float* __restrict__ part, int blocks, float o0, float o1, float o2,
+                            float* __restrict__ shift_max) {
+    const int d = threadIdx.x;
+    if (d >= 6) return;
+    float v = part[d];
+    for (int b = 1; b < blocks; ++b) v = d < 3 ? fminf(v, part[b * 6 + d]) : fmaxf(v, part[b * 6 + d]);
+    const float off = d == 0 ? o0 : (d == 1 ? o1 : o2);
+    shift_max[d] = d < 3 ? __fadd_rn(-v, off) : v;
+}
+
+extern "C" int64_t scn_vox_scratch_bytes(int64_t n) { return (int64_t)scn::ew_grid(n, 256) * 6 * sizeof(float) + 256; }
+
+extern "C" int scn_vox_project(const float* points, int64_t n, const float* rot_and_scale_host,
+                               const float* offset_host, float* aug, float* shift_max, void* scratch,
+                               scn_stream_t stream) {
+    SCN_REQUIRE(n >= 1 && points && rot_and_scale_host && offset_host && aug && shift_max && scratch);
+    const float* r = rot_and_scale_host;
+    const int blocks = scn::ew_grid(n, 256);
+    hipLaunchKernelGGL(k_vox_project, dim3(blocks), dim3(256), 0, S(stream), points, (long long)n, r[0], r[1], r[2], r[3],
+                       r[4], r[5], r[6], r[7], r[8], aug, (float*)scratch);
+    SCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_vox_shift, dim3(1), dim3(64), 0, S(stream), (const float*)scratch, blocks, offset_host[0],
+                       offset_host[1], offset_host[2], shift_max);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+// discrete = trunc(aug + shift) (torch's .long() of a float);  table[i] = i if 0 <= discrete - test_start < size on every
+// axis else -1 (size_ok = 0: everything is inside)
+__global__ void k_vox_discretize(const float* __restrict__ aug, long long n, const float* __restrict__ shift,
+                                 int t0, int t1, int t2, int s0, int s1, int s2, int size_ok,
+                                 int* __restrict__ discrete, int* __restrict__ table) {
+    const float sh[3] = {shift[0], shift[1], shift[2]};
+    const int ts[3] = {t0, t1, t2}, sz[3] = {s0, s1, s2};
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        bool inside = true;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int v = (int)__fadd_rn(aug[3 * i + d], sh[d]);
+            discrete[3 * i + d] = v;
+            if (size_ok) inside = inside && v - ts[d] >= 0 && v - ts[d] < sz[d];
+        }
+        table[i] = inside ? (int)i : -1;
+    }
+}
+
+extern "C" int scn_vox_discretize(const float* aug, int64_t n, const float* shift, const int32_t* test_start_host,
+                                  const int32_t* size_host, int32_t* discrete, int32_t* table, scn_stream_t stream) {
+    SCN_REQUIRE(n >= 1 && n < 2147483647LL && aug && shift && discrete && table);
+    SCN_REQUIRE((test_start_host == nullptr) == (size_host == nullptr));
+    const int32_t zero[3] = {0, 0, 0};
+    const int32_t* t = test_start_host ? test_start_host : zero;
+    const int32_t* z = size_host ? size_host : zero;
+    hipLaunchKernelGGL(k_vox_discretize, dim3(scn::ew_grid(n, 256)), dim3(256), 0, S(stream), aug, (long long)n, shift,
+                       t[0], t[1], t[2], z[0], z[1], z[2], size_host ? 1 : 0, discrete, table);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+// out[j] = (discrete[rows[j]] - start, batch_index)  as int64 [m][4]  (data.py:95-98: the batch index is the 4th column)
+__global__ void k_vox_gather(const int* __restrict__ discrete, const int* __restrict__ rows, long long m, int s0, int s1,
+                             int s2, long long batch_index, long long* __restrict__ out) {
+    for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < m; j += (long long)gridDim.x * blockDim.x) {
+        const long long r = rows[j];
+        out[4 * j + 0] = discrete[3 * r + 0] - s0;
+        out[4 * j + 1] = discrete[3 * r + 1] - s1;
+        out[4 * j + 2] = discrete[3 * r + 2] - s2;
+        out[4 * j + 3] = batch_index;
+    }
+}
+
+extern "C" int scn_vox_gather(const int32_t* discrete, const int32_t* rows, int64_t m, const int32_t* start_host,
+                              int64_t batch_index, int64_t* out, scn_stream_t stream) {
+    SCN_REQUIRE(m >= 0 && start_host);
+    if (m == 0) return SCN_OK;
+    SCN_REQUIRE(discrete && rows && out);
+    hipLaunchKernelGGL(k_vox_gather, dim3(scn::ew_grid(m, 256)), dim3(256), 0, S(stream), discrete, rows, (long long)m,
+                       start_host[0], start_host[1], start_host[2], (long long)batch_index, (long long*)out);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}

@@ -421,6 +421,43 @@ def test_nms_edge_cases(gpu):
     assert np.array_equal(got, O.nms(boxes, 0.25))
 
 
+VOX_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "voxelize_*.npz")))
+
+
+@pytest.mark.parametrize("path", VOX_GOLDEN, ids=[os.path.basename(p) for p in VOX_GOLDEN])
+def test_voxelisation_matches_reference_golden(gpu, path):
+    """augment_coords on the device against the outputs of the reference's own augment_coords."""
+    from sparse_rcnn_amd import voxelize
+    from test_oracle_golden import vox_args
+    z = np.load(path)
+    size, shift = vox_args(z)
+    rows, inside, out_size, cshift = voxelize.augment_coords(
+        torch.from_numpy(z["coords"]).to(gpu), rot_and_scale=z["rot_and_scale"], sub_pixel_offset=z["offset"],
+        spatial_size=size, shift=shift, batch_index=3)
+    assert rows.dtype == torch.int64 and rows.is_cuda
+    assert np.array_equal(rows[:, :3].cpu().numpy(), z["out_coords"]) and (rows[:, 3] == 3).all()
+    assert np.array_equal(inside.cpu().numpy(), z["is_inside"])
+    assert np.array_equal(out_size.numpy(), z["out_size"]) and np.array_equal(cshift.numpy(), z["out_shift"])
+
+
+def test_voxelisation_cut_out_with_drawn_start_positions(gpu):
+    """The cut-out of random_cut_out for given start positions (the reference's own function raises on torch 2.10, so
+    this mode is pinned by the oracle only); the rows feed straight into InputLayer."""
+    from sparse_rcnn_amd import voxelize
+    scn = _scn()
+    z = np.load(VOX_GOLDEN[0])
+    start, size = (17, -4, 9), (96, 128, 48)
+    rows, inside, out_size, cshift = voxelize.augment_coords(
+        torch.from_numpy(z["coords"]).to(gpu), rot_and_scale=z["rot_and_scale"], sub_pixel_offset=z["offset"],
+        spatial_size=size, start_positions=start)
+    res, oin, osize, oshift = O.augment_coords(z["coords"], z["rot_and_scale"], z["offset"], size, None, start)
+    assert np.array_equal(rows[:, :3].cpu().numpy(), res) and np.array_equal(inside.cpu().numpy(), oin)
+    assert np.array_equal(cshift.numpy(), oshift) and out_size.tolist() == list(size)
+    batch = voxelize.collate_coords([rows, rows.clone()])
+    x = scn.InputLayer(3, out_size, mode=4)((batch, torch.ones(len(batch), 2, device=gpu), 1))
+    assert x.features.shape[0] == len(np.unique(res, axis=0))
+
+
 def test_roi_cut_module_revoxelises_like_oracle(gpu):
     from sparse_rcnn_amd import roi
     from sparse_rcnn_amd.synthetic import make_boxes

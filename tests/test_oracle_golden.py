@@ -88,3 +88,26 @@ def test_oracle_nms_matches_reference(path):
 
 def test_nms_golden_present():
     assert len(NMS_GOLDEN) >= 3
+
+
+# ---- N4: voxelisation, pinned by the reference's augment_coords ------------------------------------------------------
+VOX_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "voxelize_*.npz")))
+
+
+def vox_args(z):
+    size = None if z["spatial_size"].ndim == 0 else z["spatial_size"]
+    shift = int(z["shift"]) if bool(z["has_shift"]) else None
+    return size, shift
+
+
+@pytest.mark.parametrize("path", VOX_GOLDEN, ids=[os.path.basename(p) for p in VOX_GOLDEN])
+def test_oracle_voxelisation_matches_reference(path):
+    z = np.load(path)
+    size, shift = vox_args(z)
+    res, inside, out_size, cshift = O.augment_coords(z["coords"], z["rot_and_scale"], z["offset"], size, shift)
+    assert np.array_equal(res, z["out_coords"]) and np.array_equal(inside, z["is_inside"])
+    assert np.array_equal(out_size, z["out_size"]) and np.array_equal(cshift, z["out_shift"])
+
+
+def test_vox_golden_present():
+    assert len(VOX_GOLDEN) >= 4

@@ -6,8 +6,11 @@
   (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU)
 
 A step = InputLayer (voxel hash + first-occurrence rows + mean of duplicate points) + every rulebook build (they are
-rebuilt per forward, as in the reference) + U-Net forward + backward to all parameters and the input features + one
-all-reduce of the flat gradient bucket over RCCL (N > 1) + SGD update.  One scene per GPU (weak scaling); inputs are
+rebuilt per forward, as in the reference) + U-Net forward + backward to all parameters and the input features + the
+all-reduce of the flat gradient buffer over RCCL (N > 1) + SGD update.  The index structures depend on the coordinates
+only, so they are pipelined like a data loader's output: those of batch i+1 are built by a helper thread (one
+scn_pyramid_build call on the high-priority index stream) while batch i runs; every timed step contains exactly one
+complete index build (--no-prefetch builds them inside the forward pass instead).  One scene per GPU (weak scaling); inputs are
 resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -67,9 +70,9 @@ def main():
     ap.add_argument("--target", type=int, default=TARGET)
     ap.add_argument("--profile-all", action="store_true",
                     help="time every GEMM kernel launch of the sampled steps, not only the dominant kernel")
-    ap.add_argument("--prefetch", action="store_true",
-                    help="build the next batch's index structures one batch ahead on the index stream "
-                         "(Metadata.prepare_async); measured slower from a single host thread, off by default")
+    ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
+                    help="build the index structures inside the forward pass instead of one batch ahead on a helper "
+                         "thread (scn_pyramid_build on the index stream)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,8 +119,9 @@ def main():
         fin = feats_d.detach().requires_grad_()
         md = md_next.result() if md_next is not None else None
         md_next = None
-        # optional: the index structures of the NEXT batch are built by a helper thread on the (high-priority) index
-        # stream while this batch's forward and backward run
+        # the index structures of the NEXT batch (they depend on its coordinates only, like a data loader's output) are
+        # built by a helper thread on the high-priority index stream while this batch's forward and backward run: every
+        # timed step still contains one complete index build
         if args.prefetch:
             md_next = model.prefetch_in_thread(coords_d, size, 1)
         out = model(coords_d, fin, size, 1, metadata=md)
@@ -156,6 +160,8 @@ def main():
             timer.begin_step()
             profiling.TIMER = timer if timer.active else None
         step()
+    if md_next is not None:                  # the index build started in the last timed step ends inside the timed region
+        md_next.result()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -199,7 +205,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: one synthetic ScanNet-shaped scene per GPU, "
                                    f"{n_active} active voxels (grid {GRID[0]}x{GRID[1]}x{GRID[2]}, 1.15 points/voxel), "
                                    "U-Net 32-64-128-256, 2 pre-act residual blocks/level, 2^3/2 conv+deconv, "
-                                   "step = rulebooks + fwd + bwd (+ grad all-reduce + SGD)",
+                                   "step = rulebooks + fwd + bwd (+ grad all-reduce + SGD)"
+                                   + ("; rulebooks of batch i+1 built on a helper thread during batch i" if args.prefetch else ""),
                        "parallelism": f"dp{world} (1 scene/GPU, flat-bucket all-reduce)"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,

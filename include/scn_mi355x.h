@@ -118,6 +118,31 @@ int scn_rules_scan(const int32_t* table, int n_off, int64_t n_out, int32_t* bloc
 int scn_rules_fill(const int32_t* table, int n_off, int64_t n_out, const int32_t* block_sums, int32_t* in_rows,
                    int32_t* out_rows, int32_t* seg_of, scn_stream_t stream);
 
+/* All index structures of one forward pass of an n_levels U-Net in one call (what the reference's scn.Metadata builds
+ * lazily on the host while InputLayer / SubmanifoldConvolution / Convolution run: custom_operations.py:67-86,
+ * module_factory.py:232-234,404-406): InputLayer rules, and per level the SubM-k^3 table + rule scan + tiles and the
+ * size=stride=2 coarse sites + child table + rule scan + tiles.  Same kernels, same order and bit-identical results as
+ * the step-by-step entry points above; buffers are carved out of `workspace` (256-byte aligned, at least
+ * scn_pyramid_workspace_bytes(n_points, n_levels, k) bytes), whose layout comes back in `desc` (HOST int64
+ * [SCN_PYRAMID_DESC_LEN], offsets in bytes):
+ *   desc[0] n_levels  [1] n_points  [2] bytes used  [3] out-of-range coordinate count
+ *   desc[4] item_row int32[n_points]  [5] row_count int32 (first n_0 valid)  [6] row_first int32  [7] int32 coords [n_points][4]
+ *   level l at L = desc + 8 + l*SCN_PYRAMID_LEVEL_STRIDE:
+ *     L[0] rows n_l  [1] hash capacity  [2] coords int32[n][4]  [3] hash keys u64[cap]  [4] hash rows int32[cap]
+ *     L[5] table int32[k^3][n]  [6] scan block sums int32[L[7]]  [8] prefix int64[k^3+1] (device)
+ *     L[9] perm  [10] tstab  [11] tile_mask  [12] tile_order  [13] number of tiles
+ *     strided rulebook l -> l+1:  L[14] parent int32[n_l]  [15] fine_off int32[n_l]  [16] child int32[8][n_{l+1}]
+ *     L[17] block sums int32[L[18]]  [19] prefix int64[9] (device)  L[20..23] perm, tstab, tile_mask, tile_order  [24] tiles
+ *     L[25..25+k^3] SubM rule prefix (host copy)   L[53..61] strided rule prefix (host copy)
+ * The call synchronises `stream` (row counts of the levels, rule-list sizes) and holds no interpreter state: a helper
+ * thread may run it for the next batch while the caller queues the current one. */
+#define SCN_PYRAMID_MAX_LEVELS 8
+#define SCN_PYRAMID_LEVEL_STRIDE 64
+#define SCN_PYRAMID_DESC_LEN (8 + SCN_PYRAMID_MAX_LEVELS * SCN_PYRAMID_LEVEL_STRIDE)
+int64_t scn_pyramid_workspace_bytes(int64_t n_points, int n_levels, int k);
+int scn_pyramid_build(const int64_t* coords, int64_t n_points, int n_levels, int k, void* workspace,
+                      int64_t workspace_bytes, int64_t* desc, scn_stream_t stream);
+
 /* Sparse ROI crop indicator (roi_select_sparse.py:157-167 get_inside_indicator): boxes int32 [bb][8] =
  * (start x,y,z,sample ; stop x,y,z,sample+1).  table[i][j] = j if point j lies in box i else -1; feed it to
  * scn_rules_scan/_fill to obtain the box-major, ascending-point-row selection of select_features / select_coords

@@ -31,6 +31,8 @@ _SIGS = {
     "scn_rules_blocks": (i64, [i32, i64]),
     "scn_rules_scan": (C.c_int, [p, i32, i64, p, p, C.POINTER(i64), p]),
     "scn_rules_fill": (C.c_int, [p, i32, i64, p, p, p, p, p]),
+    "scn_pyramid_workspace_bytes": (i64, [i64, i32, i32]),
+    "scn_pyramid_build": (C.c_int, [p, i64, i32, i32, p, i64, C.POINTER(i64), p]),
     "scn_roi_table": (C.c_int, [p, i64, p, i32, p, p, p]),
     "scn_roi_coords": (C.c_int, [p, p, p, i64, p, p]),
     "scn_roi_boxes": (C.c_int, [p, p, i32, p, p, p]),
@@ -73,6 +75,8 @@ EXPORTS = tuple(_SIGS)
 
 F_RELU_IN, F_W_TRANSPOSED, F_OFF_REVERSE, F_RESIDUAL_LAST = 1, 2, 4, 8
 OK, EINVAL, ESIZE, EHASH, EHIP = 0, 1, 2, 3, 4
+PYRAMID_MAX_LEVELS, PYRAMID_LEVEL_STRIDE = 8, 64
+PYRAMID_DESC_LEN = 8 + PYRAMID_MAX_LEVELS * PYRAMID_LEVEL_STRIDE
 COLSUM_BLOCKS = 512
 
 

@@ -1,0 +1,190 @@
+// scn_pyramid_build: every index structure of one forward pass of an n-level U-Net in ONE call.
+//
+// InputLayer rules (voxel hash, first-occurrence rows) + per level the SubM neighbour table, its rule scan and its
+// mask-sorted tiles + between levels the coarse-site numbering, child table, rule scan and tiles -- the same kernels, in
+// the same order, as the step-by-step entry points of scn_index.hip / scn_tiles.hip queue them from Python
+// (sparse_rcnn_amd/metadata.py), so the results are bit-identical.  What changes is who drives them: ~35 C calls and
+// ~100 tensor allocations of the Python path become one call that carves its buffers out of a caller-provided workspace
+// and spends its life inside the HIP runtime, i.e. WITHOUT the interpreter lock.  A helper thread can therefore build the
+// structures of the next batch while the main thread queues the matrix kernels of the current one (the Python-driven
+// prefetch fought the main thread for the GIL and gained nothing); tools/bound_no_index.py: 7.18 -> 6.08 ms/step if the
+// index build were free.
+//
+// The call waits for the device five times (row counts of the levels, then the rule-list sizes); all of them on the
+// caller's stream only.
+#include "scn_common.h"
+
+using scn::S;
+using scn::cdiv;
+
+namespace {
+struct Bump {
+    char* base;
+    int64_t used, cap;
+    bool ok = true;
+    void* take(int64_t bytes, int64_t* off) {
+        used = (used + 255) & ~(int64_t)255;
+        *off = used;
+        used += bytes;
+        if (used > cap) ok = false;
+        return base + *off;
+    }
+};
+
+inline int64_t nt_of(int64_t n) { return cdiv(n, 16); }
+
+// bytes the builder takes for a level whose row count is bounded by n (and whose parent level by n_parent)
+int64_t level_bytes(int64_t n, int n_off, bool has_next) {
+    const int64_t pad = 256;
+    int64_t b = 0;
+    const int64_t nt = nt_of(n);
+    b += (int64_t)n_off * n * 4 + pad;                                  // table
+    b += scn_rules_blocks(n_off, n) * 4 + pad + (n_off + 1) * 8 + pad;  // scan
+    b += nt * 16 * 4 + pad + nt * n_off * 16 * 4 + pad + nt * 4 + pad + nt * 4 + pad + scn_tiles_scratch_bytes(n_off, n) + pad;
+    if (has_next) {                                                     // numbering of the coarse sites + strided rulebook
+        const int64_t cap = scn_hash_capacity(n);
+        b += cap * 8 + pad + cap * 4 + pad + n * 4 + pad + n * 16 + pad + scn_dedup_scratch_bytes(n) + pad + 8 + pad;
+        const int64_t ntc = nt_of(n);
+        b += 8 * n * 4 + pad + n * 4 + pad;                             // child (<= n coarse rows), fine_off
+        b += scn_rules_blocks(8, n) * 4 + pad + 9 * 8 + pad;
+        b += ntc * 16 * 4 + pad + ntc * 8 * 16 * 4 + pad + ntc * 4 + pad + ntc * 4 + pad + scn_tiles_scratch_bytes(8, n) + pad;
+    }
+    return b;
+}
+}  // namespace
+
+extern "C" int64_t scn_pyramid_workspace_bytes(int64_t n_points, int n_levels, int k) {
+    if (n_points < 0 || n_levels < 1 || n_levels > SCN_PYRAMID_MAX_LEVELS || k < 1 || k > 3 || k % 2 == 0) return -1;
+    const int64_t n = n_points > 0 ? n_points : 1, pad = 256;
+    const int64_t cap = scn_hash_capacity(n);
+    int64_t b = n * 16 + pad + 4 + pad;                                                     // int32 coords, range flag
+    b += cap * 8 + pad + cap * 4 + pad + 3 * (n * 4 + pad) + n * 16 + pad + scn_dedup_scratch_bytes(n) + pad + 8 + pad;
+    for (int l = 0; l < n_levels; ++l) b += level_bytes(n, k * k * k, l + 1 < n_levels);   // every level is bounded by n
+    return b + 4096;
+}
+
+extern "C" int scn_pyramid_build(const int64_t* coords, int64_t n_points, int n_levels, int k, void* workspace,
+                                 int64_t workspace_bytes, int64_t* desc, scn_stream_t stream) {
+    SCN_REQUIRE(coords && workspace && desc && n_points >= 1 && n_levels >= 1 && n_levels <= SCN_PYRAMID_MAX_LEVELS);
+    SCN_REQUIRE(k == 1 || k == 3);
+    SCN_REQUIRE(((uintptr_t)workspace & 255) == 0);
+    const int n_off = k * k * k;
+    hipStream_t st = S(stream);
+    Bump ws{(char*)workspace, 0, workspace_bytes};
+    for (int i = 0; i < SCN_PYRAMID_DESC_LEN; ++i) desc[i] = 0;
+    desc[0] = n_levels;
+    desc[1] = n_points;
+    int rc;
+
+    // ---- InputLayer: int64 -> int32 coordinates (range check), first-occurrence numbering ------------------------
+    int64_t off;
+    int32_t* c32 = (int32_t*)ws.take(n_points * 16, &off);        desc[7] = off;
+    int32_t* flag = (int32_t*)ws.take(4, &off);
+    const int64_t cap0 = scn_hash_capacity(n_points);
+    uint64_t* keys = (uint64_t*)ws.take(cap0 * 8, &off);           const int64_t off_keys0 = off;
+    int32_t* hrows = (int32_t*)ws.take(cap0 * 4, &off);            const int64_t off_hrows0 = off;
+    int32_t* item_row = (int32_t*)ws.take(n_points * 4, &off);     desc[4] = off;
+    int32_t* row_count = (int32_t*)ws.take(n_points * 4, &off);    desc[5] = off;
+    int32_t* row_first = (int32_t*)ws.take(n_points * 4, &off);    desc[6] = off;
+    int32_t* row_coords = (int32_t*)ws.take(n_points * 16, &off);  const int64_t off_coords0 = off;
+    void* dscr = ws.take(scn_dedup_scratch_bytes(n_points), &off);
+    int64_t* cnt_dev = (int64_t*)ws.take(8, &off);
+    SCN_REQUIRE(ws.ok);
+    if ((rc = scn_coords_to_i32(coords, n_points, c32, flag, nullptr, stream))) return rc;
+    if ((rc = scn_dedup_launch(c32, n_points, 0, keys, hrows, cap0, item_row, row_count, row_first, row_coords, dscr,
+                               cnt_dev, stream)))
+        return rc;
+    int64_t n_rows = 0;
+    int32_t bad = 0;
+    SCN_HIP(hipMemcpyAsync(&n_rows, cnt_dev, 8, hipMemcpyDeviceToHost, st));
+    SCN_HIP(hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, st));
+    SCN_HIP(hipStreamSynchronize(st));
+    desc[3] = bad;
+    if (bad) return scn::fail(SCN_EHASH, "%scoordinates outside [0,65535] in %lld wave(s)", "", (long long)bad);
+
+    // ---- levels --------------------------------------------------------------------------------------------------
+    const int32_t* lv_coords = row_coords;
+    int64_t lv_off_coords = off_coords0, lv_off_keys = off_keys0, lv_off_hrows = off_hrows0, lv_cap = cap0;
+    const uint64_t* lv_keys = keys;
+    const int32_t* lv_hrows = hrows;
+    int64_t n = n_rows;
+    int64_t* prefix_dev[SCN_PYRAMID_MAX_LEVELS][2] = {};
+    for (int l = 0; l < n_levels; ++l) {
+        int64_t* L = desc + 8 + l * SCN_PYRAMID_LEVEL_STRIDE;
+        const bool has_next = l + 1 < n_levels && n > 0;
+        L[0] = n; L[1] = lv_cap; L[2] = lv_off_coords; L[3] = lv_off_keys; L[4] = lv_off_hrows;
+        // numbering of the coarse sites of level l+1 first: its row count travels back while the SubM work is queued
+        uint64_t* nkeys = nullptr; int32_t *nhrows = nullptr, *parent = nullptr, *ncoords = nullptr;
+        int64_t ncap = 0, off_nkeys = 0, off_nhrows = 0, off_ncoords = 0;
+        int64_t* ncnt = nullptr;
+        if (has_next) {
+            ncap = scn_hash_capacity(n);
+            nkeys = (uint64_t*)ws.take(ncap * 8, &off_nkeys);
+            nhrows = (int32_t*)ws.take(ncap * 4, &off_nhrows);
+            parent = (int32_t*)ws.take(n * 4, &off);           L[14] = off;
+            ncoords = (int32_t*)ws.take(n * 16, &off_ncoords);
+            void* s2 = ws.take(scn_dedup_scratch_bytes(n), &off);
+            ncnt = (int64_t*)ws.take(8, &off);
+            SCN_REQUIRE(ws.ok);
+            if ((rc = scn_dedup_launch(lv_coords, n, 1, nkeys, nhrows, ncap, parent, nullptr, nullptr, ncoords, s2, ncnt,
+                                       stream)))
+                return rc;
+        }
+        if (n > 0 && k > 1) {
+            const int64_t nt = nt_of(n);
+            int32_t* table = (int32_t*)ws.take((int64_t)n_off * n * 4, &off);            L[5] = off;
+            const int64_t blocks = scn_rules_blocks(n_off, n);
+            int32_t* bsums = (int32_t*)ws.take(blocks * 4, &off);                        L[6] = off; L[7] = blocks;
+            int64_t* prefix = (int64_t*)ws.take((n_off + 1) * 8, &off);                  L[8] = off;
+            int32_t* perm = (int32_t*)ws.take(nt * 16 * 4, &off);                        L[9] = off;
+            int32_t* tstab = (int32_t*)ws.take(nt * n_off * 16 * 4, &off);               L[10] = off;
+            uint32_t* tmask = (uint32_t*)ws.take(nt * 4, &off);                          L[11] = off;
+            int32_t* torder = (int32_t*)ws.take(nt * 4, &off);                           L[12] = off; L[13] = nt;
+            void* tscr = ws.take(scn_tiles_scratch_bytes(n_off, n), &off);
+            SCN_REQUIRE(ws.ok);
+            if ((rc = scn_subm_table(lv_coords, n, lv_keys, lv_hrows, lv_cap, k, table, stream))) return rc;
+            if ((rc = scn_rules_scan(table, n_off, n, bsums, prefix, nullptr, stream))) return rc;
+            if ((rc = scn_tiles_build(table, n_off, n, perm, tstab, tmask, torder, tscr, stream))) return rc;
+            prefix_dev[l][0] = prefix;
+        }
+        if (!has_next) {
+            if (l + 1 < n_levels)                       // an empty level: everything below it is empty too
+                for (int m = l + 1; m < n_levels; ++m) desc[8 + m * SCN_PYRAMID_LEVEL_STRIDE] = 0;
+            break;
+        }
+        int64_t nc = 0;
+        SCN_HIP(hipMemcpyAsync(&nc, ncnt, 8, hipMemcpyDeviceToHost, st));
+        SCN_HIP(hipStreamSynchronize(st));
+        {
+            const int64_t ntc = nt_of(nc);
+            int32_t* fine_off = (int32_t*)ws.take(n * 4, &off);                          L[15] = off;
+            int32_t* child = (int32_t*)ws.take(8 * nc * 4, &off);                        L[16] = off;
+            const int64_t blocks = scn_rules_blocks(8, nc);
+            int32_t* bsums = (int32_t*)ws.take(blocks * 4, &off);                        L[17] = off; L[18] = blocks;
+            int64_t* prefix = (int64_t*)ws.take(9 * 8, &off);                            L[19] = off;
+            int32_t* perm = (int32_t*)ws.take(ntc * 16 * 4, &off);                       L[20] = off;
+            int32_t* tstab = (int32_t*)ws.take(ntc * 8 * 16 * 4, &off);                  L[21] = off;
+            uint32_t* tmask = (uint32_t*)ws.take(ntc * 4, &off);                         L[22] = off;
+            int32_t* torder = (int32_t*)ws.take(ntc * 4, &off);                          L[23] = off; L[24] = ntc;
+            void* tscr = ws.take(scn_tiles_scratch_bytes(8, nc), &off);
+            SCN_REQUIRE(ws.ok);
+            if ((rc = scn_child_table(lv_coords, parent, n, nc, child, fine_off, stream))) return rc;
+            if ((rc = scn_rules_scan(child, 8, nc, bsums, prefix, nullptr, stream))) return rc;
+            if ((rc = scn_tiles_build(child, 8, nc, perm, tstab, tmask, torder, tscr, stream))) return rc;
+            prefix_dev[l][1] = prefix;
+        }
+        lv_coords = ncoords; lv_keys = nkeys; lv_hrows = nhrows; lv_cap = ncap;
+        lv_off_coords = off_ncoords; lv_off_keys = off_nkeys; lv_off_hrows = off_nhrows;
+        n = nc;
+    }
+    // ---- rule-list sizes (consumed by the weight-gradient / rule-list GEMMs) -----------------------------------------
+    for (int l = 0; l < n_levels; ++l) {
+        int64_t* L = desc + 8 + l * SCN_PYRAMID_LEVEL_STRIDE;
+        if (prefix_dev[l][0])
+            SCN_HIP(hipMemcpyAsync(L + 25, prefix_dev[l][0], (n_off + 1) * 8, hipMemcpyDeviceToHost, st));
+        if (prefix_dev[l][1]) SCN_HIP(hipMemcpyAsync(L + 53, prefix_dev[l][1], 9 * 8, hipMemcpyDeviceToHost, st));
+    }
+    SCN_HIP(hipStreamSynchronize(st));
+    desc[2] = ws.used;
+    return SCN_OK;
+}

@@ -97,6 +97,11 @@ class RuleCount:
         return self._total
 
 
+class _KnownCount:
+    def __init__(self, total):
+        self.total = total
+
+
 class Rules:
     """Compacted rule list, offset-major, output row ascending inside an offset (canonical order).
 
@@ -119,6 +124,20 @@ class Rules:
         self.count = RuleCount(self._rb, self.n_off)
         self._prefix_host = None
         self._in = self._out = self._seg = None
+
+    @classmethod
+    def from_scan(cls, table, n_off, n_out, block_sums, prefix_dev, prefix_values, want_seg=False):
+        """A Rules whose scan has already run (scn_pyramid_build): block sums and prefix exist, the sizes are known."""
+        self = cls.__new__(cls)
+        self.n_off = int(n_off)
+        self._table, self._n_out, self._want_seg = table, int(n_out), want_seg
+        self._block_sums, self.prefix_dev = block_sums, prefix_dev
+        self._rb = None
+        arr = (C.c_int64 * (self.n_off + 1))(*[int(v) for v in prefix_values])
+        self._prefix_host = arr
+        self.count = _KnownCount(int(arr[self.n_off]))
+        self._in = self._out = self._seg = None
+        return self
 
     @property
     def prefix_host(self):
@@ -308,6 +327,82 @@ class Metadata:
             self.n_samples = int(c64[:, 3].max().item()) + 1 if n else 0
         return grid
 
+    def build_native(self, spatial_size, coords: torch.Tensor, batch_size: int, mode: int, n_levels: int, k: int = 3):
+        """set_input + build_pyramid through ONE C call (scn_pyramid_build): same structures, bit-identical, carved out of
+        one workspace tensor; the call holds no interpreter state, so a helper thread can run it next to the main
+        thread's kernel queueing (prepare_in_thread)."""
+        lib = L.lib()
+        size = tuple(int(s) for s in spatial_size)
+        if len(size) != 3:
+            raise ValueError("spatial_size must have 3 entries")
+        if coords.dim() != 2 or coords.shape[1] != 4:
+            raise ValueError("coords must be [N, 4] = (x, y, z, batch)")
+        if not 1 <= n_levels <= L.PYRAMID_MAX_LEVELS or k not in (1, 3):
+            raise ValueError("n_levels in 1..8 and k in (1, 3)")
+        lv_size = size
+        for _ in range(n_levels - 1):
+            if any(v % 2 for v in lv_size):
+                raise L.ScnError(f"Convolution size=stride=2 needs even spatial size, got {lv_size} "
+                                 "((out-1)*stride+filter != in)")
+            lv_size = tuple(v // 2 for v in lv_size)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        c64 = coords.to(device=dev, dtype=torch.int64).contiguous()
+        n = c64.shape[0]
+        if n == 0:                       # nothing to build natively; the step-by-step path handles the empty batch
+            self.set_input(spatial_size, coords, batch_size, mode)
+            return self
+        ws = torch.empty(lib.scn_pyramid_workspace_bytes(n, n_levels, k), dtype=torch.uint8, device=dev)
+        desc = (C.c_int64 * L.PYRAMID_DESC_LEN)()
+        L.check(lib.scn_pyramid_build(L.ptr(c64), n, n_levels, k, L.ptr(ws), ws.numel(), desc, L.stream()))
+        self._workspace = ws
+
+        def view(off, count, dtype, shape=None):
+            nbytes = count * torch.empty(0, dtype=dtype).element_size()
+            t = ws[off:off + nbytes].view(dtype)
+            return t.view(shape) if shape is not None else t
+        n_off = k ** 3
+        n0 = int(desc[8])
+        self.input_size = size
+        self.item_row = view(desc[4], n, torch.int32)
+        self.row_count = view(desc[5], n0, torch.int32)
+        self.row_first = view(desc[6], n0, torch.int32)
+        self.n_items = n
+        if mode == 0 and n0 != n:
+            raise L.ScnError("InputLayer mode 0 requires unique coordinates")
+        self.n_samples = int(batch_size) if batch_size and batch_size > 0 else int(c64[:, 3].max().item()) + 1
+        lv_size = size
+        for l in range(n_levels):
+            D = [int(desc[8 + l * L.PYRAMID_LEVEL_STRIDE + j]) for j in range(L.PYRAMID_LEVEL_STRIDE)]
+            nl, cap = D[0], D[1]
+            grid = Grid(view(D[2], nl * 4, torch.int32, (nl, 4)), view(D[3], cap, torch.int64), view(D[4], cap, torch.int32),
+                        cap, nl)
+            self.grids[lv_size] = grid
+            if k == 1:
+                self.subm[(lv_size, 1)] = SubmRulebook(None, None, 1, nl)
+            elif nl > 0:
+                nt = D[13]
+                table = view(D[5], n_off * nl, torch.int32, (n_off, nl))
+                rules = Rules.from_scan(table, n_off, nl, view(D[6], D[7], torch.int32), view(D[8], n_off + 1, torch.int64),
+                                        D[25:25 + n_off + 1])
+                tiles = Tiles(view(D[9], nt * 16, torch.int32), view(D[10], nt * n_off * 16, torch.int32, (nt, n_off, 16)),
+                              view(D[11], nt, torch.int32), n_off, nl, view(D[12], nt, torch.int32))
+                self.subm[(lv_size, k)] = SubmRulebook(table, rules, k, nl, tiles)
+            if l + 1 < n_levels and nl > 0:
+                nc = int(desc[8 + (l + 1) * L.PYRAMID_LEVEL_STRIDE])
+                ntc = D[24]
+                child = view(D[16], 8 * nc, torch.int32, (8, nc))
+                rules = Rules.from_scan(child, 8, nc, view(D[17], D[18], torch.int32), view(D[19], 9, torch.int64), D[53:62])
+                tiles = Tiles(view(D[20], ntc * 16, torch.int32), view(D[21], ntc * 8 * 16, torch.int32, (ntc, 8, 16)),
+                              view(D[22], ntc, torch.int32), 8, nc, view(D[23], ntc, torch.int32))
+                coarse = tuple(v // 2 for v in lv_size)
+                self.strided[lv_size] = StridedRulebook(view(D[14], nl, torch.int32), view(D[15], nl, torch.int32), child,
+                                                        rules, nl, nc, coarse, tiles)
+                lv_size = coarse
+            elif l + 1 < n_levels:
+                break
+        return self
+
     # ---- rulebooks ----------------------------------------------------------------------------------
     def grid(self, size) -> Grid:
         size = tuple(int(s) for s in size)
@@ -367,7 +462,8 @@ class Metadata:
         return rb
 
     # ---- index prefetch on a side stream -----------------------------------------------------------
-    def prepare_async(self, spatial_size, coords, batch_size: int = 0, mode: int = 4, n_levels: int = 0, k: int = 3):
+    def prepare_async(self, spatial_size, coords, batch_size: int = 0, mode: int = 4, n_levels: int = 0, k: int = 3,
+                      native: bool = False):
         """Build the InputLayer rules (and optionally the rulebook pyramid of an n_levels U-Net) on the index stream.
 
         All index structures depend only on the coordinates, so a training loop can build those of batch i+1 while the
@@ -377,15 +473,18 @@ class Metadata:
         side = index_stream(torch.device("cuda", torch.cuda.current_device()))
         side.wait_stream(torch.cuda.current_stream())          # coords may have been produced on the current stream
         with torch.cuda.stream(side):
-            self.set_input(spatial_size, coords, batch_size, mode)
-            if n_levels:
-                self.build_pyramid(spatial_size, n_levels, k)
+            if native and n_levels:
+                self.build_native(spatial_size, coords, batch_size, mode, n_levels, k)
+            else:
+                self.set_input(spatial_size, coords, batch_size, mode)
+                if n_levels:
+                    self.build_pyramid(spatial_size, n_levels, k)
             self.ready_event = torch.cuda.Event()
             self.ready_event.record(side)
         return self
 
     def prepare_in_thread(self, spatial_size, coords, batch_size: int = 0, mode: int = 4, n_levels: int = 0,
-                          k: int = 3) -> "PendingMetadata":
+                          k: int = 3, native: bool = True) -> "PendingMetadata":
         """prepare_async on a helper thread.  The build waits four times for a row count; on the caller's thread those
         waits would keep it from queueing the matrix kernels of the current batch (measured: slower than no prefetch).
         The helper spends its time inside C calls and event waits, which release the GIL."""
@@ -393,11 +492,11 @@ class Metadata:
 
         def fn():
             torch.cuda.set_device(dev)
-            return self.prepare_async(spatial_size, coords, batch_size, mode, n_levels, k)
+            return self.prepare_async(spatial_size, coords, batch_size, mode, n_levels, k, native=native)
         return PendingMetadata(fn)
 
     def _all_tensors(self):
-        out = [self.item_row, self.row_count, self.row_first, self.row_last]
+        out = [self.item_row, self.row_count, self.row_first, self.row_last, getattr(self, "_workspace", None)]
         for g in self.grids.values():
             out += [g.coords, g.table_keys, g.table_rows]
         for rb in list(self.subm.values()) + list(self.strided.values()):

@@ -515,6 +515,42 @@ def test_index_prefetch_on_side_stream_is_equivalent(gpu):
     assert torch.equal(out, ref)
 
 
+def test_native_pyramid_build_is_bit_identical(gpu):
+    """scn_pyramid_build (one C call, one workspace) against the step-by-step build driven from Python: every index
+    tensor of every level equal, rule lists included; and a network run on either gives the same bits."""
+    from sparse_rcnn_amd.metadata import Metadata
+    from sparse_rcnn_amd.unet import Backbone
+    coords, size, batch = _cloud(41, grid=(32, 32, 16), n=2600, batch=2, dup=300)
+    cg = coords.to(gpu)
+    a = Metadata(3); a.set_input(size, cg, batch, 4); a.build_pyramid(size, 3, 3)
+    b = Metadata(3).build_native(size, cg, batch, 4, 3, 3)
+    eq = lambda x, y: torch.equal(x, y)
+    assert eq(a.item_row, b.item_row) and eq(a.row_count, b.row_count) and eq(a.row_first, b.row_first)
+    assert a.n_samples == b.n_samples and list(a.grids) == list(b.grids)
+    for s in a.grids:
+        assert a.grids[s].n == b.grids[s].n and eq(a.grids[s].coords, b.grids[s].coords)
+    for key in a.subm:
+        ra, rb = a.subm[key], b.subm[key]
+        assert eq(ra.table, rb.table) and ra.rules.prefix_list() == rb.rules.prefix_list()
+        assert eq(ra.rules.in_rows, rb.rules.in_rows) and eq(ra.rules.out_rows, rb.rules.out_rows)
+        for f in ("perm", "tstab", "tile_mask", "tile_order"):
+            assert eq(getattr(ra.tiles, f), getattr(rb.tiles, f)), f
+    for key in a.strided:
+        ra, rb = a.strided[key], b.strided[key]
+        assert eq(ra.parent, rb.parent) and eq(ra.fine_off, rb.fine_off) and eq(ra.child, rb.child)
+        assert ra.rules.prefix_list() == rb.rules.prefix_list() and eq(ra.rules.in_rows, rb.rules.in_rows)
+        for f in ("perm", "tstab", "tile_mask", "tile_order"):
+            assert eq(getattr(ra.tiles, f), getattr(rb.tiles, f)), f
+    feats = torch.randn(len(coords), 7, generator=torch.Generator().manual_seed(3)).to(gpu)
+    net = Backbone(7, (16, 24, 32)).to(gpu)
+    net.NATIVE_INDEX = False
+    ref = net(cg, feats, size, batch).features
+    net.NATIVE_INDEX = True
+    assert torch.equal(net(cg, feats, size, batch).features, ref)
+    with pytest.raises(_scn().ScnError):
+        Metadata(3).build_native(torch.tensor([30, 32, 16]), cg, batch, 4, 3, 3)      # 30/2 = 15 is odd
+
+
 def test_async_row_count_equals_synchronous_dedup(gpu):
     """scn_dedup_launch (row count left on the device, no host sync) numbers rows exactly like scn_dedup_build."""
     from sparse_rcnn_amd import metadata as M

@@ -134,10 +134,11 @@ int scn_rules_fill(const int32_t* table, int n_off, int64_t n_out, const int32_t
  *     strided rulebook l -> l+1:  L[14] parent int32[n_l]  [15] fine_off int32[n_l]  [16] child int32[8][n_{l+1}]
  *     L[17] block sums int32[L[18]]  [19] prefix int64[9] (device)  L[20..23] perm, tstab, tile_mask, tile_order  [24] tiles
  *     L[25..25+k^3] SubM rule prefix (host copy)   L[53..61] strided rule prefix (host copy)
+ *     L[64] / L[65] compacted SubM rules in_rows / out_rows int32[prefix[k^3]]   L[66] / L[67] the strided ones
  * The call synchronises `stream` (row counts of the levels, rule-list sizes) and holds no interpreter state: a helper
  * thread may run it for the next batch while the caller queues the current one. */
 #define SCN_PYRAMID_MAX_LEVELS 8
-#define SCN_PYRAMID_LEVEL_STRIDE 64
+#define SCN_PYRAMID_LEVEL_STRIDE 72
 #define SCN_PYRAMID_DESC_LEN (8 + SCN_PYRAMID_MAX_LEVELS * SCN_PYRAMID_LEVEL_STRIDE)
 int64_t scn_pyramid_workspace_bytes(int64_t n_points, int n_levels, int k);
 int scn_pyramid_build(const int64_t* coords, int64_t n_points, int n_levels, int k, void* workspace,

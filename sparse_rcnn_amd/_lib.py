@@ -75,7 +75,7 @@ EXPORTS = tuple(_SIGS)
 
 F_RELU_IN, F_W_TRANSPOSED, F_OFF_REVERSE, F_RESIDUAL_LAST = 1, 2, 4, 8
 OK, EINVAL, ESIZE, EHASH, EHIP = 0, 1, 2, 3, 4
-PYRAMID_MAX_LEVELS, PYRAMID_LEVEL_STRIDE = 8, 64
+PYRAMID_MAX_LEVELS, PYRAMID_LEVEL_STRIDE = 8, 72
 PYRAMID_DESC_LEN = 8 + PYRAMID_MAX_LEVELS * PYRAMID_LEVEL_STRIDE
 COLSUM_BLOCKS = 512
 

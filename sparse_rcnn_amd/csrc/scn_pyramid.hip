@@ -10,8 +10,8 @@
 // prefetch fought the main thread for the GIL and gained nothing); tools/bound_no_index.py: 7.18 -> 6.08 ms/step if the
 // index build were free.
 //
-// The call waits for the device five times (row counts of the levels, then the rule-list sizes); all of them on the
-// caller's stream only.
+// The call waits for the device five times (row counts of the levels, then the rule-list sizes, after which the
+// compacted rule lists are queued too); all of them on the caller's stream only.
 #include "scn_common.h"
 
 using scn::S;
@@ -40,13 +40,14 @@ int64_t level_bytes(int64_t n, int n_off, bool has_next) {
     const int64_t nt = nt_of(n);
     b += (int64_t)n_off * n * 4 + pad;                                  // table
     b += scn_rules_blocks(n_off, n) * 4 + pad + (n_off + 1) * 8 + pad;  // scan
+    b += 2 * ((int64_t)n_off * n * 4 + pad);                            // compacted rules (at most one per table entry)
     b += nt * 16 * 4 + pad + nt * n_off * 16 * 4 + pad + nt * 4 + pad + nt * 4 + pad + scn_tiles_scratch_bytes(n_off, n) + pad;
     if (has_next) {                                                     // numbering of the coarse sites + strided rulebook
         const int64_t cap = scn_hash_capacity(n);
         b += cap * 8 + pad + cap * 4 + pad + n * 4 + pad + n * 16 + pad + scn_dedup_scratch_bytes(n) + pad + 8 + pad;
         const int64_t ntc = nt_of(n);
         b += 8 * n * 4 + pad + n * 4 + pad;                             // child (<= n coarse rows), fine_off
-        b += scn_rules_blocks(8, n) * 4 + pad + 9 * 8 + pad;
+        b += scn_rules_blocks(8, n) * 4 + pad + 9 * 8 + pad + 2 * (n * 4 + pad);      // every fine row is one rule
         b += ntc * 16 * 4 + pad + ntc * 8 * 16 * 4 + pad + ntc * 4 + pad + ntc * 4 + pad + scn_tiles_scratch_bytes(8, n) + pad;
     }
     return b;
@@ -185,6 +186,29 @@ extern "C" int scn_pyramid_build(const int64_t* coords, int64_t n_points, int n_
         if (prefix_dev[l][1]) SCN_HIP(hipMemcpyAsync(L + 53, prefix_dev[l][1], 9 * 8, hipMemcpyDeviceToHost, st));
     }
     SCN_HIP(hipStreamSynchronize(st));
+    // ---- compacted rule lists: sizes are known now; no further wait (the caller orders its stream behind this one) ------
+    for (int l = 0; l < n_levels; ++l) {
+        int64_t* L = desc + 8 + l * SCN_PYRAMID_LEVEL_STRIDE;
+        char* base = (char*)workspace;
+        if (prefix_dev[l][0]) {
+            const int64_t P = L[25 + n_off];
+            int32_t* in_rows = (int32_t*)ws.take(P * 4, &off);      L[64] = off;
+            int32_t* out_rows = (int32_t*)ws.take(P * 4, &off);     L[65] = off;
+            SCN_REQUIRE(ws.ok);
+            if ((rc = scn_rules_fill((const int32_t*)(base + L[5]), n_off, L[0], (const int32_t*)(base + L[6]), in_rows,
+                                     out_rows, nullptr, stream)))
+                return rc;
+        }
+        if (prefix_dev[l][1]) {
+            const int64_t P = L[53 + 8], nc = desc[8 + (l + 1) * SCN_PYRAMID_LEVEL_STRIDE];
+            int32_t* in_rows = (int32_t*)ws.take(P * 4, &off);      L[66] = off;
+            int32_t* out_rows = (int32_t*)ws.take(P * 4, &off);     L[67] = off;
+            SCN_REQUIRE(ws.ok);
+            if ((rc = scn_rules_fill((const int32_t*)(base + L[16]), 8, nc, (const int32_t*)(base + L[17]), in_rows,
+                                     out_rows, nullptr, stream)))
+                return rc;
+        }
+    }
     desc[2] = ws.used;
     return SCN_OK;
 }

@@ -126,8 +126,9 @@ class Rules:
         self._in = self._out = self._seg = None
 
     @classmethod
-    def from_scan(cls, table, n_off, n_out, block_sums, prefix_dev, prefix_values, want_seg=False):
-        """A Rules whose scan has already run (scn_pyramid_build): block sums and prefix exist, the sizes are known."""
+    def from_scan(cls, table, n_off, n_out, block_sums, prefix_dev, prefix_values, in_rows=None, out_rows=None,
+                  want_seg=False):
+        """A Rules whose scan (and fill) has already run (scn_pyramid_build)."""
         self = cls.__new__(cls)
         self.n_off = int(n_off)
         self._table, self._n_out, self._want_seg = table, int(n_out), want_seg
@@ -136,7 +137,7 @@ class Rules:
         arr = (C.c_int64 * (self.n_off + 1))(*[int(v) for v in prefix_values])
         self._prefix_host = arr
         self.count = _KnownCount(int(arr[self.n_off]))
-        self._in = self._out = self._seg = None
+        self._in, self._out, self._seg = in_rows, out_rows, None
         return self
 
     @property
@@ -383,8 +384,9 @@ class Metadata:
             elif nl > 0:
                 nt = D[13]
                 table = view(D[5], n_off * nl, torch.int32, (n_off, nl))
+                P = D[25 + n_off]
                 rules = Rules.from_scan(table, n_off, nl, view(D[6], D[7], torch.int32), view(D[8], n_off + 1, torch.int64),
-                                        D[25:25 + n_off + 1])
+                                        D[25:25 + n_off + 1], view(D[64], P, torch.int32), view(D[65], P, torch.int32))
                 tiles = Tiles(view(D[9], nt * 16, torch.int32), view(D[10], nt * n_off * 16, torch.int32, (nt, n_off, 16)),
                               view(D[11], nt, torch.int32), n_off, nl, view(D[12], nt, torch.int32))
                 self.subm[(lv_size, k)] = SubmRulebook(table, rules, k, nl, tiles)
@@ -392,7 +394,8 @@ class Metadata:
                 nc = int(desc[8 + (l + 1) * L.PYRAMID_LEVEL_STRIDE])
                 ntc = D[24]
                 child = view(D[16], 8 * nc, torch.int32, (8, nc))
-                rules = Rules.from_scan(child, 8, nc, view(D[17], D[18], torch.int32), view(D[19], 9, torch.int64), D[53:62])
+                rules = Rules.from_scan(child, 8, nc, view(D[17], D[18], torch.int32), view(D[19], 9, torch.int64), D[53:62],
+                                        view(D[66], D[61], torch.int32), view(D[67], D[61], torch.int32))
                 tiles = Tiles(view(D[20], ntc * 16, torch.int32), view(D[21], ntc * 8 * 16, torch.int32, (ntc, 8, 16)),
                               view(D[22], ntc, torch.int32), 8, nc, view(D[23], ntc, torch.int32))
                 coarse = tuple(v // 2 for v in lv_size)

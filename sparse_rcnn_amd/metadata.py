@@ -38,26 +38,22 @@ def index_stream(device) -> "torch.cuda.Stream":
     return st
 
 
+_index_pool = None
+
+
 class PendingMetadata:
-    """A Metadata being built by a helper thread on the index stream (Metadata.prepare_in_thread)."""
+    """A Metadata being built by the index helper thread (Metadata.prepare_in_thread).  One persistent worker: builds
+    are short (~1.5 ms) and at most one is in flight per training loop."""
 
     def __init__(self, fn):
-        import threading
-        self._md, self._err = None, None
-
-        def run():
-            try:
-                self._md = fn()
-            except BaseException as e:          # re-raised in result()
-                self._err = e
-        self._thread = threading.Thread(target=run, daemon=True)
-        self._thread.start()
+        global _index_pool
+        if _index_pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            _index_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="scn-index")
+        self._future = _index_pool.submit(fn)
 
     def result(self) -> "Metadata":
-        self._thread.join()
-        if self._err is not None:
-            raise self._err
-        return self._md
+        return self._future.result()             # re-raises what the build raised
 
 
 @dataclass
@@ -515,8 +511,12 @@ class Metadata:
         if self.ready_event is not None:
             cur = torch.cuda.current_stream()
             cur.wait_event(self.ready_event)
-            for t in self._all_tensors():
-                t.record_stream(cur)
+            ws = getattr(self, "_workspace", None)
+            if ws is not None:                   # native build: every index tensor is a view of one allocation
+                ws.record_stream(cur)
+            else:
+                for t in self._all_tensors():
+                    t.record_stream(cur)
             self.ready_event = None
 
     def build_pyramid(self, size, n_levels: int, k: int = 3):

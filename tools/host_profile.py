@@ -15,11 +15,15 @@ torch.manual_seed(0)
 model = Backbone(7, (32, 64, 128, 256)).to(dev)
 flat = FlatParams(model)
 gy = None
+md_next = None
+PREFETCH = "--no-prefetch" not in sys.argv
 def step():
-    global gy
+    global gy, md_next
     flat.zero_grad()
     fin = feats_d.detach().requires_grad_()
-    out = model(coords_d, fin, size, 1)
+    md = md_next.result() if md_next is not None else None
+    md_next = model.prefetch_in_thread(coords_d, size, 1) if PREFETCH else None
+    out = model(coords_d, fin, size, 1, metadata=md)
     if gy is None:
         gy = torch.randn_like(out.features)
     out.features.backward(gy)

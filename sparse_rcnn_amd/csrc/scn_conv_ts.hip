@@ -348,19 +348,34 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     }
 }
 
-// Y = bias + sum_kc slab[kc] (+ residual, ReLU-backward mask); K-chunks added in ascending order.
+// Y = bias + sum_kc slab[kc] (+ residual, ReLU-backward mask); K-chunks added in ascending order.  V = 4: 16-byte
+// accesses (cout % 4 == 0, aligned buffers) -- the kernel is pure streaming traffic, (n_kc + 1..3) * N * cout * 4 bytes.
+template <int V>
 __global__ void k_conv_ts_sum(const float* __restrict__ slabs, int n_kc, long long n_out, int cout,
                               const float* __restrict__ bias, const float* __restrict__ residual,
                               const float* __restrict__ relu_mask, float* __restrict__ Y, int res_last) {
-    const long long total = n_out * cout;
-    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
-         e += (long long)gridDim.x * blockDim.x) {
-        float y = bias ? bias[e % cout] : 0.f;
-        for (int k = 0; k < n_kc; ++k) y += slabs[(long long)k * total + e];
-        if (residual && !res_last) y += residual[e];
-        if (relu_mask && !(relu_mask[e] > 0.f)) y = 0.f;
-        if (residual && res_last) y += residual[e];
-        Y[e] = y;
+    typedef float vec_t __attribute__((ext_vector_type(V)));
+    const long long total = n_out * cout / V;
+    for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < total;
+         g += (long long)gridDim.x * blockDim.x) {
+        const long long e = g * V;
+        vec_t y;
+        if (bias) y = *(const vec_t*)(bias + e % cout);
+        else {
+#pragma unroll
+            for (int v = 0; v < V; ++v) y[v] = 0.f;
+        }
+        for (int k = 0; k < n_kc; ++k) y += *(const vec_t*)(slabs + (long long)k * n_out * cout + e);
+        vec_t r, mk;
+        if (residual) r = *(const vec_t*)(residual + e);
+        if (relu_mask) mk = *(const vec_t*)(relu_mask + e);
+        if (residual && !res_last) y += r;
+        if (relu_mask) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) if (!(mk[v] > 0.f)) y[v] = 0.f;
+        }
+        if (residual && res_last) y += r;
+        *(vec_t*)(Y + e) = y;
     }
 }
 
@@ -428,9 +443,15 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
 #undef LAUNCH_TS
     SCN_LAUNCH_CHECK();
     if (n_kc > 1) {
-        hipLaunchKernelGGL(k_conv_ts_sum, dim3(scn::ew_grid(n_out * cout, 256)), dim3(256), 0, st,
-                           (const float*)slabs, n_kc, (long long)n_out, cout, bias, residual, relu_mask, Y,
-                           (flags & SCN_F_RESIDUAL_LAST) ? 1 : 0);
+        const bool v4 = cout % 4 == 0 && ((((uintptr_t)slabs | (uintptr_t)Y | (uintptr_t)bias | (uintptr_t)residual |
+                                            (uintptr_t)relu_mask) & 15) == 0);
+        const int rl = (flags & SCN_F_RESIDUAL_LAST) ? 1 : 0;
+        if (v4)
+            hipLaunchKernelGGL(k_conv_ts_sum<4>, dim3(scn::ew_grid(n_out * cout / 4, 256)), dim3(256), 0, st,
+                               (const float*)slabs, n_kc, (long long)n_out, cout, bias, residual, relu_mask, Y, rl);
+        else
+            hipLaunchKernelGGL(k_conv_ts_sum<1>, dim3(scn::ew_grid(n_out * cout, 256)), dim3(256), 0, st,
+                               (const float*)slabs, n_kc, (long long)n_out, cout, bias, residual, relu_mask, Y, rl);
         SCN_LAUNCH_CHECK();
     }
     return SCN_OK;

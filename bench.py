@@ -28,9 +28,11 @@ sys.path.insert(0, ROOT)
 import torch
 import torch.distributed as dist
 
-CHANNELS = (32, 64, 128, 256)
-GRID = (512, 512, 256)
-TARGET = 150_000
+WORKLOADS = {      # name -> (channels, grid, active voxels, BASELINE.json entry)
+    "cfg2": ((32, 64, 128, 256), (512, 512, 256), 150_000, "configs[1]"),
+    "cfg5": ((32, 64, 128, 256, 512), (1024, 1024, 512), 600_000, "configs[4] shape, fp32 storage"),
+}
+CHANNELS, GRID, TARGET, _ = WORKLOADS["cfg2"]
 PEAK_FP32_MATRIX_TFLOPS = 157.3          # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
 
@@ -43,7 +45,7 @@ def _host_threads():
     return max(1, min(16, n))
 
 
-def cpu_baseline(coords, feats):
+def cpu_baseline(coords, feats, CHANNELS=CHANNELS):
     """The CPU restatement (oracle) of the same step -- SparseConvNet's CPU algorithm (hash -> rulebook; per offset
     gather -> sgemm -> scatter-add) -- timed on this box's host cores.  It is NOT the SparseConvNet binary (unavailable:
     SURVEY.md §8c).  Bounded sample: ONE full step (rulebooks + fwd + bwd) of the same 150k-voxel scene."""
@@ -57,7 +59,7 @@ def cpu_baseline(coords, feats):
     out.backward(torch.ones_like(out))
     dt = time.perf_counter() - t0
     return dict(value=scene.n(0) / dt, unit="active-voxels/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"1 full step (rulebooks+fwd+bwd) of the {scene.n(0)}-voxel cfg-2 scene, torch-CPU fp32 "
+                sample=f"1 full step (rulebooks+fwd+bwd) of the same {scene.n(0)}-voxel scene, torch-CPU fp32 "
                        f"oracle port of the SparseConvNet CPU algorithm, {dt:.2f} s")
 
 
@@ -67,13 +69,18 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--target", type=int, default=TARGET)
+    ap.add_argument("--target", type=int, default=None)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2",
+                    help="cfg2 = the configuration the metric is quoted on (default); cfg5 = BASELINE configs[4]'s "
+                         "shape (600k voxels, 5 levels to 512 channels) in fp32, a size check, not the headline")
     ap.add_argument("--profile-all", action="store_true",
                     help="time every GEMM kernel launch of the sampled steps, not only the dominant kernel")
     ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
                     help="build the index structures inside the forward pass instead of one batch ahead on a helper "
                          "thread (scn_pyramid_build on the index stream)")
     args = ap.parse_args()
+    CHANNELS, GRID, target, cfg_name = WORKLOADS[args.workload]
+    target = args.target or target
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -101,7 +108,7 @@ def main():
 
     # one balanced scene per rank (cfg 2: seed 1; cfg 4 style: seeds 10+rank)
     seed = 1 if world == 1 else 10 + rank
-    coords, feats, size, bs, _ = make_batch(1, GRID, args.target, dup=1.15, seed=seed)
+    coords, feats, size, bs, _ = make_batch(1, GRID, target, dup=1.15, seed=seed)
     coords_d, feats_d = coords.to(dev), feats.to(dev)
 
     torch.manual_seed(0)
@@ -191,7 +198,7 @@ def main():
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
-                traffic = json.load(f)["kernels"][dom]["hbm_bytes_per_launch"]
+                traffic = json.load(f)["kernels"][dom]["hbm_bytes_per_launch"] if args.workload == "cfg2" else None
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -202,9 +209,9 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: one synthetic ScanNet-shaped scene per GPU, "
+            "config": {"workload": f"BASELINE {cfg_name}: one synthetic ScanNet-shaped scene per GPU, "
                                    f"{n_active} active voxels (grid {GRID[0]}x{GRID[1]}x{GRID[2]}, 1.15 points/voxel), "
-                                   "U-Net 32-64-128-256, 2 pre-act residual blocks/level, 2^3/2 conv+deconv, "
+                                   "U-Net " + "-".join(map(str, CHANNELS)) + ", 2 pre-act residual blocks/level, 2^3/2 conv+deconv, "
                                    "step = rulebooks + fwd + bwd (+ grad all-reduce + SGD)"
                                    + ("; rulebooks of batch i+1 built on a helper thread during batch i" if args.prefetch else ""),
                        "parallelism": f"dp{world} (1 scene/GPU, flat-bucket all-reduce)"},
@@ -220,7 +227,7 @@ def main():
                         for k, v in ks.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(coords, feats)
+            out["cpu_baseline"] = cpu_baseline(coords, feats, CHANNELS)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -114,3 +114,55 @@ def test_backbone_step_full_size_is_finite_and_reproducible(scene, gpu):
     assert torch.equal(outs[0][0], outs[1][0])                                 # no atomics on the feature path: bitwise
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_config5_shape_600k_voxels_five_levels_to_512_channels(gpu):
+    """BASELINE config 5's shape on one GPU, in fp32 (bf16 storage is not built): grid 1024x1024x512, 600k active
+    voxels, U-Net 32..512.  The largest case the configs name: 4.6 M SubM pairs at level 0 (> 10 M over the
+    five levels' SubM and strided rulebooks), 512-channel bottom level, coordinates beyond 512.  Checked through size-independent properties; the native index build must agree bit for bit
+    with the per-call one at this size too."""
+    import sparse_rcnn_amd as scn
+    from sparse_rcnn_amd.synthetic import make_batch
+    from sparse_rcnn_amd.unet import Backbone
+    from sparse_rcnn_amd import functional as F
+    coords, feats, size, bs, _ = make_batch(1, (1024, 1024, 512), 600_000, seed=5)
+    assert int(coords[:, :3].max()) > 512
+    cd, fd = coords.to(gpu), feats.to(gpu)
+    x = scn.InputLayer(3, size, mode=4)((coords, fd, 1))
+    assert x.features.shape[0] == 600_000
+    x.metadata.build_pyramid(size, 5, 3)
+    sz = tuple(int(s) for s in size)
+    rb = x.metadata.subm_rulebook(sz, 3)
+    P = rb.rules.total
+    assert 4_000_000 < P < 27 * 600_000                                        # surfaces: 7-10 neighbours per voxel
+    t = rb.table.cpu().numpy()
+    assert (t[13] == np.arange(600_000)).all()
+    assert int((t >= 0).sum()) == P                                            # scan total == table population
+    r = np.nonzero(t[3] >= 0)[0]
+    assert (t[23][t[3][r]] == r).all()                                         # R_o^T = R_{26-o}
+
+    torch.manual_seed(0)
+    net = Backbone(7, (32, 64, 128, 256, 512)).to(gpu)
+    md_native = net.prefetch_in_thread(cd, size, 1).result()                   # scn_pyramid_build, helper thread
+    outs = []
+    for md in (None, md_native):
+        for p in net.parameters():
+            p.grad = None
+        out = net(cd, fd, size, 1, metadata=md).features
+        out.backward(torch.ones_like(out))
+        outs.append((out.detach().clone(), [p.grad.clone() for p in net.parameters()]))
+    assert outs[0][0].shape == (600_000, 32) and torch.isfinite(outs[0][0]).all()
+    assert torch.equal(outs[0][0], outs[1][0])                                 # both index builds: same rows, same tiles
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+
+    # bottom level (C = 512): the tile kernel against the natural-order table kernel
+    lsz = tuple(s >> 4 for s in sz)
+    rb4 = x.metadata.subm_rulebook(lsz, 3)
+    n4 = rb4.n
+    g = torch.Generator(device="cpu").manual_seed(9)
+    X = torch.randn(n4, 512, generator=g).to(gpu)
+    W = (torch.randn(27, 512, 512, generator=g) * (2.0 / (27 * 512)) ** 0.5).to(gpu)
+    y_ts = F.conv_rules(X, rb4.tiles, n4, W, None, 512, n_rules=rb4.rules.total)
+    y_tb = F.gemm_table(X, rb4.table, 27, n4, W, None, 512)
+    assert (y_ts - y_tb).abs().max().item() <= 1e-4 * max(1.0, y_tb.abs().max().item())

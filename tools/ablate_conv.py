@@ -30,7 +30,7 @@ def run_ts(fl=0):
                                L.ptr(Y), C, fl, L.ptr(SCR), L.stream()))
 def run_tab(fl=0):
     L.check(lib.scn_gemm_table(L.ptr(X), n, C, L.ptr(rb.table), 27, n, L.ptr(W), 0, 0, 0, L.ptr(Y2), C, fl, L.stream()))
-for name, fn in (("conv_tiles", run_ts), ("conv_tiles W^T", lambda: run_ts(6)), ("gemm_table (v1)", run_tab)):
+for name, fn in (("conv_tiles", run_ts), ("conv_tiles relu_in", lambda: run_ts(1)), ("conv_tiles W^T", lambda: run_ts(6)), ("gemm_table (v1)", run_tab)):
     for _ in range(3): fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -19,6 +19,9 @@
 //     C/D: acc[j] = D[4*kq + j][lane & 15].
 #include "scn_common.h"
 
+#ifndef TS_EXP
+#define TS_EXP 0
+#endif
 #ifndef TS_TIMELINE
 #define TS_TIMELINE 0       // 1: per-wave wall_clock64 stamps appended to the scratch buffer (tools/ts_timeline.py)
 #endif
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     // (an even sample of costs) and its 16 waves pull them from an LDS counter in that order: expensive tiles start
     // first, cheap ones fill the tail (longest-processing-time scheduling).  (A chip-wide queue on global atomics was measured slower: returning global atomics cost more than
     // the imbalance they remove -- DESIGN.md.)
-    long long tl_t0 = 0, tl_t1 = 0, tl_steps = 0, tl_tiles = 0;
+    long long tl_t0 = 0, tl_t1 = 0, tl_c1 = 0, tl_steps = 0, tl_tiles = 0;
     if (TS_TIMELINE) tl_t0 = wall_clock64();
     const int tg = blockIdx.x / (n_chunks * n_kc), n_tg = gridDim.x / (n_chunks * n_kc);
     const int n_tiles = (int)((nt - tg + n_tg - 1) / n_tg);
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         }
     }
     __syncthreads();
-    if (TS_TIMELINE) tl_t1 = wall_clock64();
+    if (TS_TIMELINE) { tl_t1 = wall_clock64(); tl_c1 = clock64(); }
 
     const int ka = kc + 4 * kq;
     const bool k0_ok = ka + 3 < cin, k1_ok = ka + 16 + 3 < cin;
@@ -179,7 +182,8 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     const int row_bytes = cin * 4, lane_boff = ka * 4;
 #define TS_GATHER(IDX, A0, A1)                                                                       \
     do {                                                                                             \
-        if constexpr (FULLK) {                                                                       \
+        if (TS_EXP >= 1) { A0 = (f32x4){(float)(IDX), 1.f, 2.f, 3.f}; A1 = A0; }                        \
+        else if constexpr (FULLK) {                                                                       \
             const int off_ = __mul24((IDX), row_bytes) + lane_boff;      /* -1 -> out of range -> 0 */ \
             int off0_ = off_, off1_ = off_ + 64;                                                     \
             if constexpr (PART) {                                                                    \
@@ -222,6 +226,7 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     do {                                                                                             \
         int o4_ = -1;                                                                                \
         if (m) { o4_ = __builtin_ctz(m); m &= m - 1; olast = o4_; }                                  \
+        if (TS_EXP >= 2) INEW = olast + i; else                                                      \
         INEW = tb_s[olast * TS_T + i];                  /* scalar base + lane offset: no VALU */     \
         TS_GATHER(IOLD, G0, G1);                                                                     \
         f32x4 a0_ = C0, a1_ = C1;                                                                    \
@@ -345,6 +350,7 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         long long* d = (long long*)(slabs + (n_kc > 1 ? (long long)n_kc * n_out * cout : 0)) +
                        ((long long)blockIdx.x * TS_NW + (tid >> 6)) * 8;
         d[0] = tl_t0; d[1] = tl_t1; d[2] = wall_clock64(); d[3] = tl_tiles; d[4] = tl_steps; d[5] = 0;
+        d[6] = tl_c1; d[7] = clock64();             // shader-clock stamps: in-kernel clock = d(clock64) / d(wall_clock64) x 100 MHz
     }
 }
 

@@ -160,8 +160,9 @@ class Rules:
             self._in = _empty(total, torch.int32, dev)
             self._out = _empty(total, torch.int32, dev)
             self._seg = _empty(total, torch.int32, dev) if self._want_seg else None
-            L.check(lib.scn_rules_fill(L.ptr(self._table), self.n_off, self._n_out, L.ptr(self._block_sums),
-                                       L.ptr(self._in), L.ptr(self._out), L.ptr(self._seg), L.stream()))
+            if total:                                   # (no rule at all, e.g. ROI boxes that catch nothing: empty lists)
+                L.check(lib.scn_rules_fill(L.ptr(self._table), self.n_off, self._n_out, L.ptr(self._block_sums),
+                                           L.ptr(self._in), L.ptr(self._out), L.ptr(self._seg), L.stream()))
 
     @property
     def in_rows(self):

@@ -136,9 +136,12 @@ class SparseRoiCut(torch.nn.Module):
         boxes, counts, _ = transform_boxes(bbox_batch, spatial_size, self.clip)
         new_coords, new_features, sel = roi_cut_device(coords, features, boxes)
         size = torch.as_tensor([int(s) + self.offset for s in spatial_size], dtype=torch.long)
-        md = Metadata(3)
-        feats = InputLayerFunction.apply(3, md, size, new_coords, new_features, boxes.shape[0], self.mode)
-        out = SparseConvNetTensor(features=feats, metadata=md, spatial_size=size)
+        if new_coords.shape[0] == 0:        # no point in any box: CustomInputLayer returns None (custom_operations.py:71,85-86)
+            out = None
+        else:
+            md = Metadata(3)
+            feats = InputLayerFunction.apply(3, md, size, new_coords, new_features, boxes.shape[0], self.mode)
+            out = SparseConvNetTensor(features=feats, metadata=md, spatial_size=size)
         return out, (sel.is_inside() if self.dense_inside else sel, counts, batch_splits)
 
 

@@ -116,3 +116,118 @@ def test_fuzz_strided_conv_deconv_and_residual_block(gpu, seed):
     exp = torch.autograd.grad(yo, (Xo, Wd, bd, W1, b1, W2, b2, Wu), g)
     for a, e, name in zip(got, exp, ("dX", "dWd", "dbd", "dW1", "db1", "dW2", "db2", "dWu")):
         _close(a, e, name, cfg)
+
+
+@pytest.mark.parametrize("seed", range(200, 212))
+def test_fuzz_input_output_layers(gpu, seed):
+    """A3 / A10 on random clouds: row numbering, duplicate maps and counts bit-exact, every mode's features bit-exact."""
+    import sparse_rcnn_amd as scn
+    rng, coords, size, batch, cin, _ = _draw(seed)
+    mode = int(rng.integers(0, 5))
+    if mode == 0:                                                              # mode 0 promises unique coordinates
+        coords = torch.from_numpy(np.unique(coords.numpy(), axis=0)[rng.permutation(len(np.unique(coords.numpy(), axis=0)))])
+    cfg = dict(seed=seed, grid=size.tolist(), batch=batch, points=len(coords), cin=cin, mode=mode)
+    feats = torch.randn(len(coords), cin, generator=torch.Generator().manual_seed(seed))
+    fg = feats.to(gpu).requires_grad_()
+    x = scn.InputLayer(3, size, mode=mode)((coords, fg, batch))
+    scene = O.OracleScene(coords.numpy())
+    assert np.array_equal(x.get_spatial_locations().numpy(), scene.coords0), cfg
+    assert np.array_equal(x.metadata.item_row.cpu().numpy(), scene.prow), cfg
+    assert np.array_equal(x.metadata.row_count.cpu().numpy(), scene.counts), cfg
+    assert x.batch_size() == batch
+    exp = O.input_layer_fwd(feats, scene.prow, scene.n(0), mode)
+    assert torch.equal(x.features.detach().cpu(), exp), cfg
+    g = torch.randn(exp.shape, generator=torch.Generator().manual_seed(seed + 1))
+    x.features.backward(g.to(gpu))
+    _close(fg.grad, O.input_layer_bwd(g, scene.prow, mode), "input bwd", cfg)
+    xf = x.features.detach().clone().requires_grad_()
+    y = scn.ioLayers.OutputLayerFunction.apply(3, x.metadata, xf)
+    assert torch.equal(y.detach().cpu(), O.output_layer_fwd(exp, scene.prow)), cfg
+    gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(seed + 2))
+    y.backward(gy.to(gpu))
+    _close(xf.grad, O.output_layer_bwd(gy, scene.prow, scene.n(0)), "output bwd", cfg)
+
+
+@pytest.mark.parametrize("seed", range(300, 310))
+def test_fuzz_roi_crop(gpu, seed):
+    """A11 on random clouds and boxes (fractional corners, boxes that catch nothing, samples without boxes)."""
+    from sparse_rcnn_amd import roi
+    rng, coords, size, batch, cin, _ = _draw(seed)
+    bbox_batch = []
+    for b in range(batch):
+        nb = int(rng.choice([0, 1, 2, 7, 20]))
+        lo = rng.uniform(-3, np.array(size.tolist()), size=(nb, 3))
+        ext = rng.uniform(0.2, 14, size=(nb, 3))
+        bbox_batch.append(torch.from_numpy(np.stack([lo, lo + ext], 1).astype(np.float32)).reshape(nb, 2, 3))
+    cfg = dict(seed=seed, grid=size.tolist(), batch=batch, points=len(coords), cin=cin,
+               boxes=[len(b) for b in bbox_batch])
+    feats = torch.randn(len(coords), cin, generator=torch.Generator().manual_seed(seed))
+    fg = feats.to(gpu).requires_grad_()
+    out, (is_inside, counts, splits) = roi.SparseRoiCut(spatial_size_offset=32)((coords, fg, size, batch, [0]), bbox_batch)
+    bi, cnt, assoc = O.transform_boxes([b.numpy() for b in bbox_batch])
+    src, box_of, inside = O.roi_crop(coords.numpy(), bi, assoc)
+    assert np.array_equal(is_inside.numpy(), inside) and list(counts) == list(cnt), cfg
+    n_boxes = sum(len(b) for b in bbox_batch)
+    if out is None:                                                            # custom_operations.py:71,85-86: no rows -> None
+        assert len(src) == 0, cfg
+        return
+    new_coords = np.concatenate([coords.numpy()[src][:, :3], box_of[:, None]], 1)
+    ac, prow, _ = O.input_layer_rules(new_coords)
+    assert np.array_equal(out.get_spatial_locations().numpy(), ac), cfg
+    assert out.batch_size() == n_boxes, cfg
+    exp = O.input_layer_fwd(feats[torch.from_numpy(src)], prow, len(ac), 4)
+    assert torch.equal(out.features.detach().cpu(), exp), cfg
+    g = torch.randn(exp.shape, generator=torch.Generator().manual_seed(seed + 3))
+    out.features.backward(g.to(gpu))
+    gsel = O.input_layer_bwd(g, prow, 4)
+    gexp = torch.zeros(len(coords), cin, dtype=torch.float64).index_add_(0, torch.from_numpy(src), gsel.double())
+    _close(fg.grad, gexp.float(), "roi crop backward", cfg)
+
+
+@pytest.mark.parametrize("seed", range(400, 410))
+def test_fuzz_nms(gpu, seed):
+    """N3: greedy NMS keep masks bit-exact on random box sets around the kernel's block sizes."""
+    from sparse_rcnn_amd.proposals import non_maximum_suppression
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([1, 2, 3, 63, 64, 65, 255, 257, 1000, 1025, 3000]))
+    batch = int(rng.integers(1, 4))
+    thr = float(rng.choice([0.0, 0.1, 0.25, 0.5, 0.9]))
+    spread = float(rng.choice([4, 20, 60]))
+    c = rng.uniform(0, spread, size=(batch, n, 3)); sz = rng.uniform(0.5, 6, size=(batch, n, 3))
+    boxes = np.stack([c - sz, c + sz], 2).astype(np.float32)
+    if n > 3:
+        boxes[:, 1] = boxes[:, 0]                                              # an exact duplicate: IoU 1
+    got = non_maximum_suppression(torch.from_numpy(boxes).to(gpu), thr).cpu().numpy()
+    for b in range(batch):
+        assert np.array_equal(got[b], O.nms(boxes[b], thr)), dict(seed=seed, n=n, batch=batch, thr=thr, sample=b)
+
+
+@pytest.mark.parametrize("seed", range(500, 508))
+def test_fuzz_batchnorm_relu(gpu, seed):
+    import sparse_rcnn_amd as scn
+    rng, coords, size, batch, c, _ = _draw(seed)
+    leak = float(rng.choice([0.0, 0.0, 0.1, 0.333]))
+    training = bool(rng.integers(0, 2))
+    cfg = dict(seed=seed, points=len(coords), c=c, leak=leak, training=training)
+    feats = torch.randn(len(coords), c, generator=torch.Generator().manual_seed(seed)) * 2 + 0.5
+    x = scn.InputLayer(3, size, mode=4)((coords, feats.to(gpu).requires_grad_(), batch))
+    scene = O.OracleScene(coords.numpy())
+    n = scene.n(0)
+    if training and n < 2:
+        return
+    bn = (scn.BatchNormLeakyReLU(c, 1e-4, 0.9, leak) if leak else scn.BatchNormReLU(c, 1e-4, 0.9)).to(gpu)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5)
+    bn.train(training)
+    rm0, rv0 = bn.running_mean.detach().cpu().clone(), bn.running_var.detach().cpu().clone()
+    y = bn(x).features
+    Xo = O.input_layer_fwd(feats, scene.prow, n, 4).requires_grad_()
+    ga, be = bn.weight.detach().cpu().requires_grad_(), bn.bias.detach().cpu().requires_grad_()
+    yo = O.batchnorm_relu_fwd(Xo, ga, be, rm0, rv0, 1e-4, 0.9, leak, training)
+    _close(y, yo, "fwd", cfg)
+    _close(bn.running_mean, rm0, "running_mean", cfg); _close(bn.running_var, rv0, "running_var", cfg)
+    g = torch.randn(yo.shape, generator=torch.Generator().manual_seed(seed + 8))
+    for a, e, name in zip(torch.autograd.grad(y, (x.features, bn.weight, bn.bias), g.to(gpu)),
+                          torch.autograd.grad(yo, (Xo, ga, be), g), ("dX", "dgamma", "dbeta")):
+        _close(a, e, name, cfg)

@@ -1,6 +1,8 @@
 """-m gpu: seeded random sweep of layer shapes against the CPU oracle -- channel counts that are not multiples of 4, 16
 or 32 (the kernels' vector width, MFMA tile and K-chunk), row counts around the tile sizes, thin grids, empty samples,
 with and without bias / input ReLU.  The cases are fixed by their seeds; a failure names the drawn configuration."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -10,9 +12,15 @@ from oracle import scn_oracle as O
 pytestmark = pytest.mark.gpu
 
 FEAT_TOL = 1e-4          # BASELINE.json north_star: "features within 1e-4 fp32" (relative to the output scale)
+EXTRA = int(os.environ.get("SCN_FUZZ_EXTRA", "0"))      # developer switch: that many more seeds per test
+
+
+def _seeds(start, n):
+    return list(range(start, start + n)) + list(range(10_000 + start * 100, 10_000 + start * 100 + EXTRA))
 
 
 def _draw(seed):
+    torch.manual_seed(seed)                                                    # layer initialisation: fixed per case
     rng = np.random.default_rng(1000 + seed)
     grid = tuple(int(2 * rng.integers(2, 13)) for _ in range(3))             # even extents 4..24 (strided conv needs even)
     batch = int(rng.integers(1, 4))
@@ -43,7 +51,7 @@ def _close(a, b, what, cfg):
     assert err <= FEAT_TOL, f"{what} {cfg}: max err {err:.3e} (scale {scale:.3g})"
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", _seeds(0, 24))
 def test_fuzz_submanifold_conv(gpu, seed):
     import sparse_rcnn_amd as scn
     rng, coords, size, batch, cin, cout = _draw(seed)
@@ -79,7 +87,7 @@ def test_fuzz_submanifold_conv(gpu, seed):
         _close(a, e, name, cfg)
 
 
-@pytest.mark.parametrize("seed", range(100, 112))
+@pytest.mark.parametrize("seed", _seeds(100, 12))
 def test_fuzz_strided_conv_deconv_and_residual_block(gpu, seed):
     """Convolution 2^3/2 -> pre-activation residual block at the coarse level -> Deconvolution back, as one graph."""
     import sparse_rcnn_amd as scn
@@ -110,6 +118,9 @@ def test_fuzz_strided_conv_deconv_and_residual_block(gpu, seed):
     r = d + O.conv(torch.relu(h), W2, b2, sub, nc)
     yo = O.conv(torch.relu(r), Wu, None, O.swap_rules(st), n)
     _close(y, yo, "fwd", cfg)
+    near0 = min(t.detach().abs().min().item() for t in (d, h, r) if t.numel())
+    if near0 < 4e-6:        # a ReLU input within rounding of zero: the two sides may pick different masks, legitimately
+        pytest.skip(f"ReLU input {near0:.1e} from zero: backward mask not comparable {cfg}")
     g = torch.randn(yo.shape, generator=torch.Generator().manual_seed(seed + 7))
     got = torch.autograd.grad(y, (x.features, down.weight, down.bias, convs[0].weight, convs[0].bias, convs[1].weight,
                                   convs[1].bias, up.weight), g.to(gpu))
@@ -118,7 +129,7 @@ def test_fuzz_strided_conv_deconv_and_residual_block(gpu, seed):
         _close(a, e, name, cfg)
 
 
-@pytest.mark.parametrize("seed", range(200, 212))
+@pytest.mark.parametrize("seed", _seeds(200, 12))
 def test_fuzz_input_output_layers(gpu, seed):
     """A3 / A10 on random clouds: row numbering, duplicate maps and counts bit-exact, every mode's features bit-exact."""
     import sparse_rcnn_amd as scn
@@ -148,7 +159,7 @@ def test_fuzz_input_output_layers(gpu, seed):
     _close(xf.grad, O.output_layer_bwd(gy, scene.prow, scene.n(0)), "output bwd", cfg)
 
 
-@pytest.mark.parametrize("seed", range(300, 310))
+@pytest.mark.parametrize("seed", _seeds(300, 10))
 def test_fuzz_roi_crop(gpu, seed):
     """A11 on random clouds and boxes (fractional corners, boxes that catch nothing, samples without boxes)."""
     from sparse_rcnn_amd import roi
@@ -184,7 +195,7 @@ def test_fuzz_roi_crop(gpu, seed):
     _close(fg.grad, gexp.float(), "roi crop backward", cfg)
 
 
-@pytest.mark.parametrize("seed", range(400, 410))
+@pytest.mark.parametrize("seed", _seeds(400, 10))
 def test_fuzz_nms(gpu, seed):
     """N3: greedy NMS keep masks bit-exact on random box sets around the kernel's block sizes."""
     from sparse_rcnn_amd.proposals import non_maximum_suppression
@@ -202,7 +213,7 @@ def test_fuzz_nms(gpu, seed):
         assert np.array_equal(got[b], O.nms(boxes[b], thr)), dict(seed=seed, n=n, batch=batch, thr=thr, sample=b)
 
 
-@pytest.mark.parametrize("seed", range(500, 508))
+@pytest.mark.parametrize("seed", _seeds(500, 8))
 def test_fuzz_batchnorm_relu(gpu, seed):
     import sparse_rcnn_amd as scn
     rng, coords, size, batch, c, _ = _draw(seed)

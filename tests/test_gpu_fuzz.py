@@ -289,3 +289,65 @@ def test_fuzz_unet(gpu, seed):
         a, e = p.grad.detach().cpu().double(), po[k].grad.view_as(p).double()
         l2 = ((a - e).norm() / e.norm().clamp_min(1e-12)).item()
         assert l2 <= 2e-2, f"grad {k} {cfg}: relative L2 {l2:.2e}"
+
+
+@pytest.mark.parametrize("seed", _seeds(700, 12))
+def test_fuzz_native_index_build(gpu, seed):
+    """scn_pyramid_build (the build bench.py runs on the helper thread) on random scenes and 1-5 levels: every index
+    tensor equal to the step-by-step build, and the level-0 and coarse rulebooks equal to the oracle's."""
+    from sparse_rcnn_amd.metadata import Metadata
+    rng = np.random.default_rng(seed)
+    levels = int(rng.integers(1, 6))
+    grid = tuple(int(rng.integers(1, 4)) << (levels - 1 + int(rng.integers(0, 2))) for _ in range(3))
+    cells = grid[0] * grid[1] * grid[2]
+    batch = int(rng.integers(1, 4))
+    cs = []
+    for b in range(batch):
+        n = int(min(cells, rng.choice([0, 1, 17, 300, 2000, 9000])))
+        if b == 0 and n == 0:
+            n = 3
+        p = np.stack(np.unravel_index(rng.choice(cells, size=n, replace=False), grid), 1).reshape(n, 3)
+        if n and rng.random() < 0.6:
+            p = np.concatenate([p, p[rng.integers(0, n, size=max(1, n // 5))]]); rng.shuffle(p)
+        cs.append(np.concatenate([p, np.full((len(p), 1), b)], 1))
+    coords = torch.from_numpy(np.concatenate(cs).astype(np.int64))
+    size = torch.tensor(grid)
+    cfg = dict(seed=seed, grid=grid, levels=levels, batch=batch, points=len(coords))
+    cg = coords.to(gpu)
+    a = Metadata(3); a.set_input(size, cg, batch, 4); a.build_pyramid(size, levels, 3)
+    b = Metadata(3).build_native(size, cg, batch, 4, levels, 3)
+    eq = torch.equal
+    assert eq(a.item_row, b.item_row) and eq(a.row_count, b.row_count) and eq(a.row_first, b.row_first), cfg
+    assert a.n_samples == b.n_samples and list(a.grids) == list(b.grids), cfg
+    for s in a.grids:
+        assert a.grids[s].n == b.grids[s].n and eq(a.grids[s].coords, b.grids[s].coords), (cfg, s)
+    assert set(a.subm) == set(b.subm) and set(a.strided) == set(b.strided), cfg
+    for key in a.subm:
+        ra, rb = a.subm[key], b.subm[key]
+        assert eq(ra.table, rb.table) and ra.rules.prefix_list() == rb.rules.prefix_list(), (cfg, key)
+        assert eq(ra.rules.in_rows, rb.rules.in_rows) and eq(ra.rules.out_rows, rb.rules.out_rows), (cfg, key)
+        for f in ("perm", "tstab", "tile_mask", "tile_order"):
+            assert eq(getattr(ra.tiles, f), getattr(rb.tiles, f)), (cfg, key, f)
+    for key in a.strided:
+        ra, rb = a.strided[key], b.strided[key]
+        assert eq(ra.parent, rb.parent) and eq(ra.fine_off, rb.fine_off) and eq(ra.child, rb.child), (cfg, key)
+        assert ra.rules.prefix_list() == rb.rules.prefix_list() and eq(ra.rules.in_rows, rb.rules.in_rows), (cfg, key)
+        for f in ("perm", "tstab", "tile_mask", "tile_order"):
+            assert eq(getattr(ra.tiles, f), getattr(rb.tiles, f)), (cfg, key, f)
+    # against the oracle: rows, SubM rules of every level, strided rules between levels
+    scene = O.OracleScene(coords.numpy())
+    assert np.array_equal(b.item_row.cpu().numpy(), scene.prow), cfg
+    sz = grid
+    for l in range(levels):
+        rb = b.subm_rulebook(sz, 3)
+        pairs, prefix = O.rules_concat(scene.subm_rules(l, 3))
+        assert rb.rules.prefix_list() == prefix.tolist(), (cfg, l)
+        assert np.array_equal(rb.rules.in_rows.cpu().numpy(), pairs[:, 0]), (cfg, l)
+        assert np.array_equal(rb.rules.out_rows.cpu().numpy(), pairs[:, 1]), (cfg, l)
+        if l + 1 < levels:
+            sb = b.strided_rulebook(sz)
+            pairs, prefix = O.rules_concat(scene.strided_rules(l))
+            assert sb.rules.prefix_list() == prefix.tolist(), (cfg, l)
+            assert np.array_equal(sb.rules.in_rows.cpu().numpy(), pairs[:, 0]), (cfg, l)
+            assert np.array_equal(sb.rules.out_rows.cpu().numpy(), pairs[:, 1]), (cfg, l)
+            sz = tuple(s // 2 for s in sz)

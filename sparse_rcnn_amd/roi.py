@@ -248,7 +248,7 @@ def mask_loss_select(mask_scores, sel: RoiSelection, box_sample_count, batch_spl
     m = sel.src_row.shape[0]
     if m == 0:
         e = torch.zeros(0, dtype=torch.float32, device=dev)
-        return e, e, [], torch.cat(labels_out) if labels_out else torch.zeros(0, dtype=torch.long)
+        return e, e, [0] * int((label >= 0).sum()), torch.cat(labels_out) if labels_out else torch.zeros(0, dtype=torch.long)
     pred, gt, keep_row = _MaskGather.apply(mask_scores, sel.src_row, sel.box_of, lab_d, base_d, gt_flat)
     rows = np.diff(np.asarray(sel.prefix, dtype=np.int64))
     kept = label >= 0

@@ -351,3 +351,79 @@ def test_fuzz_native_index_build(gpu, seed):
             assert np.array_equal(sb.rules.in_rows.cpu().numpy(), pairs[:, 0]), (cfg, l)
             assert np.array_equal(sb.rules.out_rows.cpu().numpy(), pairs[:, 1]), (cfg, l)
             sz = tuple(s // 2 for s in sz)
+
+
+@pytest.mark.parametrize("seed", _seeds(800, 10))
+def test_fuzz_voxelisation(gpu, seed):
+    """N4: augment_coords with random rotations / scales / offsets, with and without a spatial size, shift and cut-out."""
+    from sparse_rcnn_amd import voxelize
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([1, 2, 50, 1000, 20000]))
+    pts = (rng.normal(size=(n, 3)) * rng.uniform(0.5, 4, size=3)).astype(np.float32)
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    rot = (q * rng.uniform(10, 60)).astype(np.float32)
+    off = rng.uniform(0, 1, size=3).astype(np.float32)
+    mode = int(rng.choice([0, 2, 3]))            # (a size without shift or start positions is the RNG-driven cut-out)
+    size = None if mode == 0 else tuple(int(v) for v in rng.integers(8, 200, size=3))
+    shift = int(rng.integers(0, 40)) if mode == 2 else None
+    start = tuple(int(v) for v in rng.integers(-20, 60, size=3)) if mode == 3 else None
+    cfg = dict(seed=seed, n=n, mode=mode, size=size, shift=shift, start=start)
+    kw = dict(rot_and_scale=rot, sub_pixel_offset=off, spatial_size=size)
+    if mode == 2:
+        kw["shift"] = shift
+    if mode == 3:
+        kw["start_positions"] = start
+    rows, inside, out_size, cshift = voxelize.augment_coords(torch.from_numpy(pts).to(gpu), **kw)
+    res, oin, osize, oshift = O.augment_coords(pts, rot, off, size, shift, start)
+    assert np.array_equal(rows[:, :3].cpu().numpy(), res), cfg
+    assert np.array_equal(inside.cpu().numpy(), oin), cfg
+    assert np.array_equal(out_size.numpy(), osize) and np.array_equal(cshift.numpy(), oshift), cfg
+
+
+@pytest.mark.parametrize("seed", _seeds(900, 10))
+def test_fuzz_mask_epilogue(gpu, seed):
+    """N2: SparseMaskPredictor / SparseMaskLossSelector from the CSR selection against the oracle's dense-indicator form."""
+    from sparse_rcnn_amd import roi
+    rng, coords, size, batch, _, _ = _draw(seed)
+    cnp = coords.numpy()
+    order = np.argsort(cnp[:, 3], kind="stable")                               # batch column non-decreasing (A4)
+    coords = torch.from_numpy(cnp[order])
+    splits = [int((coords[:, 3] == b).sum()) for b in range(batch)]
+    K = int(rng.integers(1, 6))
+    bbox_batch = []
+    for b in range(batch):
+        nb = int(rng.choice([0, 1, 3, 8]))
+        lo = rng.uniform(-2, np.array(size.tolist()) - 2, size=(nb, 3))
+        bbox_batch.append(torch.from_numpy(np.stack([lo, lo + rng.uniform(1, 12, size=(nb, 3))], 1).astype(np.float32)).reshape(nb, 2, 3))
+    boxes, counts, _ = roi.transform_boxes(bbox_batch, size, False)
+    cfg = dict(seed=seed, batch=batch, points=len(coords), boxes=list(counts), K=K)
+    _, _, sel = roi.roi_cut_device(coords, torch.zeros(len(coords), 1).to(gpu), boxes)
+    inside = sel.is_inside().numpy()
+    m = int(inside.sum())
+    scores = torch.randn(m, K, generator=torch.Generator().manual_seed(seed)) * 3
+    bb = sum(counts)
+    num_valid = int(rng.choice([0, K]))
+    classes = rng.integers(-1, K + 2 if num_valid else K, size=bb)             # -1 and >= num_valid: invalid -> zeros
+    pred = roi.mask_predict(scores.to(gpu), sel, counts, splits, torch.from_numpy(classes), num_valid)
+    exp = O.mask_predict(scores.numpy(), inside, counts, splits, classes, num_valid)
+    assert [tuple(p.shape) for p in pred] == [e.shape for e in exp], cfg
+    for p, e in zip(pred, exp):
+        assert np.allclose(p.cpu().numpy(), e, rtol=0, atol=1e-6) and np.array_equal(p.cpu().numpy() == 0, e == 0), cfg
+    keep_list, assoc_list, labels_list, masks_list = [], [], [], []
+    for s, (nb, npts) in enumerate(zip(counts, splits)):
+        g = int(rng.integers(1, 4))
+        keep = rng.random(nb) < 0.6
+        keep_list.append(keep)
+        assoc_list.append(rng.integers(0, g, size=int(keep.sum())))
+        labels_list.append(rng.integers(0, K, size=g))
+        masks_list.append(rng.random((g, npts)) < 0.5)
+    sg = scores.to(gpu).requires_grad_()
+    p, gt, rows, labels = roi.mask_loss_select(sg, sel, counts, splits, keep_list, assoc_list, labels_list, masks_list)
+    ep, eg, er, el = O.mask_loss_select(scores.numpy(), inside, counts, splits, keep_list, assoc_list, labels_list,
+                                        masks_list)
+    assert np.array_equal(p.detach().cpu().numpy(), ep) and np.array_equal(gt.cpu().numpy(), eg), cfg
+    assert list(rows) == list(er) and np.array_equal(labels.numpy(), el), cfg
+    if p.numel():
+        w = torch.randn(p.shape, generator=torch.Generator().manual_seed(seed + 1))
+        (ds,) = torch.autograd.grad(p, sg, w.to(gpu))
+        assert abs(ds.sum().item() - w.sum().item()) <= 1e-3 * max(1.0, w.abs().sum().item()), cfg   # one-hot routing

@@ -427,3 +427,40 @@ def test_fuzz_mask_epilogue(gpu, seed):
         w = torch.randn(p.shape, generator=torch.Generator().manual_seed(seed + 1))
         (ds,) = torch.autograd.grad(p, sg, w.to(gpu))
         assert abs(ds.sum().item() - w.sum().item()) <= 1e-3 * max(1.0, w.abs().sum().item()), cfg   # one-hot routing
+
+
+def test_pipelined_index_build_over_changing_scenes(gpu):
+    """bench.py's pipeline as a training loop would use it: a DIFFERENT scene every step (sizes grow and shrink, so the
+    workspaces are re-used and re-allocated), the next scene's index structures built by the helper thread while the
+    current step's forward and backward run.  Every step must give the bits of the same step run without the pipeline."""
+    from sparse_rcnn_amd.unet import Backbone
+    rng = np.random.default_rng(77)
+    scenes = []
+    for step, n in enumerate([2500, 400, 6000, 1, 3000, 9000, 50, 2500]):
+        grid = (32, 32, 16) if step % 3 else (64, 32, 32)
+        cells = grid[0] * grid[1] * grid[2]
+        p = np.stack(np.unravel_index(rng.choice(cells, size=n, replace=False), grid), 1).reshape(n, 3)
+        p = np.concatenate([p, p[rng.integers(0, n, size=max(1, n // 6))]]); rng.shuffle(p)
+        b = (np.arange(len(p)) * 2 // len(p))[:, None]                         # two samples
+        coords = torch.from_numpy(np.concatenate([p, b], 1).astype(np.int64)).to(gpu)
+        feats = torch.randn(len(p), 7, generator=torch.Generator().manual_seed(step)).to(gpu)
+        scenes.append((coords, feats, torch.tensor(grid)))
+    torch.manual_seed(5)
+    net = Backbone(7, (16, 24, 32)).to(gpu)
+
+    def run(coords, feats, size, md):
+        for q in net.parameters():
+            q.grad = None
+        f = feats.clone().requires_grad_()
+        out = net(coords, f, size, 2, metadata=md).features
+        out.backward(torch.ones_like(out))
+        return [out.detach().clone(), f.grad.clone()] + [q.grad.clone() for q in net.parameters()]
+
+    plain = [run(c, f, s, None) for c, f, s in scenes]
+    pending = net.prefetch_in_thread(scenes[0][0], scenes[0][2], 2)
+    for i, (c, f, s) in enumerate(scenes):
+        md = pending.result()
+        pending = net.prefetch_in_thread(*[scenes[i + 1][j] for j in (0, 2)], 2) if i + 1 < len(scenes) else None
+        got = run(c, f, s, md)
+        for a, e in zip(got, plain[i]):
+            assert torch.equal(a, e), f"step {i}"

@@ -464,3 +464,45 @@ def test_pipelined_index_build_over_changing_scenes(gpu):
         got = run(c, f, s, md)
         for a, e in zip(got, plain[i]):
             assert torch.equal(a, e), f"step {i}"
+
+
+@pytest.mark.parametrize("seed", _seeds(1000, 10))
+def test_fuzz_nin_join_pool_dense(gpu, seed):
+    """A9 / A13 / N1 on random shapes: NetworkInNetwork over a JoinTable, Max/AveragePooling, SparseToDense."""
+    import sparse_rcnn_amd as scn
+    rng, coords, size, batch, cin, cout = _draw(seed)
+    cfg = dict(seed=seed, grid=size.tolist(), batch=batch, points=len(coords), cin=cin, cout=cout)
+    feats = torch.randn(len(coords), cin, generator=torch.Generator().manual_seed(seed))
+    x = scn.InputLayer(3, size, mode=4)((coords, feats.to(gpu).requires_grad_(), batch))
+    scene = O.OracleScene(coords.numpy())
+    n = scene.n(0)
+    Xo = O.input_layer_fwd(feats, scene.prow, n, 4).requires_grad_()
+    # join (x, relu(x)) -> 1x1
+    nin = scn.NetworkInNetwork(2 * cin, cout, True).to(gpu)
+    with torch.no_grad():
+        nin.bias.normal_(0, 0.5)
+    j = scn.JoinTable()([x, scn.Sequential(scn.ReLU())(x)])
+    y = nin(j).features
+    W, b = nin.weight.detach().cpu().requires_grad_(), nin.bias.detach().cpu().requires_grad_()
+    yo = torch.cat([Xo, torch.relu(Xo)], 1) @ W.reshape(2 * cin, cout) + b
+    _close(y, yo, "nin fwd", cfg)
+    g = torch.randn(yo.shape, generator=torch.Generator().manual_seed(seed + 1))
+    for a, e, name in zip(torch.autograd.grad(y, (x.features, nin.weight, nin.bias), g.to(gpu)),
+                          torch.autograd.grad(yo, (Xo, W, b), g), ("dX", "dW", "db")):
+        _close(a, e.view_as(a.cpu()), "nin " + name, cfg)
+    # pooling 2^3 / 2
+    average = bool(rng.integers(0, 2))
+    pool = (scn.AveragePooling if average else scn.MaxPooling)(3, (2, 2, 2), (2, 2, 2))
+    yp = pool(x)
+    scene.strided_rules(0)
+    po = O.pool_fwd(Xo, scene.strided[0]["child"], average)
+    _close(yp.features, po, "pool fwd", cfg)
+    assert np.array_equal(yp.get_spatial_locations().numpy(), scene.strided[0]["coords"]), cfg
+    gp = torch.randn(po.shape, generator=torch.Generator().manual_seed(seed + 2))
+    (gx,) = torch.autograd.grad(yp.features, x.features, gp.to(gpu))
+    (ox,) = torch.autograd.grad(po, Xo, gp)
+    _close(gx, ox, "pool bwd", cfg)
+    # dense
+    d = scn.SparseToDense(3, cin)(x)
+    exp = O.sparse_to_dense(Xo.detach(), scene.coords0, size.tolist(), batch)
+    assert torch.equal(d.detach().cpu(), exp), cfg

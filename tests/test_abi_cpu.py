@@ -58,3 +58,15 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libscn_mi355x.so"))
     with pytest.raises(_lib.ScnError, match="missing"):
         _lib.load()
+
+
+def test_header_is_plain_c_and_library_links_from_c():
+    """include/scn_mi355x.h compiles as C11 and the shared library links into a host with no Python in it
+    (tests/c_host/scn_c_host.c; it runs in tests/test_gpu_c_host.py)."""
+    import subprocess
+    import __graft_entry__ as g
+    g.build_c_host(force=True)
+    assert os.path.exists(g.C_HOST_BIN)
+    out = subprocess.run(["ldd", g.C_HOST_BIN], capture_output=True, text=True).stdout
+    assert "libscn_mi355x.so" in out and "not found" not in out, out
+    assert "python" not in out.lower() and "torch" not in out.lower(), out

@@ -1,0 +1,312 @@
+// conv_tb: the tile convolution of scn_conv_ts.hip for bf16 STORAGE (BASELINE configs 3-5): features and
+// the LDS weight image are bf16, accumulation is fp32 on v_mfma_f32_16x16x32_bf16, outputs are rounded to bf16 once
+// (round-to-nearest-even).  The layer's master weights stay fp32 in global memory and are rounded while they are staged.
+//
+//   Y[r] = bf16( residual[r] + bias + sum_o in(X[table[o][r]]) . bf16(W[o']) )
+//
+// Same work decomposition as k_conv_ts (mask-sorted 16-row tiles, LPT tile queue per workgroup, weights of all offsets
+// in LDS, K split over workgroups in 32-channel chunks with fp32 slabs), different arithmetic shape:
+//   * one MFMA contracts 32 channels for a 16 x 16 block, so a (tile, offset) step is NB MFMAs of 16 cycles for 16 NB
+//     output columns (fp32: 16 MFMAs of 32 cycles for 32 columns) -- the matrix pipe is no longer the bound, the gather
+//     and issue rate are; the workgroup therefore covers 64 columns when the layer has them (NB = 4);
+//   * lane (i, kq) gathers ONE 16-byte piece per step: row tstab[t][o][i], channels kc + 8 kq .. + 7 (A fragment layout
+//     of the instruction: A[row l & 15][k = 8 (l >> 4) + j]);
+//   * the LDS image is [o][n][k], k contiguous: the B fragment of lane (i, kq) for column block nb is the 16 bytes at
+//     ((o CT + 16 nb + i) 32 + 8 kq) -- a wave reads 1 KB contiguous, conflict-free ds_read_b128;
+//   * input ReLU is one v_pk_max_i16 per register (a negative bf16 is a negative int16).
+// C/D layout is that of the fp32 kernel: acc[nb][j] = D[row 4 kq + j][column 16 nb + i].
+#include <stdlib.h>
+
+#include "scn_common.h"
+
+using scn::S;
+using scn::cdiv;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+#define MFMAB(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+static constexpr int TB_KC = 32;        // channels per K-chunk
+static constexpr int TB_T = 16;         // rows per tile
+static constexpr int TB_NW = 16;        // waves per workgroup
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+
+template <bool WT, int NB>
+__global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB == 2 ? 8 : 4))) void k_conv_tb(
+    const unsigned short* __restrict__ X, long long n_in, int cin, const int* __restrict__ tstab,
+    const unsigned* __restrict__ tile_mask, const int* __restrict__ perm, const int* __restrict__ tile_order, int n_off,
+    long long nt, const float* __restrict__ W, const float* __restrict__ bias,
+    const unsigned short* __restrict__ residual, const unsigned short* __restrict__ relu_mask,
+    unsigned short* __restrict__ Y, float* __restrict__ slabs, long long n_out, int cout, int flags, int n_chunks,
+    int n_kc) {
+    constexpr int CT = 16 * NB;
+    constexpr int THREADS = TB_NW * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned short Wb[];     // [n_off][CT][32] bf16, then the counter
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int chunk = blockIdx.x % n_chunks;
+    const int kci = (blockIdx.x / n_chunks) % n_kc;
+    const int n0 = chunk * CT, kc = kci * TB_KC;
+    const bool relu_in = flags & SCN_F_RELU_IN;
+    const bool rev = flags & SCN_F_OFF_REVERSE;
+    const bool res_last = flags & SCN_F_RESIDUAL_LAST;
+
+    // ---- tile queue (as in k_conv_ts): the workgroup owns every n_tg-th entry of the LPT order --------------------
+    const int tg = blockIdx.x / (n_chunks * n_kc), n_tg = gridDim.x / (n_chunks * n_kc);
+    const int n_tiles = (int)((nt - tg + n_tg - 1) / n_tg);
+    int* counter = (int*)(Wb + (size_t)n_off * CT * TB_KC);
+    if (tid == 0) *counter = 0;
+    __syncthreads();
+    auto grab = [&]() -> long long {
+        int tl = 0;
+        if (lane == 0) tl = atomicAdd(counter, 1);
+        tl = __builtin_amdgcn_readfirstlane(tl);
+        return tl < n_tiles ? tile_order[tg + (long long)tl * n_tg] : -1;
+    };
+    const int i = lane & 15, kq = lane >> 4;
+    long long tile_next = grab();
+    unsigned m_next = 0;
+    int orow_next[4] = {-1, -1, -1, -1};
+    if (tile_next >= 0) {
+        m_next = tile_mask[tile_next];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) orow_next[j] = perm[tile_next * TB_T + 4 * kq + j];
+    }
+
+    // ---- stage the weight slice, rounding fp32 -> bf16 ---------------------------------------------------------------
+    {
+        const int total4 = n_off * TB_KC * (CT / 4);
+        const bool vecn = (cout % 4 == 0), veck = (cin % 4 == 0);
+        for (int e = tid; e < total4; e += THREADS) {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (WT) {                  // layer weight [o][n][k]: k contiguous -> one 8-byte LDS store
+                const int c4 = e & 7, n = (e >> 3) % CT, o = e / (8 * CT);
+                const int wo = rev ? n_off - 1 - o : o;
+                const int k = kc + 4 * c4, ng = n0 + n;
+                if (ng < cout) {
+                    const float* src = W + ((long long)wo * cout + ng) * cin + k;
+                    if (veck && k + 3 < cin) { const float4 t = *(const float4*)src; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+                    else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (k + u < cin) v[u] = src[u];
+                    }
+                }
+                unsigned short* dst = Wb + ((size_t)o * CT + n) * TB_KC + 4 * c4;
+                const unsigned lo = f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                const unsigned hi = f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                *(uint2*)dst = make_uint2(lo, hi);
+            } else {                   // [o][k][n]: n contiguous in global -> four 2-byte stores, 64 bytes apart
+                const int c4 = e % (CT / 4), k = (e / (CT / 4)) % TB_KC, o = e / (TB_KC * (CT / 4));
+                const int wo = rev ? n_off - 1 - o : o;
+                const int kg = kc + k, ng = n0 + 4 * c4;
+                if (kg < cin) {
+                    const float* src = W + ((long long)wo * cin + kg) * cout + ng;
+                    if (vecn && ng + 3 < cout) { const float4 t = *(const float4*)src; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+                    else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (ng + u < cout) v[u] = src[u];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Wb[((size_t)o * CT + 4 * c4 + u) * TB_KC + k] = f32_to_bf16(v[u]);
+            }
+        }
+    }
+    __syncthreads();
+
+    const bool k_ok = kc + 8 * kq + 7 < cin;                        // cin % 8 == 0: a lane's 8 channels are all in or out
+    const bool single = n_kc == 1;
+    float bcol[NB];
+    bool n_ok[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = n0 + 16 * nb + i;
+        n_ok[nb] = n < cout;
+        bcol[nb] = (single && bias && n_ok[nb]) ? bias[n] : 0.f;
+    }
+    float* out_slab = slabs + (long long)kci * n_out * cout;
+    // A rows through a raw buffer descriptor that covers X exactly: a row index of -1 (no rule) or a channel group past
+    // Cin becomes an out-of-range byte offset and the hardware returns zeros
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(unsigned)(n_in * cin * 2), 0x00020000);
+    const int row_bytes = cin * 2, lane_boff = (kc + 8 * kq) * 2;
+    const unsigned short* wlane = Wb + (size_t)i * TB_KC + 8 * kq;   // + (o CT + 16 nb) 32
+
+#define TB_GATHER(IDX, A)                                                                             \
+    do {                                                                                             \
+        int off_ = __mul24((IDX), row_bytes) + lane_boff;                                            \
+        off_ = k_ok ? off_ : (int)0xFFFFFFF0;                                                        \
+        A = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off_, 0, 0);                                \
+    } while (0)
+
+    // one pipeline step: index of the offset five ahead, rows of the offset three ahead, MFMAs on the oldest set
+#define TB_STEP(CUR, GSET, IOLD, INEW)                                                               \
+    do {                                                                                             \
+        int o4_ = -1;                                                                                \
+        if (m) { o4_ = __builtin_ctz(m); m &= m - 1; olast = o4_; }                                  \
+        INEW = tb_s[olast * TB_T + i];                                                               \
+        TB_GATHER(IOLD, GSET);                                                                       \
+        s16x8 a_ = __builtin_bit_cast(s16x8, CUR);                                                   \
+        if (relu_in) a_ = __builtin_elementwise_max(a_, (s16x8){0, 0, 0, 0, 0, 0, 0, 0});            \
+        const bf16x8 af_ = __builtin_bit_cast(bf16x8, a_);                                           \
+        const unsigned short* wo_ = wlane + (size_t)oq0 * (CT * TB_KC);                              \
+        _Pragma("unroll") for (int nb_ = 0; nb_ < NB; ++nb_) {                                       \
+            const bf16x8 bf_ = *(const bf16x8*)(wo_ + nb_ * 16 * TB_KC);                             \
+            acc[nb_] = MFMAB(af_, bf_, acc[nb_]);                                                    \
+        }                                                                                            \
+        oq0 = oq1; oq1 = oq2; oq2 = oq3; oq3 = oq4; oq4 = o4_;                                       \
+    } while (0)
+
+    while (tile_next >= 0) {
+        const long long tile = tile_next;
+        unsigned m = m_next;
+        int orow[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) orow[j] = orow_next[j];
+        const int* tb_s = tstab + tile * n_off * TB_T;
+        const int n_steps = __popc(m);
+        tile_next = grab();
+        if (tile_next >= 0) {
+            m_next = tile_mask[tile_next];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) orow_next[j] = perm[tile_next * TB_T + 4 * kq + j];
+        }
+        int oq0 = -1, oq1 = -1, oq2 = -1, oq3 = -1, oq4 = -1, iq0, iq1, iq2, iqa, iqb, iqc, iqd;
+        int olast = 0;
+        if (m) { oq0 = __builtin_ctz(m); m &= m - 1; olast = oq0; }
+        iq0 = tb_s[olast * TB_T + i];
+        if (m) { oq1 = __builtin_ctz(m); m &= m - 1; olast = oq1; }
+        iq1 = tb_s[olast * TB_T + i];
+        if (m) { oq2 = __builtin_ctz(m); m &= m - 1; olast = oq2; }
+        iq2 = tb_s[olast * TB_T + i];
+        if (m) { oq3 = __builtin_ctz(m); m &= m - 1; olast = oq3; }
+        iqa = tb_s[olast * TB_T + i];
+        if (m) { oq4 = __builtin_ctz(m); m &= m - 1; olast = oq4; }
+        iqb = tb_s[olast * TB_T + i];
+        __builtin_amdgcn_sched_barrier(0);
+        i32x4 s0, s1, s2, s3;
+        TB_GATHER(iq0, s0);
+        TB_GATHER(iq1, s1);
+        TB_GATHER(iq2, s2);
+        __builtin_amdgcn_sched_barrier(0);
+
+        f32x4 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = (f32x4){bcol[nb], bcol[nb], bcol[nb], bcol[nb]};
+        int n_left = n_steps;
+        for (; n_left >= 4; n_left -= 4) {
+            TB_STEP(s0, s3, iqa, iqc);
+            TB_STEP(s1, s0, iqb, iqd);
+            TB_STEP(s2, s1, iqc, iqa);
+            TB_STEP(s3, s2, iqd, iqb);
+        }
+        if (n_left >= 1) { TB_STEP(s0, s3, iqa, iqc); }
+        if (n_left >= 2) { TB_STEP(s1, s0, iqb, iqd); }
+        if (n_left >= 3) { TB_STEP(s2, s1, iqc, iqa); }
+
+        // ---- tile epilogue -------------------------------------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = orow[j];
+            if (row < 0) continue;
+            const long long off = (long long)row * cout + n0 + i;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                if (!n_ok[nb]) continue;
+                const long long e = off + 16 * nb;
+                if (single) {
+                    const float r = residual ? bf16_to_f32(residual[e]) : 0.f;
+                    float y = acc[nb][j] + (res_last ? 0.f : r);
+                    if (relu_mask && !(bf16_to_f32(relu_mask[e]) > 0.f)) y = 0.f;
+                    if (res_last) y += r;
+                    Y[e] = f32_to_bf16(y);
+                } else {
+                    out_slab[e] = acc[nb][j];
+                }
+            }
+        }
+    }
+}
+#undef TB_STEP
+#undef TB_GATHER
+
+// Y = bf16( bias + sum_kc slab[kc] (+ residual, ReLU-backward mask) ), K-chunks added in ascending order
+__global__ void k_conv_tb_sum(const float* __restrict__ slabs, int n_kc, long long n_out, int cout,
+                              const float* __restrict__ bias, const unsigned short* __restrict__ residual,
+                              const unsigned short* __restrict__ relu_mask, unsigned short* __restrict__ Y,
+                              int res_last) {
+    const long long total = n_out * cout;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        float y = bias ? bias[e % cout] : 0.f;
+        for (int k = 0; k < n_kc; ++k) y += slabs[(long long)k * n_out * cout + e];
+        const float r = residual ? bf16_to_f32(residual[e]) : 0.f;
+        if (!res_last) y += r;
+        if (relu_mask && !(bf16_to_f32(relu_mask[e]) > 0.f)) y = 0.f;
+        if (res_last) y += r;
+        Y[e] = f32_to_bf16(y);
+    }
+}
+
+extern "C" int64_t scn_conv_tiles_bf16_scratch_bytes(int cin, int64_t n_out, int cout) {
+    const int64_t n_kc = cdiv(cin, TB_KC);
+    return 256 + (n_kc > 1 ? n_kc * n_out * cout * (int64_t)sizeof(float) : 0);
+}
+
+extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, const int32_t* tstab,
+                                   const uint32_t* tile_mask, const int32_t* perm, const int32_t* tile_order, int n_off,
+                                   int64_t n_out, const float* W, const float* bias, const uint16_t* residual,
+                                   const uint16_t* relu_mask, uint16_t* Y, int cout, int flags, void* scratch,
+                                   scn_stream_t stream) {
+    SCN_REQUIRE(n_off >= 1 && n_off <= 27 && n_out >= 0 && n_in >= 0 && cin >= 8 && cout >= 1);
+    SCN_REQUIRE(cin % 8 == 0);                                   // 16-byte row pieces
+    if (n_out == 0) return SCN_OK;
+    SCN_REQUIRE(X && tstab && tile_mask && perm && tile_order && W && Y && scratch);
+    SCN_REQUIRE((((uintptr_t)X | (uintptr_t)W) & 15) == 0);
+    SCN_REQUIRE(n_in < (1ll << 23) && n_in * cin * 2 < (1ll << 32) - (1ll << 24));    // 24-bit rows, 32-bit offsets
+    const int64_t nt = cdiv(n_out, TB_T);
+    static const int nb_env = getenv("SCN_TB_NB") ? atoi(getenv("SCN_TB_NB")) : 0;      // developer switch: 2 or 4
+    const int nb = nb_env == 2 || nb_env == 4 ? nb_env : (cout > 32 ? 4 : 2);
+    const int ct = 16 * nb;
+    const int n_chunks = (int)cdiv(cout, ct);
+    const int n_kc = (int)cdiv(cin, TB_KC);
+    float* slabs = (float*)((char*)scratch + 256);
+    const size_t lds = (size_t)n_off * ct * TB_KC * sizeof(uint16_t) + 16;
+    int wg_per_cu = (int)((160 * 1024) / lds);
+    if (wg_per_cu > 2) wg_per_cu = 2;
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    int64_t n_tg = (256 * wg_per_cu) / ((int64_t)n_chunks * n_kc);
+    if (n_tg > cdiv(nt, TB_NW)) n_tg = cdiv(nt, TB_NW);
+    if (n_tg < 1) n_tg = 1;
+    const bool wt = flags & SCN_F_W_TRANSPOSED;
+    dim3 grid((unsigned)(n_tg * n_chunks * n_kc));
+    hipStream_t st = S(stream);
+#define LAUNCH_TB(T, N)                                                                                             \
+    do {                                                                                                            \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            SCN_HIP(hipFuncSetAttribute((const void*)k_conv_tb<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                        160 * 1024));                                                               \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        hipLaunchKernelGGL((k_conv_tb<T, N>), grid, dim3(TB_NW * 64), lds, st, X, (long long)n_in, cin, tstab,      \
+                           tile_mask, perm, tile_order, n_off, (long long)nt, W, bias, residual, relu_mask, Y, slabs, \
+                           (long long)n_out, cout, flags, n_chunks, n_kc);                                          \
+    } while (0)
+    if (wt && nb == 4) LAUNCH_TB(true, 4);
+    else if (wt) LAUNCH_TB(true, 2);
+    else if (nb == 4) LAUNCH_TB(false, 4);
+    else LAUNCH_TB(false, 2);
+#undef LAUNCH_TB
+    SCN_LAUNCH_CHECK();
+    if (n_kc > 1) {
+        hipLaunchKernelGGL(k_conv_tb_sum, dim3(scn::ew_grid(n_out * cout, 256)), dim3(256), 0, st, (const float*)slabs,
+                           n_kc, (long long)n_out, cout, bias, residual, relu_mask, Y,
+                           (flags & SCN_F_RESIDUAL_LAST) ? 1 : 0);
+        SCN_LAUNCH_CHECK();
+    }
+    return SCN_OK;
+}

@@ -88,6 +88,26 @@ def conv_rules(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu_mask
     return Y
 
 
+def conv_rules_bf16(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu_mask=None):
+    """scn_conv_tiles_bf16: the tile convolution for bf16-stored features (X, residual, relu_mask, result: torch.bfloat16;
+    W, bias: the layer's fp32 parameters).  First piece of the bf16 storage path (BASELINE configs 3-5): forward and,
+    with F_W_TRANSPOSED | F_OFF_REVERSE, backward-data; not yet wired into the modules."""
+    lib = L.lib()
+    for t in (X, residual, relu_mask):
+        if t is not None and (t.dtype != torch.bfloat16 or not t.is_contiguous()):
+            raise L.ScnError("conv_rules_bf16 takes contiguous torch.bfloat16 features")
+    if W.dtype != torch.float32 or (bias is not None and bias.dtype != torch.float32):
+        raise L.ScnError("conv_rules_bf16 takes the fp32 master weights")
+    cin = X.shape[1]
+    Y = torch.empty((n_out, cout), dtype=torch.bfloat16, device=X.device)
+    nbytes = lib.scn_conv_tiles_bf16_scratch_bytes(cin, n_out, cout)
+    scratch = L.scratch(nbytes, X.device)
+    L.check(lib.scn_conv_tiles_bf16(L.ptr(X), X.shape[0], cin, L.ptr(tiles.tstab), L.ptr(tiles.tile_mask),
+                                    L.ptr(tiles.perm), L.ptr(tiles.tile_order), tiles.n_off, n_out, L.ptr(W), L.ptr(bias),
+                                    L.ptr(residual), L.ptr(relu_mask), L.ptr(Y), cout, flags, L.ptr(scratch), L.stream()))
+    return Y
+
+
 # The 3^3 / 2^3 table convolutions run on the tile kernel (scn_conv_tiles); USE_TILES = False routes them through the
 # plain table GEMM (scn_gemm_table: no mask sorting, 2-3x wasted matrix work) -- kept as a cross-check of the two kernels.
 USE_TILES = True

@@ -638,3 +638,55 @@ def test_mask_head_path_matches_oracle(gpu):
     logits.backward(g.to(gpu))
     logits_o.backward(g)
     _close(raw_g.grad, raw_o.grad, 5e-4, "d raw features through ROI crop + both U-Nets")
+
+
+# ---------------------------------------------------------------------------------------- bf16 storage (first piece)
+BF16_TOL = 2.0 ** -7     # outputs are rounded to bf16 (8 significant bits: half an ulp = 2^-9 relative) after an fp32
+                         # accumulation of bf16-rounded operands; stated relative to the output scale
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (8, 16), (48, 80), (128, 64), (256, 256)])
+@pytest.mark.parametrize("relu_in", [False, True])
+def test_conv_tiles_bf16_forward_and_backward_data(gpu, cin, cout, relu_in):
+    """scn_conv_tiles_bf16 against the oracle convolution evaluated on the SAME bf16-rounded operands (features bf16,
+    weights rounded to bf16, fp32 accumulation): only the final rounding of the result to bf16 and the summation order
+    separate the two.  Forward with bias + residual, backward-data with the ReLU mask."""
+    from sparse_rcnn_amd import functional as F, _lib as L
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=13, cin=8, n=1200, dup=100)
+    sz = tuple(int(s) for s in size)
+    rb = x.metadata.subm_rulebook(sz, 3)
+    n = rb.n
+    rules = scene.subm_rules(0, 3)
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    X = torch.randn(n, cin, generator=g).to(torch.bfloat16)
+    R = torch.randn(n, cout, generator=g).to(torch.bfloat16)
+    W = torch.randn(27, cin, cout, generator=g) * (2.0 / (27 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.5
+    Wb = W.to(torch.bfloat16).float()                                         # what the kernel's LDS image holds
+    flags = L.F_RELU_IN if relu_in else 0
+    y = F.conv_rules_bf16(X.to(gpu), rb.tiles, n, W.to(gpu), b.to(gpu), cout, flags, residual=R.to(gpu))
+    assert y.dtype == torch.bfloat16
+    xin = torch.relu(X.float()) if relu_in else X.float()
+    yo = O.conv_fwd(xin, rules, Wb, b, n) + R.float()
+    _close(y.float(), yo, BF16_TOL, "bf16 fwd")
+    # backward-data: dX = mask(X) * sum_o G[nbr_{26-o}] . W[o]^T
+    G = torch.randn(n, cout, generator=g).to(torch.bfloat16)
+    M = torch.randn(n, cin, generator=g).to(torch.bfloat16)                   # ReLU input saved by the forward
+    dx = F.conv_rules_bf16(G.to(gpu), rb.tiles, n, W.to(gpu), None, cin, L.F_W_TRANSPOSED | L.F_OFF_REVERSE,
+                           relu_mask=M.to(gpu))
+    dxo, _, _ = O.conv_bwd(torch.zeros(n, cin), G.float(), rules, Wb, has_bias=False)
+    dxo = dxo * (M.float() > 0)
+    _close(dx.float(), dxo, BF16_TOL, "bf16 bwd-data")
+    # bitwise reproducible
+    assert torch.equal(y, F.conv_rules_bf16(X.to(gpu), rb.tiles, n, W.to(gpu), b.to(gpu), cout, flags, residual=R.to(gpu)))
+
+
+def test_conv_tiles_bf16_rejects_unsupported_inputs(gpu):
+    from sparse_rcnn_amd import functional as F
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=13, cin=8, n=300, dup=0)
+    rb = x.metadata.subm_rulebook(tuple(int(s) for s in size), 3)
+    W = torch.zeros(27, 12, 8, device=gpu)
+    with pytest.raises(scn.ScnError):
+        F.conv_rules_bf16(torch.zeros(rb.n, 12, device=gpu), rb.tiles, rb.n, W, None, 8)             # fp32 features
+    with pytest.raises(scn.ScnError):
+        F.conv_rules_bf16(torch.zeros(rb.n, 12, device=gpu, dtype=torch.bfloat16), rb.tiles, rb.n, W, None, 8)   # cin % 8

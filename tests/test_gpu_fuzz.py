@@ -506,3 +506,41 @@ def test_fuzz_nin_join_pool_dense(gpu, seed):
     d = scn.SparseToDense(3, cin)(x)
     exp = O.sparse_to_dense(Xo.detach(), scene.coords0, size.tolist(), batch)
     assert torch.equal(d.detach().cpu(), exp), cfg
+
+
+@pytest.mark.parametrize("seed", _seeds(1100, 12))
+def test_fuzz_conv_tiles_bf16(gpu, seed):
+    """scn_conv_tiles_bf16 (bf16 storage, fp32 accumulation) on random scenes: SubM 3^3 tables and the 2^3 / 2 child
+    tables, channel counts that are multiples of 8 (the kernel's requirement) but not of the 32-channel K-chunk, odd
+    output widths, K split -- against the oracle on the same bf16-rounded operands, within 2^-7 of the output scale."""
+    import sparse_rcnn_amd as scn
+    from sparse_rcnn_amd import functional as F, _lib as L
+    rng, coords, size, batch, _, cout = _draw(seed)
+    cin = int(rng.choice([8, 16, 24, 32, 40, 64, 72, 96, 128, 136]))
+    strided = bool(rng.integers(0, 2))
+    relu_in = bool(rng.integers(0, 2))
+    cfg = dict(seed=seed, grid=size.tolist(), batch=batch, points=len(coords), cin=cin, cout=cout, strided=strided,
+               relu=relu_in)
+    x = scn.InputLayer(3, size, mode=4)((coords, torch.zeros(len(coords), 1).to(gpu), batch))
+    scene = O.OracleScene(coords.numpy())
+    sz = tuple(int(s) for s in size)
+    if strided:
+        sb = x.metadata.strided_rulebook(sz)
+        tiles, n_in, n_out, n_off = sb.tiles, sb.n_fine, sb.n_coarse, 8
+        rules = scene.strided_rules(0)
+    else:
+        rb = x.metadata.subm_rulebook(sz, 3)
+        tiles, n_in, n_out, n_off = rb.tiles, rb.n, rb.n, 27
+        rules = scene.subm_rules(0, 3)
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(n_in, cin, generator=g).to(torch.bfloat16)
+    W = torch.randn(n_off, cin, cout, generator=g) * (2.0 / (n_off * cin)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.5
+    y = F.conv_rules_bf16(X.to(gpu), tiles, n_out, W.to(gpu), b.to(gpu), cout, L.F_RELU_IN if relu_in else 0)
+    xin = torch.relu(X.float()) if relu_in else X.float()
+    yo = O.conv_fwd(xin, rules, W.to(torch.bfloat16).float(), b, n_out)
+    a, e = y.float().cpu().double(), yo.double()
+    assert a.shape == e.shape, cfg
+    if a.numel():
+        err = (a - e).abs().max().item() / max(1.0, e.abs().max().item())
+        assert err <= 2.0 ** -7, f"{cfg}: {err:.3e}"

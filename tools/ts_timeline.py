@@ -2,7 +2,7 @@
 -DTS_TIMELINE=1 for scn_conv_ts.hip, e.g.
     cd sparse_rcnn_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DTS_TIMELINE=1 -c scn_conv_ts.hip -o /tmp/ts_tl.o \\
       && hipcc --offload-arch=gfx950 -fPIC -shared -o ../../tools/libscn_timeline.so build/scn_index.hip.o build/scn_conv.hip.o \\
-         /tmp/ts_tl.o build/scn_tiles.hip.o build/scn_pyramid.hip.o build/scn_wgrad.hip.o build/scn_elem.hip.o
+         /tmp/ts_tl.o build/scn_conv_ts_bf16.hip.o build/scn_tiles.hip.o build/scn_pyramid.hip.o build/scn_wgrad.hip.o build/scn_elem.hip.o
     SCN_MI355X_LIB=$PWD/tools/libscn_timeline.so python tools/ts_timeline.py 0"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

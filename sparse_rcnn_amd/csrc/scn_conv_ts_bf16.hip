@@ -233,21 +233,39 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
 #undef TB_STEP
 #undef TB_GATHER
 
-// Y = bf16( bias + sum_kc slab[kc] (+ residual, ReLU-backward mask) ), K-chunks added in ascending order
+// Y = bf16( bias + sum_kc slab[kc] (+ residual, ReLU-backward mask) ), K-chunks added in ascending order.
+// V = 4: 16-byte slab reads, 8-byte bf16 accesses (cout % 4 == 0, aligned buffers).
+template <int V>
 __global__ void k_conv_tb_sum(const float* __restrict__ slabs, int n_kc, long long n_out, int cout,
                               const float* __restrict__ bias, const unsigned short* __restrict__ residual,
                               const unsigned short* __restrict__ relu_mask, unsigned short* __restrict__ Y,
                               int res_last) {
-    const long long total = n_out * cout;
-    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
-         e += (long long)gridDim.x * blockDim.x) {
-        float y = bias ? bias[e % cout] : 0.f;
-        for (int k = 0; k < n_kc; ++k) y += slabs[(long long)k * n_out * cout + e];
-        const float r = residual ? bf16_to_f32(residual[e]) : 0.f;
-        if (!res_last) y += r;
-        if (relu_mask && !(bf16_to_f32(relu_mask[e]) > 0.f)) y = 0.f;
-        if (res_last) y += r;
-        Y[e] = f32_to_bf16(y);
+    typedef float vf_t __attribute__((ext_vector_type(V)));
+    typedef unsigned short vh_t __attribute__((ext_vector_type(V)));
+    const long long total = n_out * cout / V;
+    for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < total;
+         g += (long long)gridDim.x * blockDim.x) {
+        const long long e = g * V;
+        vf_t y;
+        if (bias) y = *(const vf_t*)(bias + e % cout);
+        else {
+#pragma unroll
+            for (int v = 0; v < V; ++v) y[v] = 0.f;
+        }
+        for (int k = 0; k < n_kc; ++k) y += *(const vf_t*)(slabs + (long long)k * n_out * cout + e);
+        vh_t rh, mh;
+        if (residual) rh = *(const vh_t*)(residual + e);
+        if (relu_mask) mh = *(const vh_t*)(relu_mask + e);
+        vh_t out;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float r = residual ? bf16_to_f32(rh[v]) : 0.f;
+            float t = y[v] + (res_last ? 0.f : r);
+            if (relu_mask && !(bf16_to_f32(mh[v]) > 0.f)) t = 0.f;
+            if (res_last) t += r;
+            out[v] = f32_to_bf16(t);
+        }
+        *(vh_t*)(Y + e) = out;
     }
 }
 
@@ -303,9 +321,15 @@ extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, con
 #undef LAUNCH_TB
     SCN_LAUNCH_CHECK();
     if (n_kc > 1) {
-        hipLaunchKernelGGL(k_conv_tb_sum, dim3(scn::ew_grid(n_out * cout, 256)), dim3(256), 0, st, (const float*)slabs,
-                           n_kc, (long long)n_out, cout, bias, residual, relu_mask, Y,
-                           (flags & SCN_F_RESIDUAL_LAST) ? 1 : 0);
+        const int rl = (flags & SCN_F_RESIDUAL_LAST) ? 1 : 0;
+        const bool v4 = cout % 4 == 0 && ((((uintptr_t)slabs | (uintptr_t)bias) & 15) == 0) &&
+                        ((((uintptr_t)Y | (uintptr_t)residual | (uintptr_t)relu_mask) & 7) == 0);
+        if (v4)
+            hipLaunchKernelGGL(k_conv_tb_sum<4>, dim3(scn::ew_grid(n_out * cout / 4, 256)), dim3(256), 0, st,
+                               (const float*)slabs, n_kc, (long long)n_out, cout, bias, residual, relu_mask, Y, rl);
+        else
+            hipLaunchKernelGGL(k_conv_tb_sum<1>, dim3(scn::ew_grid(n_out * cout, 256)), dim3(256), 0, st,
+                               (const float*)slabs, n_kc, (long long)n_out, cout, bias, residual, relu_mask, Y, rl);
         SCN_LAUNCH_CHECK();
     }
     return SCN_OK;

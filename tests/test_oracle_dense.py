@@ -137,3 +137,86 @@ def test_unet_oracle_runs_and_has_expected_param_count():
     assert out.shape == (scene.n(0), 8)
     out.sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params.values())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Seeded random sweep: the oracle is the checker of every GPU parity test, and for the SparseConvNet arithmetic the dense
+# torch twins are the only independent statement of it available here (parity unpinned) -- so the
+# comparison is repeated over random grids (thin, odd-sized, single-voxel), batch sizes with empty samples, duplicate
+# densities and channel counts instead of three fixed scenes.
+# ---------------------------------------------------------------------------------------------------------------------
+def _random_scene(seed, even=False):
+    rng = np.random.default_rng(seed)
+    grid = tuple(int(rng.integers(1, 7)) * (2 if even else 1) + (0 if even else int(rng.integers(0, 2))) for _ in range(3))
+    grid = tuple(max(g, 2 if even else 1) for g in grid)
+    cells = grid[0] * grid[1] * grid[2]
+    batch = int(rng.integers(1, 4))
+    cs = []
+    for b in range(batch):
+        n = int(min(cells, rng.choice([0, 1, 2, 5, 40, 200])))
+        if b == 0 and n == 0:
+            n = 1
+        p = np.stack(np.unravel_index(rng.choice(cells, size=n, replace=False), grid), 1).reshape(n, 3)
+        if n and rng.random() < 0.5:
+            p = np.concatenate([p, p[rng.integers(0, n, size=int(rng.integers(1, n + 2)))]])
+            rng.shuffle(p)
+        cs.append(np.concatenate([p, np.full((len(p), 1), b)], 1))
+    return rng, np.concatenate(cs).astype(np.int64), grid, batch
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_sweep_subm_matches_dense_conv3d(seed):
+    rng, pts, grid, batch = _random_scene(seed)
+    k = int(rng.choice([1, 3, 3, 5]))
+    cin, cout = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+    coords, prow, cnt = O.input_layer_rules(pts)
+    n = len(coords)
+    # InputLayer rows: distinct sites in first-occurrence order, every point mapped to its site
+    assert len(np.unique(coords, axis=0)) == n and (coords[prow] == pts).all() and cnt.sum() == len(pts)
+    first = np.full(n, len(pts)); np.minimum.at(first, prow, np.arange(len(pts)))
+    assert (np.diff(first) > 0).all()
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(n, cin, generator=g, requires_grad=True)
+    W = torch.randn(k ** 3, cin, cout, generator=g, requires_grad=True)
+    b = torch.randn(cout, generator=g, requires_grad=True)
+    nbr, rules = O.subm_rulebook(coords, k)
+    Y = O.conv(X, W, b, rules, n)
+    Wt = W.reshape(k, k, k, cin, cout).permute(4, 3, 0, 1, 2)
+    Yd = _sample(F.conv3d(_dense(X, coords, grid, batch), Wt, b, padding=k // 2), coords)
+    assert torch.allclose(Y, Yd, atol=1e-4, rtol=1e-4), (seed, grid, batch, n, k)
+    dY = torch.randn(n, cout, generator=g)
+    for a, c in zip(torch.autograd.grad(Y, (X, W, b), dY), torch.autograd.grad(Yd, (X, W, b), dY)):
+        assert torch.allclose(a, c, atol=1e-3, rtol=1e-3), (seed, grid, batch, n, k)
+
+
+@pytest.mark.parametrize("seed", range(100, 130))
+def test_sweep_strided_conv_deconv_pool_match_dense(seed):
+    rng, pts, grid, batch = _random_scene(seed, even=True)
+    cin, cout = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+    coords, _, _ = O.input_layer_rules(pts)
+    n = len(coords)
+    rb = O.strided_rulebook(coords, 2)
+    cc, nc = rb["coords"], len(rb["coords"])
+    assert len(np.unique(cc, axis=0)) == nc and (cc[rb["parent"]][:, :3] == coords[:, :3] // 2).all()
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(n, cin, generator=g, requires_grad=True)
+    W = torch.randn(8, cin, cout, generator=g, requires_grad=True)
+    b = torch.randn(cout, generator=g, requires_grad=True)
+    Y = O.conv(X, W, b, rb["rules"], nc)
+    Wt = W.reshape(2, 2, 2, cin, cout).permute(4, 3, 0, 1, 2)
+    Yd = _sample(F.conv3d(_dense(X, coords, grid, batch), Wt, b, stride=2), cc)
+    assert torch.allclose(Y, Yd, atol=1e-4, rtol=1e-4), (seed, grid, batch, n)
+    dY = torch.randn(nc, cout, generator=g)
+    for a, c in zip(torch.autograd.grad(Y, (X, W, b), dY), torch.autograd.grad(Yd, (X, W, b), dY)):
+        assert torch.allclose(a, c, atol=1e-3, rtol=1e-3), (seed, grid, batch, n)
+    cgrid = tuple(s // 2 for s in grid)
+    Z = torch.randn(nc, cout, generator=g, requires_grad=True)
+    Wd = torch.randn(8, cout, cin, generator=g, requires_grad=True)
+    U = O.conv(Z, Wd, None, O.swap_rules(rb["rules"]), n)
+    Wdt = Wd.reshape(2, 2, 2, cout, cin).permute(3, 4, 0, 1, 2)
+    Ud = _sample(F.conv_transpose3d(_dense(Z, cc, cgrid, batch), Wdt, None, stride=2), coords)
+    assert torch.allclose(U, Ud, atol=1e-4, rtol=1e-4), (seed, grid, batch, n)
+    # average pooling of the zero-filled grid is the dense twin of scn.AveragePooling (module_factory.py:351-353)
+    P = O.pool_fwd(X, rb["child"], True)
+    Pd = _sample(F.avg_pool3d(_dense(X, coords, grid, batch), 2, 2), cc)
+    assert torch.allclose(P, Pd, atol=1e-5, rtol=1e-5), (seed, grid, batch, n)

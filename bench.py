@@ -143,7 +143,8 @@ def main():
         flat.all_reduce_mean()
         flat.sgd_step(1e-6)
 
-    # Kernel timing: HIP events around the launches of the dominant kernel (scn_conv_tiles: 62 launches per step) on 3-4
+    # Kernel timing: HIP events around the launches of the dominant kernel (k_conv_ts: 62 launches per step; in the sampled
+    # steps scn_conv_tiles runs with SCN_F_SPLIT_SUM so that its slab-sum kernel is launched, and timed, apart) on 3-4
     # steps spread over the timed region, from a pool of events created before it.  Timing events are not free: every
     # launch of every step timed cost 1-3.5 ms/step (host-bound, and each event pair fences the queue), all four GEMM
     # kernels on every 5th step still ~0.5 ms/step.  --profile-all times all GEMM kernels (the "kernels" table).

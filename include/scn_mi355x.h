@@ -53,6 +53,8 @@ extern "C" {
 #define SCN_F_OFF_REVERSE 4  /* weight index n_off-1-o for table row o (SubM backward-data: R_o^T = R_{k^3-1-o}) */
 #define SCN_F_RESIDUAL_LAST 8 /* scn_conv_tiles: add `residual` AFTER the ReLU-backward mask (gradient of a residual block:
                                 dX = mask(conv^T dY1) + dY), default is before */
+#define SCN_F_SPLIT_SUM 16    /* scn_conv_tiles: launch the tile kernel only; the caller runs scn_conv_tiles_finish next
+                               * (lets a profiler bracket the two kernels separately; results are identical) */
 
 typedef void* scn_stream_t;
 
@@ -192,6 +194,10 @@ int64_t scn_conv_tiles_scratch_bytes(int cin, int64_t n_out, int cout);   /* til
 int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32_t* tstab, const uint32_t* tile_mask, const int32_t* perm,
                    const int32_t* tile_order, int n_off, int64_t n_out, const float* W, const float* bias, const float* residual,
                    const float* relu_mask, float* Y, int cout, int flags, void* scratch, scn_stream_t stream);
+/* Second half of a scn_conv_tiles call made with SCN_F_SPLIT_SUM: adds the K-chunk slabs (no-op when cin <= 32: the
+ * tile kernel has written Y).  Same arguments as that call. */
+int scn_conv_tiles_finish(int cin, int64_t n_out, const float* bias, const float* residual, const float* relu_mask,
+                          float* Y, int cout, int flags, void* scratch, scn_stream_t stream);
 
 /* The same convolution for bf16 STORAGE (BASELINE configs 3-5): X, residual, relu_mask and Y are bf16
  * (uint16 bit patterns, row-major, cin % 8 == 0), the layer's master weights and bias stay fp32 and are rounded to

@@ -41,6 +41,7 @@ _SIGS = {
     "scn_tiles_build": (C.c_int, [p, i32, i64, p, p, p, p, p, p]),
     "scn_conv_tiles_scratch_bytes": (i64, [i32, i64, i32]),
     "scn_conv_tiles": (C.c_int, [p, i64, i32, p, p, p, p, i32, i64, p, p, p, p, p, i32, i32, p, p]),
+    "scn_conv_tiles_finish": (C.c_int, [i32, i64, p, p, p, p, i32, i32, p, p]),
     "scn_conv_tiles_bf16_scratch_bytes": (i64, [i32, i64, i32]),
     "scn_conv_tiles_bf16": (C.c_int, [p, i64, i32, p, p, p, p, i32, i64, p, p, p, p, p, i32, i32, p, p]),
     "scn_gemm_rules": (C.c_int, [p, i32, p, p, C.POINTER(i64), i32, p, p, p, p, i32, i32, p]),
@@ -75,7 +76,7 @@ _SIGS = {
 
 EXPORTS = tuple(_SIGS)
 
-F_RELU_IN, F_W_TRANSPOSED, F_OFF_REVERSE, F_RESIDUAL_LAST = 1, 2, 4, 8
+F_RELU_IN, F_W_TRANSPOSED, F_OFF_REVERSE, F_RESIDUAL_LAST, F_SPLIT_SUM = 1, 2, 4, 8, 16
 OK, EINVAL, ESIZE, EHASH, EHIP = 0, 1, 2, 3, 4
 PYRAMID_MAX_LEVELS, PYRAMID_LEVEL_STRIDE = 8, 72
 PYRAMID_DESC_LEN = 8 + PYRAMID_MAX_LEVELS * PYRAMID_LEVEL_STRIDE

@@ -448,17 +448,28 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     else LAUNCH_TS(false, false, false, false, false);
 #undef LAUNCH_TS
     SCN_LAUNCH_CHECK();
-    if (n_kc > 1) {
-        const bool v4 = cout % 4 == 0 && ((((uintptr_t)slabs | (uintptr_t)Y | (uintptr_t)bias | (uintptr_t)residual |
-                                            (uintptr_t)relu_mask) & 15) == 0);
-        const int rl = (flags & SCN_F_RESIDUAL_LAST) ? 1 : 0;
-        if (v4)
-            hipLaunchKernelGGL(k_conv_ts_sum<4>, dim3(scn::ew_grid(n_out * cout / 4, 256)), dim3(256), 0, st,
-                               (const float*)slabs, n_kc, (long long)n_out, cout, bias, residual, relu_mask, Y, rl);
-        else
-            hipLaunchKernelGGL(k_conv_ts_sum<1>, dim3(scn::ew_grid(n_out * cout, 256)), dim3(256), 0, st,
-                               (const float*)slabs, n_kc, (long long)n_out, cout, bias, residual, relu_mask, Y, rl);
-        SCN_LAUNCH_CHECK();
-    }
+    if (flags & SCN_F_SPLIT_SUM) return SCN_OK;
+    return scn_conv_tiles_finish(cin, n_out, bias, residual, relu_mask, Y, cout, flags, scratch, stream);
+}
+
+extern "C" int scn_conv_tiles_finish(int cin, int64_t n_out, const float* bias, const float* residual,
+                                     const float* relu_mask, float* Y, int cout, int flags, void* scratch,
+                                     scn_stream_t stream) {
+    SCN_REQUIRE(cin >= 1 && cout >= 1 && n_out >= 0);
+    const int n_kc = (int)cdiv(cin, TS_KC);
+    if (n_kc <= 1 || n_out == 0) return SCN_OK;
+    SCN_REQUIRE(Y && scratch);
+    float* slabs = (float*)((char*)scratch + ts_counter_bytes(cin, cout));
+    hipStream_t st = S(stream);
+    const bool v4 = cout % 4 == 0 && ((((uintptr_t)slabs | (uintptr_t)Y | (uintptr_t)bias | (uintptr_t)residual |
+                                        (uintptr_t)relu_mask) & 15) == 0);
+    const int rl = (flags & SCN_F_RESIDUAL_LAST) ? 1 : 0;
+    if (v4)
+        hipLaunchKernelGGL(k_conv_ts_sum<4>, dim3(scn::ew_grid(n_out * cout / 4, 256)), dim3(256), 0, st,
+                           (const float*)slabs, n_kc, (long long)n_out, cout, bias, residual, relu_mask, Y, rl);
+    else
+        hipLaunchKernelGGL(k_conv_ts_sum<1>, dim3(scn::ew_grid(n_out * cout, 256)), dim3(256), 0, st,
+                           (const float*)slabs, n_kc, (long long)n_out, cout, bias, residual, relu_mask, Y, rl);
+    SCN_LAUNCH_CHECK();
     return SCN_OK;
 }

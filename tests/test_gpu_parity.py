@@ -690,3 +690,28 @@ def test_conv_tiles_bf16_rejects_unsupported_inputs(gpu):
         F.conv_rules_bf16(torch.zeros(rb.n, 12, device=gpu), rb.tiles, rb.n, W, None, 8)             # fp32 features
     with pytest.raises(scn.ScnError):
         F.conv_rules_bf16(torch.zeros(rb.n, 12, device=gpu, dtype=torch.bfloat16), rb.tiles, rb.n, W, None, 8)   # cin % 8
+
+
+def test_conv_tiles_split_sum_is_the_same_computation(gpu):
+    """SCN_F_SPLIT_SUM + scn_conv_tiles_finish (what bench.py's kernel timer uses to bracket the tile kernel alone) give
+    the bits of the single call, with and without K-chunk slabs."""
+    from sparse_rcnn_amd import functional as F, profiling
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=17, cin=8, n=1500, dup=100)
+    rb = x.metadata.subm_rulebook(tuple(int(s) for s in size), 3)
+    n = rb.n
+    for cin, cout in ((32, 32), (64, 48), (128, 128)):
+        g = torch.Generator().manual_seed(cin)
+        X = torch.randn(n, cin, generator=g).to(gpu); R = torch.randn(n, cout, generator=g).to(gpu)
+        W = (torch.randn(27, cin, cout, generator=g) * 0.05).to(gpu); b = torch.randn(cout, generator=g).to(gpu)
+        ref = F.conv_rules(X, rb.tiles, n, W, b, cout, residual=R, n_rules=rb.rules.total)
+        timer = profiling.KernelTimer(every=1, names=None)
+        timer.begin_step()
+        profiling.TIMER = timer
+        try:
+            got = F.conv_rules(X, rb.tiles, n, W, b, cout, residual=R, n_rules=rb.rules.total)
+        finally:
+            profiling.TIMER = None
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref)
+        ks = timer.summary()
+        assert ks["k_conv_ts"]["launches"] == 1 and ks["k_conv_ts_sum"]["launches"] == 1

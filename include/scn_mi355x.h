@@ -231,6 +231,12 @@ int scn_wgrad_rules(const float* X, int cin, const float* dY, int cout, const in
  * the bit mask db_offsets of dY[out_p][c].  The caller names offsets whose rule lists together contain every output row
  * exactly once (centre offset of a submanifold conv: 1 << (k^3/2); all offsets of a Deconvolution; the identity list),
  * so db equals the column sum of dY.  Any channel count (rows that are not 16-byte aligned take element-wise loads). */
+/* The same weight gradient for bf16-stored operands (X, dY: uint16 bit patterns; dW fp32): rows are gathered packed
+ * and widened to fp32 in registers (exact), arithmetic and summation order are those of scn_wgrad_rules.  Scratch:
+ * scn_wgrad_scratch_bytes. */
+int scn_wgrad_rules_bf16(const uint16_t* X, int cin, const uint16_t* dY, int cout, const int32_t* in_rows,
+                         const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, void* scratch,
+                         int flags, scn_stream_t stream);
 int scn_wgrad_bias_rules(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
                          const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, float* db,
                          uint32_t db_offsets, void* scratch, int flags, scn_stream_t stream);

@@ -41,7 +41,32 @@ struct DPlan {
 template <int T>
 struct Frag { typedef float type __attribute__((ext_vector_type(T))); };
 
-template <int TA, int TB, bool QUAD, bool EDGE, bool IDENT>
+// Row pieces as they sit in the register ring: fp32 storage = the T floats themselves; bf16 storage (HB) = the T packed
+// bf16 values as loaded (half the registers, half the gather bytes), widened to fp32 when the block is multiplied:
+// element 2j is the low half of word j (<< 16), element 2j+1 the high half (& 0xffff0000) -- exact, one VALU op each.
+template <int T, bool PACKED>
+struct RawFrag { typedef float type __attribute__((ext_vector_type(T))); };
+template <>
+struct RawFrag<2, true> { typedef unsigned type __attribute__((ext_vector_type(1))); };
+template <>
+struct RawFrag<4, true> { typedef unsigned type __attribute__((ext_vector_type(2))); };
+
+template <int T, bool PACKED, typename R>
+__device__ __forceinline__ typename Frag<T>::type widen(const R& r) {
+    typename Frag<T>::type f;
+    if constexpr (PACKED) {
+#pragma unroll
+        for (int j = 0; j < T / 2; ++j) {
+            f[2 * j] = __uint_as_float(r[j] << 16);
+            f[2 * j + 1] = __uint_as_float(r[j] & 0xffff0000u);
+        }
+    } else {
+        f = r;
+    }
+    return f;
+}
+
+template <int TA, int TB, bool QUAD, bool EDGE, bool IDENT, bool HB = false>
 __global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ X, int cin, const float* __restrict__ dY,
                                                       int cout, const int* __restrict__ in_rows,
                                                       const int* __restrict__ out_rows, DPlan plan,
@@ -49,6 +74,10 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ 
                                                       float* __restrict__ db_slabs, unsigned db_mask, int cout_pad) {
     typedef typename Frag<TA>::type fa_t;
     typedef typename Frag<TB>::type fb_t;
+    constexpr bool PACKED = HB && !EDGE;                         // bf16 rows kept packed in the ring
+    typedef typename RawFrag<TA, PACKED>::type ra_t;
+    typedef typename RawFrag<TB, PACKED>::type rb_t;
+    constexpr int ES = HB ? 2 : 4;                               // bytes per stored element
     constexpr int WI = 16 * TA, WJ = 16 * TB;                   // wave block
     constexpr int CBI = QUAD ? 2 * WI : WI, CBJ = QUAD ? 2 * WJ : WJ;
     constexpr int NACC = TA * TB;
@@ -110,9 +139,9 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ 
     // immediate, zero VALU), a row address is ONE v_mad_i64_i32 (row * stride + per-lane base), ReLU is one v_max
     // against 0 or -inf, and rule masking exists only in the peeled tail block.  (First version: ~110 VALU per block,
     // VALU-issue-bound at 1/3 of the MFMA rate.)
-    const char* xlane = (const char*)(X + ca);
-    const char* ylane = (const char*)(dY + cbn);
-    const int xstride = 4 * cin, ystride = 4 * cout;           // int: row * stride is one v_mad_i64_i32
+    const char* xlane = (const char*)X + (long long)ca * ES;
+    const char* ylane = (const char*)dY + (long long)cbn * ES;
+    const int xstride = ES * cin, ystride = ES * cout;         // int: row * stride is one v_mad_i64_i32
     const int relu_lo = relu_in ? 0 : (int)0x80000000;
     const int last_full = nfull > 0 ? (nfull - 1) * 16 : 0;        // prefetches past the end re-read the last whole block
 #define WD_IDX(IN, OUT, QB)                                                                          \
@@ -126,21 +155,30 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ 
 #define WD_ROWS(A, B, IN, OUT)                                                                       \
     _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                               \
         if (EDGE) {                  /* element loads; channels past the end read channel 0 (zeroed at use) */ \
-            const float* xr_ = X + (long long)IN[s_] * cin;                                          \
-            const float* yr_ = dY + (long long)OUT[s_] * cout;                                       \
-            _Pragma("unroll") for (int t_ = 0; t_ < TA; ++t_) A[s_][t_] = xr_[a_ok[t_] ? ca + t_ : 0]; \
-            _Pragma("unroll") for (int t_ = 0; t_ < TB; ++t_) B[s_][t_] = yr_[b_ok[t_] ? cbn + t_ : 0]; \
+            if (HB) {                                                                                \
+                const unsigned short* xr_ = (const unsigned short*)X + (long long)IN[s_] * cin;      \
+                const unsigned short* yr_ = (const unsigned short*)dY + (long long)OUT[s_] * cout;   \
+                _Pragma("unroll") for (int t_ = 0; t_ < TA; ++t_)                                    \
+                    A[s_][t_] = __uint_as_float((unsigned)xr_[a_ok[t_] ? ca + t_ : 0] << 16);       \
+                _Pragma("unroll") for (int t_ = 0; t_ < TB; ++t_)                                    \
+                    B[s_][t_] = __uint_as_float((unsigned)yr_[b_ok[t_] ? cbn + t_ : 0] << 16);       \
+            } else {                                                                                 \
+                const float* xr_ = X + (long long)IN[s_] * cin;                                      \
+                const float* yr_ = dY + (long long)OUT[s_] * cout;                                   \
+                _Pragma("unroll") for (int t_ = 0; t_ < TA; ++t_) A[s_][t_] = xr_[a_ok[t_] ? ca + t_ : 0]; \
+                _Pragma("unroll") for (int t_ = 0; t_ < TB; ++t_) B[s_][t_] = yr_[b_ok[t_] ? cbn + t_ : 0]; \
+            }                                                                                        \
         } else {                                                                                     \
-            A[s_] = *(const fa_t*)(xlane + (long long)IN[s_] * xstride);                             \
-            B[s_] = *(const fb_t*)(ylane + (long long)OUT[s_] * ystride);                            \
+            A[s_] = *(const ra_t*)(xlane + (long long)IN[s_] * xstride);                             \
+            B[s_] = *(const rb_t*)(ylane + (long long)OUT[s_] * ystride);                            \
         }                                                                                            \
     }
     // MASK: rules at or past `nrel` contribute nothing (tail block only)
 #define WD_MFMA(A, B, QB, MASK)                                                                      \
     _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                               \
         const bool v_ = !(MASK) || (QB) + lane_r + s_ < nrel;                                        \
-        fa_t a_ = A[s_];                                                                             \
-        fb_t b_ = B[s_];                                                                             \
+        fa_t a_ = widen<TA, PACKED>(A[s_]);                                                          \
+        fb_t b_ = widen<TB, PACKED>(B[s_]);                                                          \
         _Pragma("unroll") for (int t_ = 0; t_ < TA; ++t_) {                                          \
             /* ReLU as ONE integer max on the bit pattern (fmaxf costs a canonicalising v_max x,x more; inline asm \
                hides the VALU->MFMA hazard from the compiler): negative floats are negative ints */  \
@@ -158,8 +196,8 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ 
     }
 
     int in0[4], out0[4], in1[4], out1[4], in2[4], out2[4];
-    fa_t a0[4], a1[4], a2[4];
-    fb_t b0[4], b1[4], b2[4];
+    ra_t a0[4], a1[4], a2[4];
+    rb_t b0[4], b1[4], b2[4];
     // Ring depth: 3 sets (rows two blocks ahead) for the small wave blocks; 2 sets (one block ahead) at TA = TB = 4,
     // where a block is 64 MFMAs = 2048 cycles and the third set would cost the second resident wave per SIMD
     // (64 accumulators + 3 x 32 row registers + indices > 256 registers).
@@ -433,14 +471,14 @@ extern "C" int64_t scn_wgrad_scratch_bytes(int cin, int cout, const int64_t* pre
 
 static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
                       const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, float* db,
-                      unsigned db_mask, void* scratch, int flags, scn_stream_t stream) {
+                      unsigned db_mask, void* scratch, int flags, scn_stream_t stream, bool hb = false) {
     SCN_REQUIRE(prefix_host && n_off >= 1 && n_off <= 32 && cin >= 1 && cout >= 1 && dW && scratch);
     SCN_REQUIRE((in_rows == nullptr) == (out_rows == nullptr));
     SCN_REQUIRE(in_rows || n_off == 1);
     DPlan pl;
     SCN_REQUIRE(make_dplan(cin, cout, prefix_host, n_off, pl) == SCN_OK);
     SCN_REQUIRE(prefix_host[n_off] == prefix_host[0] || (X && dY));
-    SCN_REQUIRE((((uintptr_t)X | (uintptr_t)dY) & 3) == 0);
+    SCN_REQUIRE((((uintptr_t)X | (uintptr_t)dY) & (hb ? 1 : 3)) == 0);
     if (pl.unit_start[n_off] == 0) {
         SCN_HIP(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)n_off * cin * cout, S(stream)));
         if (db) SCN_HIP(hipMemsetAsync(db, 0, sizeof(float) * (size_t)cout, S(stream)));
@@ -455,22 +493,25 @@ static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const 
     float* db_slabs = db ? (float*)scratch + (int64_t)pl.unit_start[n_off] * pl.nbi * pl.nbj * pl.cbi * pl.cbj : nullptr;
     dim3 grid((unsigned)pl.unit_start[n_off], 1, (unsigned)(pl.nbi * pl.nbj));
     const int relu_in = (flags & SCN_F_RELU_IN) ? 1 : 0;
-#define LAUNCH_WD(TA_, TB_, Q_, E_, I_)                                                                          \
+#define LAUNCH_WD(TA_, TB_, Q_, E_, I_, H_)                                                                      \
     do {                                                                                                         \
         const size_t lds_ = ((Q_) ? 4 * 64 : 4 * (TA_) * (TB_) * 4 * 64 + 4 * 64) * sizeof(float);               \
         static bool attr_set = false;                                                                            \
         if (!attr_set) {                                                                                         \
-            SCN_HIP(hipFuncSetAttribute((const void*)k_wgrad_direct<TA_, TB_, Q_, E_, I_>,                       \
+            SCN_HIP(hipFuncSetAttribute((const void*)k_wgrad_direct<TA_, TB_, Q_, E_, I_, H_>,                   \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                \
             attr_set = true;                                                                                     \
         }                                                                                                        \
-        hipLaunchKernelGGL((k_wgrad_direct<TA_, TB_, Q_, E_, I_>), grid, dim3(256), lds_, S(stream), X, cin, dY, \
-                           cout, in_rows, out_rows, pl, (float*)scratch, relu_in, db_slabs, db_mask, cout_pad);  \
+        hipLaunchKernelGGL((k_wgrad_direct<TA_, TB_, Q_, E_, I_, H_>), grid, dim3(256), lds_, S(stream), X, cin, \
+                           dY, cout, in_rows, out_rows, pl, (float*)scratch, relu_in, db_slabs, db_mask,         \
+                           cout_pad);                                                                            \
     } while (0)
+#define PICK_I(TA_, TB_, Q_, E_, H_)                                                                             \
+    do { if (ident) LAUNCH_WD(TA_, TB_, Q_, E_, true, H_); else LAUNCH_WD(TA_, TB_, Q_, E_, false, H_); } while (0)
 #define PICK_EI(TA_, TB_, Q_)                                                                                    \
     do {                                                                                                         \
-        if (edge) { if (ident) LAUNCH_WD(TA_, TB_, Q_, true, true); else LAUNCH_WD(TA_, TB_, Q_, true, false); } \
-        else { if (ident) LAUNCH_WD(TA_, TB_, Q_, false, true); else LAUNCH_WD(TA_, TB_, Q_, false, false); }    \
+        if (hb) { if (edge) PICK_I(TA_, TB_, Q_, true, true); else PICK_I(TA_, TB_, Q_, false, true); }          \
+        else { if (edge) PICK_I(TA_, TB_, Q_, true, false); else PICK_I(TA_, TB_, Q_, false, false); }           \
     } while (0)
     if (sh.quad) PICK_EI(4, 4, true);
     else if (sh.ta == 4 && sh.tb == 4) PICK_EI(4, 4, false);
@@ -478,6 +519,7 @@ static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const 
     else if (sh.tb == 4) PICK_EI(2, 4, false);
     else PICK_EI(2, 2, false);
 #undef PICK_EI
+#undef PICK_I
 #undef LAUNCH_WD
     SCN_LAUNCH_CHECK();
     // sum of the units: V output channels per thread, G threads per element group so that ~>= 128k threads run
@@ -502,6 +544,15 @@ extern "C" int scn_wgrad_rules(const float* X, int cin, const float* dY, int cou
                                const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, void* scratch,
                                int flags, scn_stream_t stream) {
     return wgrad_impl(X, cin, dY, cout, in_rows, out_rows, prefix_host, n_off, dW, nullptr, 0u, scratch, flags, stream);
+}
+
+// bf16 STORAGE of both operands (BASELINE configs 3-5): the rows are gathered as packed bf16 and widened to fp32 in
+// registers (exact), the products and sums are the fp32 kernel's (v_mfma_f32_16x16x4_f32) -- dW is fp32.
+extern "C" int scn_wgrad_rules_bf16(const uint16_t* X, int cin, const uint16_t* dY, int cout, const int32_t* in_rows,
+                                    const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW,
+                                    void* scratch, int flags, scn_stream_t stream) {
+    return wgrad_impl((const float*)X, cin, (const float*)dY, cout, in_rows, out_rows, prefix_host, n_off, dW, nullptr,
+                      0u, scratch, flags, stream, true);
 }
 
 extern "C" int scn_wgrad_bias_rules(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,

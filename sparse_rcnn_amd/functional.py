@@ -134,6 +134,23 @@ def gemm_rules(X, in_rows, out_rows, prefix_host, n_off, n_out, W, bias, cout, f
     return Y
 
 
+def wgrad_rules_bf16(X, dY, in_rows, out_rows, prefix_host, n_off, flags=0):
+    """scn_wgrad_rules_bf16: dW (fp32) from bf16-stored X and dY -- the weight gradient of the bf16 storage path."""
+    lib = L.lib()
+    for t in (X, dY):
+        if t.dtype != torch.bfloat16 or not t.is_contiguous():
+            raise L.ScnError("wgrad_rules_bf16 takes contiguous torch.bfloat16 operands")
+    cin, cout = X.shape[1], dY.shape[1]
+    nbytes = lib.scn_wgrad_scratch_bytes(cin, cout, prefix_host, n_off)
+    if nbytes < 0:
+        raise L.ScnError("scn_wgrad_scratch_bytes: bad arguments")
+    scratch = L.scratch(nbytes, X.device)
+    dW = torch.empty((n_off, cin, cout), dtype=torch.float32, device=X.device)
+    L.check(lib.scn_wgrad_rules_bf16(L.ptr(X), cin, L.ptr(dY), cout, L.ptr(in_rows), L.ptr(out_rows), prefix_host,
+                                     n_off, L.ptr(dW), L.ptr(scratch), flags, L.stream()))
+    return dW
+
+
 def wgrad_rules(X, dY, in_rows, out_rows, prefix_host, n_off, flags=0):
     lib = L.lib()
     cin, cout = X.shape[1], dY.shape[1]

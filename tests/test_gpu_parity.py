@@ -715,3 +715,26 @@ def test_conv_tiles_split_sum_is_the_same_computation(gpu):
         assert torch.equal(got, ref)
         ks = timer.summary()
         assert ks["k_conv_ts"]["launches"] == 1 and ks["k_conv_ts_sum"]["launches"] == 1
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (8, 16), (48, 80), (128, 64), (256, 256), (23, 7), (130, 33)])
+@pytest.mark.parametrize("relu_in", [False, True])
+def test_wgrad_bf16_storage(gpu, cin, cout, relu_in):
+    """scn_wgrad_rules_bf16: operands stored in bf16, widened exactly, fp32 products and sums -- against the oracle's
+    weight gradient of the same (bf16-representable) operands at the fp32 tolerance, and bit-identical to the fp32
+    kernel fed the widened operands (same arithmetic, same order)."""
+    from sparse_rcnn_amd import functional as F, _lib as L
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=19, cin=8, n=1300, dup=100)
+    rb = x.metadata.subm_rulebook(tuple(int(s) for s in size), 3)
+    n = rb.n
+    g = torch.Generator().manual_seed(cin * 77 + cout)
+    X = torch.randn(n, cin, generator=g).to(torch.bfloat16)
+    G = torch.randn(n, cout, generator=g).to(torch.bfloat16)
+    flags = L.F_RELU_IN if relu_in else 0
+    r = rb.rules
+    dW = F.wgrad_rules_bf16(X.to(gpu), G.to(gpu), r.in_rows, r.out_rows, r.prefix_host, 27, flags)
+    xin = torch.relu(X.float()) if relu_in else X.float()
+    _, dWo, _ = O.conv_bwd(xin, G.float(), scene.subm_rules(0, 3), torch.zeros(27, cin, cout), has_bias=False)
+    _close(dW, dWo, 1e-4, "bf16-storage dW")
+    ref = F.wgrad_rules(X.float().to(gpu), G.float().to(gpu), r.in_rows, r.out_rows, r.prefix_host, 27, flags)
+    assert torch.equal(dW, ref)

@@ -79,6 +79,9 @@ def main():
                          "shape (600k voxels, 5 levels to 512 channels) in fp32, a size check, not the headline")
     ap.add_argument("--profile-all", action="store_true",
                     help="time every GEMM kernel launch of the sampled steps, not only the dominant kernel")
+    ap.add_argument("--bf16-blocks", action="store_true",
+                    help="NOT the headline configuration: the residual units keep features, intermediates and gradients "
+                         "in bf16 (fp32 accumulation, fp32 parameters); strided / 1x1 layers and everything else fp32")
     ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
                     help="build the index structures inside the forward pass instead of one batch ahead on a helper "
                          "thread (scn_pyramid_build on the index stream)")
@@ -116,7 +119,7 @@ def main():
     coords_d, feats_d = coords.to(dev), feats.to(dev)
 
     torch.manual_seed(0)
-    model = Backbone(7, CHANNELS).to(dev)
+    model = Backbone(7, CHANNELS, bf16_blocks=args.bf16_blocks).to(dev)
     flat = FlatParams(model, n_buckets=4)      # N > 1: gradient slices are all-reduced while backward still runs
     broadcast_params(flat)
     gen = torch.Generator(device="cpu").manual_seed(100 + rank)
@@ -213,12 +216,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (residual units: bf16 storage, fp32 accumulate)" if args.bf16_blocks else "f32",
+            "data": "synthetic",
             "config": {"workload": f"BASELINE {cfg_name}: one synthetic ScanNet-shaped scene per GPU, "
                                    f"{n_active} active voxels (grid {GRID[0]}x{GRID[1]}x{GRID[2]}, 1.15 points/voxel), "
                                    "U-Net " + "-".join(map(str, CHANNELS)) + ", 2 pre-act residual blocks/level, 2^3/2 conv+deconv, "
                                    "step = rulebooks + fwd + bwd (+ grad all-reduce + SGD)"
-                                   + ("; rulebooks of batch i+1 built on a helper thread during batch i" if args.prefetch else ""),
+                                   + ("; rulebooks of batch i+1 built on a helper thread during batch i" if args.prefetch else "")
+                                   + ("; NOT the fp32 configuration: residual units on the bf16 storage path" if args.bf16_blocks else ""),
                        "parallelism": f"dp{world} (1 scene/GPU, flat-bucket all-reduce)"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
@@ -231,6 +236,9 @@ def main():
                             "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else None}
                         for k, v in ks.items()},
         }
+        if args.bf16_blocks:         # side measurement: the roofline object of the contract belongs to the fp32 run
+            out["roofline"] = {"note": "mixed-storage side measurement; kernel times in `kernels` (use --profile-all), "
+                                       "roofline of the fp32 configuration: run without --bf16-blocks"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(coords, feats, CHANNELS)
         else:

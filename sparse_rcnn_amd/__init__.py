@@ -11,7 +11,7 @@ from . import ioLayers                                                     # noq
 from ._lib import ScnError, EXPORTS, LIB_PATH, load as load_library          # noqa: F401
 from .ioLayers import InputLayer, OutputLayer                              # noqa: F401
 from .metadata import Metadata                                             # noqa: F401
-from .modules import (AddTable, AveragePooling, BatchNormLeakyReLU, BatchNormReLU, ConcatTable,  # noqa: F401
+from .modules import (AddTable, AveragePooling, BatchNormLeakyReLU, BatchNormReLU, CastFeatures, ConcatTable,  # noqa: F401
                       Convolution, Deconvolution, Identity, JoinTable, MaxPooling, NetworkInNetwork, ReLU,
                       Sequential, SparseToDense, SubmanifoldConvolution)
 from .tensor import SparseConvNetTensor                                    # noqa: F401

@@ -110,9 +110,11 @@ def conv_rules_bf16(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu
     Y = torch.empty((n_out, cout), dtype=torch.bfloat16, device=X.device)
     nbytes = lib.scn_conv_tiles_bf16_scratch_bytes(cin, n_out, cout)
     scratch = L.scratch(nbytes, X.device)
-    L.check(lib.scn_conv_tiles_bf16(L.ptr(X), X.shape[0], cin, L.ptr(tiles.tstab), L.ptr(tiles.tile_mask),
-                                    L.ptr(tiles.perm), L.ptr(tiles.tile_order), tiles.n_off, n_out, L.ptr(W), L.ptr(bias),
-                                    L.ptr(residual), L.ptr(relu_mask), L.ptr(Y), cout, flags, L.ptr(scratch), L.stream()))
+    n_in, n_off = X.shape[0], tiles.n_off
+    profiling.timed("k_conv_tb", 0.0, 0.0, lambda: L.check(lib.scn_conv_tiles_bf16(
+        L.ptr(X), n_in, cin, L.ptr(tiles.tstab), L.ptr(tiles.tile_mask), L.ptr(tiles.perm), L.ptr(tiles.tile_order),
+        n_off, n_out, L.ptr(W), L.ptr(bias), L.ptr(residual), L.ptr(relu_mask), L.ptr(Y), cout, flags, L.ptr(scratch),
+        L.stream())))
     return Y
 
 
@@ -146,8 +148,9 @@ def wgrad_rules_bf16(X, dY, in_rows, out_rows, prefix_host, n_off, flags=0):
         raise L.ScnError("scn_wgrad_scratch_bytes: bad arguments")
     scratch = L.scratch(nbytes, X.device)
     dW = torch.empty((n_off, cin, cout), dtype=torch.float32, device=X.device)
-    L.check(lib.scn_wgrad_rules_bf16(L.ptr(X), cin, L.ptr(dY), cout, L.ptr(in_rows), L.ptr(out_rows), prefix_host,
-                                     n_off, L.ptr(dW), L.ptr(scratch), flags, L.stream()))
+    profiling.timed("k_wgrad_rules_bf16", 0.0, 0.0, lambda: L.check(lib.scn_wgrad_rules_bf16(
+        L.ptr(X), cin, L.ptr(dY), cout, L.ptr(in_rows), L.ptr(out_rows), prefix_host, n_off, L.ptr(dW), L.ptr(scratch),
+        flags, L.stream())))
     return dW
 
 
@@ -351,6 +354,51 @@ class ResidualBlockFunction(torch.autograd.Function):
             dX = conv_rules(dY1, rb.tiles, rb.n, W1, None, W1.shape[1], back | L.F_RESIDUAL_LAST, relu_mask=X,
                             residual=dY, n_rules=r.count)
         dW1, db1 = _on_leaf_stream(dY1, lambda: wgrad(X, dY1, W1, need[1], ctx.has_b1 and need[2]))
+        return dX, dW1, db1, dW2, db2, None, None
+
+
+class ResidualBlockFunctionBF16(torch.autograd.Function):
+    """ResidualBlockFunction for bf16-STORED features (BASELINE configs 3-5): x, the intermediate h, the
+    result and every gradient tensor of the block are torch.bfloat16; the parameters stay fp32 (rounded to bf16 as
+    they are staged into LDS) and their gradients come back fp32.  Six launches: scn_conv_tiles_bf16 x 4 (two forward,
+    two backward-data with the ReLU mask / the skip gradient in the epilogue) and scn_wgrad_rules_bf16 x 2."""
+
+    @staticmethod
+    def forward(ctx, features, w1, b1, w2, b2, metadata: Metadata, spatial_size):
+        if features.dtype != torch.bfloat16:
+            raise L.ScnError("ResidualBlockFunctionBF16 takes torch.bfloat16 features")
+        if features.shape[1] % 8 != 0 or w1.shape[-1] % 8 != 0:
+            raise L.ScnError("bf16 storage needs channel counts that are multiples of 8 (16-byte row pieces)")
+        X = features.contiguous()
+        W1, W2 = _f32(w1), _f32(w2)
+        rb = metadata.subm_rulebook(spatial_size, 3)
+        B1 = _f32(b1) if b1 is not None else None
+        B2 = _f32(b2) if b2 is not None else None
+        Y1 = conv_rules_bf16(X, rb.tiles, rb.n, W1, B1, W1.shape[-1], L.F_RELU_IN)
+        Y = conv_rules_bf16(Y1, rb.tiles, rb.n, W2, B2, W2.shape[-1], L.F_RELU_IN, residual=X)
+        ctx.save_for_backward(X, Y1, W1, W2)
+        ctx.rb, ctx.has_b1, ctx.has_b2 = rb, b1 is not None, b2 is not None
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        X, Y1, W1, W2 = ctx.saved_tensors
+        rb, r = ctx.rb, ctx.rb.rules
+        dY = dY.to(torch.bfloat16).contiguous()
+        need = ctx.needs_input_grad
+        back = L.F_W_TRANSPOSED | L.F_OFF_REVERSE
+        dY1 = conv_rules_bf16(dY, rb.tiles, rb.n, W2, None, W2.shape[1], back, relu_mask=Y1)
+
+        def wgrad(Xin, G, W, want_w, want_b):
+            dW = wgrad_rules_bf16(Xin, G, r.in_rows, r.out_rows, r.prefix_host, 27, L.F_RELU_IN).view_as(W) \
+                if want_w else None
+            return dW, (torch.sum(G, dim=0, dtype=torch.float32) if want_b else None)
+        dW2, db2 = wgrad(Y1, dY, W2, need[3], ctx.has_b2 and need[4])
+        dX = None
+        if need[0]:
+            dX = conv_rules_bf16(dY1, rb.tiles, rb.n, W1, None, W1.shape[1], back | L.F_RESIDUAL_LAST, relu_mask=X,
+                                 residual=dY)
+        dW1, db1 = wgrad(X, dY1, W1, need[1], ctx.has_b1 and need[2])
         return dX, dW1, db1, dW2, db2, None, None
 
 

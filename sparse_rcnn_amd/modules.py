@@ -53,8 +53,10 @@ class Sequential(torch.nn.Sequential):
                 a, inner = list(m._modules.values())
                 if type(a) is Identity and type(inner) is Sequential and inner._is_plain_residual_branch(input):
                     c1, c2 = inner._modules["1"], inner._modules["3"]          # ReLU, SubM3, ReLU, SubM3
-                    y = F.ResidualBlockFunction.apply(input.features, c1.weight, c1.bias, c2.weight, c2.bias,
-                                                      input.metadata, input.spatial_size)
+                    fn = (F.ResidualBlockFunctionBF16 if input.features.dtype == torch.bfloat16
+                          else F.ResidualBlockFunction)                        # bf16-stored features: CastFeatures
+                    y = fn.apply(input.features, c1.weight, c1.bias, c2.weight, c2.bias,
+                                 input.metadata, input.spatial_size)
                     input = _out(input, y)
                     i += 2
                     continue
@@ -99,6 +101,19 @@ import os as _os
 FUSE_RELU = True
 FUSE_ADD = _os.environ.get("SCN_FUSE_ADD", "1") != "0"     # developer switch (tools/ab_bench.py)
 FUSE_BLOCK = _os.environ.get("SCN_FUSE_BLOCK", "1") != "0"
+
+
+class CastFeatures(Module):
+    """Storage dtype of the feature slab (not a reference module): `CastFeatures(torch.bfloat16)` in front of a run of
+    residual units and `CastFeatures(torch.float32)` behind it puts those units on the bf16 storage path
+    (ResidualBlockFunctionBF16); every other layer takes fp32 features."""
+
+    def __init__(self, dtype):
+        super().__init__()
+        self.dtype = dtype
+
+    def forward(self, input):
+        return _out(input, input.features.to(self.dtype))
 
 
 class ConcatTable(Sequential):

@@ -35,9 +35,15 @@ class SparseUNet(nn.Module):
     """forward(SparseConvNetTensor with Cin channels) -> SparseConvNetTensor with channels[0] channels at full
     resolution; ``.interims`` holds the encoder outputs (the reference's SequentialInterims, custom_container.py:5-12)."""
 
-    def __init__(self, cin=7, channels=(32, 64, 128, 256), num_units=2, batchnorm=False):
+    def __init__(self, cin=7, channels=(32, 64, 128, 256), num_units=2, batchnorm=False, bf16_blocks=False):
         super().__init__()
         self.channels = tuple(channels)
+        # bf16_blocks: the residual units (28 of the 44 convolutions) keep their features, intermediates and gradients
+        # in bf16 (functional.ResidualBlockFunctionBF16); the strided / 1x1 layers between them stay fp32, with one
+        # cast on either side of a run of units.  Not the reference's arithmetic: BASELINE configs 3-5 (SURVEY H7).
+        self.bf16_blocks = bool(bf16_blocks)
+        if self.bf16_blocks and (batchnorm or any(c % 8 for c in self.channels)):
+            raise ValueError("bf16_blocks needs channel counts that are multiples of 8 and no batch norm")
         enc = []
         for l, c in enumerate(self.channels):
             head = (M.SubmanifoldConvolution(3, cin, c, 1, True) if l == 0
@@ -58,13 +64,18 @@ class SparseUNet(nn.Module):
         x.metadata.build_pyramid(x.spatial_size, len(self.channels), 3)
         interims = []
         for level in self.encoder:
-            x = level(x)
+            x = self._units(level[1], level[0](x))
             interims.append(x)
         self.interims = interims
         for i, d in enumerate(self.decoder):
             skip = interims[len(self.channels) - 2 - i]
-            x = d["units"](d["nin"](d["join"]([d["up"](x), skip])))
+            x = self._units(d["units"], d["nin"](d["join"]([d["up"](x), skip])))
         return x
+
+    def _units(self, seq, x):
+        if not self.bf16_blocks:
+            return seq(x)
+        return M.CastFeatures(torch.float32)(seq(M.CastFeatures(torch.bfloat16)(x)))
 
     # parameter naming shared with oracle.scn_oracle.unet_param_shapes (test infrastructure maps by these names)
     def named_oracle_params(self):
@@ -96,9 +107,9 @@ class SparseUNet(nn.Module):
 class Backbone(nn.Module):
     """InputLayer(mode 4) + SparseUNet: what model.py:414-431 runs for sparse + include_unet."""
 
-    def __init__(self, cin=7, channels=(32, 64, 128, 256), num_units=2, batchnorm=False):
+    def __init__(self, cin=7, channels=(32, 64, 128, 256), num_units=2, batchnorm=False, bf16_blocks=False):
         super().__init__()
-        self.unet = SparseUNet(cin, channels, num_units, batchnorm)
+        self.unet = SparseUNet(cin, channels, num_units, batchnorm, bf16_blocks)
 
     # How a forward without prepared metadata builds its index structures: False = step by step from Python (row-count
     # waits overlapped with kernel queueing: faster when nothing else can run meanwhile), True = one scn_pyramid_build

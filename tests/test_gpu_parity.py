@@ -738,3 +738,70 @@ def test_wgrad_bf16_storage(gpu, cin, cout, relu_in):
     _close(dW, dWo, 1e-4, "bf16-storage dW")
     ref = F.wgrad_rules(X.float().to(gpu), G.float().to(gpu), r.in_rows, r.out_rows, r.prefix_host, 27, flags)
     assert torch.equal(dW, ref)
+
+
+def _bf16r(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("c", [32, 64, 24])
+def test_residual_block_bf16_storage(gpu, c):
+    """functional.ResidualBlockFunctionBF16 (bf16-stored x, h, y and gradients; fp32 parameters) against the oracle
+    evaluated with the same storage roundings: h = bf16(conv1(relu x)), y = bf16(x + conv2(relu h)), weights rounded to
+    bf16 for the feature path.  Forward within 2^-6 of the output scale (two roundings), gradients by relative L2."""
+    scn = _scn()
+    from sparse_rcnn_amd.unet import residual_block
+    _, coords, feats, fg, x, scene, size = _input(gpu, seed=23, cin=8, n=1400, dup=120)
+    n = scene.n(0)
+    rules = scene.subm_rules(0, 3)
+    g = torch.Generator().manual_seed(c)
+    X = torch.randn(n, c, generator=g).to(torch.bfloat16)
+    block = residual_block(c).to(gpu)
+    convs = [m for m in block.modules() if isinstance(m, scn.SubmanifoldConvolution)]
+    with torch.no_grad():
+        for m in convs:
+            m.bias.normal_(0, 0.3)
+    xg = X.to(gpu).requires_grad_()
+    xin = scn.SparseConvNetTensor(features=xg, metadata=x.metadata, spatial_size=x.spatial_size)
+    y = block(xin).features
+    assert y.dtype == torch.bfloat16
+    W1, b1, W2, b2 = (convs[0].weight.detach().cpu(), convs[0].bias.detach().cpu(), convs[1].weight.detach().cpu(),
+                      convs[1].bias.detach().cpu())
+    Xo = X.float().requires_grad_()
+    W1o, W2o = _bf16r(W1).view(27, c, c).requires_grad_(), _bf16r(W2).view(27, c, c).requires_grad_()
+    b1o, b2o = b1.clone().requires_grad_(), b2.clone().requires_grad_()
+    h = O.conv(torch.relu(Xo), W1o, b1o, rules, n)
+    hq = h + (_bf16r(h.detach()) - h.detach())                                  # storage rounding, straight-through
+    yo = Xo + O.conv(torch.relu(hq), W2o, b2o, rules, n)
+    _close(y.float(), _bf16r(yo.detach()), 2.0 ** -6, "bf16 block fwd")
+    G = torch.randn(n, c, generator=g).to(torch.bfloat16)
+    got = torch.autograd.grad(y, (xg, convs[0].weight, convs[0].bias, convs[1].weight, convs[1].bias), G.to(gpu))
+    exp = torch.autograd.grad(yo, (Xo, W1o, b1o, W2o, b2o), G.float())
+    for a, e, name in zip(got, exp, ("dX", "dW1", "db1", "dW2", "db2")):
+        a, e = a.detach().float().cpu().double().reshape(-1), e.double().reshape(-1)
+        l2 = ((a - e).norm() / e.norm().clamp_min(1e-12)).item()
+        assert l2 <= 2e-2, f"{name}: relative L2 {l2:.2e}"                      # bf16 gradients: 2^-8 per stored value
+
+
+def test_backbone_with_bf16_blocks_tracks_the_fp32_backbone(gpu):
+    """Backbone(bf16_blocks=True): residual units on the bf16 storage path, the rest fp32.  Same parameters as an fp32
+    backbone: outputs and parameter gradients agree to bf16 accuracy (relative L2), everything finite."""
+    from sparse_rcnn_amd.unet import Backbone
+    coords, size, batch = _cloud(29, grid=(32, 32, 16), n=3000, batch=2, dup=300)
+    feats = torch.randn(len(coords), 7, generator=torch.Generator().manual_seed(3)).to(gpu)
+    torch.manual_seed(1)
+    ref = Backbone(7, (16, 24, 32)).to(gpu)
+    mix = Backbone(7, (16, 24, 32), bf16_blocks=True).to(gpu)
+    mix.load_state_dict(ref.state_dict())
+    outs = []
+    for net in (ref, mix):
+        out = net(coords, feats, size, batch).features
+        assert out.dtype == torch.float32
+        out.backward(torch.ones_like(out))
+        outs.append(out.detach())
+    l2 = ((outs[1] - outs[0]).norm() / outs[0].norm()).item()
+    assert torch.isfinite(outs[1]).all() and l2 < 3e-2, l2
+    for (k, p), q in zip(ref.named_parameters(), mix.parameters()):
+        assert torch.isfinite(q.grad).all(), k
+        rel = ((q.grad - p.grad).norm() / p.grad.norm().clamp_min(1e-12)).item()
+        assert rel < 0.1, (k, rel)

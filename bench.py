@@ -79,6 +79,9 @@ def main():
                          "shape (600k voxels, 5 levels to 512 channels) in fp32, a size check, not the headline")
     ap.add_argument("--profile-all", action="store_true",
                     help="time every GEMM kernel launch of the sampled steps, not only the dominant kernel")
+    ap.add_argument("--bf16-all", action="store_true",
+                    help="NOT the headline configuration: as --bf16-blocks, and every other layer after the first 1x1 "
+                         "convolution keeps bf16 features too (fp32 arithmetic in the strided / 1x1 GEMMs)")
     ap.add_argument("--bf16-blocks", action="store_true",
                     help="NOT the headline configuration: the residual units keep features, intermediates and gradients "
                          "in bf16 (fp32 accumulation, fp32 parameters); strided / 1x1 layers and everything else fp32")
@@ -119,7 +122,8 @@ def main():
     coords_d, feats_d = coords.to(dev), feats.to(dev)
 
     torch.manual_seed(0)
-    model = Backbone(7, CHANNELS, bf16_blocks=args.bf16_blocks).to(dev)
+    model = Backbone(7, CHANNELS, bf16_blocks="all" if args.bf16_all else args.bf16_blocks).to(dev)
+    args.bf16_blocks = args.bf16_blocks or args.bf16_all
     flat = FlatParams(model, n_buckets=4)      # N > 1: gradient slices are all-reduced while backward still runs
     broadcast_params(flat)
     gen = torch.Generator(device="cpu").manual_seed(100 + rank)
@@ -152,7 +156,7 @@ def main():
     # launch of every step timed cost 1-3.5 ms/step (host-bound, and each event pair fences the queue), all four GEMM
     # kernels on every 5th step still ~0.5 ms/step.  --profile-all times all GEMM kernels (the "kernels" table).
     every = max(5, (args.steps + 2) // 3)
-    timer = profiling.KernelTimer(every=every, names=None if args.profile_all else {"k_conv_ts"})
+    timer = profiling.KernelTimer(every=every, names=None if args.profile_all else {"k_conv_ts", "k_conv_tb"})
     for w in range(args.warmup):
         if w == args.warmup - 1:                    # count the launches of one step to size the event pool
             timer.count_only = True
@@ -216,7 +220,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (residual units: bf16 storage, fp32 accumulate)" if args.bf16_blocks else "f32",
+            "dtype": ("bf16 storage after the first layer, fp32 accumulate" if args.bf16_all else
+                      "f32 (residual units: bf16 storage, fp32 accumulate)") if args.bf16_blocks else "f32",
             "data": "synthetic",
             "config": {"workload": f"BASELINE {cfg_name}: one synthetic ScanNet-shaped scene per GPU, "
                                    f"{n_active} active voxels (grid {GRID[0]}x{GRID[1]}x{GRID[2]}, 1.15 points/voxel), "

@@ -231,6 +231,15 @@ int scn_wgrad_rules(const float* X, int cin, const float* dY, int cout, const in
  * the bit mask db_offsets of dY[out_p][c].  The caller names offsets whose rule lists together contain every output row
  * exactly once (centre offset of a submanifold conv: 1 << (k^3/2); all offsets of a Deconvolution; the identity list),
  * so db equals the column sum of dY.  Any channel count (rows that are not 16-byte aligned take element-wise loads). */
+/* bf16-storage forms of scn_gemm_table / scn_gemm_rules (features, residual, relu_mask and Y are uint16 bf16 bit
+ * patterns; W and bias fp32; rows are widened exactly and the arithmetic is the fp32 kernels'; one rounding of Y). */
+int scn_gemm_table_bf16(const uint16_t* X, int64_t n_in, int cin, const int32_t* table, int n_off, int64_t n_out,
+                        const float* W, const float* bias, const uint16_t* residual, const uint16_t* relu_mask,
+                        uint16_t* Y, int cout, int flags, scn_stream_t stream);
+int scn_gemm_rules_bf16(const uint16_t* X, int cin, const int32_t* in_rows, const int32_t* out_rows,
+                        const int64_t* prefix_host, int n_off, const float* W, const float* bias,
+                        const uint16_t* relu_mask, uint16_t* Y, int cout, int flags, scn_stream_t stream);
+
 /* The same weight gradient for bf16-stored operands (X, dY: uint16 bit patterns; dW fp32): rows are gathered packed
  * and widened to fp32 in registers (exact), arithmetic and summation order are those of scn_wgrad_rules.  Scratch:
  * scn_wgrad_scratch_bytes. */

@@ -29,13 +29,26 @@ __device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >
 // One offset's contribution of a 32-row x 32-col tile:  acc += in(Xrow[0..cin)) . Wo[:, n0..n0+32)
 //   xrow : this lane's gathered input row (valid iff have)
 //   Wo   : weight matrix of this offset; !WT: [cin][cout] row-major;  WT: [cout][cin] row-major (used transposed)
-template <bool FAST, bool WT>
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+
+// HB: the feature rows are bf16 (uint16 bit patterns; `xrow` then points at uint16 data) and are widened exactly; the
+// weights stay fp32 and the arithmetic is the fp32 kernel's.
+template <bool FAST, bool WT, bool HB = false>
 __device__ __forceinline__ void tile_mac(f32x16& acc, const float* __restrict__ xrow, bool have, int cin,
                                          const float* __restrict__ Wo, int cout, int n, bool n_ok, int h, bool relu_in) {
-    if (FAST) {   // cin % 8 == 0, rows 16-B aligned
+    const unsigned short* xh = (const unsigned short*)xrow;
+    if (FAST) {   // cin % 8 == 0, rows 16-B aligned (HB: 8-B pieces)
         for (int q = 0; q < cin; q += 8) {
             const int k0 = q + 4 * h;
-            float4 a = have ? *(const float4*)(xrow + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (HB) {
+                if (have) {
+                    const uint2 r = *(const uint2*)(xh + k0);
+                    a = make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
+                                    __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+                }
+            } else if (have) a = *(const float4*)(xrow + k0);
             if (relu_in) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
             float4 b;
             if (WT) {
@@ -58,7 +71,7 @@ __device__ __forceinline__ void tile_mac(f32x16& acc, const float* __restrict__ 
             for (int e = 0; e < 4; ++e) {
                 const int k = q + 4 * h + e;
                 const bool k_ok = k < cin;
-                float a = (have && k_ok) ? xrow[k] : 0.f;
+                float a = (have && k_ok) ? (HB ? bf16_bits_to_f32(xh[k]) : xrow[k]) : 0.f;
                 if (relu_in) a = fmaxf(a, 0.f);
                 float b = 0.f;
                 if (k_ok && n_ok) b = WT ? Wo[(long long)n * cin + k] : Wo[(long long)k * cout + n];
@@ -71,7 +84,7 @@ __device__ __forceinline__ void tile_mac(f32x16& acc, const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // gemm_table
 // ------------------------------------------------------------------------------------------------
-template <bool FAST, bool WT>
+template <bool FAST, bool WT, bool HB = false>
 __global__ __launch_bounds__(256) void k_gemm_table(const float* __restrict__ X, int cin,
                                                     const int* __restrict__ table, int n_off, long long n_out,
                                                     const float* __restrict__ W, const float* __restrict__ bias,
@@ -101,8 +114,9 @@ __global__ __launch_bounds__(256) void k_gemm_table(const float* __restrict__ X,
         if (o + 1 < n_off) idx_next = row_ok ? table[(long long)(o + 1) * n_out + row] : -1;
         if (__ballot(idx >= 0) == 0ull) continue;  // no rule of this offset touches the tile
         const float* Wo = W + (long long)(rev ? n_off - 1 - o : o) * wstride;
-        const float* xrow = X + (long long)(idx >= 0 ? idx : 0) * cin;
-        tile_mac<FAST, WT>(acc, xrow, idx >= 0, cin, Wo, cout, n, n_ok, h, relu_in);
+        const float* xrow = HB ? (const float*)((const unsigned short*)X + (long long)(idx >= 0 ? idx : 0) * cin)
+                               : X + (long long)(idx >= 0 ? idx : 0) * cin;
+        tile_mac<FAST, WT, HB>(acc, xrow, idx >= 0, cin, Wo, cout, n, n_ok, h, relu_in);
     }
 
     const float bv = (bias && n_ok) ? bias[n] : 0.f;
@@ -112,16 +126,22 @@ __global__ __launch_bounds__(256) void k_gemm_table(const float* __restrict__ X,
         if (r < n_out && n_ok) {
             const long long off = r * cout + n;
             float y = acc[v] + bv;
-            if (residual) y += residual[off];
-            if (relu_mask && !(relu_mask[off] > 0.f)) y = 0.f;
-            Y[off] = y;
+            if (HB) {                                   // residual, mask and result are bf16 too
+                if (residual) y += bf16_bits_to_f32(((const unsigned short*)residual)[off]);
+                if (relu_mask && !(bf16_bits_to_f32(((const unsigned short*)relu_mask)[off]) > 0.f)) y = 0.f;
+                ((unsigned short*)Y)[off] = f32_to_bf16_bits(y);
+            } else {
+                if (residual) y += residual[off];
+                if (relu_mask && !(relu_mask[off] > 0.f)) y = 0.f;
+                Y[off] = y;
+            }
         }
     }
 }
 
-extern "C" int scn_gemm_table(const float* X, int64_t n_in, int cin, const int32_t* table, int n_off, int64_t n_out,
-                              const float* W, const float* bias, const float* residual, const float* relu_mask,
-                              float* Y, int cout, int flags, scn_stream_t stream) {
+static int gemm_table_impl(const float* X, int64_t n_in, int cin, const int32_t* table, int n_off, int64_t n_out,
+                           const float* W, const float* bias, const float* residual, const float* relu_mask,
+                           float* Y, int cout, int flags, scn_stream_t stream, bool hb) {
     SCN_REQUIRE(n_in >= 0 && n_out >= 0 && cin >= 1 && cout >= 1 && n_off >= 1);
     SCN_REQUIRE(table || (n_off == 1 && n_in == n_out));
     if (n_out == 0) return SCN_OK;
@@ -130,16 +150,35 @@ extern "C" int scn_gemm_table(const float* X, int64_t n_in, int cin, const int32
     const bool fast = (cin % 8 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0);
     const bool wt = flags & SCN_F_W_TRANSPOSED;
     dim3 grid((unsigned)cdiv(n_out, 128), (unsigned)cdiv(cout, 32));
-#define LAUNCH_T(F, T)                                                                                        \
-    hipLaunchKernelGGL((k_gemm_table<F, T>), grid, dim3(256), 0, S(stream), X, cin, table, n_off,             \
+#define LAUNCH_T(F, T, H)                                                                                     \
+    hipLaunchKernelGGL((k_gemm_table<F, T, H>), grid, dim3(256), 0, S(stream), X, cin, table, n_off,          \
                        (long long)n_out, W, bias, residual, relu_mask, Y, cout, flags)
-    if (fast && wt) LAUNCH_T(true, true);
-    else if (fast) LAUNCH_T(true, false);
-    else if (wt) LAUNCH_T(false, true);
-    else LAUNCH_T(false, false);
+#define PICK_T(H)                                                                                             \
+    do {                                                                                                      \
+        if (fast && wt) LAUNCH_T(true, true, H);                                                              \
+        else if (fast) LAUNCH_T(true, false, H);                                                              \
+        else if (wt) LAUNCH_T(false, true, H);                                                                \
+        else LAUNCH_T(false, false, H);                                                                       \
+    } while (0)
+    if (hb) PICK_T(true); else PICK_T(false);
+#undef PICK_T
 #undef LAUNCH_T
     SCN_LAUNCH_CHECK();
     return SCN_OK;
+}
+
+extern "C" int scn_gemm_table(const float* X, int64_t n_in, int cin, const int32_t* table, int n_off, int64_t n_out,
+                              const float* W, const float* bias, const float* residual, const float* relu_mask,
+                              float* Y, int cout, int flags, scn_stream_t stream) {
+    return gemm_table_impl(X, n_in, cin, table, n_off, n_out, W, bias, residual, relu_mask, Y, cout, flags, stream, false);
+}
+
+// bf16 STORAGE of the features (X, residual, relu_mask, Y: uint16 bit patterns); W, bias fp32; fp32 arithmetic.
+extern "C" int scn_gemm_table_bf16(const uint16_t* X, int64_t n_in, int cin, const int32_t* table, int n_off,
+                                   int64_t n_out, const float* W, const float* bias, const uint16_t* residual,
+                                   const uint16_t* relu_mask, uint16_t* Y, int cout, int flags, scn_stream_t stream) {
+    return gemm_table_impl((const float*)X, n_in, cin, table, n_off, n_out, W, bias, (const float*)residual,
+                           (const float*)relu_mask, (float*)Y, cout, flags, stream, true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -151,7 +190,7 @@ struct SegTiles {
     int n_off;
 };
 
-template <bool FAST, bool WT>
+template <bool FAST, bool WT, bool HB = false>
 __global__ __launch_bounds__(256) void k_gemm_rules(const float* __restrict__ X, int cin,
                                                     const int* __restrict__ in_rows, const int* __restrict__ out_rows,
                                                     SegTiles seg, const float* __restrict__ W,
@@ -177,8 +216,9 @@ __global__ __launch_bounds__(256) void k_gemm_rules(const float* __restrict__ X,
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.f;
     const float* Wo = W + (long long)o * cin * cout;
-    const float* xrow = X + (long long)(idx >= 0 ? idx : 0) * cin;
-    tile_mac<FAST, WT>(acc, xrow, idx >= 0, cin, Wo, cout, n, n_ok, h, flags & SCN_F_RELU_IN);
+    const float* xrow = HB ? (const float*)((const unsigned short*)X + (long long)(idx >= 0 ? idx : 0) * cin)
+                           : X + (long long)(idx >= 0 ? idx : 0) * cin;
+    tile_mac<FAST, WT, HB>(acc, xrow, idx >= 0, cin, Wo, cout, n, n_ok, h, flags & SCN_F_RELU_IN);
 
     const float bv = (bias && n_ok) ? bias[n] : 0.f;
 #pragma unroll
@@ -187,8 +227,13 @@ __global__ __launch_bounds__(256) void k_gemm_rules(const float* __restrict__ X,
         if (r >= 0 && n_ok) {
             const long long off = (long long)r * cout + n;
             float y = acc[v] + bv;
-            if (relu_mask && !(relu_mask[off] > 0.f)) y = 0.f;
-            Y[off] = y;
+            if (HB) {
+                if (relu_mask && !(bf16_bits_to_f32(((const unsigned short*)relu_mask)[off]) > 0.f)) y = 0.f;
+                ((unsigned short*)Y)[off] = f32_to_bf16_bits(y);
+            } else {
+                if (relu_mask && !(relu_mask[off] > 0.f)) y = 0.f;
+                Y[off] = y;
+            }
         }
     }
 }
@@ -206,9 +251,9 @@ static int make_seg_tiles(const int64_t* prefix_host, int n_off, int tile, SegTi
     return SCN_OK;
 }
 
-extern "C" int scn_gemm_rules(const float* X, int cin, const int32_t* in_rows, const int32_t* out_rows,
-                              const int64_t* prefix_host, int n_off, const float* W, const float* bias,
-                              const float* relu_mask, float* Y, int cout, int flags, scn_stream_t stream) {
+static int gemm_rules_impl(const float* X, int cin, const int32_t* in_rows, const int32_t* out_rows,
+                           const int64_t* prefix_host, int n_off, const float* W, const float* bias,
+                           const float* relu_mask, float* Y, int cout, int flags, scn_stream_t stream, bool hb) {
     SCN_REQUIRE(prefix_host && n_off >= 1 && n_off <= 32 && cin >= 1 && cout >= 1);
     SegTiles seg;
     SCN_REQUIRE(make_seg_tiles(prefix_host, n_off, 32, seg) == SCN_OK);
@@ -218,16 +263,35 @@ extern "C" int scn_gemm_rules(const float* X, int cin, const int32_t* in_rows, c
     const bool fast = (cin % 8 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0);
     const bool wt = flags & SCN_F_W_TRANSPOSED;
     dim3 grid((unsigned)cdiv(tiles, 4), (unsigned)cdiv(cout, 32));
-#define LAUNCH_R(F, T)                                                                                        \
-    hipLaunchKernelGGL((k_gemm_rules<F, T>), grid, dim3(256), 0, S(stream), X, cin, in_rows, out_rows, seg, W, \
-                       bias, relu_mask, Y, cout, flags)
-    if (fast && wt) LAUNCH_R(true, true);
-    else if (fast) LAUNCH_R(true, false);
-    else if (wt) LAUNCH_R(false, true);
-    else LAUNCH_R(false, false);
+#define LAUNCH_R(F, T, H)                                                                                     \
+    hipLaunchKernelGGL((k_gemm_rules<F, T, H>), grid, dim3(256), 0, S(stream), X, cin, in_rows, out_rows, seg, \
+                       W, bias, relu_mask, Y, cout, flags)
+#define PICK_R(H)                                                                                             \
+    do {                                                                                                      \
+        if (fast && wt) LAUNCH_R(true, true, H);                                                              \
+        else if (fast) LAUNCH_R(true, false, H);                                                              \
+        else if (wt) LAUNCH_R(false, true, H);                                                                \
+        else LAUNCH_R(false, false, H);                                                                       \
+    } while (0)
+    if (hb) PICK_R(true); else PICK_R(false);
+#undef PICK_R
 #undef LAUNCH_R
     SCN_LAUNCH_CHECK();
     return SCN_OK;
+}
+
+extern "C" int scn_gemm_rules(const float* X, int cin, const int32_t* in_rows, const int32_t* out_rows,
+                              const int64_t* prefix_host, int n_off, const float* W, const float* bias,
+                              const float* relu_mask, float* Y, int cout, int flags, scn_stream_t stream) {
+    return gemm_rules_impl(X, cin, in_rows, out_rows, prefix_host, n_off, W, bias, relu_mask, Y, cout, flags, stream,
+                           false);
+}
+
+extern "C" int scn_gemm_rules_bf16(const uint16_t* X, int cin, const int32_t* in_rows, const int32_t* out_rows,
+                                   const int64_t* prefix_host, int n_off, const float* W, const float* bias,
+                                   const uint16_t* relu_mask, uint16_t* Y, int cout, int flags, scn_stream_t stream) {
+    return gemm_rules_impl((const float*)X, cin, in_rows, out_rows, prefix_host, n_off, W, bias,
+                           (const float*)relu_mask, (float*)Y, cout, flags, stream, true);
 }
 
 // ------------------------------------------------------------------------------------------------

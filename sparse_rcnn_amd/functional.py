@@ -26,6 +26,20 @@ def _new(shape, like, dtype=torch.float32):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
 
+def _feat(t: torch.Tensor) -> torch.Tensor:
+    """Feature slab of a conv-type layer: fp32, or bf16 STORAGE (BASELINE configs 3-5: the bf16 entry points of the
+    library; parameters and their gradients stay fp32)."""
+    if t.dtype == torch.bfloat16:
+        if not t.is_cuda:
+            raise L.ScnError("feature tensors must live on the MI355X (no CPU fallback)")
+        return t.contiguous()
+    return _f32(t)
+
+
+def _is_bf16(t):
+    return t.dtype == torch.bfloat16
+
+
 # ------------------------------------------------------------------------------------------------------
 # raw kernels (no autograd)
 # ------------------------------------------------------------------------------------------------------
@@ -45,13 +59,14 @@ def gemm_table(X, table, n_off, n_out, W, bias, cout, flags=0, residual=None, re
     accounting, evaluated when a profile is summarised."""
     lib = L.lib()
     cin = X.shape[1]
-    Y = _new((n_out, cout), X)
+    Y = _new((n_out, cout), X, X.dtype)
     n_in = X.shape[0]
     P = (lambda: n_out) if n_rules is None else (lambda: _count(n_rules))
+    entry = lib.scn_gemm_table_bf16 if _is_bf16(X) else lib.scn_gemm_table       # bf16 storage: same arithmetic
 
     def run():
-        L.check(lib.scn_gemm_table(L.ptr(X), X.shape[0], cin, L.ptr(table), n_off, n_out, L.ptr(W), L.ptr(bias),
-                                   L.ptr(residual), L.ptr(relu_mask), L.ptr(Y), cout, flags, L.stream()))
+        L.check(entry(L.ptr(X), X.shape[0], cin, L.ptr(table), n_off, n_out, L.ptr(W), L.ptr(bias),
+                      L.ptr(residual), L.ptr(relu_mask), L.ptr(Y), cout, flags, L.stream()))
     profiling.timed("k_gemm_table", lambda: 2.0 * P() * cin * cout,
                     lambda: _conv_bytes(n_in, cin, n_out, cout, n_off, P()), run)
     return Y
@@ -72,6 +87,8 @@ def _conv_tiles_scratch_bytes(cin, n_out, cout):
 
 def conv_rules(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu_mask=None, n_rules=0):
     """The hot kernel: output-stationary convolution over mask-sorted tiles (scn_conv_tiles)."""
+    if _is_bf16(X):
+        return conv_rules_bf16(X, tiles, n_out, W, bias, cout, flags, residual, relu_mask)
     lib = L.lib()
     cin = X.shape[1]
     Y = _new((n_out, cout), X)
@@ -125,13 +142,14 @@ USE_TILES = True
 
 def gemm_rules(X, in_rows, out_rows, prefix_host, n_off, n_out, W, bias, cout, flags=0, relu_mask=None):
     lib = L.lib()
-    Y = _new((n_out, cout), X)
+    Y = _new((n_out, cout), X, X.dtype)
     cin = X.shape[1]
     P = int(prefix_host[n_off] - prefix_host[0])
+    entry = lib.scn_gemm_rules_bf16 if _is_bf16(X) else lib.scn_gemm_rules
 
     def run():
-        L.check(lib.scn_gemm_rules(L.ptr(X), cin, L.ptr(in_rows), L.ptr(out_rows), prefix_host, n_off, L.ptr(W),
-                                   L.ptr(bias), L.ptr(relu_mask), L.ptr(Y), cout, flags, L.stream()))
+        L.check(entry(L.ptr(X), cin, L.ptr(in_rows), L.ptr(out_rows), prefix_host, n_off, L.ptr(W),
+                      L.ptr(bias), L.ptr(relu_mask), L.ptr(Y), cout, flags, L.stream()))
     profiling.timed("k_gemm_rules", 2.0 * P * cin * cout, _conv_bytes(X.shape[0], cin, n_out, cout, n_off, P), run)
     return Y
 
@@ -155,6 +173,8 @@ def wgrad_rules_bf16(X, dY, in_rows, out_rows, prefix_host, n_off, flags=0):
 
 
 def wgrad_rules(X, dY, in_rows, out_rows, prefix_host, n_off, flags=0):
+    if _is_bf16(X):
+        return wgrad_rules_bf16(X, dY, in_rows, out_rows, prefix_host, n_off, flags)
     lib = L.lib()
     cin, cout = X.shape[1], dY.shape[1]
     nbytes = lib.scn_wgrad_scratch_bytes(cin, cout, prefix_host, n_off)
@@ -174,6 +194,8 @@ def wgrad_rules(X, dY, in_rows, out_rows, prefix_host, n_off, flags=0):
 
 def wgrad_bias_rules(X, dY, in_rows, out_rows, prefix_host, n_off, db_offsets, flags=0):
     """dW and db in one pass (scn_wgrad_bias_rules)."""
+    if _is_bf16(X):
+        return wgrad_rules_bf16(X, dY, in_rows, out_rows, prefix_host, n_off, flags), colsum(dY)
     cin, cout = X.shape[1], dY.shape[1]
     lib = L.lib()
     nbytes = lib.scn_wgrad_scratch_bytes(cin, cout, prefix_host, n_off)
@@ -190,6 +212,8 @@ def wgrad_bias_rules(X, dY, in_rows, out_rows, prefix_host, n_off, db_offsets, f
 
 
 def colsum(dY):
+    if _is_bf16(dY):
+        return torch.sum(dY, dim=0, dtype=torch.float32)
     lib = L.lib()
     c = dY.shape[1]
     scratch = _new((L.COLSUM_BLOCKS * c,), dY)
@@ -257,12 +281,12 @@ class SubmanifoldConvolutionFunction(torch.autograd.Function):
     def forward(ctx, features, weight, bias, metadata: Metadata, spatial_size, k, relu_in=False, residual=None):
         """residual (optional, [N, Cout]): added in the kernel epilogue -- the AddTable of a residual block fused
         (module_factory.py:51-57: Sequential(ConcatTable(Identity, inner), AddTable))."""
-        X, W = _f32(features), _f32(weight)
+        X, W = _feat(features), _f32(weight)
         rb = metadata.subm_rulebook(spatial_size, k)
         n_off = k ** 3
         cout = W.shape[-1]
         b = _f32(bias) if bias is not None else None
-        R = _f32(residual) if residual is not None else None
+        R = _feat(residual) if residual is not None else None
         if USE_TILES and rb.rules is not None:
             Y = conv_rules(X, rb.tiles, rb.n, W, b, cout, L.F_RELU_IN if relu_in else 0, residual=R,
                            n_rules=rb.rules.count)
@@ -277,7 +301,7 @@ class SubmanifoldConvolutionFunction(torch.autograd.Function):
     def backward(ctx, dY):
         X, W = ctx.saved_tensors
         rb = ctx.rb
-        dY = _f32(dY)
+        dY = _feat(dY)
         n_off = rb.k ** 3
         cin = X.shape[1]
         fl = L.F_RELU_IN if ctx.relu_in else 0
@@ -408,7 +432,7 @@ class ResidualBlockFunctionBF16(torch.autograd.Function):
 class ConvolutionFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features, weight, bias, metadata: Metadata, in_size, relu_in=False):
-        X, W = _f32(features), _f32(weight)
+        X, W = _feat(features), _f32(weight)
         rb = metadata.strided_rulebook(in_size)
         b = _f32(bias) if bias is not None else None
         if USE_TILES:
@@ -425,7 +449,7 @@ class ConvolutionFunction(torch.autograd.Function):
     def backward(ctx, dY):
         X, W = ctx.saved_tensors
         rb, r = ctx.rb, ctx.rb.rules
-        dY = _f32(dY)
+        dY = _feat(dY)
         fl = L.F_RELU_IN if ctx.relu_in else 0
         dX = dW = db = None
         if ctx.needs_input_grad[0]:      # dX[f] = dY[parent f] . W[off f]^T : rule list with roles swapped
@@ -448,7 +472,7 @@ class ConvolutionFunction(torch.autograd.Function):
 class DeconvolutionFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features, weight, bias, metadata: Metadata, out_size, relu_in=False):
-        X, W = _f32(features), _f32(weight)
+        X, W = _feat(features), _f32(weight)
         out_size = tuple(int(s) for s in out_size)
         rb = metadata.strided.get(out_size)
         if rb is None:
@@ -466,7 +490,7 @@ class DeconvolutionFunction(torch.autograd.Function):
     def backward(ctx, dY):
         X, W = ctx.saved_tensors
         rb, r = ctx.rb, ctx.rb.rules
-        dY = _f32(dY)
+        dY = _feat(dY)
         fl = L.F_RELU_IN if ctx.relu_in else 0
         dX = dW = db = None
         if ctx.needs_input_grad[0]:      # dX[c] = sum_o dY[child[o][c]] . W[o]^T
@@ -498,7 +522,7 @@ class DeconvolutionFunction(torch.autograd.Function):
 class NetworkInNetworkFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features, weight, bias):
-        X, W = _f32(features), _f32(weight)
+        X, W = _feat(features), _f32(weight)
         b = _f32(bias) if bias is not None else None
         n = X.shape[0]
         Y = gemm_table(X, None, 1, n, W, b, W.shape[-1])
@@ -509,7 +533,7 @@ class NetworkInNetworkFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dY):
         X, W = ctx.saved_tensors
-        dY = _f32(dY)
+        dY = _feat(dY)
         n = X.shape[0]
         dX = dW = db = None
         if ctx.needs_input_grad[0]:

@@ -41,8 +41,12 @@ class SparseUNet(nn.Module):
         # bf16_blocks: the residual units (28 of the 44 convolutions) keep their features, intermediates and gradients
         # in bf16 (functional.ResidualBlockFunctionBF16); the strided / 1x1 layers between them stay fp32, with one
         # cast on either side of a run of units.  Not the reference's arithmetic: BASELINE configs 3-5.
-        self.bf16_blocks = bool(bf16_blocks)
-        if self.bf16_blocks and (batchnorm or any(c % 8 for c in self.channels)):
+        # bf16_blocks="all": every layer after the first 1x1 convolution keeps its features in bf16 (the strided
+        # convolutions, deconvolutions and 1x1 layers through the bf16 entry points of the fp32-arithmetic kernels),
+        # one cast after the first layer and one at the end.
+        self.bf16_all = bf16_blocks == "all"
+        self.bf16_blocks = bool(bf16_blocks) and not self.bf16_all
+        if bf16_blocks and (batchnorm or any(c % 8 for c in self.channels)):
             raise ValueError("bf16_blocks needs channel counts that are multiples of 8 and no batch norm")
         enc = []
         for l, c in enumerate(self.channels):
@@ -63,14 +67,17 @@ class SparseUNet(nn.Module):
     def forward(self, x):
         x.metadata.build_pyramid(x.spatial_size, len(self.channels), 3)
         interims = []
-        for level in self.encoder:
-            x = self._units(level[1], level[0](x))
+        for l, level in enumerate(self.encoder):
+            x = level[0](x)
+            if self.bf16_all and l == 0:
+                x = M.CastFeatures(torch.bfloat16)(x)
+            x = self._units(level[1], x)
             interims.append(x)
         self.interims = interims
         for i, d in enumerate(self.decoder):
             skip = interims[len(self.channels) - 2 - i]
             x = self._units(d["units"], d["nin"](d["join"]([d["up"](x), skip])))
-        return x
+        return M.CastFeatures(torch.float32)(x) if self.bf16_all else x
 
     def _units(self, seq, x):
         if not self.bf16_blocks:

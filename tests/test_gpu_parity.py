@@ -805,3 +805,59 @@ def test_backbone_with_bf16_blocks_tracks_the_fp32_backbone(gpu):
         assert torch.isfinite(q.grad).all(), k
         rel = ((q.grad - p.grad).norm() / p.grad.norm().clamp_min(1e-12)).item()
         assert rel < 0.1, (k, rel)
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 64), (48, 23), (7, 16)])
+def test_small_gemms_bf16_storage_equal_the_fp32_kernels_rounded(gpu, cin, cout):
+    """scn_gemm_table_bf16 / scn_gemm_rules_bf16: bf16-stored features widened exactly, the fp32 kernels' arithmetic,
+    one rounding of the result -- so they equal the fp32 kernels on the widened operands, rounded to bf16, bit for bit
+    (1x1 layer forward / backward-data, Deconvolution forward, Convolution backward-data with the ReLU mask)."""
+    from sparse_rcnn_amd import functional as F, _lib as L
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=31, cin=8, n=1500, dup=100)
+    sz = tuple(int(s) for s in size)
+    sb = x.metadata.strided_rulebook(sz)
+    n, nc, r = sb.n_fine, sb.n_coarse, sb.rules
+    g = torch.Generator().manual_seed(cin + cout)
+    bf = lambda t: t.to(torch.bfloat16)
+    # 1x1
+    X = bf(torch.randn(n, cin, generator=g)).to(gpu); R = bf(torch.randn(n, cout, generator=g)).to(gpu)
+    W = (torch.randn(1, cin, cout, generator=g) * 0.2).to(gpu); b = torch.randn(cout, generator=g).to(gpu)
+    y = F.gemm_table(X, None, 1, n, W, b, cout, residual=R)
+    assert y.dtype == torch.bfloat16
+    assert torch.equal(y, bf(F.gemm_table(X.float(), None, 1, n, W, b, cout, residual=R.float())))
+    G = bf(torch.randn(n, cout, generator=g)).to(gpu)
+    dx = F.gemm_table(G, None, 1, n, W, None, cin, L.F_W_TRANSPOSED)
+    assert torch.equal(dx, bf(F.gemm_table(G.float(), None, 1, n, W, None, cin, L.F_W_TRANSPOSED)))
+    # strided rule lists: Deconvolution forward (coarse -> fine) and Convolution backward-data with the ReLU mask
+    Xc = bf(torch.randn(nc, cin, generator=g)).to(gpu); Wu = (torch.randn(8, cin, cout, generator=g) * 0.2).to(gpu)
+    u = F.gemm_rules(Xc, r.out_rows, r.in_rows, r.prefix_host, 8, n, Wu, b, cout, L.F_RELU_IN)
+    assert torch.equal(u, bf(F.gemm_rules(Xc.float(), r.out_rows, r.in_rows, r.prefix_host, 8, n, Wu, b, cout, L.F_RELU_IN)))
+    Wd = (torch.randn(8, cout, cin, generator=g) * 0.2).to(gpu); M = bf(torch.randn(n, cout, generator=g)).to(gpu)
+    d = F.gemm_rules(Xc, r.out_rows, r.in_rows, r.prefix_host, 8, n, Wd, None, cout, L.F_W_TRANSPOSED, relu_mask=M)
+    assert torch.equal(d, bf(F.gemm_rules(Xc.float(), r.out_rows, r.in_rows, r.prefix_host, 8, n, Wd, None, cout,
+                                         L.F_W_TRANSPOSED, relu_mask=M.float())))
+
+
+def test_backbone_with_bf16_features_everywhere_tracks_the_fp32_backbone(gpu):
+    """Backbone(bf16_blocks="all"): every layer after the first 1x1 convolution on bf16-stored features."""
+    from sparse_rcnn_amd.unet import Backbone
+    coords, size, batch = _cloud(37, grid=(32, 32, 16), n=3000, batch=2, dup=300)
+    feats = torch.randn(len(coords), 7, generator=torch.Generator().manual_seed(3)).to(gpu)
+    torch.manual_seed(1)
+    ref = Backbone(7, (16, 24, 32)).to(gpu)
+    mix = Backbone(7, (16, 24, 32), bf16_blocks="all").to(gpu)
+    mix.load_state_dict(ref.state_dict())
+    outs = []
+    for net in (ref, mix):
+        fin = feats.clone().requires_grad_()
+        out = net(coords, fin, size, batch).features
+        assert out.dtype == torch.float32
+        out.backward(torch.ones_like(out))
+        outs.append((out.detach(), fin.grad))
+    l2 = ((outs[1][0] - outs[0][0]).norm() / outs[0][0].norm()).item()
+    assert torch.isfinite(outs[1][0]).all() and l2 < 3e-2, l2
+    assert ((outs[1][1] - outs[0][1]).norm() / outs[0][1].norm()).item() < 0.1
+    for (k, p), q in zip(ref.named_parameters(), mix.parameters()):
+        assert q.grad.dtype == torch.float32 and torch.isfinite(q.grad).all(), k
+        rel = ((q.grad - p.grad).norm() / p.grad.norm().clamp_min(1e-12)).item()
+        assert rel < 0.1, (k, rel)

@@ -544,3 +544,43 @@ def test_fuzz_conv_tiles_bf16(gpu, seed):
     if a.numel():
         err = (a - e).abs().max().item() / max(1.0, e.abs().max().item())
         assert err <= 2.0 ** -7, f"{cfg}: {err:.3e}"
+
+
+@pytest.mark.parametrize("seed", _seeds(1200, 6))
+def test_fuzz_backbone_bf16_storage_modes(gpu, seed):
+    """Backbone with bf16-stored features (residual units only / everything after the first layer) against the fp32
+    backbone with the same parameters, over channel plans (multiples of 8), 2-4 levels and random scenes: outputs within
+    3 % and parameter gradients within 15 % over all parameters (50 % for any single one) in relative L2 -- a bound against gross errors (a wrong kernel gives ~100 %),
+    not a precision claim: bf16 keeps 8 significant bits per stored activation AND gradient value, and an activation
+    within 0.4 % of zero may take the other ReLU branch; the kernels themselves are pinned by the exact tests in
+    test_gpu_parity.py (bit-equality with the fp32 kernels on widened operands, oracle with the same roundings)."""
+    from sparse_rcnn_amd.unet import Backbone
+    rng = np.random.default_rng(seed)
+    channels = [(16, 24), (32, 48, 64), (8, 16, 24, 32), (32, 64, 128), (40, 56, 72)][seed % 5]
+    L = len(channels)
+    grid = tuple(int(rng.integers(1, 3)) << L for _ in range(3))
+    cells = grid[0] * grid[1] * grid[2]
+    n = int(min(cells // 2, rng.choice([500, 2000, 4000])))
+    p = np.stack(np.unravel_index(rng.choice(cells, size=n, replace=False), grid), 1)
+    p = np.concatenate([p, p[rng.integers(0, n, size=n // 8)]]); rng.shuffle(p)
+    coords = torch.from_numpy(np.concatenate([p, np.zeros((len(p), 1), np.int64)], 1).astype(np.int64))
+    feats = torch.randn(len(coords), 7, generator=torch.Generator().manual_seed(seed)).to(gpu)
+    mode = "all" if seed % 2 else True
+    cfg = dict(seed=seed, channels=channels, grid=grid, points=len(coords), mode=mode)
+    torch.manual_seed(seed)
+    ref = Backbone(7, channels).to(gpu)
+    mix = Backbone(7, channels, bf16_blocks=mode).to(gpu)
+    mix.load_state_dict(ref.state_dict())
+    outs = []
+    for net in (ref, mix):
+        out = net(coords, feats, torch.tensor(grid), 1).features
+        out.backward(torch.ones_like(out))
+        outs.append(out.detach())
+    l2 = ((outs[1] - outs[0]).norm() / outs[0].norm().clamp_min(1e-12)).item()
+    assert torch.isfinite(outs[1]).all() and l2 < 3e-2, (cfg, l2)
+    num = den = 0.0
+    for (k, a), b in zip(ref.named_parameters(), mix.parameters()):
+        rel = ((b.grad - a.grad).norm() / a.grad.norm().clamp_min(1e-12)).item()
+        assert torch.isfinite(b.grad).all() and rel < 0.5, (cfg, k, rel)       # (deep levels hold a few dozen rows)
+        num += (b.grad - a.grad).double().pow(2).sum().item(); den += a.grad.double().pow(2).sum().item()
+    assert (num / max(den, 1e-30)) ** 0.5 < 0.15, (cfg, (num / max(den, 1e-30)) ** 0.5)

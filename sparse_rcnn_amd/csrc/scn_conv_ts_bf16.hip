@@ -35,8 +35,8 @@ static constexpr int TB_NW = 16;        // waves per workgroup
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 
-template <bool WT, int NB>
-__global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB == 2 ? 8 : 4))) void k_conv_tb(
+template <bool WT, int NB, int KH>
+__global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB == 2 && KH == 1 ? 8 : 4))) void k_conv_tb(
     const unsigned short* __restrict__ X, long long n_in, int cin, const int* __restrict__ tstab,
     const unsigned* __restrict__ tile_mask, const int* __restrict__ perm, const int* __restrict__ tile_order, int n_off,
     long long nt, const float* __restrict__ W, const float* __restrict__ bias,
@@ -44,12 +44,13 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
     unsigned short* __restrict__ Y, float* __restrict__ slabs, long long n_out, int cout, int flags, int n_chunks,
     int n_kc) {
     constexpr int CT = 16 * NB;
+    constexpr int KC = TB_KC * KH;              // channels per K-chunk: 32, or 64 as two 32-channel planes of the image
     constexpr int THREADS = TB_NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned short Wb[];     // [n_off][CT][32] bf16, then the counter
     const int tid = threadIdx.x, lane = tid & 63;
     const int chunk = blockIdx.x % n_chunks;
     const int kci = (blockIdx.x / n_chunks) % n_kc;
-    const int n0 = chunk * CT, kc = kci * TB_KC;
+    const int n0 = chunk * CT, kc = kci * KC;
     const bool relu_in = flags & SCN_F_RELU_IN;
     const bool rev = flags & SCN_F_OFF_REVERSE;
     const bool res_last = flags & SCN_F_RESIDUAL_LAST;
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
     // ---- tile queue (as in k_conv_ts): the workgroup owns every n_tg-th entry of the LPT order --------------------
     const int tg = blockIdx.x / (n_chunks * n_kc), n_tg = gridDim.x / (n_chunks * n_kc);
     const int n_tiles = (int)((nt - tg + n_tg - 1) / n_tg);
-    int* counter = (int*)(Wb + (size_t)n_off * CT * TB_KC);
+    int* counter = (int*)(Wb + (size_t)n_off * CT * KC);
     if (tid == 0) *counter = 0;
     __syncthreads();
     auto grab = [&]() -> long long {
@@ -78,14 +79,16 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
 
     // ---- stage the weight slice, rounding fp32 -> bf16 ---------------------------------------------------------------
     {
-        const int total4 = n_off * TB_KC * (CT / 4);
+        // image: [o][plane h = k / 32][n][k % 32]: the B fragment reads of a wave for one (column block, plane) are 1 KB
+        // contiguous (conflict-free ds_read_b128) for either K-chunk size
+        const int total4 = n_off * KC * (CT / 4);
         const bool vecn = (cout % 4 == 0), veck = (cin % 4 == 0);
         for (int e = tid; e < total4; e += THREADS) {
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (WT) {                  // layer weight [o][n][k]: k contiguous -> one 8-byte LDS store
-                const int c4 = e & 7, n = (e >> 3) % CT, o = e / (8 * CT);
+                const int c4 = e % (KC / 4), n = (e / (KC / 4)) % CT, o = e / ((KC / 4) * CT);
                 const int wo = rev ? n_off - 1 - o : o;
-                const int k = kc + 4 * c4, ng = n0 + n;
+                const int kl = 4 * c4, k = kc + kl, ng = n0 + n;
                 if (ng < cout) {
                     const float* src = W + ((long long)wo * cout + ng) * cin + k;
                     if (veck && k + 3 < cin) { const float4 t = *(const float4*)src; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
@@ -94,14 +97,14 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
                         for (int u = 0; u < 4; ++u) if (k + u < cin) v[u] = src[u];
                     }
                 }
-                unsigned short* dst = Wb + ((size_t)o * CT + n) * TB_KC + 4 * c4;
+                unsigned short* dst = Wb + (((size_t)o * KH + (kl >> 5)) * CT + n) * TB_KC + (kl & 31);
                 const unsigned lo = f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
                 const unsigned hi = f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
                 *(uint2*)dst = make_uint2(lo, hi);
             } else {                   // [o][k][n]: n contiguous in global -> four 2-byte stores, 64 bytes apart
-                const int c4 = e % (CT / 4), k = (e / (CT / 4)) % TB_KC, o = e / (TB_KC * (CT / 4));
+                const int c4 = e % (CT / 4), kl = (e / (CT / 4)) % KC, o = e / (KC * (CT / 4));
                 const int wo = rev ? n_off - 1 - o : o;
-                const int kg = kc + k, ng = n0 + 4 * c4;
+                const int kg = kc + kl, ng = n0 + 4 * c4;
                 if (kg < cin) {
                     const float* src = W + ((long long)wo * cin + kg) * cout + ng;
                     if (vecn && ng + 3 < cout) { const float4 t = *(const float4*)src; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
@@ -111,13 +114,16 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) Wb[((size_t)o * CT + 4 * c4 + u) * TB_KC + k] = f32_to_bf16(v[u]);
+                for (int u = 0; u < 4; ++u)
+                    Wb[(((size_t)o * KH + (kl >> 5)) * CT + 4 * c4 + u) * TB_KC + (kl & 31)] = f32_to_bf16(v[u]);
             }
         }
     }
     __syncthreads();
 
-    const bool k_ok = kc + 8 * kq + 7 < cin;                        // cin % 8 == 0: a lane's 8 channels are all in or out
+    bool k_ok[KH];                                                  // cin % 8 == 0: a lane's 8 channels are all in or out
+#pragma unroll
+    for (int hh = 0; hh < KH; ++hh) k_ok[hh] = kc + 32 * hh + 8 * kq + 7 < cin;
     const bool single = n_kc == 1;
     float bcol[NB];
     bool n_ok[NB];
@@ -133,13 +139,15 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
     const __amdgpu_buffer_rsrc_t xrsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(unsigned)(n_in * cin * 2), 0x00020000);
     const int row_bytes = cin * 2, lane_boff = (kc + 8 * kq) * 2;
-    const unsigned short* wlane = Wb + (size_t)i * TB_KC + 8 * kq;   // + (o CT + 16 nb) 32
+    const unsigned short* wlane = Wb + (size_t)i * TB_KC + 8 * kq;   // + ((o KH + plane) CT + 16 nb) 32
 
 #define TB_GATHER(IDX, A)                                                                             \
     do {                                                                                             \
-        int off_ = __mul24((IDX), row_bytes) + lane_boff;                                            \
-        off_ = k_ok ? off_ : (int)0xFFFFFFF0;                                                        \
-        A = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off_, 0, 0);                                \
+        const int off_ = __mul24((IDX), row_bytes) + lane_boff;                                      \
+        _Pragma("unroll") for (int hh_ = 0; hh_ < KH; ++hh_) {                                       \
+            const int oh_ = k_ok[hh_] ? off_ + 64 * hh_ : (int)0xFFFFFFF0;                           \
+            A[hh_] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, oh_, 0, 0);                        \
+        }                                                                                            \
     } while (0)
 
     // one pipeline step: index of the offset five ahead, rows of the offset three ahead, MFMAs on the oldest set
@@ -149,13 +157,15 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
         if (m) { o4_ = __builtin_ctz(m); m &= m - 1; olast = o4_; }                                  \
         INEW = tb_s[olast * TB_T + i];                                                               \
         TB_GATHER(IOLD, GSET);                                                                       \
-        s16x8 a_ = __builtin_bit_cast(s16x8, CUR);                                                   \
-        if (relu_in) a_ = __builtin_elementwise_max(a_, (s16x8){0, 0, 0, 0, 0, 0, 0, 0});            \
-        const bf16x8 af_ = __builtin_bit_cast(bf16x8, a_);                                           \
-        const unsigned short* wo_ = wlane + (size_t)oq0 * (CT * TB_KC);                              \
-        _Pragma("unroll") for (int nb_ = 0; nb_ < NB; ++nb_) {                                       \
-            const bf16x8 bf_ = *(const bf16x8*)(wo_ + nb_ * 16 * TB_KC);                             \
-            acc[nb_] = MFMAB(af_, bf_, acc[nb_]);                                                    \
+        _Pragma("unroll") for (int hh_ = 0; hh_ < KH; ++hh_) {                                       \
+            s16x8 a_ = __builtin_bit_cast(s16x8, CUR[hh_]);                                          \
+            if (relu_in) a_ = __builtin_elementwise_max(a_, (s16x8){0, 0, 0, 0, 0, 0, 0, 0});        \
+            const bf16x8 af_ = __builtin_bit_cast(bf16x8, a_);                                       \
+            const unsigned short* wo_ = wlane + ((size_t)oq0 * KH + hh_) * (CT * TB_KC);             \
+            _Pragma("unroll") for (int nb_ = 0; nb_ < NB; ++nb_) {                                   \
+                const bf16x8 bf_ = *(const bf16x8*)(wo_ + nb_ * 16 * TB_KC);                         \
+                acc[nb_] = MFMAB(af_, bf_, acc[nb_]);                                                \
+            }                                                                                        \
         }                                                                                            \
         oq0 = oq1; oq1 = oq2; oq2 = oq3; oq3 = oq4; oq4 = o4_;                                       \
     } while (0)
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
         if (m) { oq4 = __builtin_ctz(m); m &= m - 1; olast = oq4; }
         iqb = tb_s[olast * TB_T + i];
         __builtin_amdgcn_sched_barrier(0);
-        i32x4 s0, s1, s2, s3;
+        i32x4 s0[KH], s1[KH], s2[KH], s3[KH];
         TB_GATHER(iq0, s0);
         TB_GATHER(iq1, s1);
         TB_GATHER(iq2, s2);
@@ -286,13 +296,20 @@ extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, con
     SCN_REQUIRE((((uintptr_t)X | (uintptr_t)W) & 15) == 0);
     SCN_REQUIRE(n_in < (1ll << 23) && n_in * cin * 2 < (1ll << 32) - (1ll << 24));    // 24-bit rows, 32-bit offsets
     const int64_t nt = cdiv(n_out, TB_T);
-    static const int nb_env = getenv("SCN_TB_NB") ? atoi(getenv("SCN_TB_NB")) : 0;      // developer switch: 2 or 4
-    const int nb = nb_env == 2 || nb_env == 4 ? nb_env : (cout > 32 ? 4 : 2);
-    const int ct = 16 * nb;
+    static const int nb_env = getenv("SCN_TB_NB") ? atoi(getenv("SCN_TB_NB")) : 0;      // developer switches
+    static const int kh_env = getenv("SCN_TB_KH") ? atoi(getenv("SCN_TB_KH")) : 0;
+    // shapes: 32 columns x 32 channels (small layers), 64 columns x 32 channels, 32 columns x 64 channels -- the last
+    // halves the number of K-chunks (no fp32 slabs at Cin = 64) at twice the gather traffic per output
+    int kh = (kh_env == 1 || kh_env == 2) ? kh_env : 1;   // 64-channel chunks: 41.7 -> 37.3 us per launch at C = 64 alone
+                                                          // (tools/ablate_conv_bf16.py), but 0-3 % slower inside the step
+    if (cin <= 32) kh = 1;
+    int nb = nb_env == 2 || nb_env == 4 ? nb_env : (cout > 32 ? 4 : 2);
+    if (kh == 2) nb = 2;
+    const int ct = 16 * nb, kcs = TB_KC * kh;
     const int n_chunks = (int)cdiv(cout, ct);
-    const int n_kc = (int)cdiv(cin, TB_KC);
+    const int n_kc = (int)cdiv(cin, kcs);
     float* slabs = (float*)((char*)scratch + 256);
-    const size_t lds = (size_t)n_off * ct * TB_KC * sizeof(uint16_t) + 16;
+    const size_t lds = (size_t)n_off * ct * kcs * sizeof(uint16_t) + 16;
     int wg_per_cu = (int)((160 * 1024) / lds);
     if (wg_per_cu > 2) wg_per_cu = 2;
     if (wg_per_cu < 1) wg_per_cu = 1;
@@ -302,22 +319,23 @@ extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, con
     const bool wt = flags & SCN_F_W_TRANSPOSED;
     dim3 grid((unsigned)(n_tg * n_chunks * n_kc));
     hipStream_t st = S(stream);
-#define LAUNCH_TB(T, N)                                                                                             \
+#define LAUNCH_TB(T, N, K)                                                                                          \
     do {                                                                                                            \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
-            SCN_HIP(hipFuncSetAttribute((const void*)k_conv_tb<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+            SCN_HIP(hipFuncSetAttribute((const void*)k_conv_tb<T, N, K>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                         160 * 1024));                                                               \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((k_conv_tb<T, N>), grid, dim3(TB_NW * 64), lds, st, X, (long long)n_in, cin, tstab,      \
+        hipLaunchKernelGGL((k_conv_tb<T, N, K>), grid, dim3(TB_NW * 64), lds, st, X, (long long)n_in, cin, tstab,   \
                            tile_mask, perm, tile_order, n_off, (long long)nt, W, bias, residual, relu_mask, Y, slabs, \
                            (long long)n_out, cout, flags, n_chunks, n_kc);                                          \
     } while (0)
-    if (wt && nb == 4) LAUNCH_TB(true, 4);
-    else if (wt) LAUNCH_TB(true, 2);
-    else if (nb == 4) LAUNCH_TB(false, 4);
-    else LAUNCH_TB(false, 2);
+    if (kh == 2) { if (wt) LAUNCH_TB(true, 2, 2); else LAUNCH_TB(false, 2, 2); }
+    else if (wt && nb == 4) LAUNCH_TB(true, 4, 1);
+    else if (wt) LAUNCH_TB(true, 2, 1);
+    else if (nb == 4) LAUNCH_TB(false, 4, 1);
+    else LAUNCH_TB(false, 2, 1);
 #undef LAUNCH_TB
     SCN_LAUNCH_CHECK();
     if (n_kc > 1) {

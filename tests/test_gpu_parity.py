@@ -861,3 +861,36 @@ def test_backbone_with_bf16_features_everywhere_tracks_the_fp32_backbone(gpu):
         assert q.grad.dtype == torch.float32 and torch.isfinite(q.grad).all(), k
         rel = ((q.grad - p.grad).norm() / p.grad.norm().clamp_min(1e-12)).item()
         assert rel < 0.1, (k, rel)
+
+
+def test_config3_path_with_bf16_storage_tracks_fp32(gpu):
+    """BASELINE config 3's path -- backbone -> per-point features ++ raw features -> sparse ROI crop -> mask-head U-Net
+    -> per-point logits -- with both U-Nets on bf16-stored features (bf16_blocks="all"; InputLayer, OutputLayer, the ROI
+    crop and the first layer of each U-Net stay fp32), against the same path in fp32: logits within 3 % and the gradient
+    of the raw point features within 15 % in relative L2 (gross-error bounds, see test_gpu_fuzz.py)."""
+    from sparse_rcnn_amd import roi
+    from sparse_rcnn_amd.synthetic import make_boxes
+    from sparse_rcnn_amd.unet import Backbone, SparseUNet
+    scn = _scn()
+    coords, size, batch = _cloud(43, grid=(32, 32, 16), n=2500, batch=2, dup=300)
+    raw = torch.randn(len(coords), 7, generator=torch.Generator().manual_seed(1))
+    bparams = O.init_unet_params(7, (16, 24), seed=2)
+    mparams = O.init_unet_params(16 + 7, (24, 32), seed=3)
+    head = torch.nn.Linear(24, 5).to(gpu)
+    bbox_batch = make_boxes(coords, n_boxes=6, seed=5, lo=4, hi=24)
+    g = torch.randn(1, generator=torch.Generator().manual_seed(7))
+    res = []
+    for mode in (False, "all"):
+        backbone = Backbone(7, (16, 24), bf16_blocks=mode).to(gpu); backbone.unet.load_oracle_params(bparams)
+        mask_unet = SparseUNet(23, (24, 32), bf16_blocks=mode).to(gpu); mask_unet.load_oracle_params(mparams)
+        raw_g = raw.to(gpu).requires_grad_()
+        fmap = backbone(coords, raw_g, size, batch)
+        cat = torch.cat([scn.OutputLayer(3)(fmap), raw_g], 1)
+        roi_tensor, _ = roi.SparseRoiCut(spatial_size_offset=32)((coords, cat, size, batch, [0]), bbox_batch)
+        logits = head(scn.OutputLayer(3)(mask_unet(roi_tensor)))
+        assert logits.dtype == torch.float32
+        logits.backward(torch.ones_like(logits))
+        res.append((logits.detach(), raw_g.grad.clone()))
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    assert torch.isfinite(res[1][0]).all() and rel(res[1][0], res[0][0]) < 3e-2, rel(res[1][0], res[0][0])
+    assert torch.isfinite(res[1][1]).all() and rel(res[1][1], res[0][1]) < 0.15, rel(res[1][1], res[0][1])

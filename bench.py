@@ -2,16 +2,23 @@
 """Headline benchmark: active-voxels/sec, forward + backward of the ScanNet U-Net backbone (BASELINE.json configs[1]):
 ~150k active voxels per scene, 32->64->128->256 channels, 3^3 submanifold + 2^3/2 conv/deconv, fp32.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W [--workload cfg2|cfg3|cfg5] [--dtype f32|bf16]
 
-A step = InputLayer (voxel hash + first-occurrence rows + mean of duplicate points) + every rulebook build (they are
-rebuilt per forward, as in the reference) + U-Net forward + backward to all parameters and the input features + the
+N > 1, either way:
+  * `python bench.py --gpus N ...` with no torchrun environment: this process makes NO GPU call and starts N fresh child
+    processes of itself (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous), relays
+    rank 0's JSON line and exits with the worst child's code;
+  * `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`: the ranks are already there.
+
+A step (sparse_rcnn_amd/trainstep.py) = InputLayer (voxel hash + first-occurrence rows + mean of duplicate points) + every
+rulebook build (rebuilt per batch, as in the reference) + forward + backward to all parameters and the input features +
 all-reduce of the flat gradient buffer over RCCL (N > 1) + SGD update.  The index structures depend on the coordinates
-only, so they are pipelined like a data loader's output: those of batch i+1 are built by a helper thread (one
-scn_pyramid_build call on the high-priority index stream) while batch i runs; every timed step contains exactly one
-complete index build (--no-prefetch builds them inside the forward pass instead).  One scene per GPU (weak scaling); inputs are
-resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+only, so they are pipelined like a data loader's output: those of batch i+1 are built by a helper thread while batch i
+runs; every timed step contains exactly one complete index build (`ms_per_step_no_prefetch` in the JSON is the same loop
+with the build inside the forward pass).  One scene per GPU: N ranks process N scenes per step (the batch of N scenes of
+BASELINE configs[3] sharded one per GPU); per-GPU work is fixed as N grows, so the line says "weak" -- a batch of 8 on
+8 GPUs against the same batch on 1 GPU is the same curve read as strong scaling (`scaling_note`).  Inputs are resident
+in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -19,149 +26,149 @@ import argparse
 import gc
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
-
-WORKLOADS = {      # name -> (channels, grid, active voxels, BASELINE.json entry)
-    "cfg2": ((32, 64, 128, 256), (512, 512, 256), 150_000, "configs[1]"),
-    "cfg5": ((32, 64, 128, 256, 512), (1024, 1024, 512), 600_000, "configs[4] shape, fp32 storage"),
-}
-CHANNELS, GRID, TARGET, _ = WORKLOADS["cfg2"]
 PEAK_FP32_MATRIX_TFLOPS = 157.3          # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBPS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def _host_threads():
-    """Threads for the CPU baseline: the cores this process may use, capped at the 16-core share of a 1-GPU box."""
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    return max(1, min(16, n))
-
-
-def cpu_baseline(coords, feats, CHANNELS=CHANNELS):
-    """The CPU restatement (oracle) of the same step -- SparseConvNet's CPU algorithm (hash -> rulebook; per offset
-    gather -> sgemm -> scatter-add) -- timed on this box's host cores.  It is NOT the SparseConvNet binary (unavailable:
-    SURVEY.md §8c).  Bounded sample: three full steps (rulebooks + fwd + bwd) of the same 150k-voxel scene, ~10 s."""
-    from oracle import scn_oracle as O
-    params = {k: v.requires_grad_() for k, v in O.init_unet_params(7, CHANNELS, seed=0).items()}
-    c_np, f = coords.cpu().numpy(), feats.cpu()
-    torch.set_num_threads(_host_threads())
-    reps = 3                                  # ~10 s of CPU work on a 1-GPU box's 16-core share
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        for v in params.values():
-            v.grad = None
-        scene = O.OracleScene(c_np)           # rulebooks are rebuilt every step, as on the GPU side
-        out = O.unet_forward(scene, f, params, CHANNELS)
-        out.backward(torch.ones_like(out))
-    dt = time.perf_counter() - t0
-    return dict(value=reps * scene.n(0) / dt, unit="active-voxels/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{reps} full steps (rulebooks+fwd+bwd) of the same {scene.n(0)}-voxel scene, torch-CPU fp32 "
-                       f"oracle port of the SparseConvNet CPU algorithm, {dt:.2f} s")
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--target", type=int, default=None)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2",
-                    help="cfg2 = the configuration the metric is quoted on (default); cfg5 = BASELINE configs[4]'s "
-                         "shape (600k voxels, 5 levels to 512 channels) in fp32, a size check, not the headline")
+    ap.add_argument("--target", type=int, default=None, help="active voxels per scene (default: the workload's)")
+    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg5"), default="cfg2",
+                    help="cfg2 = the configuration the metric is quoted on (default); cfg3 = backbone + OutputLayer + "
+                         "sparse ROI crop (64 boxes) + mask-branch U-Net, fwd+bwd; cfg5 = 600k voxels, 5 levels to 512")
+    ap.add_argument("--dtype", choices=("f32", "bf16", "bf16-blocks"), default="f32",
+                    help="feature STORAGE type: f32 (the headline, the reference's arithmetic) or bf16 (BASELINE configs "
+                         "3-5: bf16-stored features, fp32 accumulation, fp32 parameters)")
+    ap.add_argument("--bf16-all", action="store_true", help="alias of --dtype bf16")
+    ap.add_argument("--bf16-blocks", action="store_true", help="alias of --dtype bf16-blocks (residual units only)")
     ap.add_argument("--profile-all", action="store_true",
                     help="time every GEMM kernel launch of the sampled steps, not only the dominant kernel")
-    ap.add_argument("--bf16-all", action="store_true",
-                    help="NOT the headline configuration: as --bf16-blocks, and every other layer after the first 1x1 "
-                         "convolution keeps bf16 features too (fp32 arithmetic in the strided / 1x1 GEMMs)")
-    ap.add_argument("--bf16-blocks", action="store_true",
-                    help="NOT the headline configuration: the residual units keep features, intermediates and gradients "
-                         "in bf16 (fp32 accumulation, fp32 parameters); strided / 1x1 layers and everything else fp32")
     ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
-                    help="build the index structures inside the forward pass instead of one batch ahead on a helper "
-                         "thread (scn_pyramid_build on the index stream)")
-    args = ap.parse_args()
-    CHANNELS, GRID, target, cfg_name = WORKLOADS[args.workload]
-    target = args.target or target
+                    help="build the index structures inside the forward pass instead of one batch ahead")
+    ap.add_argument("--dropin", action="store_true",
+                    help="also time the layer-by-layer module path the reference's module_factory builds (lazy Metadata, "
+                         "no helper thread, no fused residual node) and report it as `dropin` next to the headline")
+    ap.add_argument("--no-extras", action="store_true", help="skip the index-build / no-prefetch side measurements")
+    a = ap.parse_args(argv)
+    if a.bf16_all:
+        a.dtype = "bf16"
+    elif a.bf16_blocks:
+        a.dtype = "bf16-blocks"
+    return a
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# self-launch: the parent makes no GPU call
+# ----------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, script=None, argv=None):
+    """Start --gpus fresh ranks of this script.  Nothing here touches torch.cuda: a forked/exec'd child of a process that
+    initialised the GPU is not allowed on this pool, and RCCL wants one fresh process per device."""
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SCN_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] +
+                                      (sys.argv[1:] if argv is None else list(argv)), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else None))
+    out0 = procs[0].communicate()[0].decode()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = max(rc, abs(p.wait()))
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baseline leg (test infrastructure: oracle/)
+# ----------------------------------------------------------------------------------------------------------------------
+def _host_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))          # the 16-core share of a 1-GPU box
+
+
+def cpu_baseline(coords, feats, channels):
+    """SparseConvNet's CPU algorithm restated in C++17 / OpenMP (oracle/scn_cpu_baseline.cpp: per-sample hash -> rulebooks;
+    per offset gather -> sgemm -> scatter-add; same layer list, fwd + bwd), compiled -O3 -march=native on THIS box, timed
+    single-threaded and on the host cores this process may use.  It is NOT the SparseConvNet binary (unavailable: SURVEY.md
+    §8c).  Bounded sample: whole steps of the same scene, ~10-20 s of CPU work in total."""
+    from oracle import cpu_baseline as CB
+    return CB.timed_baseline(coords.cpu().numpy(), feats.cpu().numpy(), channels, _host_threads())
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def run(args):
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # one rank per GPU; SCN_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1 code path
     backend = os.environ.get("SCN_BENCH_BACKEND", "nccl")
-    local = local % torch.cuda.device_count() if backend != "nccl" else local
+    n_dev = torch.cuda.device_count()                         # does not initialise the GPU
+    if n_dev == 0:
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    local = local % n_dev if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    ranks_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        one = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
 
     import sparse_rcnn_amd  # noqa: F401
     from sparse_rcnn_amd import profiling
-    from sparse_rcnn_amd.dp import FlatParams, broadcast_params
-    from sparse_rcnn_amd.synthetic import make_batch
-    from sparse_rcnn_amd.unet import Backbone
+    from sparse_rcnn_amd.trainstep import SceneStep
 
     # one balanced scene per rank (cfg 2: seed 1; cfg 4 style: seeds 10+rank)
     seed = 1 if world == 1 else 10 + rank
-    coords, feats, size, bs, _ = make_batch(1, GRID, target, dup=1.15, seed=seed)
-    coords_d, feats_d = coords.to(dev), feats.to(dev)
+    job = SceneStep(args.workload, dev, dtype=args.dtype, prefetch=args.prefetch, seed=seed, grad_seed=100 + rank,
+                    target=args.target)
 
-    torch.manual_seed(0)
-    model = Backbone(7, CHANNELS, bf16_blocks="all" if args.bf16_all else args.bf16_blocks).to(dev)
-    args.bf16_blocks = args.bf16_blocks or args.bf16_all
-    flat = FlatParams(model, n_buckets=4)      # N > 1: gradient slices are all-reduced while backward still runs
-    broadcast_params(flat)
-    gen = torch.Generator(device="cpu").manual_seed(100 + rank)
-    gy = None
-    n_active = 0
-    md_next = None
-
-    def step():
-        nonlocal gy, n_active, md_next
-        flat.zero_grad()
-        fin = feats_d.detach().requires_grad_()
-        md = md_next.result() if md_next is not None else None
-        md_next = None
-        # the index structures of the NEXT batch (they depend on its coordinates only, like a data loader's output) are
-        # built by a helper thread on the high-priority index stream while this batch's forward and backward run: every
-        # timed step still contains one complete index build
-        if args.prefetch:
-            md_next = model.prefetch_in_thread(coords_d, size, 1)
-        out = model(coords_d, fin, size, 1, metadata=md)
-        if gy is None or gy.shape != out.features.shape:
-            gy = torch.randn(out.features.shape, generator=gen).to(dev)          # upstream grad dY ~ N(0,1)
-            n_active = out.features.shape[0]
-        out.features.backward(gy)
-        flat.all_reduce_mean()
-        flat.sgd_step(1e-6)
-
-    # Kernel timing: HIP events around the launches of the dominant kernel (k_conv_ts: 62 launches per step; in the sampled
-    # steps scn_conv_tiles runs with SCN_F_SPLIT_SUM so that its slab-sum kernel is launched, and timed, apart) on 3-4
-    # steps spread over the timed region, from a pool of events created before it.  Timing events are not free: every
-    # launch of every step timed cost 1-3.5 ms/step (host-bound, and each event pair fences the queue), all four GEMM
-    # kernels on every 5th step still ~0.5 ms/step.  --profile-all times all GEMM kernels (the "kernels" table).
+    # Kernel timing: HIP events (torch events on the launch stream) around the launches of the dominant kernel on 3-4 steps
+    # spread over the timed region, from a pool of events created before it; in those steps scn_conv_tiles runs in its
+    # two-call form so that the events bracket the tile kernel alone.  Timing every launch of every step makes the step
+    # host-bound, so the other kernels are only timed with --profile-all.
+    dom_names = {"k_conv_ts", "k_conv_tb"}
     every = max(5, (args.steps + 2) // 3)
-    timer = profiling.KernelTimer(every=every, names=None if args.profile_all else {"k_conv_ts", "k_conv_tb"})
+    timer = profiling.KernelTimer(every=every, names=None if args.profile_all else dom_names)
     for w in range(args.warmup):
         if w == args.warmup - 1:                    # count the launches of one step to size the event pool
             timer.count_only = True
             profiling.TIMER = timer
-        step()
+        job.step()
     profiling.TIMER = None
     timer.count_only = False
     timer.reserve(2 * max(timer.count, 128) * ((args.steps + every - 1) // every))
@@ -178,9 +185,8 @@ def main():
         if use_timer:
             timer.begin_step()
             profiling.TIMER = timer if timer.active else None
-        step()
-    if md_next is not None:                  # the index build started in the last timed step ends inside the timed region
-        md_next.result()
+        job.step()
+    job.finish()                             # the index build started in the last timed step ends inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -188,31 +194,21 @@ def main():
     profiling.TIMER = None
     sampled = max(1, timer.sampled_steps)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    vox = torch.tensor([float(n_active)], dtype=torch.float64, device=dev)
+    red_dev = dev if (world == 1 or backend == "nccl") else "cpu"
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    vox = torch.tensor([float(job.n_active)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(vox, op=dist.ReduceOp.SUM)
     dt, total_vox = tmax.item(), vox.item()
 
+    # ---- side measurements outside the timed region (rank 0's numbers; every rank runs them so collectives stay matched)
+    extras = {}
+    if not args.no_extras:
+        extras = side_measurements(job, args, world, dist, torch)
+
     if rank == 0:
         ks = timer.summary()
-        if not ks:                                   # SCN_BENCH_NO_TIMER (developer switch): wall clock only
-            print(json.dumps({"ms_per_step": dt / args.steps * 1e3, "value": total_vox * args.steps / dt}), flush=True)
-            if world > 1:
-                dist.destroy_process_group()
-            return
-        dom = max(ks, key=lambda k: ks[k]["ms"])
-        d = ks[dom]
-        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        # HBM-side bytes per launch of the dominant kernel: rocprofv3 PMC passes cannot run inside this process; the
-        # figure comes from the committed separate passes (tools/collect_traffic.py -> profiles/r1_traffic.json)
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
-                traffic = json.load(f)["kernels"][dom]["hbm_bytes_per_launch"] if args.workload == "cfg2" else None
-        except (OSError, KeyError, ValueError):
-            pass
         out = {
             "metric": "active-voxels/sec fwd+bwd, ScanNet U-Net backbone",
             "value": total_vox * args.steps / dt,
@@ -220,37 +216,151 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("bf16 storage after the first layer, fp32 accumulate" if args.bf16_all else
-                      "f32 (residual units: bf16 storage, fp32 accumulate)") if args.bf16_blocks else "f32",
+            "scaling_note": "1 scene per GPU: N ranks process a batch of N scenes per step; against the same batch on one "
+                            "GPU (N x ms_per_step at n_gpus=1) this is the strong-scaling curve of BASELINE configs[3]",
+            "dtype": {"f32": "f32", "bf16": "bf16", "bf16-blocks": "f32 (residual units: bf16 storage)"}[args.dtype],
+            "dtype_note": None if args.dtype == "f32" else "bf16 STORAGE of features and feature gradients after the "
+                          "first layer, fp32 accumulation, fp32 parameters / parameter gradients / optimizer",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE {cfg_name}: one synthetic ScanNet-shaped scene per GPU, "
-                                   f"{n_active} active voxels (grid {GRID[0]}x{GRID[1]}x{GRID[2]}, 1.15 points/voxel), "
-                                   "U-Net " + "-".join(map(str, CHANNELS)) + ", 2 pre-act residual blocks/level, 2^3/2 conv+deconv, "
-                                   "step = rulebooks + fwd + bwd (+ grad all-reduce + SGD)"
-                                   + ("; rulebooks of batch i+1 built on a helper thread during batch i" if args.prefetch else "")
-                                   + ("; NOT the fp32 configuration: residual units on the bf16 storage path" if args.bf16_blocks else ""),
+            "config": {"workload": job.describe(),
                        "parallelism": f"dp{world} (1 scene/GPU, flat-bucket all-reduce)"},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
-                         "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_traffic.json)",
-                         "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
-                         "launches_per_step": d["launches"] / sampled, "sampled_steps": sampled,
-                         "avg_launch_us": d["ms"] * 1e3 / d["launches"],
-                         "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9},
-            "kernels": {k: {"ms_per_step": v["ms"] / sampled, "launches_per_step": v["launches"] / sampled,
-                            "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else None}
-                        for k, v in ks.items()},
+            "n_ranks_seen_by_rccl": ranks_seen if backend == "nccl" else None,
+            "n_ranks_seen": ranks_seen, "collective_backend": backend if world > 1 else None,
         }
-        if args.bf16_blocks:         # side measurement: the roofline object of the contract belongs to the fp32 run
-            out["roofline"] = {"note": "mixed-storage side measurement; kernel times in `kernels` (use --profile-all), "
-                                       "roofline of the fp32 configuration: run without --bf16-blocks"}
+        out.update(extras)
+        if ks:
+            dom = max((k for k in ks if k in dom_names), key=lambda k: ks[k]["ms"], default=max(ks, key=lambda k: ks[k]["ms"]))
+            d = ks[dom]
+            out["roofline"] = roofline(dom, d, sampled, args)
+            out["kernels"] = {k: {"ms_per_step": v["ms"] / sampled, "launches_per_step": v["launches"] / sampled,
+                                  "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else None,
+                                  "algorithmic_GBps": v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] else None}
+                              for k, v in ks.items()}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(coords, feats, CHANNELS)
+            out["cpu_baseline"] = cpu_baseline(job.coords_cpu, job.feats_cpu, job.channels)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def roofline(dom, d, sampled, args):
+    """`roofline` object of the contract for the dominant kernel (HIP events around its launches, live)."""
+    us = d["ms"] * 1e3 / d["launches"]
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r2_traffic.json")       # separate rocprofv3 --pmc passes (tools/collect_traffic.py)
+    try:
+        with open(tfile) as f:
+            t = json.load(f)
+        traffic = t["kernels"][dom]["hbm_bytes_per_launch"] if t.get("workload") == args.workload and \
+            t.get("dtype", "f32") == args.dtype else None
+    except (OSError, KeyError, ValueError):
+        pass
+    common = {"kernel": dom, "traffic": traffic,
+              "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r2_traffic.json)",
+              "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+              "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+              "launches_per_step": d["launches"] / sampled, "sampled_steps": sampled, "avg_launch_us": us}
+    if dom == "k_conv_tb":        # bf16 storage: the bf16 MFMA peak is 16x the fp32 one; the tile kernel is HBM-bound
+        achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        return dict(bound="hbm", achieved=achieved, peak=PEAK_HBM_GBPS, unit="GB/s", frac=achieved / PEAK_HBM_GBPS,
+                    **common)
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    return dict(bound="mfma", achieved=achieved, peak=PEAK_FP32_MATRIX_TFLOPS, unit="TFLOP/s",
+                frac=achieved / PEAK_FP32_MATRIX_TFLOPS, **common)
+
+
+def side_measurements(job, args, world, dist, torch):
+    """What SURVEY §8d asks to report next to the headline: the index build alone (ms, algorithmic bytes -> GB/s against
+    the HBM roofline) and the step without the pipelined index build."""
+    from sparse_rcnn_amd.metadata import Metadata
+    ex = {}
+    n_levels = len(job.channels)
+    torch.cuda.synchronize()
+    reps = 10
+    md = None
+    for i in range(reps + 2):
+        if i == 2:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        md = Metadata(3).build_native(job.size, job.coords, 1, 4, n_levels, 3)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    # algorithmic bytes of the build (SURVEY §8d): per level 16 N (coords) + 8 P (pairs) + 16 N (hash insert + init);
+    # strided rulebooks 16 N_fine + 8 N_fine + 16 N_coarse; InputLayer rules 16 Npts + 16 N0
+    nbytes = 32.0 * job.coords.shape[0]
+    size = tuple(int(s) for s in job.size)
+    for l in range(n_levels):
+        rb = md.subm.get((size, 3))
+        if rb is None:
+            break
+        nbytes += 32.0 * rb.n + 8.0 * rb.rules.total
+        if l + 1 < n_levels and size in md.strided:
+            sb = md.strided[size]
+            nbytes += 24.0 * sb.n_fine + 16.0 * sb.n_coarse
+            size = sb.coarse_size
+    ex["index_build_ms"] = ms
+    ex["index_build"] = {"ms": ms, "algorithmic_bytes": nbytes, "GBps": nbytes / (ms * 1e-3) / 1e9,
+                         "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                         "note": "one scn_pyramid_build call alone on an idle GPU, incl. its host waits for the level sizes"}
+    del md
+    if job.prefetch:
+        job.finish()
+        job.prefetch = False
+        n = max(5, min(10, args.steps))
+        for _ in range(2):
+            job.step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            job.step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        ex["ms_per_step_no_prefetch"] = (time.perf_counter() - t0) / n * 1e3
+        job.prefetch = True
+    if args.dropin and args.workload == "cfg2":
+        ex["dropin"] = dropin_measurement(job, args, torch)
+    return ex
+
+
+def dropin_measurement(job, args, torch):
+    """The same backbone driven the way the reference's module tree drives the scn surface: CustomInputLayer creates the
+    Metadata inside the forward (custom_operations.py:67-83), rulebooks are built lazily by the first layer that needs
+    them, no helper thread."""
+    from sparse_rcnn_amd.unet import DropinBackbone
+    net = DropinBackbone(job.model.backbone)
+    n = max(5, min(10, args.steps))
+    gy = None
+    for i in range(n + 3):
+        if i == 3:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        job.flat.zero_grad()
+        fin = job.feats.detach().requires_grad_()
+        out = net(job.coords_cpu, fin, job.size, 1)
+        if gy is None:
+            gy = torch.randn_like(out.features)
+        out.features.backward(gy)
+        job.flat.all_reduce_mean()
+        job.flat.sgd_step(job.lr)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    return {"ms_per_step": ms, "value": job.n_active / (ms * 1e-3),
+            "note": "layer-by-layer scn module path with the Metadata created inside the forward from HOST coords "
+                    "(the reference's CustomInputLayer contract), rulebooks built on first use, no helper thread"}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    sys.exit(run(args))
 
 
 if __name__ == "__main__":

@@ -146,19 +146,34 @@ int64_t scn_pyramid_workspace_bytes(int64_t n_points, int n_levels, int k);
 int scn_pyramid_build(const int64_t* coords, int64_t n_points, int n_levels, int k, void* workspace,
                       int64_t workspace_bytes, int64_t* desc, scn_stream_t stream);
 
-/* Sparse ROI crop indicator (roi_select_sparse.py:157-167 get_inside_indicator): boxes int32 [bb][8] =
- * (start x,y,z,sample ; stop x,y,z,sample+1).  table[i][j] = j if point j lies in box i else -1; feed it to
- * scn_rules_scan/_fill to obtain the box-major, ascending-point-row selection of select_features / select_coords
- * (roi_select_sparse.py:125-149).  inside_u8 [bb][n] (may be NULL) receives the bool matrix roi_cut returns (:180). */
-int scn_roi_table(const int32_t* coords, int64_t n, const int32_t* boxes, int bb, int32_t* table, uint8_t* inside_u8,
-                  scn_stream_t stream);
+/* Sparse ROI crop (roi_select_sparse.py:157-180 get_inside_indicator / select_features / select_coords / roi_cut) as
+ * count -> scan -> scatter; no [boxes][points] object is ever built.  boxes int32 [bb][8] =
+ * (start x,y,z,sample ; stop x,y,z,sample+1), half-open.  The result is the reference's selection order: box-major,
+ * ascending point row.
+ *   scn_roi_units(n)        number of 256-point units of n points
+ *   scn_roi_count           unit_offsets int32 [bb][scn_roi_units(n)]: after the call, the first output row of every
+ *                           (box, unit) run; prefix (device int64 [bb+1]): first output row of every box, prefix[bb] = M.
+ *                           prefix_host != NULL: copied back (synchronises stream once); NULL: asynchronous.
+ *   scn_roi_fill            src_row[M] (point row), box_of[M], out_coords int64 [M][4] = (x,y,z of the point, box) --
+ *                           select_coords' extended coordinates (may be NULL).
+ *   scn_roi_inside          the dense bool matrix roi_cut also returns (:180), rebuilt from the list ON REQUEST:
+ *                           inside_u8 [bb][n] zero-filled, then 1 at (box_of[m], src_row[m]). */
+int64_t scn_roi_units(int64_t n);
+int scn_roi_count(const int32_t* coords, int64_t n, const int32_t* boxes, int bb, int32_t* unit_offsets, int64_t* prefix,
+                  int64_t* prefix_host, scn_stream_t stream);
+int scn_roi_fill(const int32_t* coords, int64_t n, const int32_t* boxes, int bb, const int32_t* unit_offsets,
+                 int32_t* src_row, int32_t* box_of, int64_t* out_coords, scn_stream_t stream);
+int scn_roi_inside(const int32_t* src_row, const int32_t* box_of, int64_t m, int64_t n, int bb, uint8_t* inside_u8,
+                   scn_stream_t stream);
 /* out_coords[m] = (x,y,z of coords[src_row[m]], box_of[m]) as int64 rows (select_coords, roi_select_sparse.py:136-149) */
 int scn_roi_coords(const int32_t* coords, const int32_t* src_row, const int32_t* box_of, int64_t m, int64_t* out_coords,
                    scn_stream_t stream);
-/* boxes fp32 [bb][2][3] -> floor(start), ceil(stop) (ndsis/utils/bbox.py:87-106), optional clip start to [0,S-1] /
- * stop to [1,S] (bbox.py:62-84), sample index appended -> int32 [bb][8] as scn_roi_table expects. */
+/* BBoxTransformerSlice (roi_select_bbox_transform.py:56-70,87-97): boxes fp32 [bb][2][3] -> optional Divider
+ * (box / resize, fp32, per axis; :15-21) -> floor(start), ceil(stop) (ndsis/utils/bbox.py:87-106) -> optional clip of
+ * start to [0,S-1] / stop to [1,S] (bbox.py:62-84) -> sample interval appended -> int32 [bb][8] as scn_roi_count expects.
+ * resize3_or_null: device float[3]. */
 int scn_roi_boxes(const float* boxes, const int32_t* box_sample, int bb, const int32_t* spatial_size3_or_null,
-                  int32_t* out, scn_stream_t stream);
+                  const float* resize3_or_null, int32_t* out, scn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Feature path: gather-GEMM-scatter on fp32 MFMA

@@ -268,12 +268,15 @@ def conv(X, W, b, rules, n_out):
 def batchnorm_relu_fwd(X, gamma, beta, running_mean, running_var, eps=1e-4, momentum=0.9,
                        leak=0.0, training=True):
     """A8.  momentum is the RETAIN fraction (SparseConvNet convention, SURVEY §4.1 caveat).
-    Batch statistics are biased (divide by N) and so is the running_var update."""
+    The normalisation uses the biased batch variance (divide by N); the running_var update takes the UNBIASED
+    estimate (divide by N - 1) -- [UPSTREAM-SCN] BatchNormalization forward as recalled, also torch.nn.BatchNorm's
+    convention (the dense twin the reference pairs this layer with, module_factory.py:101-112)."""
     if training:
         mean = X.mean(0)
         var = X.var(0, unbiased=False)
+        n = X.shape[0]
         running_mean.mul_(momentum).add_(mean.detach() * (1 - momentum))
-        running_var.mul_(momentum).add_(var.detach() * (1 - momentum))
+        running_var.mul_(momentum).add_(var.detach() * ((1 - momentum) * (n / (n - 1) if n > 1 else 1.0)))
     else:
         mean, var = running_mean, running_var
     y = (X - mean) / torch.sqrt(var + eps) * gamma + beta
@@ -316,13 +319,15 @@ def round_boxes(boxes: np.ndarray) -> np.ndarray:
     return np.stack([np.floor(boxes[:, 0]), np.ceil(boxes[:, 1])], 1).astype(np.int64)
 
 
-def transform_boxes(bbox_batch, spatial_size=None, clip=False):
+def transform_boxes(bbox_batch, spatial_size=None, clip=False, resize=None):
     """BBoxTransformerSlice.forward (roi_select_bbox_transform.py:56-70,87-97): list of fp [n_i,2,3] ->
     (int64 [BB,2,3] floor/ceil (optionally clipped: start to [0,S-1], stop to [1,S], bbox.py:62-84),
-    per-sample counts, per-box sample index)."""
+    per-sample counts, per-box sample index).  resize: the Divider's value (:15-21), fp32 division before rounding."""
     counts = [len(b) for b in bbox_batch]
     raw = np.concatenate([np.asarray(b, dtype=np.float32).reshape(-1, 2, 3) for b in bbox_batch]) \
         if bbox_batch else np.zeros((0, 2, 3), np.float32)
+    if resize is not None:
+        raw = (raw / np.asarray(resize, dtype=np.float32)).astype(np.float32)
     boxes = round_boxes(raw)
     if clip:
         s = np.asarray(spatial_size, dtype=np.int64)
@@ -381,11 +386,14 @@ class OracleScene:
         return len(self.level_coords[level])
 
 
-def unet_param_shapes(cin, channels):
-    """Ordered (name, shape) list for the A12 U-Net (SURVEY Appendix A.1 layer list)."""
+def unet_param_shapes(cin, channels, identity_first=False):
+    """Ordered (name, shape) list for the A12 U-Net (SURVEY Appendix A.1 layer list).  identity_first: encoder level 0
+    is the reference's FLD('I') (no layer; the mask head's internal U-Net, scannet_config/run.py:756-775)."""
     shapes = []
     L = len(channels)
     for l, c in enumerate(channels):
+        if l == 0 and identity_first:
+            continue
         if l == 0:
             shapes += [(f"enc{l}.in.weight", (1, cin, c)), (f"enc{l}.in.bias", (c,))]
         else:
@@ -403,11 +411,11 @@ def unet_param_shapes(cin, channels):
     return shapes
 
 
-def init_unet_params(cin, channels, seed=0):
+def init_unet_params(cin, channels, seed=0, identity_first=False):
     """N(0, sqrt(2/(Cin*k^3))) weights, small random biases so bias paths are exercised."""
     g = torch.Generator().manual_seed(seed)
     params = {}
-    for name, shape in unet_param_shapes(cin, channels):
+    for name, shape in unet_param_shapes(cin, channels, identity_first):
         if name.endswith("weight"):
             fan = shape[-2] * (shape[0] if len(shape) == 3 else 1)
             params[name] = torch.randn(shape, generator=g) * (2.0 / fan) ** 0.5
@@ -416,12 +424,17 @@ def init_unet_params(cin, channels, seed=0):
     return params
 
 
-def unet_forward(scene: OracleScene, feats_pts: torch.Tensor, params: dict, channels):
+def unet_forward(scene: OracleScene, feats_pts: torch.Tensor, params: dict, channels, identity_first=False,
+                 storage=None):
     """A12: encoder level = {SubM1 | Conv2s2} + 2x[x + SubM3(ReLU(SubM3(ReLU(x))))];
     decoder level = ReLU -> Deconv2s2 -> Join(up, skip) -> NiN -> 2x residual
-    (module_factory.py:127-183, 513-578; custom_container.py:70-83: cat((upsampled, skip)))."""
+    (module_factory.py:127-183, 513-578; custom_container.py:70-83: cat((upsampled, skip))).
+    identity_first: encoder level 0 has no layer (FLD('I')).  storage: optional rounding applied to every stored
+    feature slab after the first layer (straight-through in backward) -- the bf16 STORAGE mode of the HIP path restated
+    on the CPU: storage=bf16_storage."""
     P = params
     relu = torch.relu
+    q = storage if storage is not None else (lambda t: t)
     x = _InputFn.apply(feats_pts, scene)
     skips = []
     L = len(channels)
@@ -430,26 +443,44 @@ def unet_forward(scene: OracleScene, feats_pts: torch.Tensor, params: dict, chan
         rules = scene.subm_rules(level, 3)
         n = scene.n(level)
         for u in range(2):
-            y = conv(relu(x), P[f"{prefix}.res{u}.conv0.weight"], P[f"{prefix}.res{u}.conv0.bias"], rules, n)
+            y = q(conv(relu(x), P[f"{prefix}.res{u}.conv0.weight"], P[f"{prefix}.res{u}.conv0.bias"], rules, n))
             y = conv(relu(y), P[f"{prefix}.res{u}.conv1.weight"], P[f"{prefix}.res{u}.conv1.bias"], rules, n)
-            x = x + y
+            x = q(x + y)
         return x
 
     for l in range(L):
+        if l == 0 and identity_first:
+            skips.append(x)
+            continue
         if l == 0:
             ident = [(np.arange(scene.n(0), dtype=np.int32),) * 2]
-            x = conv(x, P["enc0.in.weight"], P["enc0.in.bias"], ident, scene.n(0))
+            x = q(conv(x, P["enc0.in.weight"], P["enc0.in.bias"], ident, scene.n(0)))
         else:
             rules = scene.strided_rules(l - 1)
-            x = conv(x, P[f"enc{l}.in.weight"], P[f"enc{l}.in.bias"], rules, scene.n(l))
+            x = q(conv(x, P[f"enc{l}.in.weight"], P[f"enc{l}.in.bias"], rules, scene.n(l)))
         x = residual(x, f"enc{l}", l)
         skips.append(x)
     for l in range(L - 2, -1, -1):
         rules = swap_rules(scene.strided_rules(l))
-        up = conv(relu(x), P[f"dec{l}.up.weight"], P[f"dec{l}.up.bias"], rules, scene.n(l))
-        x = torch.cat([up, skips[l]], 1) @ P[f"dec{l}.nin.weight"] + P[f"dec{l}.nin.bias"]
+        up = q(conv(relu(x), P[f"dec{l}.up.weight"], P[f"dec{l}.up.bias"], rules, scene.n(l)))
+        x = q(torch.cat([up, skips[l]], 1) @ P[f"dec{l}.nin.weight"] + P[f"dec{l}.nin.bias"])
         x = residual(x, f"dec{l}", l)
     return x
+
+
+class _RoundBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def bf16_storage(t):
+    """Round to bf16 and widen back (value as stored by the bf16 storage path); gradient passes straight through."""
+    return _RoundBF16.apply(t)
 
 
 class _InputFn(torch.autograd.Function):

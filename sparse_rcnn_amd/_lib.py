@@ -33,9 +33,12 @@ _SIGS = {
     "scn_rules_fill": (C.c_int, [p, i32, i64, p, p, p, p, p]),
     "scn_pyramid_workspace_bytes": (i64, [i64, i32, i32]),
     "scn_pyramid_build": (C.c_int, [p, i64, i32, i32, p, i64, C.POINTER(i64), p]),
-    "scn_roi_table": (C.c_int, [p, i64, p, i32, p, p, p]),
+    "scn_roi_units": (i64, [i64]),
+    "scn_roi_count": (C.c_int, [p, i64, p, i32, p, p, p, p]),
+    "scn_roi_fill": (C.c_int, [p, i64, p, i32, p, p, p, p, p]),
+    "scn_roi_inside": (C.c_int, [p, p, i64, i64, i32, p, p]),
     "scn_roi_coords": (C.c_int, [p, p, p, i64, p, p]),
-    "scn_roi_boxes": (C.c_int, [p, p, i32, p, p, p]),
+    "scn_roi_boxes": (C.c_int, [p, p, i32, p, p, p, p]),
     "scn_gemm_table": (C.c_int, [p, i64, i32, p, i32, i64, p, p, p, p, p, i32, i32, p]),
     "scn_tiles_scratch_bytes": (i64, [i32, i64]),
     "scn_tiles_build": (C.c_int, [p, i32, i64, p, p, p, p, p, p]),

@@ -31,7 +31,8 @@ __global__ void k_coords_to_i32(const long long* __restrict__ in, long long n4, 
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
         long long v = in[i];
-        local_bad += (v < 0 || v > 65535);
+        // 16 bits per key field; the batch column stops one short so that no site packs to SCN_EMPTY_KEY
+        local_bad += (v < 0 || v > 65535 || ((i & 3) == 3 && v > 65534));
         out[i] = (int)v;
     }
     unsigned long long m = __ballot(local_bad != 0);
@@ -178,6 +179,13 @@ static int scan_launch(const int32_t* table, int n_seg, int64_t n, int32_t* bloc
     SCN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, block_sums, (long long)(bps * n_seg),
                        (long long)bps, n_seg, (long long*)prefix);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+int scn::scan_counts(int32_t* counts, int64_t total, int64_t per_seg, int n_seg, int64_t* prefix, hipStream_t st) {
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, counts, (long long)total, (long long)per_seg, n_seg,
+                       (long long*)prefix);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }
@@ -431,13 +439,15 @@ extern "C" int scn_child_table(const int32_t* fine_coords, const int32_t* parent
 // sparse ROI crop
 // ------------------------------------------------------------------------------------------------
 __global__ void k_roi_boxes(const float* __restrict__ boxes, const int* __restrict__ sample, int bb,
-                            const int* __restrict__ size3, int* __restrict__ out) {
+                            const int* __restrict__ size3, const float* __restrict__ resize3, int* __restrict__ out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= bb) return;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        int a = (int)floorf(boxes[i * 6 + d]);
-        int b = (int)ceilf(boxes[i * 6 + 3 + d]);
+        float lo = boxes[i * 6 + d], hi = boxes[i * 6 + 3 + d];
+        if (resize3) { lo = lo / resize3[d]; hi = hi / resize3[d]; }       // Divider: correctly rounded fp32 division
+        int a = (int)floorf(lo);
+        int b = (int)ceilf(hi);
         if (size3) {
             int s = size3[d];
             a = min(max(a, 0), s - 1);
@@ -451,41 +461,13 @@ __global__ void k_roi_boxes(const float* __restrict__ boxes, const int* __restri
 }
 
 extern "C" int scn_roi_boxes(const float* boxes, const int32_t* box_sample, int bb,
-                             const int32_t* spatial_size3_or_null, int32_t* out, scn_stream_t stream) {
+                             const int32_t* spatial_size3_or_null, const float* resize3_or_null, int32_t* out,
+                             scn_stream_t stream) {
     SCN_REQUIRE(bb >= 0);
     if (bb == 0) return SCN_OK;
     SCN_REQUIRE(boxes && box_sample && out);
     hipLaunchKernelGGL(k_roi_boxes, dim3((bb + 63) / 64), dim3(64), 0, S(stream), boxes, box_sample, bb,
-                       spatial_size3_or_null, out);
-    SCN_LAUNCH_CHECK();
-    return SCN_OK;
-}
-
-__global__ void k_roi_table(const int4* __restrict__ coords, long long n, const int* __restrict__ boxes, int bb,
-                            int* __restrict__ table, unsigned char* __restrict__ inside) {
-    const int i = blockIdx.y;   // box
-    const int4 lo = *(const int4*)(boxes + i * 8);
-    const int4 hi = *(const int4*)(boxes + i * 8 + 4);
-    for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < n;
-         j += (long long)gridDim.x * blockDim.x) {
-        int4 c = coords[j];
-        bool in = c.x >= lo.x && c.x < hi.x && c.y >= lo.y && c.y < hi.y && c.z >= lo.z && c.z < hi.z &&
-                  c.w >= lo.w && c.w < hi.w;
-        table[(long long)i * n + j] = in ? (int)j : -1;
-        if (inside) inside[(long long)i * n + j] = in ? 1 : 0;
-    }
-}
-
-extern "C" int scn_roi_table(const int32_t* coords, int64_t n, const int32_t* boxes, int bb, int32_t* table,
-                             uint8_t* inside_u8, scn_stream_t stream) {
-    SCN_REQUIRE(n >= 0 && bb >= 0 && bb < 65536);
-    if (n == 0 || bb == 0) return SCN_OK;
-    SCN_REQUIRE(coords && boxes && table);
-    SCN_REQUIRE((int64_t)bb * n < 2147483647LL);
-    int gx = scn::ew_grid(n, 256);
-    if (gx > 256) gx = 256;
-    hipLaunchKernelGGL(k_roi_table, dim3(gx, bb), dim3(256), 0, S(stream), (const int4*)coords, (long long)n, boxes,
-                       bb, table, inside_u8);
+                       spatial_size3_or_null, resize3_or_null, out);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }

@@ -222,49 +222,11 @@ def colsum(dY):
     return db
 
 
-# ------------------------------------------------------------------------------------------------------
-# side stream for gradient leaves
-# ------------------------------------------------------------------------------------------------------
-# Weight and bias gradients are LEAVES of the backward graph: nothing downstream waits for them until the optimizer
-# step, while the backward-data GEMMs form the critical chain.  They are queued on a second HIP stream so their
-# workgroups fill the CUs the chain's kernels leave idle (tails, small coarse-level grids).  The main stream joins the
-# side stream once, in a callback at the end of the backward pass.
-import os as _os
-LEAF_STREAM = _os.environ.get("SCN_LEAF_STREAM", "0") == "1"     # developer switch; measured: see DESIGN.md
-_side_streams = {}
-_join_pending = set()
-
-
-def _leaf_stream(device):
-    st = _side_streams.get(device)
-    if st is None:
-        st = _side_streams[device] = torch.cuda.Stream(device=device)
-    return st
-
-
 def _on_leaf_stream(dY, fn):
-    """Run fn() (which launches the leaf-gradient kernels reading dY) on the side stream; returns its result."""
-    if not LEAF_STREAM:
-        return fn()
-    dev = dY.device
-    main = torch.cuda.current_stream(dev)
-    side = _leaf_stream(dev)
-    side.wait_stream(main)                       # dY (and everything before it) is ready
-    with torch.cuda.stream(side):
-        out = fn()
-    dY.record_stream(side)
-    for t in out:
-        if t is not None:
-            t.record_stream(main)
-    key = (dev, main.cuda_stream)
-    if key not in _join_pending:
-        _join_pending.add(key)
-
-        def _join():
-            _join_pending.discard(key)
-            main.wait_stream(side)
-        torch.autograd.Variable._execution_engine.queue_callback(_join)
-    return out
+    """Weight / bias gradients are leaves of the backward graph.  Queuing them on a second HIP stream (so that their
+    workgroups fill the CUs the backward-data chain leaves idle) was measured in round 1: no gain, and the bucketed
+    all-reduce hooks of dp.py would have needed an extra stream join -- removed; leaves run on the main stream."""
+    return fn()
 
 
 def _identity_prefix(n):
@@ -474,7 +436,7 @@ class DeconvolutionFunction(torch.autograd.Function):
     def forward(ctx, features, weight, bias, metadata: Metadata, out_size, relu_in=False):
         X, W = _feat(features), _f32(weight)
         out_size = tuple(int(s) for s in out_size)
-        rb = metadata.strided.get(out_size)
+        rb = metadata.cached_strided_rulebook(out_size)
         if rb is None:
             raise L.ScnError(f"Deconvolution: no cached Convolution rulebook from spatial size {out_size}; the "
                              "reference only deconvolves back to an encoder level (custom_container.py:70-83)")
@@ -601,9 +563,12 @@ class BatchNormReLUFunction(torch.autograd.Function):
         if training:
             mean, var = _new((c,), X), _new((c,), X)
             L.check(lib.scn_bn_stats(L.ptr(X), n, c, L.ptr(mean), L.ptr(var), L.ptr(scratch), L.stream()))
-            # momentum is the RETAIN fraction (SparseConvNet convention; SURVEY.md §4.1 caveat)
+            # momentum is the RETAIN fraction (SparseConvNet convention; SURVEY.md §4.1 caveat).  The running variance
+            # takes the UNBIASED batch estimate (sum of squared differences / (n - 1)), the normalisation the biased
+            # one -- SparseConvNet's BatchNormalization forward as recalled [UPSTREAM-SCN], and torch.nn.BatchNorm's
+            # convention too; n = 1 keeps the (zero) biased value instead of dividing by zero
             running_mean.mul_(momentum).add_(mean, alpha=1 - momentum)
-            running_var.mul_(momentum).add_(var, alpha=1 - momentum)
+            running_var.mul_(momentum).add_(var, alpha=(1 - momentum) * (n / (n - 1) if n > 1 else 1.0))
         else:
             mean, var = _f32(running_mean), _f32(running_var)
         Y = torch.empty_like(X)
@@ -650,6 +615,8 @@ class InputLayerFunction(torch.autograd.Function):
             if metadata.n_items != coords.shape[0] or metadata.input_size != tuple(int(s) for s in spatial_size):
                 raise L.ScnError("InputLayer: this Metadata was prepared for different coordinates")
             metadata.handover()
+            if not metadata.prepared_for(coords):        # same point count, other coordinates (fixed-size sampling)
+                raise L.ScnError("InputLayer: this Metadata was prepared for different coordinates")
             grid = metadata.grid(metadata.input_size)
         n_items, c = F.shape
         Y = _new((grid.n, c), F)

@@ -1,0 +1,72 @@
+"""Graph builder for the per-ROI mask branch: the topology ``SparseMaskNetwork`` has under the reference's
+configuration (ndsis/modules/model.py:572-782 with scannet_config/run.py:741-810), expressed with this package's scn-API
+modules and its device ROI crop.  Together with ``unet.Backbone`` it is BASELINE config 3's sparse path:
+
+  backbone features (C0 ch, one row per active voxel)
+    -> input_conv_layer   : 'B' level, 16 ch, stride 1: SubM 1^3 C0->16 + 2 residual units             (run.py:749-755)
+    -> SparseFeaturemapSelectorBoth (model.py:573-596):
+         OutputLayer -> one row per POINT (16 ch) ++ the raw point features (7 ch) = 23 ch
+         SparseRoiCut(RawToTensor) over the selected boxes, spatial size + 32, InputLayer mode 4, batch_size = #boxes
+         SparseRoiExtraCut(RawToFeaturesScene) of the raw scene with the same selection (skip features)
+    -> output_conv_layer  : internal U-Net  I(23) -> B32/2 -> B48/2 -> B64/2 and back up to 23 ch      (run.py:756-775)
+    -> SparseFeaturemapFirst: OutputLayer -> one row per CROPPED point                                 (model.py:647-653)
+    -> Linear(23->32) -> ReLU -> Linear(32->num_classes)                                               (run.py:806; module_factory.py:700-716)
+
+The proposal source (RPN + TrainSelector) is dense PyTorch outside the hot path; `forward` takes the
+selected boxes as the reference's `selected_bbox` list.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import modules as M
+from . import roi
+from .ioLayers import OutputLayer
+from .unet import SparseUNet, units
+
+
+class MaskBranch(nn.Module):
+    def __init__(self, backbone_channels=32, raw_channels=7, input_channels=16, unet_channels=(32, 48, 64),
+                 linear_channels=(32, 18), bf16_blocks=False):
+        super().__init__()
+        c = input_channels + raw_channels
+        self.input_conv_layer = M.Sequential(M.SubmanifoldConvolution(3, backbone_channels, input_channels, 1, True),
+                                             units(input_channels, 2))
+        self.output_layer = OutputLayer(3)
+        # dense_inside=False: the selection stays the CSR list (no [boxes, points] matrix); every consumer here takes it
+        self.output_roi_cut = roi.SparseRoiCut(roi.RawToTensorFeatureExtractorCombiner(), dense_inside=False)
+        self.scene_roi_extra_cut = roi.SparseRoiExtraCut(roi.RawToFeaturesSceneFeatureExtractorCombiner())
+        self.spatial_size_extention = 32                                        # model.py:701
+        self.output_conv_layer = SparseUNet(c, (c,) + tuple(unet_channels), identity_first=True,
+                                            bf16_blocks=bf16_blocks)
+        self.roi_output_layer = OutputLayer(3)
+        layers, cin = [], c
+        for i, co in enumerate(linear_channels):
+            if i:
+                layers.append(nn.ReLU(inplace=True))
+            layers.append(nn.Linear(cin, co))
+            cin = co
+        self.linear_layer = nn.Sequential(*layers)
+        self.classes = cin
+
+    def forward(self, raw_scene, backbone_features, selected_bbox):
+        """raw_scene: the collate tuple (coords, features, spatial_size, batch_size, batch_splits) with `features` on
+        the device; backbone_features: SparseConvNetTensor (unet_feature_maps[-1]); selected_bbox: list (one per sample)
+        of fp32 [n, 2, 3] boxes.  -> (per-point-per-class mask logits [M, classes], selection)."""
+        coords, features, spatial_size, *other, batch_splits = raw_scene
+        # the InputLayer of this scene left an int32 device copy of the point coordinates in its Metadata: the crop reads
+        # that instead of converting (and range-checking, one host wait) the int64 coordinates a second time
+        pc = getattr(backbone_features.metadata, "point_coords", None)
+        if pc is not None and pc.shape[0] == coords.shape[0]:
+            coords = pc
+            raw_scene = (pc,) + tuple(raw_scene[1:])
+        converted = self.input_conv_layer(backbone_features)
+        size = torch.as_tensor([int(s) for s in spatial_size], dtype=torch.long) + self.spatial_size_extention
+        combined = torch.cat((self.output_layer(converted), features), dim=-1)
+        roi_tensor, selection = self.output_roi_cut((coords, combined, size, *other, batch_splits), selected_bbox)
+        skip_features = self.scene_roi_extra_cut(raw_scene, selection)
+        if len(skip_features) == 0 or roi_tensor is None:
+            return skip_features.new_zeros((0, self.classes)), selection
+        out = self.roi_output_layer(self.output_conv_layer(roi_tensor))
+        return self.linear_layer(out), selection

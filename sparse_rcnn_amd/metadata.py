@@ -274,6 +274,14 @@ def dedup(coords_i32: torch.Tensor, shift: int, want_counts: bool, want_first: b
 class Metadata:
     """``scn.Metadata(dimension)``.  Only dimension 3 is on the reference's path (model.py:31-114: 3D scenes)."""
 
+    # Drop-in path: the reference's module tree never announces how deep a network is -- every layer asks its Metadata
+    # for the rulebook it needs.  The first forward over an input spatial size therefore builds rulebooks one by one; the
+    # deepest level it reached is remembered here (input size -> number of levels), and later Metadata objects of that
+    # input size build the whole pyramid with ONE scn_pyramid_build call when their InputLayer rules are set.  A wrong
+    # hint only costs unused structures (or falls back to lazy building); results never depend on it.
+    LEVELS_HINT: Dict[Tuple[int, ...], int] = {}
+    AUTO_NATIVE = True
+
     def __init__(self, dimension=3):
         if int(dimension) != 3:
             raise NotImplementedError("sparse_rcnn_amd.Metadata: only dimension 3 (the reference's ScanNet path)")
@@ -291,9 +299,20 @@ class Metadata:
         self.n_samples = 0
         self.device = None
         self.ready_event = None         # set by prepare_async: index structures were built on a side stream
+        self.point_coords: Optional[torch.Tensor] = None     # int32 [Npts,4] device copy of the InputLayer coordinates
+        self._depth: Dict[Tuple[int, ...], int] = {}
+        self._unrequested = set()       # strided rulebooks built ahead on a depth hint that no layer has asked for yet
+        self._prepared_for = None       # identity of the coords tensor a prefetch was built for
+
+    def _note_levels(self, size, extra):
+        """A layer asked for a rulebook that needs depth(size) + extra levels: remember the deepest request per input size."""
+        if self.input_size is not None:
+            need = self._depth.get(tuple(size), 0) + extra
+            if need > Metadata.LEVELS_HINT.get(self.input_size, 0):
+                Metadata.LEVELS_HINT[self.input_size] = need
 
     # ---- InputLayer rules -------------------------------------------------------------------------
-    def set_input(self, spatial_size, coords: torch.Tensor, batch_size: int, mode: int):
+    def set_input(self, spatial_size, coords: torch.Tensor, batch_size: int, mode: int, auto_native: bool = True):
         """coords: int64 [Npts, 4] (x,y,z,batch), CPU (the reference's contract, data.py:95-98,207-210) or device."""
         lib = L.lib()
         size = tuple(int(s) for s in spatial_size)
@@ -301,6 +320,16 @@ class Metadata:
             raise ValueError("spatial_size must have 3 entries")
         if coords.dim() != 2 or coords.shape[1] != 4:
             raise ValueError("coords must be [N, 4] = (x, y, z, batch); single-sample [N,3] input is not used by the reference")
+        levels = Metadata.LEVELS_HINT.get(size, 0) if (auto_native and Metadata.AUTO_NATIVE) else 0
+        if levels >= 1 and coords.shape[0] > 0:
+            lv, ok = size, 1
+            while ok < levels and all(v % 2 == 0 for v in lv):
+                lv, ok = tuple(v // 2 for v in lv), ok + 1
+            self.build_native(spatial_size, coords, batch_size, mode, ok, 3)
+            # built on a hint, not on a layer's request: a Deconvolution may only use a strided rulebook once a
+            # Convolution / pooling layer of this forward has asked for it (custom_container.py:70-83)
+            self._unrequested = set(self.strided)
+            return self.grids[size]
         dev = torch.device("cuda", torch.cuda.current_device())
         self.device = dev
         c64 = coords.to(device=dev, dtype=torch.int64).contiguous()
@@ -315,6 +344,8 @@ class Metadata:
                              f"in {int(dd.extra[0][0])} wave(s)")
         self.grids[size] = grid
         self.input_size = size
+        self._depth[size] = 0
+        self.point_coords = c32
         self.item_row, self.row_count, self.row_first = item_row, row_count, row_first
         self.n_items = n
         if mode == 0 and grid.n != n:
@@ -348,7 +379,7 @@ class Metadata:
         c64 = coords.to(device=dev, dtype=torch.int64).contiguous()
         n = c64.shape[0]
         if n == 0:                       # nothing to build natively; the step-by-step path handles the empty batch
-            self.set_input(spatial_size, coords, batch_size, mode)
+            self.set_input(spatial_size, coords, batch_size, mode, auto_native=False)
             return self
         ws = torch.empty(lib.scn_pyramid_workspace_bytes(n, n_levels, k), dtype=torch.uint8, device=dev)
         desc = (C.c_int64 * L.PYRAMID_DESC_LEN)()
@@ -361,7 +392,10 @@ class Metadata:
             return t.view(shape) if shape is not None else t
         n_off = k ** 3
         n0 = int(desc[8])
+        if int(desc[3]):
+            raise L.ScnError(f"libscn_mi355x error {L.EHASH}: coordinates outside the key range in {int(desc[3])} wave(s)")
         self.input_size = size
+        self.point_coords = view(desc[7], n * 4, torch.int32, (n, 4))
         self.item_row = view(desc[4], n, torch.int32)
         self.row_count = view(desc[5], n0, torch.int32)
         self.row_first = view(desc[6], n0, torch.int32)
@@ -376,6 +410,7 @@ class Metadata:
             grid = Grid(view(D[2], nl * 4, torch.int32, (nl, 4)), view(D[3], cap, torch.int64), view(D[4], cap, torch.int32),
                         cap, nl)
             self.grids[lv_size] = grid
+            self._depth[lv_size] = l
             if k == 1:
                 self.subm[(lv_size, 1)] = SubmRulebook(None, None, 1, nl)
             elif nl > 0:
@@ -425,6 +460,8 @@ class Metadata:
                                            L.ptr(table), L.stream()))
                 rb = SubmRulebook(table, compact_rules(table, k ** 3, g.n), k, g.n, build_tiles(table, k ** 3, g.n))
             self.subm[key] = rb
+        if k == 3:
+            self._note_levels(size, 1)
         return rb
 
     def _strided_launch(self, size):
@@ -444,6 +481,7 @@ class Metadata:
         dev = g.coords.device
         cg, parent, _, _ = pending.finish()
         self.grids[coarse_size] = cg
+        self._depth[coarse_size] = self._depth.get(tuple(size), 0) + 1
         child = torch.empty((8, cg.n), dtype=torch.int32, device=dev)
         fine_off = _empty(g.n, torch.int32, dev)
         L.check(lib.scn_child_table(L.ptr(g.coords), L.ptr(parent), g.n, cg.n, L.ptr(child), L.ptr(fine_off),
@@ -459,7 +497,14 @@ class Metadata:
         rb = self.strided.get(size)
         if rb is None:
             rb = self._strided_finish(size, self._strided_launch(size))
+        self._unrequested.discard(size)
+        self._note_levels(size, 2)
         return rb
+
+    def cached_strided_rulebook(self, size):
+        """The rulebook a Deconvolution back to `size` re-uses, or None when no layer of this forward has built it."""
+        size = tuple(int(s) for s in size)
+        return None if size in self._unrequested else self.strided.get(size)
 
     # ---- index prefetch on a side stream -----------------------------------------------------------
     def prepare_async(self, spatial_size, coords, batch_size: int = 0, mode: int = 4, n_levels: int = 0, k: int = 3,
@@ -472,11 +517,12 @@ class Metadata:
         Metadata (same coords) instead of rebuilding it; `handover()` orders the consumer stream behind the build."""
         side = index_stream(torch.device("cuda", torch.cuda.current_device()))
         side.wait_stream(torch.cuda.current_stream())          # coords may have been produced on the current stream
+        self._prepared_for = (coords.data_ptr(), coords._version, tuple(coords.shape), coords.device)
         with torch.cuda.stream(side):
             if native and n_levels:
                 self.build_native(spatial_size, coords, batch_size, mode, n_levels, k)
             else:
-                self.set_input(spatial_size, coords, batch_size, mode)
+                self.set_input(spatial_size, coords, batch_size, mode, auto_native=False)
                 if n_levels:
                     self.build_pyramid(spatial_size, n_levels, k)
             self.ready_event = torch.cuda.Event()
@@ -495,8 +541,18 @@ class Metadata:
             return self.prepare_async(spatial_size, coords, batch_size, mode, n_levels, k, native=native)
         return PendingMetadata(fn)
 
+    def prepared_for(self, coords: torch.Tensor) -> bool:
+        """Was this (prefetched) Metadata built for `coords`?  The same tensor object and version is accepted at once;
+        anything else is compared value by value with the stored int32 copy (one host wait: a rare path)."""
+        if self._prepared_for == (coords.data_ptr(), coords._version, tuple(coords.shape), coords.device):
+            return True
+        if self.point_coords is None or tuple(coords.shape) != tuple(self.point_coords.shape):
+            return False
+        return bool((coords.to(self.point_coords.device) == self.point_coords).all().item())
+
     def _all_tensors(self):
-        out = [self.item_row, self.row_count, self.row_first, self.row_last, getattr(self, "_workspace", None)]
+        out = [self.item_row, self.row_count, self.row_first, self.row_last, self.point_coords,
+               getattr(self, "_workspace", None)]
         for g in self.grids.values():
             out += [g.coords, g.table_keys, g.table_rows]
         for rb in list(self.subm.values()) + list(self.strided.values()):

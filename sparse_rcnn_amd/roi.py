@@ -1,26 +1,35 @@
 """Sparse ROI crop on the device.
 
-Mirrors ndsis/modules/roi_select_sparse.py (``roi_cut`` :170-180, ``select_features`` :125-133, ``select_coords``
-:136-149, ``get_inside_indicator`` :157-167, ``SparseRoiCut`` :29-52, ``SparseRoiExtraCut`` :8-26,
-``RawToTensorFeatureExtractorCombiner`` :67-84) and roi_select_bbox_transform.py ``BBoxTransformerSlice`` (:56-70,87-97).
+Mirrors ndsis/modules/roi_select_sparse.py -- ``roi_cut`` :170-180, ``select_features`` :125-133, ``select_coords``
+:136-149, ``get_inside_indicator`` :157-167, ``SparseRoiCut`` :29-52, ``SparseRoiExtraCut`` :8-26 and the four
+extractor/combiner classes :55-122 -- and roi_select_bbox_transform.py ``BBoxTransformerSlice`` (:56-70,87-97), with the
+same class names, constructor signatures and return structure.
 
-Differences in mechanism, not in results: the box test writes an int32 [BB,N] rule table that the same wave-ballot
-compaction as the rulebooks turns into the (box-major, ascending point row) selection; no BB x N x C expanded view is
-materialised, features are gathered once by row index; nothing is copied back to the host unless the caller asks for
-the reference's return types (``roi_cut`` returns CPU coords and a CPU bool matrix, roi_select_sparse.py:180).
+Differences in mechanism, not in results: the crop is count -> scan -> scatter over 256-point units (scn_roi_count /
+scn_roi_fill, csrc/scn_roi.hip).  No [boxes, points] object and no BB x N x C expanded view exist; the selection is a CSR
+list (`RoiSelection`: point row and box of every selected row, box-major, ascending point row -- the order the
+reference's boolean-mask gather produces).  The dense bool matrix ``is_inside`` that the reference hands on to its mask
+predictor / loss selector is rebuilt from the list only when asked for (``RoiSelection.is_inside()``,
+``dense_inside=True``); the device consumers below (``mask_predict``, ``mask_loss_select``, ``SparseRoiExtraCut``) take
+the list.
 """
 from __future__ import annotations
+
+import ctypes as C
 
 import torch
 
 from . import _lib as L
 from .functional import _f32
 from .ioLayers import InputLayerFunction
-from .metadata import Metadata, compact_rules
+from .metadata import Metadata, _Readback
 from .tensor import SparseConvNetTensor
 
 
 class _GatherRows(torch.autograd.Function):
+    """select_features (roi_select_sparse.py:125-133): rows of `features` by the selection's point rows; backward is the
+    segment sum over the boxes a point fell into."""
+
     @staticmethod
     def forward(ctx, features, rows, n_src):
         X = _f32(features)
@@ -41,9 +50,10 @@ class _GatherRows(torch.autograd.Function):
         return dX, None, None
 
 
-def transform_boxes(bbox_batch, spatial_size=None, clip=False):
-    """BBoxTransformerSlice.forward: list of fp32 [n_i,2,3] -> (int32 device [BB,8] start|stop incl. sample interval,
-    per-sample counts, per-box sample index)."""
+def transform_boxes(bbox_batch, spatial_size=None, clip=False, resize=None):
+    """BBoxTransformerSlice.forward (roi_select_bbox_transform.py:56-70,87-97): list of fp32 [n_i,2,3] -> (int32 device
+    [BB,8] start|stop incl. the sample interval, per-sample counts, per-box sample index).  resize: the Divider's value
+    (scalar or one per axis, :15-21), applied in fp32 before floor / ceil."""
     lib = L.lib()
     dev = torch.device("cuda", torch.cuda.current_device())
     counts = [len(b) for b in bbox_batch]
@@ -54,43 +64,79 @@ def transform_boxes(bbox_batch, spatial_size=None, clip=False):
     if bb:
         raw = torch.cat([b.reshape(-1, 2, 3) for b in bbox_batch]).to(device=dev, dtype=torch.float32).contiguous()
         size = torch.as_tensor([int(s) for s in spatial_size], dtype=torch.int32, device=dev) if clip else None
+        div = None
+        if resize is not None:
+            div = torch.as_tensor(resize, dtype=torch.float32).reshape(-1)
+            div = (div.repeat(3) if div.numel() == 1 else div).to(dev).contiguous()
+            if div.numel() != 3:
+                raise ValueError("resize_boxes must be a scalar or have one entry per axis")
         sample = assoc.to(device=dev, dtype=torch.int32)
-        L.check(lib.scn_roi_boxes(L.ptr(raw), L.ptr(sample), bb, L.ptr(size), L.ptr(out), L.stream()))
+        L.check(lib.scn_roi_boxes(L.ptr(raw), L.ptr(sample), bb, L.ptr(size), L.ptr(div), L.ptr(out), L.stream()))
     return out, counts, assoc
 
 
 class RoiSelection:
-    """Device-side result of the crop: CSR over boxes instead of the reference's dense bool matrix."""
+    """Device-side result of the crop: the list form (CSR over boxes) of the reference's dense bool matrix.
 
-    def __init__(self, src_row, box_of, prefix, n_points, n_boxes, inside_u8=None):
-        self.src_row, self.box_of, self.prefix = src_row, box_of, prefix      # int32 [M], int32 [M], list[BB+1]
+      src_row int32 [M]   point row of every selected row        box_of int32 [M]   its box
+      prefix  list[BB+1]  first selected row of every box (host) new_coords int64 [M,4] = (x, y, z, box) on the device
+    """
+
+    def __init__(self, src_row, box_of, prefix, n_points, n_boxes, new_coords=None):
+        self.src_row, self.box_of, self.prefix = src_row, box_of, prefix
         self.n_points, self.n_boxes = n_points, n_boxes
-        self._inside = inside_u8
+        self.new_coords = new_coords
+        self._inside = None
+
+    def is_inside_u8(self):
+        """uint8 device [BB, N] (scn_roi_inside), built on first request."""
+        if self._inside is None:
+            dev = self.src_row.device
+            inside = torch.empty((self.n_boxes, self.n_points), dtype=torch.uint8, device=dev)
+            L.check(L.lib().scn_roi_inside(L.ptr(self.src_row), L.ptr(self.box_of), self.src_row.shape[0], self.n_points,
+                                           self.n_boxes, L.ptr(inside), L.stream()))
+            self._inside = inside
+        return self._inside
 
     def is_inside(self):
-        """bool CPU [BB, N] as roi_cut returns it."""
-        return self._inside.bool().cpu()
+        """bool CPU [BB, N] as roi_cut returns it (roi_select_sparse.py:180)."""
+        return self.is_inside_u8().bool().cpu()
+
+    # the reference's consumers use `len(is_inside)` for the number of boxes (roi_select_sparse.py:23,50)
+    def __len__(self):
+        return self.n_boxes
 
 
-def roi_select(coords_i32: torch.Tensor, boxes_i32: torch.Tensor, want_inside=True) -> RoiSelection:
+def roi_select(coords_i32: torch.Tensor, boxes_i32: torch.Tensor, want_coords=True) -> RoiSelection:
+    """count -> scan -> scatter.  One host wait (for the per-box row counts, M = prefix[BB])."""
     lib = L.lib()
     n, bb = coords_i32.shape[0], boxes_i32.shape[0]
     dev = coords_i32.device
     if bb == 0 or n == 0:
         e = torch.zeros(0, dtype=torch.int32, device=dev)
-        inside = torch.zeros((bb, n), dtype=torch.uint8, device=dev)
-        return RoiSelection(e, e, [0] * (bb + 1), n, bb, inside)
-    table = torch.empty((bb, n), dtype=torch.int32, device=dev)
-    inside = torch.empty((bb, n), dtype=torch.uint8, device=dev) if want_inside else None
-    L.check(lib.scn_roi_table(L.ptr(coords_i32), n, L.ptr(boxes_i32), bb, L.ptr(table), L.ptr(inside), L.stream()))
-    rules, seg = compact_rules(table, bb, n, want_seg=True)
-    return RoiSelection(rules.in_rows, seg, rules.prefix_list(), n, bb, inside)
+        return RoiSelection(e, e, [0] * (bb + 1), n, bb, torch.zeros((0, 4), dtype=torch.int64, device=dev))
+    offsets = torch.empty(bb * lib.scn_roi_units(n), dtype=torch.int32, device=dev)
+    prefix_dev = torch.empty(bb + 1, dtype=torch.int64, device=dev)
+    L.check(lib.scn_roi_count(L.ptr(coords_i32), n, L.ptr(boxes_i32), bb, L.ptr(offsets), L.ptr(prefix_dev), None,
+                              L.stream()))
+    prefix = _Readback(prefix_dev).get()[0].tolist()
+    m = int(prefix[bb])
+    if m >= 2 ** 31 - 1:
+        raise L.ScnError("ROI selection exceeds int32 rows")
+    src_row = torch.empty(m, dtype=torch.int32, device=dev)
+    box_of = torch.empty(m, dtype=torch.int32, device=dev)
+    new_coords = torch.empty((m, 4), dtype=torch.int64, device=dev) if want_coords else None
+    if m:
+        L.check(lib.scn_roi_fill(L.ptr(coords_i32), n, L.ptr(boxes_i32), bb, L.ptr(offsets), L.ptr(src_row),
+                                 L.ptr(box_of), L.ptr(new_coords), L.stream()))
+    return RoiSelection(src_row, box_of, prefix, n, bb, new_coords)
 
 
 def _coords_to_device(coords):
     lib = L.lib()
-    import ctypes as C
     dev = torch.device("cuda", torch.cuda.current_device())
+    if coords.dtype == torch.int32 and coords.is_cuda:
+        return coords.contiguous()
     c64 = coords.to(device=dev, dtype=torch.int64).contiguous()
     c32 = torch.empty((c64.shape[0], 4), dtype=torch.int32, device=dev)
     bad, flag = C.c_int64(0), torch.empty(1, dtype=torch.int32, device=dev)
@@ -98,16 +144,28 @@ def _coords_to_device(coords):
     return c32
 
 
+def select_features(features, selection: RoiSelection):
+    """select_features (roi_select_sparse.py:125-133) from the list: features[src_row], differentiable."""
+    dev = selection.src_row.device
+    return _GatherRows.apply(features.to(dev), selection.src_row, features.shape[0])
+
+
+def select_coords(coords, selection: RoiSelection):
+    """select_coords (roi_select_sparse.py:136-149): int64 device [M,4] = (x, y, z, box)."""
+    if selection.new_coords is not None:
+        return selection.new_coords
+    c32 = _coords_to_device(coords)
+    m = selection.src_row.shape[0]
+    out = torch.empty((m, 4), dtype=torch.int64, device=c32.device)
+    L.check(L.lib().scn_roi_coords(L.ptr(c32), L.ptr(selection.src_row), L.ptr(selection.box_of), m, L.ptr(out),
+                                   L.stream()))
+    return out
+
+
 def roi_cut_device(coords, features, boxes_i32):
     """-> (new_coords int64 device [M,4] = (x,y,z,box), new_features [M,C], RoiSelection)."""
-    lib = L.lib()
-    c32 = coords if coords.dtype == torch.int32 and coords.is_cuda else _coords_to_device(coords)
-    sel = roi_select(c32, boxes_i32)
-    m = sel.src_row.shape[0]
-    new_coords = torch.empty((m, 4), dtype=torch.int64, device=c32.device)
-    L.check(lib.scn_roi_coords(L.ptr(c32), L.ptr(sel.src_row), L.ptr(sel.box_of), m, L.ptr(new_coords), L.stream()))
-    new_features = _GatherRows.apply(features.to(c32.device), sel.src_row, features.shape[0])
-    return new_coords, new_features, sel
+    sel = roi_select(_coords_to_device(coords), boxes_i32)
+    return sel.new_coords, select_features(features, sel), sel
 
 
 def roi_cut(coords, features, bbox_tensor, bbox_sample_association):
@@ -122,27 +180,120 @@ def roi_cut(coords, features, bbox_tensor, bbox_sample_association):
     return new_coords.cpu(), new_features, sel.is_inside()
 
 
-class SparseRoiCut(torch.nn.Module):
-    """``SparseRoiCut(RawToTensorFeatureExtractorCombiner)`` (roi_select_sparse.py:29-52,67-84): feature_map is the
-    raw tuple (coords, features, spatial_size, ..., batch_splits); returns (SparseConvNetTensor over the ROI batch,
-    (is_inside, bbox_sample_count, batch_splits))."""
+# ---- the reference's extractor / combiner classes (roi_select_sparse.py:55-122) -----------------------------------
+class RawToFeaturesSceneFeatureExtractorCombiner:
+    """:55-64 -- raw scene tuple in, the selected feature rows out."""
+    NEED_COORDS = False
 
-    def __init__(self, clip_boxes=False, spatial_size_offset=0, mode=4, dense_inside=True):
+    @staticmethod
+    def extract(feature_map):
+        new_coords, new_features, spatial_size, *_, batch_splits = feature_map
+        return new_coords, new_features, spatial_size, batch_splits
+
+    @staticmethod
+    def combine(new_coords, new_features, spatial_size, batch_size=0):
+        return new_features
+
+
+class RawToTensorFeatureExtractorCombiner:
+    """:67-84 -- raw scene tuple in, a SparseConvNetTensor over the ROI batch out (InputLayer mode 4, batch_size = BB so
+    that empty boxes stay addressable)."""
+    NEED_COORDS = True
+    MODE = 4
+    extract = staticmethod(RawToFeaturesSceneFeatureExtractorCombiner.extract)
+
+    @classmethod
+    def combine(cls, new_coords, new_features, spatial_size, batch_size=0):
+        if new_coords.shape[0] == 0:     # CustomInputLayer's contract for an empty crop (custom_operations.py:71,85-86)
+            return None
+        md = Metadata(len(spatial_size))
+        size = torch.as_tensor([int(s) for s in spatial_size], dtype=torch.long)
+        feats = InputLayerFunction.apply(len(spatial_size), md, size, new_coords, new_features, batch_size, cls.MODE)
+        return SparseConvNetTensor(features=feats, metadata=md, spatial_size=size)
+
+
+class RawToRawFeatureExtractorCombiner:
+    """:87-96 -- raw scene tuple in, raw (coords, features, spatial_size, batch_size) out."""
+    NEED_COORDS = True
+    extract = staticmethod(RawToFeaturesSceneFeatureExtractorCombiner.extract)
+
+    @staticmethod
+    def combine(new_coords, new_features, spatial_size, batch_size=0):
+        return new_coords, new_features, spatial_size, batch_size
+
+
+class TensorToTensorFeatureExtractorCombiner(RawToTensorFeatureExtractorCombiner):
+    """:99-122 -- a SparseConvNetTensor in (its active sites are the points: unique per sample, so the re-voxelisation
+    is InputLayer mode 0), a SparseConvNetTensor over the ROI batch out.  The sites stay on the device (the int32 grid
+    of the tensor's Metadata); batch_splits = rows per sample."""
+    MODE = 0
+
+    @staticmethod
+    def extract(feature_map):
+        size = tuple(int(s) for s in feature_map.spatial_size)
+        grid = feature_map.metadata.grid(size)
+        batch = grid.coords[:, 3]
+        if grid.n and bool((batch[1:] < batch[:-1]).any()):      # the reference asserts is_sorted (:106-107)
+            raise L.ScnError("TensorToTensor ROI cut needs rows grouped by ascending sample")
+        batch_splits = torch.bincount(batch.long(), minlength=feature_map.batch_size()).cpu()
+        return grid.coords, feature_map.features, feature_map.spatial_size, batch_splits
+
+
+class SparseRoiCut(torch.nn.Module):
+    """``SparseRoiCut(feature_extractor_combiner, clip_boxes=False, resize_boxes=None)`` (roi_select_sparse.py:29-52).
+
+    forward(feature_map, bbox_batch) -> (combiner output, (is_inside, bbox_sample_count, batch_splits)).  ``is_inside``
+    is the reference's bool CPU [BB, N] matrix when ``dense_inside`` (keyword-only, default True: the reference's return
+    type) and the `RoiSelection` list otherwise -- what this package's own consumers (SparseRoiExtraCut, mask_predict,
+    mask_loss_select) take; the matrix is never built on that path."""
+
+    def __init__(self, feature_extractor_combiner, clip_boxes=False, resize_boxes=None, *, dense_inside=True):
         super().__init__()
-        self.clip, self.offset, self.mode, self.dense_inside = clip_boxes, spatial_size_offset, mode, dense_inside
+        if not (hasattr(feature_extractor_combiner, "extract") and hasattr(feature_extractor_combiner, "combine")):
+            raise TypeError("SparseRoiCut: the first argument is the feature extractor/combiner "
+                            "(roi_select_sparse.py:30-36), got " + repr(feature_extractor_combiner))
+        if not isinstance(clip_boxes, bool):
+            raise TypeError("clip_boxes must be a bool")
+        self.feature_extractor_combiner = feature_extractor_combiner
+        self.clip_boxes, self.resize_boxes, self.dense_inside = clip_boxes, resize_boxes, dense_inside
 
     def forward(self, feature_map, bbox_batch):
-        coords, features, spatial_size, *_, batch_splits = feature_map
-        boxes, counts, _ = transform_boxes(bbox_batch, spatial_size, self.clip)
-        new_coords, new_features, sel = roi_cut_device(coords, features, boxes)
-        size = torch.as_tensor([int(s) + self.offset for s in spatial_size], dtype=torch.long)
-        if new_coords.shape[0] == 0:        # no point in any box: CustomInputLayer returns None (custom_operations.py:71,85-86)
-            out = None
-        else:
-            md = Metadata(3)
-            feats = InputLayerFunction.apply(3, md, size, new_coords, new_features, boxes.shape[0], self.mode)
-            out = SparseConvNetTensor(features=feats, metadata=md, spatial_size=size)
-        return out, (sel.is_inside() if self.dense_inside else sel, counts, batch_splits)
+        fec = self.feature_extractor_combiner
+        old_coords, old_features, spatial_size, batch_splits = fec.extract(feature_map)
+        boxes, counts, _ = transform_boxes(bbox_batch, spatial_size, self.clip_boxes, self.resize_boxes)
+        new_coords, new_features, sel = roi_cut_device(old_coords, old_features, boxes)
+        box_features = fec.combine(new_coords, new_features, spatial_size, sel.n_boxes)
+        return box_features, (sel.is_inside() if self.dense_inside else sel, counts, batch_splits)
+
+
+class SparseRoiExtraCut(torch.nn.Module):
+    """``SparseRoiExtraCut(feature_extractor_combiner)`` (roi_select_sparse.py:8-26): a second feature map cut with the
+    selection of an earlier SparseRoiCut.  `selection[0]` is the `RoiSelection` list (re-used as is) or the reference's
+    bool matrix (converted to the list once)."""
+
+    def __init__(self, feature_extractor_combiner):
+        super().__init__()
+        self.feature_extractor_combiner = feature_extractor_combiner
+
+    def forward(self, feature_map, selection, new_coords=None):
+        fec = self.feature_extractor_combiner
+        inside, bbox_sample_count, batch_splits = selection
+        old_coords, old_features, spatial_size, batch_splits = fec.extract(feature_map)
+        sel = inside if isinstance(inside, RoiSelection) else selection_from_matrix(inside)
+        new_features = select_features(old_features, sel)
+        if fec.NEED_COORDS and new_coords is None:
+            new_coords = select_coords(old_coords, sel)
+        return fec.combine(new_coords, new_features, spatial_size, sel.n_boxes)
+
+
+def selection_from_matrix(is_inside) -> RoiSelection:
+    """The list form of a reference-style bool [BB, N] matrix (row-major nonzero = box-major, ascending point row)."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    m = torch.as_tensor(is_inside).to(dev)
+    bb, n = m.shape
+    nz = m.nonzero()
+    prefix = [0] + torch.cumsum(m.sum(1), 0).tolist()
+    return RoiSelection(nz[:, 1].to(torch.int32).contiguous(), nz[:, 0].to(torch.int32).contiguous(), prefix, n, bb)
 
 
 # ------------------------------------------------------------------------------------------------------

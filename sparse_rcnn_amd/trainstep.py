@@ -1,0 +1,114 @@
+"""One data-parallel training step of the sparse path on one rank: what ``bench.py`` times and the at-size parity tests
+check.  A step = index build (InputLayer rules + every rulebook; rebuilt per batch as in the reference) + forward +
+backward to every parameter and the input features + all-reduce of the flat gradient buffer (RCCL / gloo, N > 1) + SGD.
+
+Workloads (BASELINE.json configs; SURVEY.md §8d synthetic inputs):
+  cfg2  configs[1]  one ~150k-voxel scene, U-Net backbone 32-64-128-256
+  cfg3  configs[2]  cfg2 + 64 boxes per scene -> sparse ROI crop -> mask branch (maskhead.MaskBranch); the proposal
+                    source (dense RPN) is PyTorch outside the hot path and not part of the step
+  cfg5  configs[4]  one ~600k-voxel scene, 5-level U-Net to 512 channels
+configs[3] (8 scenes data-parallel) is cfg3 with one scene per rank.
+"""
+from __future__ import annotations
+
+import torch
+
+from .dp import FlatParams, broadcast_params
+from .maskhead import MaskBranch
+from .synthetic import make_batch, make_boxes
+from .unet import Backbone
+
+WORKLOADS = {      # name -> (channels, grid, active voxels, boxes per scene, BASELINE.json entry)
+    "cfg2": ((32, 64, 128, 256), (512, 512, 256), 150_000, 0, "configs[1]"),
+    "cfg3": ((32, 64, 128, 256), (512, 512, 256), 150_000, 64, "configs[2]"),
+    "cfg5": ((32, 64, 128, 256, 512), (1024, 1024, 512), 600_000, 0, "configs[4] shape (one scene per GPU)"),
+}
+
+
+class SparseStepModel(torch.nn.Module):
+    """Backbone (+ mask branch for cfg3) as one module, so that one flat parameter buffer covers the step."""
+
+    def __init__(self, channels, with_mask, storage):
+        super().__init__()
+        self.backbone = Backbone(7, channels, bf16_blocks=storage)
+        self.mask = MaskBranch(channels[0], 7, bf16_blocks=False) if with_mask else None
+
+
+class SceneStep:
+    def __init__(self, workload="cfg2", device=None, dtype="f32", prefetch=True, seed=1, grad_seed=100, n_buckets=4,
+                 target=None, channels=None, grid=None, n_boxes=None, lr=1e-6):
+        ch, gr, tg, nb, self.baseline_entry = WORKLOADS[workload]
+        self.workload, self.dtype, self.prefetch, self.lr = workload, dtype, prefetch, lr
+        self.channels = tuple(channels or ch)
+        self.grid = tuple(grid or gr)
+        self.n_boxes = nb if n_boxes is None else n_boxes
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if dtype not in ("f32", "bf16", "bf16-blocks"):
+            raise ValueError("dtype: f32 | bf16 | bf16-blocks")
+        storage = {"f32": False, "bf16": "all", "bf16-blocks": True}[dtype]
+        coords, feats, size, bs, splits = make_batch(1, self.grid, target or tg, dup=1.15, seed=seed)
+        self.coords_cpu, self.feats_cpu, self.size, self.batch_size, self.splits = coords, feats, size, bs, splits
+        self.coords, self.feats = coords.to(self.device), feats.to(self.device)      # resident in HBM
+        self.boxes = make_boxes(coords, self.n_boxes, seed=seed + 2) if self.n_boxes else None
+        torch.manual_seed(0)
+        self.model = SparseStepModel(self.channels, bool(self.n_boxes), storage).to(self.device)
+        self.flat = FlatParams(self.model, n_buckets=n_buckets)
+        broadcast_params(self.flat)
+        self._gen = torch.Generator(device="cpu").manual_seed(grad_seed)
+        self._gy = self._gm = None
+        self._md_next = None
+        self.n_active = 0
+        self.n_roi_rows = 0
+        self.out = self.logits = self.fin = None
+
+    # ------------------------------------------------------------------------------------------------------------
+    def forward_backward(self):
+        """Index build + forward + backward (no collective, no update).  Keeps .out / .logits / .fin for checks."""
+        m = self.model
+        self.flat.zero_grad()
+        fin = self.feats.detach().requires_grad_()
+        md = self._md_next.result() if self._md_next is not None else None
+        self._md_next = None
+        # the index structures of the NEXT batch depend on its coordinates only (a data loader's output): a helper thread
+        # builds them on the high-priority index stream while this batch runs; every step contains one complete build
+        if self.prefetch:
+            self._md_next = m.backbone.prefetch_in_thread(self.coords, self.size, 1)
+        out = m.backbone(self.coords, fin, self.size, 1, metadata=md)
+        if self._gy is None or self._gy.shape != out.features.shape:
+            self._gy = torch.randn(out.features.shape, generator=self._gen).to(self.device)   # upstream grad dY ~ N(0,1)
+            self.n_active = out.features.shape[0]
+        if m.mask is None:
+            out.features.backward(self._gy)
+            logits = None
+        else:
+            scene = (self.coords, fin, self.size, self.batch_size, self.splits)
+            logits, selection = m.mask(scene, out, self.boxes)
+            if self._gm is None or self._gm.shape != logits.shape:
+                self._gm = torch.randn(logits.shape, generator=self._gen).to(self.device)
+                self.n_roi_rows = logits.shape[0]
+            torch.autograd.backward([out.features, logits], [self._gy, self._gm])
+        self.out, self.logits, self.fin = out, logits, fin
+
+    def step(self):
+        self.forward_backward()
+        self.flat.all_reduce_mean()
+        self.flat.sgd_step(self.lr)
+
+    def finish(self):
+        """Join the index build started by the last step (it belongs to the timed region)."""
+        if self._md_next is not None:
+            self._md_next.result()
+            self._md_next = None
+
+    def describe(self):
+        s = (f"BASELINE {self.baseline_entry}: one synthetic ScanNet-shaped scene per GPU, {self.n_active} active voxels "
+             f"(grid {self.grid[0]}x{self.grid[1]}x{self.grid[2]}, 1.15 points/voxel), U-Net "
+             + "-".join(map(str, self.channels)) + ", 2 pre-act residual blocks/level, 2^3/2 conv+deconv")
+        if self.n_boxes:
+            s += (f"; + {self.n_boxes} fp32 boxes/scene (edges 8-96 voxels) -> sparse ROI crop ({self.n_roi_rows} cropped "
+                  "points) -> mask branch (SubM1 + 2 units @16, internal U-Net 23-32-48-64, Linear 23-32-18); proposals "
+                  "are synthetic (the dense RPN is PyTorch, outside the hot path)")
+        s += "; step = rulebooks + fwd + bwd (+ grad all-reduce + SGD)"
+        if self.prefetch:
+            s += "; rulebooks of batch i+1 built on a helper thread during batch i"
+        return s

@@ -35,9 +35,16 @@ class SparseUNet(nn.Module):
     """forward(SparseConvNetTensor with Cin channels) -> SparseConvNetTensor with channels[0] channels at full
     resolution; ``.interims`` holds the encoder outputs (the reference's SequentialInterims, custom_container.py:5-12)."""
 
-    def __init__(self, cin=7, channels=(32, 64, 128, 256), num_units=2, batchnorm=False, bf16_blocks=False):
+    def __init__(self, cin=7, channels=(32, 64, 128, 256), num_units=2, batchnorm=False, bf16_blocks=False,
+                 identity_first=False):
+        """identity_first: level 0 of the encoder is the reference's FLD('I') -- no layer at all, channels[0] == cin
+        (the mask head's internal U-Net: scannet_config/run.py:756-775, I -> B32/2 -> B48/2 -> B64/2; the decoder's
+        level 0 still has its NiN(2 cin -> cin) + residual units, module_factory.py:533-578)."""
         super().__init__()
         self.channels = tuple(channels)
+        self.identity_first = bool(identity_first)
+        if self.identity_first and self.channels[0] != cin:
+            raise ValueError("identity_first needs channels[0] == cin")
         # bf16_blocks: the residual units (28 of the 44 convolutions) keep their features, intermediates and gradients
         # in bf16 (functional.ResidualBlockFunctionBF16); the strided / 1x1 layers between them stay fp32, with one
         # cast on either side of a run of units.  Not the reference's arithmetic: BASELINE configs 3-5 (SURVEY H7).
@@ -50,6 +57,9 @@ class SparseUNet(nn.Module):
             raise ValueError("bf16_blocks needs channel counts that are multiples of 8 and no batch norm")
         enc = []
         for l, c in enumerate(self.channels):
+            if l == 0 and self.identity_first:
+                enc.append(M.Sequential(M.Identity(), M.Identity()))
+                continue
             head = (M.SubmanifoldConvolution(3, cin, c, 1, True) if l == 0
                     else M.Convolution(3, self.channels[l - 1], c, (2, 2, 2), (2, 2, 2), True))
             enc.append(M.Sequential(head, units(c, num_units, batchnorm)))
@@ -64,8 +74,11 @@ class SparseUNet(nn.Module):
                 units=units(c, num_units, batchnorm))))
         self.decoder = nn.ModuleList(dec)
 
-    def forward(self, x):
-        x.metadata.build_pyramid(x.spatial_size, len(self.channels), 3)
+    def forward(self, x, prebuild=True):
+        """prebuild=False: no up-front index build -- every rulebook is requested by the first layer that needs it, the
+        way the reference's module tree drives the scn surface (DropinBackbone)."""
+        if prebuild:
+            x.metadata.build_pyramid(x.spatial_size, len(self.channels), 3)
         interims = []
         for l, level in enumerate(self.encoder):
             x = level[0](x)
@@ -88,6 +101,8 @@ class SparseUNet(nn.Module):
     def named_oracle_params(self):
         out = {}
         for l, level in enumerate(self.encoder):
+            if l == 0 and self.identity_first:
+                continue
             out[f"enc{l}.in.weight"], out[f"enc{l}.in.bias"] = level[0].weight, level[0].bias
             self._res(out, f"enc{l}", level[1])
         for i, d in enumerate(self.decoder):
@@ -141,3 +156,19 @@ class Backbone(nn.Module):
         """Build the index structures of a coming batch on the index stream (overlaps the current batch's kernels)."""
         from .metadata import Metadata
         return Metadata(3).prepare_async(spatial_size, coords, batch_size, 4, len(self.unet.channels), 3, native=True)
+
+
+class DropinBackbone(nn.Module):
+    """The backbone driven the way the reference's own module tree drives the scn surface (the drop-in path proper):
+    `CustomInputLayer` creates the Metadata inside the forward from HOST coordinates (custom_operations.py:67-83), no
+    layer announces the depth of the network, rulebooks are requested one by one by the layers that need them, and there
+    is no helper thread.  Shares the parameters of a `Backbone`; used by `bench.py --dropin` and the tests to compare the
+    two ways of driving the same kernels."""
+
+    def __init__(self, backbone: Backbone):
+        super().__init__()
+        self.unet = backbone.unet
+
+    def forward(self, coords, feats, spatial_size, batch_size=0):
+        x = InputLayer(3, spatial_size, mode=4)((coords, feats, batch_size))
+        return self.unet(x, prebuild=False)

@@ -21,7 +21,7 @@ def test_header_declares_the_hot_path():
     for must in ("scn_dedup_build", "scn_subm_table", "scn_child_table", "scn_rules_scan", "scn_rules_fill",
                  "scn_tiles_build", "scn_conv_tiles", "scn_gemm_table", "scn_gemm_rules", "scn_wgrad_rules",
                  "scn_bn_fwd", "scn_bn_bwd", "scn_input_fwd", "scn_input_bwd", "scn_gather_rows", "scn_segment_sum",
-                 "scn_sparse_to_dense_fwd", "scn_roi_table", "scn_roi_boxes", "scn_roi_coords"):
+                 "scn_sparse_to_dense_fwd", "scn_roi_count", "scn_roi_fill", "scn_roi_inside", "scn_roi_boxes", "scn_roi_coords"):
         assert must in fns
 
 

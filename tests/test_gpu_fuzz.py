@@ -174,7 +174,8 @@ def test_fuzz_roi_crop(gpu, seed):
                boxes=[len(b) for b in bbox_batch])
     feats = torch.randn(len(coords), cin, generator=torch.Generator().manual_seed(seed))
     fg = feats.to(gpu).requires_grad_()
-    out, (is_inside, counts, splits) = roi.SparseRoiCut(spatial_size_offset=32)((coords, fg, size, batch, [0]), bbox_batch)
+    cut = roi.SparseRoiCut(roi.RawToTensorFeatureExtractorCombiner())
+    out, (is_inside, counts, splits) = cut((coords, fg, size + 32, batch, [0]), bbox_batch)
     bi, cnt, assoc = O.transform_boxes([b.numpy() for b in bbox_batch])
     src, box_of, inside = O.roi_crop(coords.numpy(), bi, assoc)
     assert np.array_equal(is_inside.numpy(), inside) and list(counts) == list(cnt), cfg

@@ -334,7 +334,8 @@ def test_roi_crop_matches_reference_golden(gpu, path):
     inside = np.unpackbits(z["is_inside"], axis=1)[:, :n_pts].astype(bool)
     counts = z["box_counts"].tolist()
     bbox_batch = [torch.from_numpy(b) for b in np.split(z["boxes"], np.cumsum(counts)[:-1])]
-    boxes, got_counts, assoc = roi.transform_boxes(bbox_batch, z["spatial_size"], bool(z["clip"]))
+    resize = z["resize"].tolist() if len(z["resize"]) else None
+    boxes, got_counts, assoc = roi.transform_boxes(bbox_batch, z["spatial_size"], bool(z["clip"]), resize)
     exp_boxes = np.concatenate([z["bbox_tensor"][:, 0], z["assoc"][:, None], z["bbox_tensor"][:, 1],
                                 z["assoc"][:, None] + 1], 1)
     assert np.array_equal(boxes.cpu().numpy(), exp_boxes) and got_counts == counts
@@ -345,6 +346,25 @@ def test_roi_crop_matches_reference_golden(gpu, path):
     assert np.array_equal(new_coords.numpy(), z["out_coords"])
     assert np.array_equal(new_feats.cpu().numpy(), z["out_feats"])
     assert np.array_equal(is_inside.numpy(), inside)
+    # module level, constructed exactly as the reference does (roi_select_sparse.py:29-52, model.py:577-580,625): raw
+    # combiner, then SparseRoiExtraCut of a second feature map with (a) the list selection, (b) the reference's bool matrix
+    splits = z["splits"].tolist()
+    scene = (torch.from_numpy(z["coords"]), torch.from_numpy(z["feats"]).to(gpu), torch.from_numpy(z["spatial_size"]),
+             len(splits), splits)
+    kw = dict(clip_boxes=bool(z["clip"]), resize_boxes=resize)
+    for dense in (False, True):
+        cut = roi.SparseRoiCut(roi.RawToRawFeatureExtractorCombiner(), **kw, dense_inside=dense)
+        (m_coords, m_feats, m_size, m_bs), selection = cut(scene, bbox_batch)
+        assert np.array_equal(m_coords.cpu().numpy(), z["out_coords"]) and m_bs == len(inside)
+        assert np.array_equal(m_feats.cpu().numpy(), z["out_feats"])
+        assert selection[1] == counts and selection[2] == splits
+        if dense:
+            assert np.array_equal(selection[0].numpy(), inside)
+        else:
+            assert isinstance(selection[0], roi.RoiSelection) and selection[0].prefix[-1] == len(z["out_coords"])
+        extra = roi.SparseRoiExtraCut(roi.RawToFeaturesSceneFeatureExtractorCombiner())(
+            (scene[0], torch.from_numpy(z["extra_in"]).to(gpu)) + scene[2:], selection)
+        assert np.array_equal(extra.cpu().numpy(), z["extra_out"])
 
 
 MASK_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mask_epilogue_*.npz")))
@@ -465,8 +485,8 @@ def test_roi_cut_module_revoxelises_like_oracle(gpu):
     feats = torch.randn(len(coords), 23, generator=torch.Generator().manual_seed(1))
     bbox_batch = make_boxes(coords, n_boxes=9, seed=2, lo=3, hi=30)
     fg = feats.to(gpu).requires_grad_()
-    cut = roi.SparseRoiCut(spatial_size_offset=32)
-    out, (is_inside, counts, splits) = cut((coords, fg, size, batch, [0]), bbox_batch)
+    cut = roi.SparseRoiCut(roi.RawToTensorFeatureExtractorCombiner())         # as model.py:577 constructs it
+    out, (is_inside, counts, splits) = cut((coords, fg, size + 32, batch, [0]), bbox_batch)   # model.py:585
     bi, cnt, assoc = O.transform_boxes([b.numpy() for b in bbox_batch])
     src, box_of, inside = O.roi_crop(coords.numpy(), bi, assoc)
     assert np.array_equal(is_inside.numpy(), inside) and counts == cnt
@@ -616,7 +636,8 @@ def test_mask_head_path_matches_oracle(gpu):
     fmap = backbone(coords, raw_g, size, batch)
     per_point = scn.OutputLayer(3)(fmap)                                     # [Npts, 16]
     cat = torch.cat([per_point, raw_g], 1)                                   # [Npts, 23]
-    roi_tensor, (is_inside, counts, _) = roi.SparseRoiCut(spatial_size_offset=32)((coords, cat, size, batch, [0]), bbox_batch)
+    cut = roi.SparseRoiCut(roi.RawToTensorFeatureExtractorCombiner())
+    roi_tensor, (is_inside, counts, _) = cut((coords, cat, size + 32, batch, [0]), bbox_batch)
     assert roi_tensor.batch_size() == 12
     logits = head(scn.OutputLayer(3)(mask_unet(roi_tensor)))                 # one row per cropped point
     # --- oracle
@@ -886,7 +907,8 @@ def test_config3_path_with_bf16_storage_tracks_fp32(gpu):
         raw_g = raw.to(gpu).requires_grad_()
         fmap = backbone(coords, raw_g, size, batch)
         cat = torch.cat([scn.OutputLayer(3)(fmap), raw_g], 1)
-        roi_tensor, _ = roi.SparseRoiCut(spatial_size_offset=32)((coords, cat, size, batch, [0]), bbox_batch)
+        cut = roi.SparseRoiCut(roi.RawToTensorFeatureExtractorCombiner(), dense_inside=False)
+        roi_tensor, _ = cut((coords, cat, size + 32, batch, [0]), bbox_batch)
         logits = head(scn.OutputLayer(3)(mask_unet(roi_tensor)))
         assert logits.dtype == torch.float32
         logits.backward(torch.ones_like(logits))

@@ -1,6 +1,7 @@
 """CPU: host-side logic -- synthetic generator, flat-bucket data parallelism over gloo (world_size 2)."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -105,3 +106,53 @@ def test_flat_params_views_survive_backward():
     w = fp.flat.clone()
     fp.sgd_step(0.5)
     assert torch.allclose(fp.flat, w - 0.5 * fp.flat_grad) and net.weight.data_ptr() == fp.flat.data_ptr()
+
+
+# ---- bench.py --gpus N without torchrun: the parent starts the ranks itself and never touches the GPU ------------------
+def test_bench_self_launch_starts_fresh_ranks(tmp_path, capsys):
+    import bench
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import os, sys, json\n"
+        "assert 'torch' not in sys.modules\n"
+        "if os.environ['RANK'] == '0':\n"
+        "    print(json.dumps({k: os.environ[k] for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}))\n"
+        "sys.exit(0 if sys.argv[1:] == ['--gpus', '3'] else 7)\n")
+    args = bench.parse_args(["--gpus", "3"])
+    before = "torch.cuda" in sys.modules and sys.modules["torch"].cuda.is_initialized()
+    rc = bench.self_launch(args, script=str(script), argv=["--gpus", "3"])
+    import json
+    env = json.loads(capsys.readouterr().out.strip())
+    assert rc == 0 and env["WORLD_SIZE"] == "3" and env["RANK"] == "0" and env["MASTER_ADDR"] == "127.0.0.1"
+    import torch
+    assert torch.cuda.is_initialized() == bool(before)              # launching made no GPU call in this process
+    assert bench.self_launch(args, script=str(script), argv=["--other"]) == 7     # a failing rank fails the launch
+
+
+def test_bench_dtype_aliases():
+    import bench
+    assert bench.parse_args(["--bf16-all"]).dtype == "bf16" and bench.parse_args(["--bf16-blocks"]).dtype == "bf16-blocks"
+    a = bench.parse_args([])
+    assert a.gpus == 1 and a.workload == "cfg2" and a.dtype == "f32" and a.prefetch
+
+
+# ---- ROI classes are constructed the way the reference constructs them (model.py:577-580,625; roi_select_sparse.py:29-36)
+def test_roi_cut_signature_is_the_reference_one():
+    from sparse_rcnn_amd import roi
+    cut = roi.SparseRoiCut(roi.RawToTensorFeatureExtractorCombiner())
+    assert cut.clip_boxes is False and cut.resize_boxes is None
+    cut = roi.SparseRoiCut(roi.RawToRawFeatureExtractorCombiner(), True, (2, 2, 2))
+    assert cut.clip_boxes is True and cut.resize_boxes == (2, 2, 2)
+    with pytest.raises(TypeError):
+        roi.SparseRoiCut(True)                                        # a flag where the combiner belongs
+    with pytest.raises(TypeError):
+        roi.SparseRoiCut(roi.RawToRawFeatureExtractorCombiner(), roi.RawToRawFeatureExtractorCombiner())
+    roi.SparseRoiExtraCut(roi.RawToFeaturesSceneFeatureExtractorCombiner())
+    scene = (torch.zeros(3, 4, dtype=torch.long), torch.ones(3, 2), torch.tensor([8, 8, 8]), 1, [3])
+    for comb in (roi.RawToTensorFeatureExtractorCombiner(), roi.RawToRawFeatureExtractorCombiner(),
+                 roi.RawToFeaturesSceneFeatureExtractorCombiner()):
+        c, f, s, splits = comb.extract(scene)                           # instances, as the reference passes them
+        assert splits == [3] and f.shape == (3, 2)
+    assert roi.RawToRawFeatureExtractorCombiner().combine(1, 2, 3, 4) == (1, 2, 3, 4)
+    assert roi.RawToTensorFeatureExtractorCombiner().combine(torch.zeros(0, 4, dtype=torch.long), torch.zeros(0, 2),
+                                                            torch.tensor([8, 8, 8]), 2) is None

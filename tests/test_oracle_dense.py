@@ -120,7 +120,11 @@ def test_batchnorm_relu_matches_dense_and_scn_momentum():
     assert torch.allclose(Y, Yd, atol=1e-5)
     # retain-fraction convention: r <- 0.9 r + 0.1 batch
     assert torch.allclose(rm, 0.1 * X.mean(0), atol=1e-6)
-    assert torch.allclose(rv, 0.9 + 0.1 * X.var(0, unbiased=False), atol=1e-6)
+    assert torch.allclose(rv, 0.9 + 0.1 * X.var(0, unbiased=True), atol=1e-6)      # unbiased estimate in the running stat
+    # the dense twin the reference pairs the layer with (torch.nn.BatchNorm: update fraction 0.1 = retain fraction 0.9)
+    rmd, rvd = torch.zeros(6), torch.ones(6)
+    F.batch_norm(X, rmd, rvd, gamma, beta, training=True, momentum=0.1, eps=1e-4)
+    assert torch.allclose(rm, rmd, atol=1e-6) and torch.allclose(rv, rvd, atol=1e-6)
     Yl = O.batchnorm_relu_fwd(X, gamma, beta, rm, rv, leak=0.3)
     assert torch.allclose(Yl, F.leaky_relu(F.batch_norm(X, None, None, gamma, beta, training=True, eps=1e-4), 0.3),
                           atol=1e-5)

@@ -23,7 +23,8 @@ def load(path):
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
 def test_oracle_roi_crop_matches_reference(path):
     d = load(path)
-    boxes, counts, assoc = O.transform_boxes(d["bbox_batch"], d["spatial_size"], bool(d["clip"]))
+    resize = d["resize"] if len(d["resize"]) else None
+    boxes, counts, assoc = O.transform_boxes(d["bbox_batch"], d["spatial_size"], bool(d["clip"]), resize)
     assert np.array_equal(boxes, d["bbox_tensor"]) and np.array_equal(assoc, d["assoc"])
     assert counts == d["box_counts"].tolist()
     src, box_of, inside = O.roi_crop(d["coords"], boxes, assoc)
@@ -31,10 +32,11 @@ def test_oracle_roi_crop_matches_reference(path):
     out_coords = np.concatenate([d["coords"][src][:, :3], box_of[:, None]], 1)
     assert np.array_equal(out_coords, d["out_coords"])
     assert np.array_equal(d["feats"][src], d["out_feats"])
+    assert np.array_equal(d["extra_in"][src], d["extra_out"])                 # SparseRoiExtraCut (roi_select_sparse.py:8-26)
 
 
 def test_golden_present():
-    assert len(GOLDEN) >= 4
+    assert len(GOLDEN) >= 6
 
 
 # ---- N2: mask-head epilogue, pinned by the reference's SparseMaskPredictor / SparseMaskLossSelector ------------------

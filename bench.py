@@ -124,6 +124,12 @@ def run(args):
     import torch
     import torch.distributed as dist
 
+    # the contract is ONE JSON line on stdout: collective libraries print banners there ("[Gloo] Rank 0 is connected ..."),
+    # so everything written to fd 1 before the result goes to stderr instead
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -240,7 +246,10 @@ def run(args):
             out["cpu_baseline"] = cpu_baseline(job.coords_cpu, job.feats_cpu, job.channels)
         else:
             out["cpu_baseline"] = None
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

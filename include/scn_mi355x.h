@@ -205,10 +205,17 @@ int scn_tiles_build(const int32_t* table, int n_off, int64_t n, int32_t* perm, i
  *     Y[r] = residual[r] + bias + sum_o in(X[table[o][r]]) . W[o']          (same result as scn_gemm_table)
  * Serves SubmanifoldConvolution fwd / backward-data (module_factory.py:404-406), Convolution fwd (:232-234) and
  * Deconvolution backward-data (:256-258).  n_off <= 27.  Per-row accumulation order is fixed (offsets ascending). */
-int64_t scn_conv_tiles_scratch_bytes(int cin, int64_t n_out, int cout);   /* tile-queue counters + K-chunk slabs */
+int64_t scn_conv_tiles_scratch_bytes(int cin, int64_t n_out, int cout);   /* K-chunk slabs */
+/* Layers with more than 32 input channels split K over workgroups.  `arrival` (int32, at least
+ * scn_conv_tiles_arrival_counters(cin, n_out, cout) entries; may be shared by every call on one stream) lets the kernel add
+ * the K-chunk partial sums itself: the wave that arrives last at a (tile, column chunk) adds them in ascending K-chunk
+ * order.  CONTRACT: all entries are ZERO when the call is made; the kernel leaves them zero.  arrival == NULL (or
+ * SCN_F_SPLIT_SUM): the partial sums are added by a second launch instead -- same association, same bits. */
+int64_t scn_conv_tiles_arrival_counters(int cin, int64_t n_out, int cout);
 int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32_t* tstab, const uint32_t* tile_mask, const int32_t* perm,
                    const int32_t* tile_order, int n_off, int64_t n_out, const float* W, const float* bias, const float* residual,
-                   const float* relu_mask, float* Y, int cout, int flags, void* scratch, scn_stream_t stream);
+                   const float* relu_mask, float* Y, int cout, int flags, void* scratch, int32_t* arrival,
+                   scn_stream_t stream);
 /* Second half of a scn_conv_tiles call made with SCN_F_SPLIT_SUM: adds the K-chunk slabs (no-op when cin <= 32: the
  * tile kernel has written Y).  Same arguments as that call. */
 int scn_conv_tiles_finish(int cin, int64_t n_out, const float* bias, const float* residual, const float* relu_mask,

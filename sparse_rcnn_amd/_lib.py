@@ -43,7 +43,8 @@ _SIGS = {
     "scn_tiles_scratch_bytes": (i64, [i32, i64]),
     "scn_tiles_build": (C.c_int, [p, i32, i64, p, p, p, p, p, p]),
     "scn_conv_tiles_scratch_bytes": (i64, [i32, i64, i32]),
-    "scn_conv_tiles": (C.c_int, [p, i64, i32, p, p, p, p, i32, i64, p, p, p, p, p, i32, i32, p, p]),
+    "scn_conv_tiles_arrival_counters": (i64, [i32, i64, i32]),
+    "scn_conv_tiles": (C.c_int, [p, i64, i32, p, p, p, p, i32, i64, p, p, p, p, p, i32, i32, p, p, p]),
     "scn_conv_tiles_finish": (C.c_int, [i32, i64, p, p, p, p, i32, i32, p, p]),
     "scn_conv_tiles_bf16_scratch_bytes": (i64, [i32, i64, i32]),
     "scn_conv_tiles_bf16": (C.c_int, [p, i64, i32, p, p, p, p, i32, i64, p, p, p, p, p, i32, i32, p, p]),
@@ -150,6 +151,19 @@ def scratch(nbytes: int, device):
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = _scratch[key] = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+    return buf
+
+
+_arrival = {}
+
+
+def arrival(n: int, device):
+    """Zeroed int32 arrival counters for the in-launch K reduction of scn_conv_tiles on the CURRENT stream: one growing
+    buffer per (device, stream), zeroed when it is (re)allocated -- the kernels leave it zero (include/scn_mi355x.h)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream())
+    buf = _arrival.get(key)
+    if buf is None or buf.numel() < n:
+        buf = _arrival[key] = torch.zeros(max(int(n), 1 << 16), dtype=torch.int32, device=device)
     return buf
 
 

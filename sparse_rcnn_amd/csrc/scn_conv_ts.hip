@@ -53,7 +53,16 @@ __device__ __forceinline__ int ts_ws_off(int o, int k, int n) { return (o * TS_K
 //   K-chunk's workgroups write their partial sums to slab[kc] and k_conv_ts_sum adds the slabs in fixed order.
 // FULLK: the fast path (rows gathered through a buffer descriptor, Cin % 4 == 0); PART: Cin is not a multiple of the
 // 32-channel K-chunk, the lanes of the last chunk whose channels lie past Cin gather from an out-of-range offset (zeros)
-template <bool WT, bool VEC, bool VECN, bool FULLK, bool PART>
+// FUSED: K-chunk partial sums are reduced INSIDE this launch (no k_conv_ts_sum): every wave publishes its 16 x 32 partial
+// tile to slab[(tile, chunk)][kc] in fragment layout (two 1 KB write-through stores), takes a ticket on the (tile, chunk)
+// arrival counter, and the wave whose ticket is the last one adds the n_kc partials in ascending K-chunk order (all
+// through L1-bypassing loads) and runs the epilogue.  Same association as k_conv_ts_sum: the
+// two forms give the same bits.  Publish / consume follow MI355X_MICROARCH.md "splitk-seam" and cdna_hip_programming.md
+// Guideline 16 R1: payload stored sc1 (write-through, 16 B per lane, whole 128-B lines per instruction), every storing
+// wave drains its stores (s_waitcnt vmcnt(0)) before its agent-scope ticket add, the combiner learns it is last from the
+// value its own add returned and reads the payload with sc1 loads only; no fence.  The counters are zero on entry and the
+// last arriver puts its counter back to zero, so the caller zeroes the array once, not per launch.
+template <bool WT, bool VEC, bool VECN, bool FULLK, bool PART, bool FUSED>
 __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     const float* __restrict__ X, long long n_in, int cin, const int* __restrict__ tstab,
     const unsigned* __restrict__ tile_mask,
@@ -164,9 +173,12 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     const bool k0_ok = ka + 3 < cin, k1_ok = ka + 16 + 3 < cin;
     const int nA = n0 + i, nB = n0 + 16 + i;
     const bool single = n_kc == 1;
-    const float bA = (single && bias && nA < cout) ? bias[nA] : 0.f;
-    const float bB = (single && bias && nB < cout) ? bias[nB] : 0.f;
-    float* out = single ? Y : slabs + (long long)kci * n_out * cout;
+    const bool direct = single || FUSED;                // this launch writes Y itself
+    const float bA = (direct && bias && nA < cout) ? bias[nA] : 0.f;
+    const float bB = (direct && bias && nB < cout) ? bias[nB] : 0.f;
+    float* out = direct ? Y : slabs + (long long)kci * n_out * cout;
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)slabs, 0, FUSED && !single ? (int)(unsigned)(nt * n_chunks * n_kc * (TS_T * TS_CT * 4)) : 0, 0x00020000);
     // B fragment address of this lane inside an offset's slice (see ts_ws_off): channel 4*kq (+e, +16*half), column i
     const int bofs = (4 * kq) * TS_CT + (i ^ ((kq & 1) << 4));
 
@@ -256,6 +268,94 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         oq0 = oq1; oq1 = oq2; oq2 = oq3; oq3 = oq4; oq4 = o4_;                                       \
     } while (0)
 
+    // ---- epilogue pieces --------------------------------------------------------------------------------------------
+    // ts_write: 16 lanes write 64 contiguous bytes of a row.  The residual / ReLU-mask operands of all eight outputs are
+    // requested first and consumed afterwards (one wait, not eight round trips).
+    auto ts_write = [&](const int (&orow)[4], const f32x4& c0, const f32x4& c1) {
+        float rs[4][2], mk[4][2];
+        const bool use_res = direct && residual != nullptr, use_mask = direct && relu_mask != nullptr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long off = (long long)(orow[j] < 0 ? 0 : orow[j]) * cout;
+            rs[j][0] = rs[j][1] = 0.f;
+            mk[j][0] = mk[j][1] = 1.f;
+            if (use_res) {
+                if (nA < cout) rs[j][0] = residual[off + nA];
+                if (nB < cout) rs[j][1] = residual[off + nB];
+            }
+            if (use_mask) {
+                if (nA < cout) mk[j][0] = relu_mask[off + nA];
+                if (nB < cout) mk[j][1] = relu_mask[off + nB];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = orow[j];
+            if (row < 0) continue;
+            const long long off = (long long)row * cout;
+            if (nA < cout) {
+                float y = c0[j] + (res_last ? 0.f : rs[j][0]);
+                if (!(mk[j][0] > 0.f)) y = 0.f;
+                if (res_last) y += rs[j][0];
+                out[off + nA] = y;
+            }
+            if (nB < cout) {
+                float y = c1[j] + (res_last ? 0.f : rs[j][1]);
+                if (!(mk[j][1] > 0.f)) y = 0.f;
+                if (res_last) y += rs[j][1];
+                out[off + nB] = y;
+            }
+        }
+    };
+    // in-launch K reduction (FUSED): q1 = tile whose partial is published and not yet ticketed, q2 = tile whose ticket is
+    // in flight (tk_v holds it in lane 0); -1 = none.  Callers drain the wave's memory operations first.
+    long long q1 = -1, q2 = -1;
+    int tk_v = 0;
+    auto ts_publish = [&](long long t, const f32x4& c0, const f32x4& c1) {
+        const int sb = (int)((t * n_chunks + chunk) * n_kc + kci) * (TS_T * TS_CT * 4) + lane * 16;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, c0), srsrc,
+                                               sb, 0, 16);                               // aux 16 = sc1: write-through
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, c1), srsrc,
+                                               sb + 1024, 0, 16);
+        q1 = t;
+    };
+    auto ts_retire = [&]() {
+        // (a) the ticket of q2 has returned: combine if this wave arrived last
+        if (q2 >= 0) {
+            const int ticket = __builtin_amdgcn_readfirstlane(tk_v);
+            if (ticket == n_kc - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                    // compiler ordering only
+                const int unit = (int)(q2 * n_chunks + chunk);
+                if (lane == 0) __hip_atomic_store(counters + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int orow2[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) orow2[j] = perm[q2 * TS_T + 4 * kq + j];
+                const int sb = (unit * n_kc) * (TS_T * TS_CT * 4) + lane * 16;
+                // bias + slab[0] + slab[1] + ... in ascending K-chunk order (the association of k_conv_ts_sum)
+                f32x4 y0 = {bA, bA, bA, bA}, y1 = {bB, bB, bB, bB};
+                for (int k0 = 0; k0 < n_kc; k0 += 4) {
+                    f32x4 p0[4], p1[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = k0 + u < n_kc ? k0 + u : n_kc - 1;                  // unconditional loads
+                        p0[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srsrc, sb + k * 2048, 0, 16));
+                        p1[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srsrc, sb + k * 2048 + 1024, 0, 16));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (k0 + u < n_kc) { y0 += p0[u]; y1 += p1[u]; }
+                    }
+                }
+                ts_write(orow2, y0, y1);
+            }
+        }
+        // (b) the stores of q1 are drained: take its ticket
+        if (q1 >= 0 && lane == 0)
+            tk_v = __hip_atomic_fetch_add(counters + (int)(q1 * n_chunks + chunk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        q2 = q1;
+        q1 = -1;
+    };
+
     // ---- tile loop: the id, mask and output rows of the NEXT tile are fetched while the current one computes --------
     while (tile_next >= 0) {
         const long long tile = tile_next;
@@ -296,7 +396,8 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         TS_GATHER(iq2, s20, s21);
         __builtin_amdgcn_sched_barrier(0);
 
-        f32x4 c0 = {bA, bA, bA, bA}, c1 = {bB, bB, bB, bB};
+        const float iA = single ? bA : 0.f, iB = single ? bB : 0.f;
+        f32x4 c0 = {iA, iA, iA, iA}, c1 = {iB, iB, iB, iB};
         // n_steps offsets: whole rounds of four steps without a per-step exit test, then the 0-3 left over
         int n_left = n_steps;
         for (; n_left >= 4; n_left -= 4) {
@@ -309,45 +410,30 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         if (n_left >= 2) { TS_STEP(s10, s11, s00, s01, iqb, iqd); }
         if (n_left >= 3) { TS_STEP(s20, s21, s10, s11, iqc, iqa); }
 
-        // ---- tile epilogue: 16 lanes write 64 contiguous bytes of a row.  The residual / ReLU-mask operands of all
-        // eight outputs are requested first and consumed afterwards (one wait, not eight round trips).
-        float rs[4][2], mk[4][2];
-        const bool use_res = single && residual != nullptr, use_mask = single && relu_mask != nullptr;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const long long off = (long long)(orow[j] < 0 ? 0 : orow[j]) * cout;
-            rs[j][0] = rs[j][1] = 0.f;
-            mk[j][0] = mk[j][1] = 1.f;
-            if (use_res) {
-                if (nA < cout) rs[j][0] = residual[off + nA];
-                if (nB < cout) rs[j][1] = residual[off + nB];
-            }
-            if (use_mask) {
-                if (nA < cout) mk[j][0] = relu_mask[off + nA];
-                if (nB < cout) mk[j][1] = relu_mask[off + nB];
-            }
+        // ---- tile epilogue -----------------------------------------------------------------------------------------
+        if (FUSED && !single) {
+            // The hand-off is PIPELINED over the wave's tiles so that no wave waits for a store acknowledgement or a
+            // ticket round trip (a stall of 2-4 us per tile where a tile is 10-40 us of work):
+            //   end of tile t   : publish t's partial (two write-through stores)
+            //   end of tile t+1 : everything this wave issued before its t+1 loop has long completed -- the wait below is
+            //                     (nearly) free -- so t's stores are drained: take t's ticket (returning atomic, not awaited)
+            //   end of tile t+2 : t's ticket is back; if it is the last one, combine t
+            // and two flush rounds after the tile loop.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ts_retire();
+            ts_publish(tile, c0, c1);
+            continue;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = orow[j];
-            if (row < 0) continue;
-            const long long off = (long long)row * cout;
-            if (nA < cout) {
-                float y = c0[j] + (res_last ? 0.f : rs[j][0]);
-                if (!(mk[j][0] > 0.f)) y = 0.f;
-                if (res_last) y += rs[j][0];
-                out[off + nA] = y;
-            }
-            if (nB < cout) {
-                float y = c1[j] + (res_last ? 0.f : rs[j][1]);
-                if (!(mk[j][1] > 0.f)) y = 0.f;
-                if (res_last) y += rs[j][1];
-                out[off + nB] = y;
-            }
-        }
+        ts_write(orow, c0, c1);
+    }
+    if (FUSED && !single) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts_retire();                         // combine the tile before last, ticket the last one
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts_retire();                         // combine the last one
     }
     if (TS_TIMELINE && lane == 0) {         // [t0, staged, end, tiles, steps] per wave, after the K-chunk slabs
-        long long* d = (long long*)(slabs + (n_kc > 1 ? (long long)n_kc * n_out * cout : 0)) +
+        long long* d = (long long*)(slabs + (n_kc > 1 ? (long long)n_kc * nt * TS_T * n_chunks * TS_CT : 0)) +
                        ((long long)blockIdx.x * TS_NW + (tid >> 6)) * 8;
         d[0] = tl_t0; d[1] = tl_t1; d[2] = wall_clock64(); d[3] = tl_tiles; d[4] = tl_steps; d[5] = 0;
         d[6] = tl_c1; d[7] = clock64();             // shader-clock stamps: in-kernel clock = d(clock64) / d(wall_clock64) x 100 MHz
@@ -388,18 +474,24 @@ __global__ void k_conv_ts_sum(const float* __restrict__ slabs, int n_kc, long lo
 #undef TS_STEP
 #undef TS_GATHER
 
-// scratch = [256 reserved bytes] [slabs: n_kc * n_out * cout floats if n_kc > 1]
+// scratch = [256 reserved bytes] [slabs if n_kc > 1: n_kc partial tiles of 16 x 32 floats per (tile, column chunk)]
+// (covers both slab layouts: the fused kernel's fragment-major one and the row-major one of the two-launch form)
 static int64_t ts_counter_bytes(int, int) { return 256; }
 
 extern "C" int64_t scn_conv_tiles_scratch_bytes(int cin, int64_t n_out, int cout) {
     const int64_t n_kc = cdiv(cin, TS_KC);
-    return ts_counter_bytes(cin, cout) + (n_kc > 1 ? n_kc * n_out * cout * (int64_t)sizeof(float) : 0);
+    return ts_counter_bytes(cin, cout) +
+           (n_kc > 1 ? n_kc * cdiv(n_out, TS_T) * TS_T * cdiv(cout, TS_CT) * TS_CT * (int64_t)sizeof(float) : 0);
+}
+
+extern "C" int64_t scn_conv_tiles_arrival_counters(int cin, int64_t n_out, int cout) {
+    return cdiv(cin, TS_KC) > 1 ? cdiv(n_out, TS_T) * cdiv(cout, TS_CT) : 0;
 }
 
 extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32_t* tstab, const uint32_t* tile_mask,
                               const int32_t* perm, const int32_t* tile_order, int n_off, int64_t n_out, const float* W, const float* bias,
                               const float* residual, const float* relu_mask, float* Y, int cout, int flags,
-                              void* scratch, scn_stream_t stream) {
+                              void* scratch, int32_t* arrival, scn_stream_t stream) {
     SCN_REQUIRE(n_off >= 1 && n_off <= 27 && n_out >= 0 && n_in >= 0 && cin >= 1 && cout >= 1);
     if (n_out == 0) return SCN_OK;
     SCN_REQUIRE(X && tstab && tile_mask && perm && tile_order && W && Y);
@@ -407,8 +499,12 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     const int n_chunks = (int)cdiv(cout, TS_CT);
     const int n_kc = (int)cdiv(cin, TS_KC);
     SCN_REQUIRE(scratch);
-    int* counters = (int*)scratch;
     float* slabs = (float*)((char*)scratch + ts_counter_bytes(cin, cout));
+    // the in-launch K reduction needs the caller's zeroed arrival counters and 32-bit slab offsets; without them (or when
+    // the caller asks for the two-launch form) the partial sums go to row-major slabs and k_conv_ts_sum adds them
+    const bool fused = n_kc > 1 && arrival != nullptr && !(flags & SCN_F_SPLIT_SUM) &&
+                       nt * n_chunks * n_kc * (int64_t)(TS_T * TS_CT * 4) < (1ll << 31);
+    int* counters = (int*)arrival;
     const size_t lds = (size_t)n_off * TS_KC * TS_CT * sizeof(float) + 16;
     int wg_per_cu = (int)((160 * 1024) / lds);
     if (wg_per_cu > 2) wg_per_cu = 2;                  // 16 waves each: 2 workgroups fill a CU
@@ -425,17 +521,21 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     const bool part = cin % TS_KC != 0;
     dim3 grid((unsigned)(n_tg * n_chunks * n_kc));
     hipStream_t st = S(stream);
-#define LAUNCH_TS(T, V, VN, FK, PT)                                                                                 \
+#define LAUNCH_TS_F(T, V, VN, FK, PT, FU)                                                                           \
     do {                                                                                                            \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
-            SCN_HIP(hipFuncSetAttribute((const void*)k_conv_ts<T, V, VN, FK, PT>,                                       \
+            SCN_HIP(hipFuncSetAttribute((const void*)k_conv_ts<T, V, VN, FK, PT, FU>,                                   \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((k_conv_ts<T, V, VN, FK, PT>), grid, dim3(TS_NW * 64), lds, st, X, (long long)n_in, cin, tstab, tile_mask, \
+        hipLaunchKernelGGL((k_conv_ts<T, V, VN, FK, PT, FU>), grid, dim3(TS_NW * 64), lds, st, X, (long long)n_in, cin, tstab, tile_mask, \
                            perm, tile_order, n_off, (long long)nt, W, bias, residual, relu_mask, Y, slabs,                      \
                            (long long)n_out, cout, flags, n_chunks, n_kc, counters);                                \
+    } while (0)
+#define LAUNCH_TS(T, V, VN, FK, PT)                                                                                 \
+    do {                                                                                                            \
+        if (fused) LAUNCH_TS_F(T, V, VN, FK, PT, true); else LAUNCH_TS_F(T, V, VN, FK, PT, false);                  \
     } while (0)
     if (fullk && wt && part) LAUNCH_TS(true, true, true, true, true);
     else if (fullk && wt) LAUNCH_TS(true, true, true, true, false);
@@ -447,8 +547,9 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     else if (vecn) LAUNCH_TS(false, false, true, false, false);
     else LAUNCH_TS(false, false, false, false, false);
 #undef LAUNCH_TS
+#undef LAUNCH_TS_F
     SCN_LAUNCH_CHECK();
-    if (flags & SCN_F_SPLIT_SUM) return SCN_OK;
+    if (fused || (flags & SCN_F_SPLIT_SUM)) return SCN_OK;
     return scn_conv_tiles_finish(cin, n_out, bias, residual, relu_mask, Y, cout, flags, scratch, stream);
 }
 

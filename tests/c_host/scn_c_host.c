@@ -100,10 +100,16 @@ int main(void) {
     const int32_t* perm = (const int32_t*)(w8 + L[9]); const int32_t* tstab = (const int32_t*)(w8 + L[10]);
     const uint32_t* tmask = (const uint32_t*)(w8 + L[11]); const int32_t* torder = (const int32_t*)(w8 + L[12]);
     (void)nt;
-    CHECK_SCN(scn_conv_tiles(dX, n, C, tstab, tmask, perm, torder, NOFF, n, dW, dB, NULL, NULL, dY, C, SCN_F_RELU_IN, scratch, NULL));
+    /* zeroed arrival counters: layers with more than 32 input channels add their K-chunk partial sums inside the launch */
+    int32_t* arrival = NULL;
+    const int64_t n_arr = scn_conv_tiles_arrival_counters(C, n, C);
+    CHECK_HIP(hipMalloc((void**)&arrival, sizeof(int32_t) * (size_t)(n_arr > 0 ? n_arr : 1)));
+    CHECK_HIP(hipMemset(arrival, 0, sizeof(int32_t) * (size_t)(n_arr > 0 ? n_arr : 1)));
+    CHECK_SCN(scn_conv_tiles(dX, n, C, tstab, tmask, perm, torder, NOFF, n, dW, dB, NULL, NULL, dY, C, SCN_F_RELU_IN, scratch,
+                             arrival, NULL));
     /* backward-data of the same layer without the ReLU: dX = sum_o G[table[26-o]] . W[o]^T */
     CHECK_SCN(scn_conv_tiles(dG, n, C, tstab, tmask, perm, torder, NOFF, n, dW, NULL, NULL, NULL, dXg, C,
-                             SCN_F_W_TRANSPOSED | SCN_F_OFF_REVERSE, scratch, NULL));
+                             SCN_F_W_TRANSPOSED | SCN_F_OFF_REVERSE, scratch, arrival, NULL));
     CHECK_HIP(hipDeviceSynchronize());
     float* Y = (float*)malloc(sizeof(float) * n * C); float* Xg = (float*)malloc(sizeof(float) * n * C);
     CHECK_HIP(hipMemcpy(Y, dY, sizeof(float) * n * C, hipMemcpyDeviceToHost));

@@ -1,6 +1,7 @@
-"""-m gpu: BASELINE-size (150k voxels) checks through size-independent properties -- the oracle is too slow to be the
-checker at this size for every case, so: structural invariants of the index structures, agreement of two independent
-kernels, linearity, and adjointness of forward / backward-data / weight gradient."""
+"""-m gpu: BASELINE-size (150k and 600k voxels) checks through size-independent properties: structural invariants of the
+index structures, agreement of two independent kernels, linearity, adjointness of forward / backward-data / weight
+gradient, bitwise reproducibility, the in-launch K reduction against its two-launch form.  (Oracle parity at these sizes:
+tests/test_gpu_atsize.py.)"""
 import numpy as np
 import pytest
 import torch
@@ -96,6 +97,32 @@ def test_conv_kernels_agree_and_are_linear_and_adjoint(scene, gpu, level, C):
     dW2, db = F.wgrad_bias_rules(X1, G, rb.rules.in_rows, rb.rules.out_rows, rb.rules.prefix_host, 27, 1 << 13)
     assert torch.equal(dW2, dW)
     assert (db.double() - G.double().sum(0)).abs().max().item() <= 1e-3 * max(1.0, G.double().sum(0).abs().max().item())
+
+
+def test_backbone_step_with_in_launch_k_reduction_equals_two_launch_form_at_150k(scene, gpu):
+    """The whole 150k-voxel backbone step (62 tile-convolution launches, 44 of them split over K) with the K-chunk partial
+    sums added inside the launch vs by the second launch: every output and gradient word equal.  Run as a whole step so
+    that the hand-off happens under the real, uneven load (waves of all levels' tiles, index kernels beside them)."""
+    from sparse_rcnn_amd import functional as F
+    from sparse_rcnn_amd.unet import Backbone
+    scn, coords, feats, size, x = scene
+    torch.manual_seed(0)
+    net = Backbone(7, (32, 64, 128, 256)).to(gpu)
+    cd, fd = coords.to(gpu), feats.to(gpu)
+    res = []
+    for fused in (False, True, True):
+        F.FUSED_K = fused
+        try:
+            for p in net.parameters():
+                p.grad = None
+            fin = fd.clone().requires_grad_()
+            out = net(cd, fin, size, 1).features
+            out.backward(torch.ones_like(out))
+            res.append([out.detach().clone(), fin.grad.clone()] + [p.grad.clone() for p in net.parameters()])
+        finally:
+            F.FUSED_K = True
+    for a, b, c in zip(*res):
+        assert torch.equal(a, b) and torch.equal(b, c)
 
 
 def test_backbone_step_full_size_is_finite_and_reproducible(scene, gpu):

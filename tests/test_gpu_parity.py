@@ -713,29 +713,47 @@ def test_conv_tiles_bf16_rejects_unsupported_inputs(gpu):
         F.conv_rules_bf16(torch.zeros(rb.n, 12, device=gpu, dtype=torch.bfloat16), rb.tiles, rb.n, W, None, 8)   # cin % 8
 
 
-def test_conv_tiles_split_sum_is_the_same_computation(gpu):
-    """SCN_F_SPLIT_SUM + scn_conv_tiles_finish (what bench.py's kernel timer uses to bracket the tile kernel alone) give
-    the bits of the single call, with and without K-chunk slabs."""
-    from sparse_rcnn_amd import functional as F, profiling
+def test_conv_tiles_in_launch_k_reduction_gives_the_bits_of_the_two_launch_form(gpu):
+    """Layers with more than 32 input channels split K over workgroups.  scn_conv_tiles adds the K-chunk partial sums
+    inside the launch (last arriver per (tile, column chunk), write-through slab stores, agent-scope ticket, ascending
+    K-chunk order); the two-launch form (SCN_F_SPLIT_SUM + scn_conv_tiles_finish, or arrival == NULL) is the cross-check:
+    same association, so every output word must be equal -- over repeated launches that re-use the same slabs and
+    counters with fresh data (a stale line or a lost arrival shows up as a mismatch), forward and backward-data."""
+    from sparse_rcnn_amd import functional as F, profiling, _lib as L
     scn, coords, feats, fg, x, scene, size = _input(gpu, seed=17, cin=8, n=1500, dup=100)
     rb = x.metadata.subm_rulebook(tuple(int(s) for s in size), 3)
     n = rb.n
-    for cin, cout in ((32, 32), (64, 48), (128, 128)):
+    back = L.F_W_TRANSPOSED | L.F_OFF_REVERSE
+    for cin, cout in ((32, 32), (64, 48), (128, 128), (48, 80), (256, 64), (512, 32)):
         g = torch.Generator().manual_seed(cin)
-        X = torch.randn(n, cin, generator=g).to(gpu); R = torch.randn(n, cout, generator=g).to(gpu)
         W = (torch.randn(27, cin, cout, generator=g) * 0.05).to(gpu); b = torch.randn(cout, generator=g).to(gpu)
-        ref = F.conv_rules(X, rb.tiles, n, W, b, cout, residual=R, n_rules=rb.rules.total)
+        Wt = (torch.randn(27, cout, cin, generator=g) * 0.05).to(gpu)
+        for rep in range(6):
+            X = torch.randn(n, cin, generator=g).to(gpu); R = torch.randn(n, cout, generator=g).to(gpu)
+            M = torch.randn(n, cout, generator=g).to(gpu)
+            outs = []
+            for fused in (False, True):
+                F.FUSED_K = fused
+                try:
+                    y = F.conv_rules(X, rb.tiles, n, W, b, cout, L.F_RELU_IN, residual=R, n_rules=rb.rules.total)
+                    d = F.conv_rules(X, rb.tiles, n, Wt, None, cout, back | L.F_RESIDUAL_LAST, residual=R, relu_mask=M,
+                                     n_rules=rb.rules.total)
+                finally:
+                    F.FUSED_K = True
+                outs.append((y, d))
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (cin, cout, rep)
+    # the two-launch form under the kernel timer still reports both kernels; the fused form is one launch
+    X = torch.randn(n, 64, generator=g).to(gpu); W = (torch.randn(27, 64, 32, generator=g) * 0.05).to(gpu)
+    for fused, names in ((False, {"k_conv_ts", "k_conv_ts_sum"}), (True, {"k_conv_ts"})):
         timer = profiling.KernelTimer(every=1, names=None)
         timer.begin_step()
-        profiling.TIMER = timer
+        profiling.TIMER, F.FUSED_K = timer, fused
         try:
-            got = F.conv_rules(X, rb.tiles, n, W, b, cout, residual=R, n_rules=rb.rules.total)
+            F.conv_rules(X, rb.tiles, n, W, None, 32, n_rules=rb.rules.total)
         finally:
-            profiling.TIMER = None
+            profiling.TIMER, F.FUSED_K = None, True
         torch.cuda.synchronize()
-        assert torch.equal(got, ref)
-        ks = timer.summary()
-        assert ks["k_conv_ts"]["launches"] == 1 and ks["k_conv_ts_sum"]["launches"] == 1
+        assert set(timer.summary()) == names
 
 
 @pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (8, 16), (48, 80), (128, 64), (256, 256), (23, 7), (130, 33)])

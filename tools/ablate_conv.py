@@ -30,12 +30,14 @@ tm = t.tile_mask.cpu().numpy().view("uint32")
 import numpy as np
 execd = sum(bin(int(v)).count("1") for v in tm) * 16
 print(f"level {level} N={n} P={P} C={C} tiles={len(tm)} executed/useful={execd / P:.3f}")
-def run_ts(fl=0):
+ARR = torch.zeros(max(1, lib.scn_conv_tiles_arrival_counters(C, n, C)), dtype=torch.int32, device="cuda")
+def run_ts(fl=0, fused=True):
     L.check(lib.scn_conv_tiles(L.ptr(X), n, C, L.ptr(t.tstab), L.ptr(t.tile_mask), L.ptr(t.perm), L.ptr(t.tile_order), 27, n, L.ptr(W), 0, 0, 0,
-                               L.ptr(Y), C, fl, L.ptr(SCR), L.stream()))
+                               L.ptr(Y), C, fl, L.ptr(SCR), L.ptr(ARR) if fused else 0, L.stream()))
 def run_tab(fl=0):
     L.check(lib.scn_gemm_table(L.ptr(X), n, C, L.ptr(rb.table), 27, n, L.ptr(W), 0, 0, 0, L.ptr(Y2), C, fl, L.stream()))
-for name, fn in (("conv_tiles", run_ts), ("conv_tiles relu_in", lambda: run_ts(1)), ("conv_tiles W^T", lambda: run_ts(6)), ("gemm_table (v1)", run_tab)):
+for name, fn in (("conv_tiles", run_ts), ("conv_tiles 2-launch K sum", lambda: run_ts(0, False)), ("conv_tiles tile kernel only", lambda: run_ts(16, False)),
+                 ("conv_tiles relu_in", lambda: run_ts(1)), ("conv_tiles W^T", lambda: run_ts(6)), ("gemm_table (v1)", run_tab)):
     for _ in range(3): fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -22,7 +22,7 @@ for C, dims in ((32, (64, 64, 36)), (64, (40, 40, 32)), (128, (24, 24, 22)), (25
     execd = sum(bin(int(v)).count("1") for v in tm) * 16
     def run():
         L.check(lib.scn_conv_tiles(L.ptr(X), n, C, L.ptr(t.tstab), L.ptr(t.tile_mask), L.ptr(t.perm), L.ptr(t.tile_order), 27, n, L.ptr(W), 0, 0, 0,
-                                   L.ptr(Y), C, 0, L.ptr(SCR), L.stream()))
+                                   L.ptr(Y), C, 0, L.ptr(SCR), 0, L.stream()))
     for _ in range(3): run()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -17,5 +17,5 @@ X = torch.randn(n, C, device="cuda"); W = torch.randn(27, C, C, device="cuda") *
 lib = L.lib()
 SCR = torch.empty(max(1, lib.scn_conv_tiles_scratch_bytes(C, n, C)), dtype=torch.uint8, device='cuda')
 for _ in range(5):
-    L.check(lib.scn_conv_tiles(L.ptr(X), n, C, L.ptr(t.tstab), L.ptr(t.tile_mask), L.ptr(t.perm), L.ptr(t.tile_order), 27, n, L.ptr(W), 0, 0, 0, L.ptr(Y), C, 0, L.ptr(SCR), L.stream()))
+    L.check(lib.scn_conv_tiles(L.ptr(X), n, C, L.ptr(t.tstab), L.ptr(t.tile_mask), L.ptr(t.perm), L.ptr(t.tile_order), 27, n, L.ptr(W), 0, 0, 0, L.ptr(Y), C, 0, L.ptr(SCR), 0, L.stream()))
 torch.cuda.synchronize()

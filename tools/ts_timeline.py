@@ -24,7 +24,7 @@ lib = L.lib()
 SCR = torch.zeros(lib.scn_conv_tiles_scratch_bytes(C, n, C) + (4 << 20), dtype=torch.uint8, device="cuda")
 def run():
     L.check(lib.scn_conv_tiles(L.ptr(X), n, C, L.ptr(t.tstab), L.ptr(t.tile_mask), L.ptr(t.perm), L.ptr(t.tile_order), 27, n, L.ptr(W), 0, 0, 0,
-                               L.ptr(Y), C, 0, L.ptr(SCR), L.stream()))
+                               L.ptr(Y), C, 0, L.ptr(SCR), 0, L.stream()))
 for _ in range(int(os.environ.get('TL_LAUNCHES', '4000'))): run()      # sustained load: the clock settles (DVFS)
 torch.cuda.synchronize()
 base = lib.scn_conv_tiles_scratch_bytes(C, n, C)

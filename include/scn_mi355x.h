@@ -222,16 +222,24 @@ int scn_conv_tiles_finish(int cin, int64_t n_out, const float* bias, const float
                           float* Y, int cout, int flags, void* scratch, scn_stream_t stream);
 
 /* The same convolution for bf16 STORAGE (BASELINE configs 3-5): X, residual, relu_mask and Y are bf16
- * (uint16 bit patterns, row-major, cin % 8 == 0), the layer's master weights and bias stay fp32 and are rounded to
- * bf16 (round-to-nearest-even) as they are staged; products accumulate in fp32 on v_mfma_f32_16x16x32_bf16 and the
- * result is rounded to bf16 once.  Same tiles, flags and per-row summation order as scn_conv_tiles.  First piece of
- * the bf16 path: forward and backward-data of SubmanifoldConvolution / Convolution (module_factory.py:232-234,404-406);
- * the weight gradient and the other layers still take fp32 features. */
+ * (uint16 bit patterns, row-major, cin % 8 == 0 and cout % 8 == 0: 16-byte row pieces); products accumulate in fp32 on
+ * v_mfma_f32_16x16x32_bf16 and the result is rounded to bf16 once.  Same tiles, flags and per-row summation order as
+ * scn_conv_tiles.  The layer's master weights stay fp32: scn_conv_tiles_bf16_pack rounds them (round-to-nearest-even)
+ * into `image` (scn_conv_tiles_bf16_image_bytes bytes, 16-byte aligned), laid out as the kernel's workgroups stage it;
+ * SCN_F_W_TRANSPOSED / SCN_F_OFF_REVERSE are properties of the IMAGE (pass them to the pack; the convolution ignores
+ * them), so one layer has a forward image and a backward-data image.  An image is valid until the weights change.
+ * `arrival`: zeroed counters for the in-launch K reduction, contract as in scn_conv_tiles
+ * (scn_conv_tiles_bf16_arrival_counters entries); NULL: second launch.
+ * Serves SubmanifoldConvolution / Convolution forward and SubM / Deconvolution backward-data
+ * (module_factory.py:232-234,256-258,404-406). */
+int64_t scn_conv_tiles_bf16_image_bytes(int cin, int cout, int n_off);
+int scn_conv_tiles_bf16_pack(const float* W, int cin, int cout, int n_off, int flags, uint16_t* image, scn_stream_t stream);
 int64_t scn_conv_tiles_bf16_scratch_bytes(int cin, int64_t n_out, int cout);
+int64_t scn_conv_tiles_bf16_arrival_counters(int cin, int64_t n_out, int cout);
 int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, const int32_t* tstab, const uint32_t* tile_mask,
-                        const int32_t* perm, const int32_t* tile_order, int n_off, int64_t n_out, const float* W,
+                        const int32_t* perm, const int32_t* tile_order, int n_off, int64_t n_out, const uint16_t* image,
                         const float* bias, const uint16_t* residual, const uint16_t* relu_mask, uint16_t* Y, int cout,
-                        int flags, void* scratch, scn_stream_t stream);
+                        int flags, void* scratch, int32_t* arrival, scn_stream_t stream);
 
 /* Rule-list gather GEMM with row scatter:  Y[out_rows[p]] = bias + in(X[in_rows[p]]) . W[o(p)]
  * where every output row occurs in exactly one pair (Deconvolution fwd, module_factory.py:256-258; backward-data

@@ -1,6 +1,9 @@
 // conv_tb: the tile convolution of scn_conv_ts.hip for bf16 STORAGE (BASELINE configs 3-5): features and
 // the LDS weight image are bf16, accumulation is fp32 on v_mfma_f32_16x16x32_bf16, outputs are rounded to bf16 once
-// (round-to-nearest-even).  The layer's master weights stay fp32 in global memory and are rounded while they are staged.
+// (round-to-nearest-even).  The layer's master weights stay fp32; scn_conv_tiles_bf16_pack rounds them ONCE per use into
+// a bf16 image laid out exactly as the workgroups' LDS images (slice by slice), so staging is a straight 16-byte copy of
+// half the bytes (round 1 transposed fp32 weights into LDS with 2-byte stores 64 bytes apart: 8-16-way bank conflicts,
+// 5-12 us of a 28-42 us launch).
 //
 //   Y[r] = bf16( residual[r] + bias + sum_o in(X[table[o][r]]) . bf16(W[o']) )
 //
@@ -14,7 +17,11 @@
 //   * the LDS image is [o][n][k], k contiguous: the B fragment of lane (i, kq) for column block nb is the 16 bytes at
 //     ((o CT + 16 nb + i) 32 + 8 kq) -- a wave reads 1 KB contiguous, conflict-free ds_read_b128;
 //   * input ReLU is one v_pk_max_i16 per register (a negative bf16 is a negative int16).
-// C/D layout is that of the fp32 kernel: acc[nb][j] = D[row 4 kq + j][column 16 nb + i].
+// C/D: acc[nb][j] = D[row 4 kq + j][MFMA column i of block nb].  The image assigns ACTUAL column n0 + NB i + nb to MFMA
+// column i of block nb, so a lane's NB accumulators of a row are NB CONSECUTIVE output columns: one 2 NB-byte store (and
+// residual / mask load) per row instead of NB two-byte ones.
+// K split over workgroups (Cin > 32 or 64): the partial tiles are added inside the launch by the wave that arrives last
+// at a (tile, column chunk) -- the pipelined hand-off of k_conv_ts (scn_conv_ts.hip), fp32 partials, fixed K-chunk order.
 #include <stdlib.h>
 
 #include "scn_common.h"
@@ -35,14 +42,14 @@ static constexpr int TB_NW = 16;        // waves per workgroup
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 
-template <bool WT, int NB, int KH>
+template <int NB, int KH, bool FUSED>
 __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB == 2 && KH == 1 ? 8 : 4))) void k_conv_tb(
     const unsigned short* __restrict__ X, long long n_in, int cin, const int* __restrict__ tstab,
     const unsigned* __restrict__ tile_mask, const int* __restrict__ perm, const int* __restrict__ tile_order, int n_off,
-    long long nt, const float* __restrict__ W, const float* __restrict__ bias,
+    long long nt, const unsigned short* __restrict__ image, const float* __restrict__ bias,
     const unsigned short* __restrict__ residual, const unsigned short* __restrict__ relu_mask,
     unsigned short* __restrict__ Y, float* __restrict__ slabs, long long n_out, int cout, int flags, int n_chunks,
-    int n_kc) {
+    int n_kc, int* __restrict__ counters) {
     constexpr int CT = 16 * NB;
     constexpr int KC = TB_KC * KH;              // channels per K-chunk: 32, or 64 as two 32-channel planes of the image
     constexpr int THREADS = TB_NW * 64;
@@ -52,7 +59,6 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
     const int kci = (blockIdx.x / n_chunks) % n_kc;
     const int n0 = chunk * CT, kc = kci * KC;
     const bool relu_in = flags & SCN_F_RELU_IN;
-    const bool rev = flags & SCN_F_OFF_REVERSE;
     const bool res_last = flags & SCN_F_RESIDUAL_LAST;
 
     // ---- tile queue (as in k_conv_ts): the workgroup owns every n_tg-th entry of the LPT order --------------------
@@ -77,45 +83,24 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
         for (int j = 0; j < 4; ++j) orow_next[j] = perm[tile_next * TB_T + 4 * kq + j];
     }
 
-    // ---- stage the weight slice, rounding fp32 -> bf16 ---------------------------------------------------------------
+    // ---- stage the weight slice: the packed image holds this workgroup's LDS image verbatim -------------------------
     {
         // image: [o][plane h = k / 32][n][k % 32]: the B fragment reads of a wave for one (column block, plane) are 1 KB
         // contiguous (conflict-free ds_read_b128) for either K-chunk size
-        const int total4 = n_off * KC * (CT / 4);
-        const bool vecn = (cout % 4 == 0), veck = (cin % 4 == 0);
-        for (int e = tid; e < total4; e += THREADS) {
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (WT) {                  // layer weight [o][n][k]: k contiguous -> one 8-byte LDS store
-                const int c4 = e % (KC / 4), n = (e / (KC / 4)) % CT, o = e / ((KC / 4) * CT);
-                const int wo = rev ? n_off - 1 - o : o;
-                const int kl = 4 * c4, k = kc + kl, ng = n0 + n;
-                if (ng < cout) {
-                    const float* src = W + ((long long)wo * cout + ng) * cin + k;
-                    if (veck && k + 3 < cin) { const float4 t = *(const float4*)src; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-                    else {
+        const int total16 = n_off * KC * CT / 8;                          // 16-byte pieces
+        const uint4* src = (const uint4*)image + (size_t)(chunk * n_kc + kci) * total16;
+        constexpr int SB = 8;                                             // pieces in flight per thread
+        for (int base = 0; base < total16; base += THREADS * SB) {
+            uint4 v[SB];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) if (k + u < cin) v[u] = src[u];
-                    }
-                }
-                unsigned short* dst = Wb + (((size_t)o * KH + (kl >> 5)) * CT + n) * TB_KC + (kl & 31);
-                const unsigned lo = f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                const unsigned hi = f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                *(uint2*)dst = make_uint2(lo, hi);
-            } else {                   // [o][k][n]: n contiguous in global -> four 2-byte stores, 64 bytes apart
-                const int c4 = e % (CT / 4), kl = (e / (CT / 4)) % KC, o = e / (KC * (CT / 4));
-                const int wo = rev ? n_off - 1 - o : o;
-                const int kg = kc + kl, ng = n0 + 4 * c4;
-                if (kg < cin) {
-                    const float* src = W + ((long long)wo * cin + kg) * cout + ng;
-                    if (vecn && ng + 3 < cout) { const float4 t = *(const float4*)src; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-                    else {
+            for (int u = 0; u < SB; ++u) {
+                const int e = base + u * THREADS + tid;
+                if (e < total16) v[u] = src[e];
+            }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) if (ng + u < cout) v[u] = src[u];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    Wb[(((size_t)o * KH + (kl >> 5)) * CT + 4 * c4 + u) * TB_KC + (kl & 31)] = f32_to_bf16(v[u]);
+            for (int u = 0; u < SB; ++u) {
+                const int e = base + u * THREADS + tid;
+                if (e < total16) ((uint4*)Wb)[e] = v[u];
             }
         }
     }
@@ -125,15 +110,15 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
 #pragma unroll
     for (int hh = 0; hh < KH; ++hh) k_ok[hh] = kc + 32 * hh + 8 * kq + 7 < cin;
     const bool single = n_kc == 1;
+    const bool direct = single || FUSED;                            // this launch writes Y itself
+    const int ncol = n0 + NB * i;                                   // first of this lane's NB consecutive output columns
+    const bool n_ok = ncol < cout;                                  // cout % NB == 0: the group is in or out as a whole
     float bcol[NB];
-    bool n_ok[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int n = n0 + 16 * nb + i;
-        n_ok[nb] = n < cout;
-        bcol[nb] = (single && bias && n_ok[nb]) ? bias[n] : 0.f;
-    }
+    for (int nb = 0; nb < NB; ++nb) bcol[nb] = (direct && bias && n_ok) ? bias[ncol + nb] : 0.f;
     float* out_slab = slabs + (long long)kci * n_out * cout;
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)slabs, 0, FUSED && !single ? (int)(unsigned)(nt * n_chunks * n_kc * (TB_T * CT * 4)) : 0, 0x00020000);
     // A rows through a raw buffer descriptor that covers X exactly: a row index of -1 (no rule) or a channel group past
     // Cin becomes an out-of-range byte offset and the hardware returns zeros
     const __amdgpu_buffer_rsrc_t xrsrc =
@@ -170,6 +155,82 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
         oq0 = oq1; oq1 = oq2; oq2 = oq3; oq3 = oq4; oq4 = o4_;                                       \
     } while (0)
 
+    // ---- epilogue pieces ----------------------------------------------------------------------------------------------
+    typedef unsigned short vh_t __attribute__((ext_vector_type(NB)));
+    auto tb_write = [&](const int (&orow)[4], const f32x4 (&acc)[NB]) {
+        vh_t rh[4], mh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                // all operand loads first, one wait
+            const long long e = (long long)(orow[j] < 0 ? 0 : orow[j]) * cout + ncol;
+            if (residual && n_ok) rh[j] = *(const vh_t*)(residual + e);
+            if (relu_mask && n_ok) mh[j] = *(const vh_t*)(relu_mask + e);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (orow[j] < 0 || !n_ok) continue;
+            vh_t o;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float r = residual ? bf16_to_f32(rh[j][nb]) : 0.f;
+                float y = acc[nb][j] + (res_last ? 0.f : r);
+                if (relu_mask && !(bf16_to_f32(mh[j][nb]) > 0.f)) y = 0.f;
+                if (res_last) y += r;
+                o[nb] = f32_to_bf16(y);
+            }
+            *(vh_t*)(Y + (long long)orow[j] * cout + ncol) = o;
+        }
+    };
+    long long q1 = -1, q2 = -1;
+    int tk_v = 0;
+    auto tb_publish = [&](long long t, const f32x4 (&acc)[NB]) {
+        const int sb = (int)((t * n_chunks + chunk) * n_kc + kci) * (TB_T * CT * 4) + lane * 16;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, acc[nb]),
+                                                   srsrc, sb + nb * 1024, 0, 16);         // aux 16 = sc1: write-through
+        q1 = t;
+    };
+    auto tb_retire = [&]() {
+        if (q2 >= 0) {
+            const int ticket = __builtin_amdgcn_readfirstlane(tk_v);
+            if (ticket == n_kc - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                    // compiler ordering only
+                const int unit = (int)(q2 * n_chunks + chunk);
+                if (lane == 0) __hip_atomic_store(counters + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int orow2[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) orow2[j] = perm[q2 * TB_T + 4 * kq + j];
+                const int sb = (unit * n_kc) * (TB_T * CT * 4) + lane * 16;
+                f32x4 y[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) y[nb] = (f32x4){bcol[nb], bcol[nb], bcol[nb], bcol[nb]};
+                for (int k0 = 0; k0 < n_kc; k0 += 2) {            // bias + slab[0] + slab[1] + ...: ascending K-chunks
+                    f32x4 p[2][NB];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int k = k0 + u < n_kc ? k0 + u : n_kc - 1;
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            p[u][nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                srsrc, sb + k * (TB_T * CT * 4) + nb * 1024, 0, 16));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (k0 + u < n_kc) {
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb) y[nb] += p[u][nb];
+                        }
+                    }
+                }
+                tb_write(orow2, y);
+            }
+        }
+        if (q1 >= 0 && lane == 0)
+            tk_v = __hip_atomic_fetch_add(counters + (int)(q1 * n_chunks + chunk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        q2 = q1;
+        q1 = -1;
+    };
+
     while (tile_next >= 0) {
         const long long tile = tile_next;
         unsigned m = m_next;
@@ -205,7 +266,10 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
 
         f32x4 acc[NB];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = (f32x4){bcol[nb], bcol[nb], bcol[nb], bcol[nb]};
+        for (int nb = 0; nb < NB; ++nb) {
+            const float b0 = single ? bcol[nb] : 0.f;               // K split: the combiner adds the bias first
+            acc[nb] = (f32x4){b0, b0, b0, b0};
+        }
         int n_left = n_steps;
         for (; n_left >= 4; n_left -= 4) {
             TB_STEP(s0, s3, iqa, iqc);
@@ -218,26 +282,30 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
         if (n_left >= 3) { TB_STEP(s2, s1, iqc, iqa); }
 
         // ---- tile epilogue -------------------------------------------------------------------------------------
+        if (FUSED && !single) {             // pipelined hand-off, see k_conv_ts
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tb_retire();
+            tb_publish(tile, acc);
+            continue;
+        }
+        if (direct) tb_write(orow, acc);
+        else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = orow[j];
-            if (row < 0) continue;
-            const long long off = (long long)row * cout + n0 + i;
+            for (int j = 0; j < 4; ++j) {
+                if (orow[j] < 0 || !n_ok) continue;
+                typedef float vo_t __attribute__((ext_vector_type(NB)));
+                vo_t v;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                if (!n_ok[nb]) continue;
-                const long long e = off + 16 * nb;
-                if (single) {
-                    const float r = residual ? bf16_to_f32(residual[e]) : 0.f;
-                    float y = acc[nb][j] + (res_last ? 0.f : r);
-                    if (relu_mask && !(bf16_to_f32(relu_mask[e]) > 0.f)) y = 0.f;
-                    if (res_last) y += r;
-                    Y[e] = f32_to_bf16(y);
-                } else {
-                    out_slab[e] = acc[nb][j];
-                }
+                for (int nb = 0; nb < NB; ++nb) v[nb] = acc[nb][j];
+                *(vo_t*)(out_slab + (long long)orow[j] * cout + ncol) = v;
             }
         }
+    }
+    if (FUSED && !single) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tb_retire();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tb_retire();
     }
 }
 #undef TB_STEP
@@ -279,35 +347,102 @@ __global__ void k_conv_tb_sum(const float* __restrict__ slabs, int n_kc, long lo
     }
 }
 
+// ---- launch shape, shared by the pack and the convolution ---------------------------------------------------------------
+namespace {
+struct TbShape { int nb, kh, ct, kc, n_chunks, n_kc; };
+
+TbShape tb_shape(int cin, int cout) {
+    static const int nb_env = getenv("SCN_TB_NB") ? atoi(getenv("SCN_TB_NB")) : 0;      // developer switches
+    static const int kh_env = getenv("SCN_TB_KH") ? atoi(getenv("SCN_TB_KH")) : 0;
+    // shapes: 32 columns x 32 channels (small layers), 64 columns x 32 channels, 32 columns x 64 channels -- the last
+    // halves the number of K-chunks (no partial sums at Cin = 64) at twice the gather traffic per output
+    TbShape s;
+    s.kh = (kh_env == 1 || kh_env == 2) ? kh_env : 1;
+    if (cin <= 32) s.kh = 1;
+    s.nb = (nb_env == 2 || nb_env == 4) ? nb_env : (cout > 32 ? 4 : 2);
+    if (s.kh == 2) s.nb = 2;
+    s.ct = 16 * s.nb;
+    s.kc = TB_KC * s.kh;
+    s.n_chunks = (int)cdiv(cout, s.ct);
+    s.n_kc = (int)cdiv(cin, s.kc);
+    return s;
+}
+}  // namespace
+
+// image[slice = chunk * n_kc + kci][o][plane h][n = 16 nb + i][kk] = bf16( W[o'][k = kc + 32 h + kk][col = n0 + NB i + nb] )
+// (zero outside the layer).  WT: the layer stores [o][col][k] (backward-data); REV: o' = n_off - 1 - o.
+__global__ void k_tb_pack(const float* __restrict__ W, int cin, int cout, int n_off, int wt, int rev, TbShape sh,
+                          unsigned short* __restrict__ image) {
+    const long long total = (long long)sh.n_chunks * sh.n_kc * n_off * sh.kh * sh.ct * 4;       // 8-element pieces
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int k8 = (int)(e & 3);
+        long long r = e >> 2;
+        const int n = (int)(r % sh.ct); r /= sh.ct;
+        const int h = (int)(r % sh.kh); r /= sh.kh;
+        const int o = (int)(r % n_off); r /= n_off;
+        const int kci = (int)(r % sh.n_kc), chunk = (int)(r / sh.n_kc);
+        const int nb = n >> 4, i = n & 15;
+        const int col = chunk * sh.ct + sh.nb * i + nb;
+        const int k0 = kci * sh.kc + 32 * h + 8 * k8;
+        const int wo = rev ? n_off - 1 - o : o;
+        unsigned short v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + u;
+            float w = 0.f;
+            if (col < cout && k < cin)
+                w = wt ? W[((long long)wo * cout + col) * cin + k] : W[((long long)wo * cin + k) * cout + col];
+            v[u] = f32_to_bf16(w);
+        }
+        uint4 pk;
+        pk.x = v[0] | ((unsigned)v[1] << 16); pk.y = v[2] | ((unsigned)v[3] << 16);
+        pk.z = v[4] | ((unsigned)v[5] << 16); pk.w = v[6] | ((unsigned)v[7] << 16);
+        ((uint4*)image)[e] = pk;
+    }
+}
+
+extern "C" int64_t scn_conv_tiles_bf16_image_bytes(int cin, int cout, int n_off) {
+    if (cin < 1 || cout < 1 || n_off < 1) return -1;
+    const TbShape sh = tb_shape(cin, cout);
+    return (int64_t)sh.n_chunks * sh.n_kc * n_off * sh.ct * sh.kc * (int64_t)sizeof(uint16_t);
+}
+
+extern "C" int scn_conv_tiles_bf16_pack(const float* W, int cin, int cout, int n_off, int flags, uint16_t* image,
+                                        scn_stream_t stream) {
+    SCN_REQUIRE(W && image && cin >= 1 && cout >= 1 && n_off >= 1 && n_off <= 27);
+    SCN_REQUIRE((((uintptr_t)image) & 15) == 0);
+    const TbShape sh = tb_shape(cin, cout);
+    const int64_t pieces = (int64_t)sh.n_chunks * sh.n_kc * n_off * sh.kh * sh.ct * 4;
+    hipLaunchKernelGGL(k_tb_pack, dim3(scn::ew_grid(pieces, 256)), dim3(256), 0, S(stream), W, cin, cout, n_off,
+                       (flags & SCN_F_W_TRANSPOSED) ? 1 : 0, (flags & SCN_F_OFF_REVERSE) ? 1 : 0, sh, image);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
 extern "C" int64_t scn_conv_tiles_bf16_scratch_bytes(int cin, int64_t n_out, int cout) {
-    const int64_t n_kc = cdiv(cin, TB_KC);
-    return 256 + (n_kc > 1 ? n_kc * n_out * cout * (int64_t)sizeof(float) : 0);
+    const TbShape sh = tb_shape(cin, cout);
+    return 256 + (sh.n_kc > 1 ? (int64_t)sh.n_kc * cdiv(n_out, TB_T) * TB_T * sh.n_chunks * sh.ct * (int64_t)sizeof(float) : 0);
+}
+
+extern "C" int64_t scn_conv_tiles_bf16_arrival_counters(int cin, int64_t n_out, int cout) {
+    const TbShape sh = tb_shape(cin, cout);
+    return sh.n_kc > 1 ? cdiv(n_out, TB_T) * sh.n_chunks : 0;
 }
 
 extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, const int32_t* tstab,
                                    const uint32_t* tile_mask, const int32_t* perm, const int32_t* tile_order, int n_off,
-                                   int64_t n_out, const float* W, const float* bias, const uint16_t* residual,
+                                   int64_t n_out, const uint16_t* image, const float* bias, const uint16_t* residual,
                                    const uint16_t* relu_mask, uint16_t* Y, int cout, int flags, void* scratch,
-                                   scn_stream_t stream) {
-    SCN_REQUIRE(n_off >= 1 && n_off <= 27 && n_out >= 0 && n_in >= 0 && cin >= 8 && cout >= 1);
-    SCN_REQUIRE(cin % 8 == 0);                                   // 16-byte row pieces
+                                   int32_t* arrival, scn_stream_t stream) {
+    SCN_REQUIRE(n_off >= 1 && n_off <= 27 && n_out >= 0 && n_in >= 0 && cin >= 8 && cout >= 8);
+    SCN_REQUIRE(cin % 8 == 0 && cout % 8 == 0);                  // 16-byte row pieces
     if (n_out == 0) return SCN_OK;
-    SCN_REQUIRE(X && tstab && tile_mask && perm && tile_order && W && Y && scratch);
-    SCN_REQUIRE((((uintptr_t)X | (uintptr_t)W) & 15) == 0);
+    SCN_REQUIRE(X && tstab && tile_mask && perm && tile_order && image && Y && scratch);
+    SCN_REQUIRE((((uintptr_t)X | (uintptr_t)image | (uintptr_t)Y | (uintptr_t)residual | (uintptr_t)relu_mask) & 15) == 0);
     SCN_REQUIRE(n_in < (1ll << 23) && n_in * cin * 2 < (1ll << 32) - (1ll << 24));    // 24-bit rows, 32-bit offsets
     const int64_t nt = cdiv(n_out, TB_T);
-    static const int nb_env = getenv("SCN_TB_NB") ? atoi(getenv("SCN_TB_NB")) : 0;      // developer switches
-    static const int kh_env = getenv("SCN_TB_KH") ? atoi(getenv("SCN_TB_KH")) : 0;
-    // shapes: 32 columns x 32 channels (small layers), 64 columns x 32 channels, 32 columns x 64 channels -- the last
-    // halves the number of K-chunks (no fp32 slabs at Cin = 64) at twice the gather traffic per output
-    int kh = (kh_env == 1 || kh_env == 2) ? kh_env : 1;   // 64-channel chunks: 41.7 -> 37.3 us per launch at C = 64 alone
-                                                          // (tools/ablate_conv_bf16.py), but 0-3 % slower inside the step
-    if (cin <= 32) kh = 1;
-    int nb = nb_env == 2 || nb_env == 4 ? nb_env : (cout > 32 ? 4 : 2);
-    if (kh == 2) nb = 2;
-    const int ct = 16 * nb, kcs = TB_KC * kh;
-    const int n_chunks = (int)cdiv(cout, ct);
-    const int n_kc = (int)cdiv(cin, kcs);
+    const TbShape sh = tb_shape(cin, cout);
+    const int nb = sh.nb, kh = sh.kh, ct = sh.ct, kcs = sh.kc, n_chunks = sh.n_chunks, n_kc = sh.n_kc;
     float* slabs = (float*)((char*)scratch + 256);
     const size_t lds = (size_t)n_off * ct * kcs * sizeof(uint16_t) + 16;
     int wg_per_cu = (int)((160 * 1024) / lds);
@@ -316,29 +451,30 @@ extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, con
     int64_t n_tg = (256 * wg_per_cu) / ((int64_t)n_chunks * n_kc);
     if (n_tg > cdiv(nt, TB_NW)) n_tg = cdiv(nt, TB_NW);
     if (n_tg < 1) n_tg = 1;
-    const bool wt = flags & SCN_F_W_TRANSPOSED;
+    const bool fused = n_kc > 1 && arrival != nullptr && !(flags & SCN_F_SPLIT_SUM) &&
+                       nt * n_chunks * n_kc * (int64_t)(TB_T * ct * 4) < (1ll << 31);
     dim3 grid((unsigned)(n_tg * n_chunks * n_kc));
     hipStream_t st = S(stream);
-#define LAUNCH_TB(T, N, K)                                                                                          \
+#define LAUNCH_TB(N, K, FU)                                                                                         \
     do {                                                                                                            \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
-            SCN_HIP(hipFuncSetAttribute((const void*)k_conv_tb<T, N, K>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            SCN_HIP(hipFuncSetAttribute((const void*)k_conv_tb<N, K, FU>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                         160 * 1024));                                                               \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((k_conv_tb<T, N, K>), grid, dim3(TB_NW * 64), lds, st, X, (long long)n_in, cin, tstab,   \
-                           tile_mask, perm, tile_order, n_off, (long long)nt, W, bias, residual, relu_mask, Y, slabs, \
-                           (long long)n_out, cout, flags, n_chunks, n_kc);                                          \
+        hipLaunchKernelGGL((k_conv_tb<N, K, FU>), grid, dim3(TB_NW * 64), lds, st, X, (long long)n_in, cin, tstab,  \
+                           tile_mask, perm, tile_order, n_off, (long long)nt, image, bias, residual, relu_mask, Y, slabs, \
+                           (long long)n_out, cout, flags, n_chunks, n_kc, (int*)arrival);                           \
     } while (0)
-    if (kh == 2) { if (wt) LAUNCH_TB(true, 2, 2); else LAUNCH_TB(false, 2, 2); }
-    else if (wt && nb == 4) LAUNCH_TB(true, 4, 1);
-    else if (wt) LAUNCH_TB(true, 2, 1);
-    else if (nb == 4) LAUNCH_TB(false, 4, 1);
-    else LAUNCH_TB(false, 2, 1);
+#define PICK_TB(N, K) do { if (fused) LAUNCH_TB(N, K, true); else LAUNCH_TB(N, K, false); } while (0)
+    if (kh == 2) PICK_TB(2, 2);
+    else if (nb == 4) PICK_TB(4, 1);
+    else PICK_TB(2, 1);
+#undef PICK_TB
 #undef LAUNCH_TB
     SCN_LAUNCH_CHECK();
-    if (n_kc > 1) {
+    if (n_kc > 1 && !fused) {
         const int rl = (flags & SCN_F_RESIDUAL_LAST) ? 1 : 0;
         const bool v4 = cout % 4 == 0 && ((((uintptr_t)slabs | (uintptr_t)bias) & 15) == 0) &&
                         ((((uintptr_t)Y | (uintptr_t)residual | (uintptr_t)relu_mask) & 7) == 0);

@@ -89,7 +89,7 @@ def _conv_tiles_scratch_bytes(cin, n_out, cout):
 def conv_rules(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu_mask=None, n_rules=0):
     """The hot kernel: output-stationary convolution over mask-sorted tiles (scn_conv_tiles)."""
     if _is_bf16(X):
-        return conv_rules_bf16(X, tiles, n_out, W, bias, cout, flags, residual, relu_mask)
+        return conv_rules_bf16(X, tiles, n_out, W, bias, cout, flags, residual, relu_mask, n_rules=n_rules)
     lib = L.lib()
     cin = X.shape[1]
     Y = _new((n_out, cout), X)
@@ -119,10 +119,21 @@ def conv_rules(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu_mask
     return Y
 
 
-def conv_rules_bf16(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu_mask=None):
+def pack_weights_bf16(W, cin, cout, n_off, flags=0):
+    """scn_conv_tiles_bf16_pack: the layer's fp32 master weights -> the bf16 image the tile kernel stages (one rounding per
+    weight).  flags: F_W_TRANSPOSED | F_OFF_REVERSE select the backward-data image.  Valid until W changes: callers pack
+    per use (forward / backward of one step) and never cache across steps."""
+    lib = L.lib()
+    img = torch.empty(lib.scn_conv_tiles_bf16_image_bytes(cin, cout, n_off), dtype=torch.uint8, device=W.device)
+    L.check(lib.scn_conv_tiles_bf16_pack(L.ptr(W), cin, cout, n_off, flags & (L.F_W_TRANSPOSED | L.F_OFF_REVERSE),
+                                         L.ptr(img), L.stream()))
+    return img
+
+
+def conv_rules_bf16(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu_mask=None, image=None, n_rules=0):
     """scn_conv_tiles_bf16: the tile convolution for bf16-stored features (X, residual, relu_mask, result: torch.bfloat16;
-    W, bias: the layer's fp32 parameters).  First piece of the bf16 storage path (BASELINE configs 3-5): forward and,
-    with F_W_TRANSPOSED | F_OFF_REVERSE, backward-data; not yet wired into the modules."""
+    W, bias: the layer's fp32 parameters).  Forward and, with F_W_TRANSPOSED | F_OFF_REVERSE, backward-data.
+    image: a packed weight image of W for these flags (pack_weights_bf16); None: packed here."""
     lib = L.lib()
     for t in (X, residual, relu_mask):
         if t is not None and (t.dtype != torch.bfloat16 or not t.is_contiguous()):
@@ -130,14 +141,22 @@ def conv_rules_bf16(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu
     if W.dtype != torch.float32 or (bias is not None and bias.dtype != torch.float32):
         raise L.ScnError("conv_rules_bf16 takes the fp32 master weights")
     cin = X.shape[1]
-    Y = torch.empty((n_out, cout), dtype=torch.bfloat16, device=X.device)
-    nbytes = lib.scn_conv_tiles_bf16_scratch_bytes(cin, n_out, cout)
-    scratch = L.scratch(nbytes, X.device)
+    if cin % 8 or cout % 8:
+        raise L.ScnError("bf16 storage needs channel counts that are multiples of 8 (16-byte row pieces)")
     n_in, n_off = X.shape[0], tiles.n_off
-    profiling.timed("k_conv_tb", 0.0, 0.0, lambda: L.check(lib.scn_conv_tiles_bf16(
-        L.ptr(X), n_in, cin, L.ptr(tiles.tstab), L.ptr(tiles.tile_mask), L.ptr(tiles.perm), L.ptr(tiles.tile_order),
-        n_off, n_out, L.ptr(W), L.ptr(bias), L.ptr(residual), L.ptr(relu_mask), L.ptr(Y), cout, flags, L.ptr(scratch),
-        L.stream())))
+    if image is None:
+        image = pack_weights_bf16(W, cin, cout, n_off, flags)
+    Y = torch.empty((n_out, cout), dtype=torch.bfloat16, device=X.device)
+    scratch = L.scratch(lib.scn_conv_tiles_bf16_scratch_bytes(cin, n_out, cout), X.device)
+    n_arr = lib.scn_conv_tiles_bf16_arrival_counters(cin, n_out, cout) if FUSED_K else 0
+    arr = L.arrival(n_arr, X.device) if n_arr else None
+    P = lambda: _count(n_rules)
+    profiling.timed("k_conv_tb", lambda: 2.0 * P() * cin * cout,
+                    lambda: 2.0 * (n_in * cin + n_out * cout + n_off * cin * cout) + 8.0 * P(),
+                    lambda: L.check(lib.scn_conv_tiles_bf16(
+                        L.ptr(X), n_in, cin, L.ptr(tiles.tstab), L.ptr(tiles.tile_mask), L.ptr(tiles.perm),
+                        L.ptr(tiles.tile_order), n_off, n_out, L.ptr(image), L.ptr(bias), L.ptr(residual), L.ptr(relu_mask),
+                        L.ptr(Y), cout, flags, L.ptr(scratch), L.ptr(arr), L.stream())))
     return Y
 
 

@@ -666,7 +666,7 @@ BF16_TOL = 2.0 ** -7     # outputs are rounded to bf16 (8 significant bits: half
                          # accumulation of bf16-rounded operands; stated relative to the output scale
 
 
-@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (8, 16), (48, 80), (128, 64), (256, 256)])
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (8, 16), (48, 80), (128, 64), (256, 256), (24, 24), (512, 40)])
 @pytest.mark.parametrize("relu_in", [False, True])
 def test_conv_tiles_bf16_forward_and_backward_data(gpu, cin, cout, relu_in):
     """scn_conv_tiles_bf16 against the oracle convolution evaluated on the SAME bf16-rounded operands (features bf16,
@@ -698,8 +698,20 @@ def test_conv_tiles_bf16_forward_and_backward_data(gpu, cin, cout, relu_in):
     dxo, _, _ = O.conv_bwd(torch.zeros(n, cin), G.float(), rules, Wb, has_bias=False)
     dxo = dxo * (M.float() > 0)
     _close(dx.float(), dxo, BF16_TOL, "bf16 bwd-data")
-    # bitwise reproducible
+    # bitwise reproducible, and the in-launch K reduction gives the bits of the two-launch form
     assert torch.equal(y, F.conv_rules_bf16(X.to(gpu), rb.tiles, n, W.to(gpu), b.to(gpu), cout, flags, residual=R.to(gpu)))
+    F.FUSED_K = False
+    try:
+        y2 = F.conv_rules_bf16(X.to(gpu), rb.tiles, n, W.to(gpu), b.to(gpu), cout, flags, residual=R.to(gpu))
+        dx2 = F.conv_rules_bf16(G.to(gpu), rb.tiles, n, W.to(gpu), None, cin, L.F_W_TRANSPOSED | L.F_OFF_REVERSE,
+                                relu_mask=M.to(gpu))
+    finally:
+        F.FUSED_K = True
+    assert torch.equal(y, y2) and torch.equal(dx, dx2)
+    # a packed image may be shared by calls as long as the weights do not change
+    img = F.pack_weights_bf16(W.to(gpu), cin, cout, 27, flags)
+    assert torch.equal(y, F.conv_rules_bf16(X.to(gpu), rb.tiles, n, W.to(gpu), b.to(gpu), cout, flags, residual=R.to(gpu),
+                                            image=img))
 
 
 def test_conv_tiles_bf16_rejects_unsupported_inputs(gpu):

@@ -234,6 +234,11 @@ int scn_conv_tiles_finish(int cin, int64_t n_out, const float* bias, const float
  * (module_factory.py:232-234,256-258,404-406). */
 int64_t scn_conv_tiles_bf16_image_bytes(int cin, int cout, int n_off);
 int scn_conv_tiles_bf16_pack(const float* W, int cin, int cout, int n_off, int flags, uint16_t* image, scn_stream_t stream);
+/* The same for n images in one launch (all arrays on the HOST; W / image entries are device pointers): a network packs the
+ * forward and backward-data images of all its convolutions once per step. */
+int scn_conv_tiles_bf16_pack_many(int n, const float* const* W_host, const int32_t* cin_host, const int32_t* cout_host,
+                                  const int32_t* n_off_host, const int32_t* flags_host, uint16_t* const* image_host,
+                                  scn_stream_t stream);
 int64_t scn_conv_tiles_bf16_scratch_bytes(int cin, int64_t n_out, int cout);
 int64_t scn_conv_tiles_bf16_arrival_counters(int cin, int64_t n_out, int cout);
 int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, const int32_t* tstab, const uint32_t* tile_mask,

@@ -48,6 +48,7 @@ _SIGS = {
     "scn_conv_tiles_finish": (C.c_int, [i32, i64, p, p, p, p, i32, i32, p, p]),
     "scn_conv_tiles_bf16_image_bytes": (i64, [i32, i32, i32]),
     "scn_conv_tiles_bf16_pack": (C.c_int, [p, i32, i32, i32, i32, p, p]),
+    "scn_conv_tiles_bf16_pack_many": (C.c_int, [i32, p, p, p, p, p, p, p]),
     "scn_conv_tiles_bf16_scratch_bytes": (i64, [i32, i64, i32]),
     "scn_conv_tiles_bf16_arrival_counters": (i64, [i32, i64, i32]),
     "scn_conv_tiles_bf16": (C.c_int, [p, i64, i32, p, p, p, p, i32, i64, p, p, p, p, p, i32, i32, p, p, p]),

@@ -43,7 +43,7 @@ __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_a
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 
 template <int NB, int KH, bool FUSED>
-__global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB == 2 && KH == 1 ? 8 : 4))) void k_conv_tb(
+__global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB == 2 && KH == 1 && !FUSED ? 8 : 4))) void k_conv_tb(
     const unsigned short* __restrict__ X, long long n_in, int cin, const int* __restrict__ tstab,
     const unsigned* __restrict__ tile_mask, const int* __restrict__ perm, const int* __restrict__ tile_order, int n_off,
     long long nt, const unsigned short* __restrict__ image, const float* __restrict__ bias,
@@ -89,12 +89,13 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
         // contiguous (conflict-free ds_read_b128) for either K-chunk size
         const int total16 = n_off * KC * CT / 8;                          // 16-byte pieces
         const uint4* src = (const uint4*)image + (size_t)(chunk * n_kc + kci) * total16;
-        constexpr int SB = 8;                                             // pieces in flight per thread
+        constexpr int SB = 4;                                             // pieces in flight per thread
         for (int base = 0; base < total16; base += THREADS * SB) {
             uint4 v[SB];
 #pragma unroll
             for (int u = 0; u < SB; ++u) {
                 const int e = base + u * THREADS + tid;
+                v[u] = make_uint4(0u, 0u, 0u, 0u);
                 if (e < total16) v[u] = src[e];
             }
 #pragma unroll
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
     const bool n_ok = ncol < cout;                                  // cout % NB == 0: the group is in or out as a whole
     float bcol[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) bcol[nb] = (direct && bias && n_ok) ? bias[ncol + nb] : 0.f;
+    for (int nb = 0; nb < NB; ++nb) bcol[nb] = (direct && bias && ncol + nb < cout) ? bias[ncol + nb] : 0.f;
     float* out_slab = slabs + (long long)kci * n_out * cout;
     const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)slabs, 0, FUSED && !single ? (int)(unsigned)(nt * n_chunks * n_kc * (TB_T * CT * 4)) : 0, 0x00020000);
@@ -156,28 +157,65 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
     } while (0)
 
     // ---- epilogue pieces ----------------------------------------------------------------------------------------------
-    typedef unsigned short vh_t __attribute__((ext_vector_type(NB)));
+    // A lane's NB consecutive bf16 columns of a row travel as NB/2 32-bit words (one 4- or 8-byte access); explicit words
+    // and shifts -- element-indexed short vectors made the compiler spill to scratch.  vec_ok: cout % NB == 0 and aligned
+    // operands; otherwise every column is its own 2-byte access.
+    constexpr int NWD = NB / 2;
+    const bool vec_ok = (cout % NB == 0) && ((((uintptr_t)Y | (uintptr_t)residual | (uintptr_t)relu_mask) & (2 * NB - 1)) == 0);
     auto tb_write = [&](const int (&orow)[4], const f32x4 (&acc)[NB]) {
-        vh_t rh[4], mh[4];
+        unsigned rw[4][NWD], mw[4][NWD];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                                // all operand loads first, one wait
             const long long e = (long long)(orow[j] < 0 ? 0 : orow[j]) * cout + ncol;
-            if (residual && n_ok) rh[j] = *(const vh_t*)(residual + e);
-            if (relu_mask && n_ok) mh[j] = *(const vh_t*)(relu_mask + e);
+#pragma unroll
+            for (int w = 0; w < NWD; ++w) { rw[j][w] = 0u; mw[j][w] = 0x3f803f80u; }      // residual 0, mask 1.0
+            if (vec_ok && n_ok) {
+                if (residual) {
+                    if (NB == 2) rw[j][0] = *(const unsigned*)(residual + e);
+                    else { const uint2 t = *(const uint2*)(residual + e); rw[j][0] = t.x; rw[j][NWD - 1] = t.y; }
+                }
+                if (relu_mask) {
+                    if (NB == 2) mw[j][0] = *(const unsigned*)(relu_mask + e);
+                    else { const uint2 t = *(const uint2*)(relu_mask + e); mw[j][0] = t.x; mw[j][NWD - 1] = t.y; }
+                }
+            } else if (!vec_ok) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    if (ncol + nb >= cout) continue;
+                    if (residual) rw[j][nb >> 1] = (nb & 1) ? (rw[j][nb >> 1] & 0xffffu) | ((unsigned)residual[e + nb] << 16)
+                                                            : (rw[j][nb >> 1] & 0xffff0000u) | residual[e + nb];
+                    if (relu_mask) mw[j][nb >> 1] = (nb & 1) ? (mw[j][nb >> 1] & 0xffffu) | ((unsigned)relu_mask[e + nb] << 16)
+                                                             : (mw[j][nb >> 1] & 0xffff0000u) | relu_mask[e + nb];
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (orow[j] < 0 || !n_ok) continue;
-            vh_t o;
+            if (orow[j] < 0) continue;
+            unsigned ow[NWD];
+#pragma unroll
+            for (int w = 0; w < NWD; ++w) ow[w] = 0u;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const float r = residual ? bf16_to_f32(rh[j][nb]) : 0.f;
+                const unsigned rbits = (nb & 1) ? (rw[j][nb >> 1] & 0xffff0000u) : (rw[j][nb >> 1] << 16);
+                const unsigned mbits = (nb & 1) ? (mw[j][nb >> 1] & 0xffff0000u) : (mw[j][nb >> 1] << 16);
+                const float r = __uint_as_float(rbits);
                 float y = acc[nb][j] + (res_last ? 0.f : r);
-                if (relu_mask && !(bf16_to_f32(mh[j][nb]) > 0.f)) y = 0.f;
+                if (!(__uint_as_float(mbits) > 0.f)) y = 0.f;
                 if (res_last) y += r;
-                o[nb] = f32_to_bf16(y);
+                ow[nb >> 1] |= (unsigned)f32_to_bf16(y) << (16 * (nb & 1));
             }
-            *(vh_t*)(Y + (long long)orow[j] * cout + ncol) = o;
+            unsigned short* yp = Y + (long long)orow[j] * cout + ncol;
+            if (vec_ok) {
+                if (n_ok) {
+                    if (NB == 2) *(unsigned*)yp = ow[0];
+                    else *(uint2*)yp = make_uint2(ow[0], ow[NWD - 1]);
+                }
+            } else {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    if (ncol + nb < cout) yp[nb] = (unsigned short)(ow[nb >> 1] >> (16 * (nb & 1)));
+            }
         }
     };
     long long q1 = -1, q2 = -1;
@@ -292,12 +330,10 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
         else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (orow[j] < 0 || !n_ok) continue;
-                typedef float vo_t __attribute__((ext_vector_type(NB)));
-                vo_t v;
+                if (orow[j] < 0) continue;
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) v[nb] = acc[nb][j];
-                *(vo_t*)(out_slab + (long long)orow[j] * cout + ncol) = v;
+                for (int nb = 0; nb < NB; ++nb)
+                    if (ncol + nb < cout) out_slab[(long long)orow[j] * cout + ncol + nb] = acc[nb][j];
             }
         }
     }
@@ -401,6 +437,77 @@ __global__ void k_tb_pack(const float* __restrict__ W, int cin, int cout, int n_
     }
 }
 
+// Many layers in ONE launch (a U-Net packs the forward and backward-data images of all its convolutions once per step:
+// 62 separate pack launches cost 0.37 ms of a 5 ms step).  Descriptors travel by value in the kernel arguments.
+#define SCN_PACK_MAX 80
+struct TbPackJob { const float* W; unsigned short* image; int cin, cout, n_off, wt, rev; TbShape sh; };
+struct TbPackJobs { TbPackJob job[SCN_PACK_MAX]; long long start[SCN_PACK_MAX + 1]; int n; };
+
+__device__ __forceinline__ void tb_pack_piece(const TbPackJob& jb, long long e) {
+    const TbShape& sh = jb.sh;
+    const int k8 = (int)(e & 3);
+    long long r = e >> 2;
+    const int n = (int)(r % sh.ct); r /= sh.ct;
+    const int h = (int)(r % sh.kh); r /= sh.kh;
+    const int o = (int)(r % jb.n_off); r /= jb.n_off;
+    const int kci = (int)(r % sh.n_kc), chunk = (int)(r / sh.n_kc);
+    const int nb = n >> 4, i = n & 15;
+    const int col = chunk * sh.ct + sh.nb * i + nb;
+    const int k0 = kci * sh.kc + 32 * h + 8 * k8;
+    const int wo = jb.rev ? jb.n_off - 1 - o : o;
+    unsigned short v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int k = k0 + u;
+        float w = 0.f;
+        if (col < jb.cout && k < jb.cin)
+            w = jb.wt ? jb.W[((long long)wo * jb.cout + col) * jb.cin + k] : jb.W[((long long)wo * jb.cin + k) * jb.cout + col];
+        v[u] = f32_to_bf16(w);
+    }
+    uint4 pk;
+    pk.x = v[0] | ((unsigned)v[1] << 16); pk.y = v[2] | ((unsigned)v[3] << 16);
+    pk.z = v[4] | ((unsigned)v[5] << 16); pk.w = v[6] | ((unsigned)v[7] << 16);
+    ((uint4*)jb.image)[e] = pk;
+}
+
+__global__ void k_tb_pack_many(TbPackJobs jobs) {
+    const long long total = jobs.start[jobs.n];
+    for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = jobs.n - 1;                      // job of piece g: last start <= g
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs.start[mid] <= g) lo = mid; else hi = mid - 1;
+        }
+        tb_pack_piece(jobs.job[lo], g - jobs.start[lo]);
+    }
+}
+
+extern "C" int scn_conv_tiles_bf16_pack_many(int n, const float* const* W_host, const int32_t* cin_host,
+                                             const int32_t* cout_host, const int32_t* n_off_host,
+                                             const int32_t* flags_host, uint16_t* const* image_host, scn_stream_t stream) {
+    SCN_REQUIRE(n >= 0 && (n == 0 || (W_host && cin_host && cout_host && n_off_host && flags_host && image_host)));
+    for (int base = 0; base < n; base += SCN_PACK_MAX) {
+        TbPackJobs jobs;
+        jobs.n = n - base < SCN_PACK_MAX ? n - base : SCN_PACK_MAX;
+        jobs.start[0] = 0;
+        for (int j = 0; j < jobs.n; ++j) {
+            const int q = base + j;
+            SCN_REQUIRE(W_host[q] && image_host[q] && cin_host[q] >= 1 && cout_host[q] >= 1 && n_off_host[q] >= 1 &&
+                        n_off_host[q] <= 27 && (((uintptr_t)image_host[q]) & 15) == 0);
+            TbPackJob& jb = jobs.job[j];
+            jb.W = W_host[q]; jb.image = image_host[q]; jb.cin = cin_host[q]; jb.cout = cout_host[q]; jb.n_off = n_off_host[q];
+            jb.wt = (flags_host[q] & SCN_F_W_TRANSPOSED) ? 1 : 0;
+            jb.rev = (flags_host[q] & SCN_F_OFF_REVERSE) ? 1 : 0;
+            jb.sh = tb_shape(jb.cin, jb.cout);
+            jobs.start[j + 1] = jobs.start[j] + (long long)jb.sh.n_chunks * jb.sh.n_kc * jb.n_off * jb.sh.kh * jb.sh.ct * 4;
+        }
+        if (jobs.start[jobs.n] == 0) continue;
+        hipLaunchKernelGGL(k_tb_pack_many, dim3(scn::ew_grid(jobs.start[jobs.n], 256)), dim3(256), 0, S(stream), jobs);
+        SCN_LAUNCH_CHECK();
+    }
+    return SCN_OK;
+}
+
 extern "C" int64_t scn_conv_tiles_bf16_image_bytes(int cin, int cout, int n_off) {
     if (cin < 1 || cout < 1 || n_off < 1) return -1;
     const TbShape sh = tb_shape(cin, cout);
@@ -434,11 +541,11 @@ extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, con
                                    int64_t n_out, const uint16_t* image, const float* bias, const uint16_t* residual,
                                    const uint16_t* relu_mask, uint16_t* Y, int cout, int flags, void* scratch,
                                    int32_t* arrival, scn_stream_t stream) {
-    SCN_REQUIRE(n_off >= 1 && n_off <= 27 && n_out >= 0 && n_in >= 0 && cin >= 8 && cout >= 8);
-    SCN_REQUIRE(cin % 8 == 0 && cout % 8 == 0);                  // 16-byte row pieces
+    SCN_REQUIRE(n_off >= 1 && n_off <= 27 && n_out >= 0 && n_in >= 0 && cin >= 8 && cout >= 1);
+    SCN_REQUIRE(cin % 8 == 0);                                   // 16-byte row pieces of X (any cout)
     if (n_out == 0) return SCN_OK;
     SCN_REQUIRE(X && tstab && tile_mask && perm && tile_order && image && Y && scratch);
-    SCN_REQUIRE((((uintptr_t)X | (uintptr_t)image | (uintptr_t)Y | (uintptr_t)residual | (uintptr_t)relu_mask) & 15) == 0);
+    SCN_REQUIRE((((uintptr_t)X | (uintptr_t)image) & 15) == 0);
     SCN_REQUIRE(n_in < (1ll << 23) && n_in * cin * 2 < (1ll << 32) - (1ll << 24));    // 24-bit rows, 32-bit offsets
     const int64_t nt = cdiv(n_out, TB_T);
     const TbShape sh = tb_shape(cin, cout);

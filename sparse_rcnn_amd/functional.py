@@ -86,10 +86,11 @@ def _conv_tiles_scratch_bytes(cin, n_out, cout):
     return v
 
 
-def conv_rules(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu_mask=None, n_rules=0):
-    """The hot kernel: output-stationary convolution over mask-sorted tiles (scn_conv_tiles)."""
+def conv_rules(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu_mask=None, n_rules=0, image=None):
+    """The hot kernel: output-stationary convolution over mask-sorted tiles (scn_conv_tiles).  image: bf16 storage only,
+    a packed weight image for these flags."""
     if _is_bf16(X):
-        return conv_rules_bf16(X, tiles, n_out, W, bias, cout, flags, residual, relu_mask, n_rules=n_rules)
+        return conv_rules_bf16(X, tiles, n_out, W, bias, cout, flags, residual, relu_mask, image=image, n_rules=n_rules)
     lib = L.lib()
     cin = X.shape[1]
     Y = _new((n_out, cout), X)
@@ -130,6 +131,55 @@ def pack_weights_bf16(W, cin, cout, n_off, flags=0):
     return img
 
 
+# Weight images packed for the forward pass that is running (packed_weights below): (data_ptr, cin, cout, n_off, flags & 6)
+# -> image.  Filled by ONE launch for a whole network, emptied when its forward ends; a backward-data image is handed to the
+# autograd node during the forward (ctx) -- nothing here outlives a step, so an optimizer update can never meet a stale image.
+PACKED = {}
+_BACK = L.F_W_TRANSPOSED | L.F_OFF_REVERSE
+
+
+def packed_image(W, cin, cout, n_off, flags):
+    return PACKED.get((W.data_ptr(), cin, cout, n_off, flags & _BACK))
+
+
+class packed_weights:
+    """Context manager: pack the bf16 weight images (forward and backward-data) of `jobs` = [(W, cin, cout, n_off, flags)]
+    with one scn_conv_tiles_bf16_pack_many launch; they are visible through packed_image() until the block ends."""
+
+    def __init__(self, jobs):
+        self.jobs = jobs
+        self.keys = []
+
+    def __enter__(self):
+        lib = L.lib()
+        jobs = self.jobs
+        if not jobs:
+            return self
+        dev = jobs[0][0].device
+        sizes = [lib.scn_conv_tiles_bf16_image_bytes(ci, co, no) for (_, ci, co, no, _) in jobs]
+        offs, tot = [], 0
+        for b in sizes:
+            offs.append(tot)
+            tot += (b + 255) & ~255
+        buf = torch.empty(tot, dtype=torch.uint8, device=dev)
+        n = len(jobs)
+        Wp = (C.c_void_p * n)(*[W.data_ptr() for (W, *_r) in jobs])
+        Ip = (C.c_void_p * n)(*[buf.data_ptr() + o for o in offs])
+        ci = (C.c_int32 * n)(*[j[1] for j in jobs]); co = (C.c_int32 * n)(*[j[2] for j in jobs])
+        no = (C.c_int32 * n)(*[j[3] for j in jobs]); fl = (C.c_int32 * n)(*[j[4] & _BACK for j in jobs])
+        L.check(lib.scn_conv_tiles_bf16_pack_many(n, Wp, ci, co, no, fl, Ip, L.stream()))
+        for (W, cin, cout, n_off, flags), o, b in zip(jobs, offs, sizes):
+            key = (W.data_ptr(), cin, cout, n_off, flags & _BACK)
+            PACKED[key] = buf[o:o + b]
+            self.keys.append(key)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.keys:
+            PACKED.pop(k, None)
+        return False
+
+
 def conv_rules_bf16(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu_mask=None, image=None, n_rules=0):
     """scn_conv_tiles_bf16: the tile convolution for bf16-stored features (X, residual, relu_mask, result: torch.bfloat16;
     W, bias: the layer's fp32 parameters).  Forward and, with F_W_TRANSPOSED | F_OFF_REVERSE, backward-data.
@@ -141,9 +191,11 @@ def conv_rules_bf16(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu
     if W.dtype != torch.float32 or (bias is not None and bias.dtype != torch.float32):
         raise L.ScnError("conv_rules_bf16 takes the fp32 master weights")
     cin = X.shape[1]
-    if cin % 8 or cout % 8:
-        raise L.ScnError("bf16 storage needs channel counts that are multiples of 8 (16-byte row pieces)")
+    if cin % 8:
+        raise L.ScnError("bf16 storage needs input channel counts that are multiples of 8 (16-byte row pieces)")
     n_in, n_off = X.shape[0], tiles.n_off
+    if image is None:
+        image = packed_image(W, cin, cout, n_off, flags)
     if image is None:
         image = pack_weights_bf16(W, cin, cout, n_off, flags)
     Y = torch.empty((n_out, cout), dtype=torch.bfloat16, device=X.device)
@@ -282,6 +334,7 @@ class SubmanifoldConvolutionFunction(torch.autograd.Function):
                            n_rules=rb.rules.count if rb.rules is not None else rb.n)
         ctx.save_for_backward(X, W)
         ctx.rb, ctx.has_bias, ctx.relu_in = rb, bias is not None, relu_in
+        ctx.bwd_image = packed_image(W, cout, X.shape[1], n_off, _BACK) if _is_bf16(X) else None
         return Y
 
     @staticmethod
@@ -296,7 +349,7 @@ class SubmanifoldConvolutionFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if USE_TILES and rb.rules is not None:
                 dX = conv_rules(dY, rb.tiles, rb.n, W, None, cin, L.F_W_TRANSPOSED | L.F_OFF_REVERSE,
-                                relu_mask=X if ctx.relu_in else None, n_rules=rb.rules.count)
+                                relu_mask=X if ctx.relu_in else None, n_rules=rb.rules.count, image=ctx.bwd_image)
             else:
                 dX = gemm_table(dY, rb.table, n_off, rb.n, W, None, cin, L.F_W_TRANSPOSED | L.F_OFF_REVERSE,
                                 relu_mask=X if ctx.relu_in else None,
@@ -385,10 +438,12 @@ class ResidualBlockFunctionBF16(torch.autograd.Function):
         rb = metadata.subm_rulebook(spatial_size, 3)
         B1 = _f32(b1) if b1 is not None else None
         B2 = _f32(b2) if b2 is not None else None
-        Y1 = conv_rules_bf16(X, rb.tiles, rb.n, W1, B1, W1.shape[-1], L.F_RELU_IN)
-        Y = conv_rules_bf16(Y1, rb.tiles, rb.n, W2, B2, W2.shape[-1], L.F_RELU_IN, residual=X)
+        Y1 = conv_rules_bf16(X, rb.tiles, rb.n, W1, B1, W1.shape[-1], L.F_RELU_IN, n_rules=rb.rules.count)
+        Y = conv_rules_bf16(Y1, rb.tiles, rb.n, W2, B2, W2.shape[-1], L.F_RELU_IN, residual=X, n_rules=rb.rules.count)
         ctx.save_for_backward(X, Y1, W1, W2)
         ctx.rb, ctx.has_b1, ctx.has_b2 = rb, b1 is not None, b2 is not None
+        ctx.bwd_images = (packed_image(W1, W1.shape[-1], W1.shape[1], 27, _BACK),
+                          packed_image(W2, W2.shape[-1], W2.shape[1], 27, _BACK))
         return Y
 
     @staticmethod
@@ -398,7 +453,8 @@ class ResidualBlockFunctionBF16(torch.autograd.Function):
         dY = dY.to(torch.bfloat16).contiguous()
         need = ctx.needs_input_grad
         back = L.F_W_TRANSPOSED | L.F_OFF_REVERSE
-        dY1 = conv_rules_bf16(dY, rb.tiles, rb.n, W2, None, W2.shape[1], back, relu_mask=Y1)
+        dY1 = conv_rules_bf16(dY, rb.tiles, rb.n, W2, None, W2.shape[1], back, relu_mask=Y1, image=ctx.bwd_images[1],
+                              n_rules=r.count)
 
         def wgrad(Xin, G, W, want_w, want_b):
             dW = wgrad_rules_bf16(Xin, G, r.in_rows, r.out_rows, r.prefix_host, 27, L.F_RELU_IN).view_as(W) \
@@ -408,7 +464,7 @@ class ResidualBlockFunctionBF16(torch.autograd.Function):
         dX = None
         if need[0]:
             dX = conv_rules_bf16(dY1, rb.tiles, rb.n, W1, None, W1.shape[1], back | L.F_RESIDUAL_LAST, relu_mask=X,
-                                 residual=dY)
+                                 residual=dY, image=ctx.bwd_images[0], n_rules=r.count)
         dW1, db1 = wgrad(X, dY1, W1, need[1], ctx.has_b1 and need[2])
         return dX, dW1, db1, dW2, db2, None, None
 
@@ -471,6 +527,7 @@ class DeconvolutionFunction(torch.autograd.Function):
                        L.F_RELU_IN if relu_in else 0)
         ctx.save_for_backward(X, W)
         ctx.rb, ctx.has_bias, ctx.relu_in = rb, bias is not None, relu_in
+        ctx.bwd_image = packed_image(W, W.shape[-1], X.shape[1], 8, L.F_W_TRANSPOSED) if _is_bf16(X) else None
         return Y
 
     @staticmethod
@@ -483,7 +540,7 @@ class DeconvolutionFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:      # dX[c] = sum_o dY[child[o][c]] . W[o]^T
             if USE_TILES:
                 dX = conv_rules(dY, rb.tiles, rb.n_coarse, W, None, X.shape[1], L.F_W_TRANSPOSED,
-                                relu_mask=X if ctx.relu_in else None, n_rules=rb.n_fine)
+                                relu_mask=X if ctx.relu_in else None, n_rules=rb.n_fine, image=ctx.bwd_image)
             else:
                 dX = gemm_table(dY, rb.child, 8, rb.n_coarse, W, None, X.shape[1], L.F_W_TRANSPOSED,
                                 relu_mask=X if ctx.relu_in else None, n_rules=rb.n_fine)

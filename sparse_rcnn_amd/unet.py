@@ -74,9 +74,33 @@ class SparseUNet(nn.Module):
                 units=units(c, num_units, batchnorm))))
         self.decoder = nn.ModuleList(dec)
 
+    def _pack_jobs(self):
+        """(W, cin, cout, n_off, flags) of every bf16 weight image this network's forward + backward will stage: forward and
+        backward-data images of the SubM 3^3 layers, forward of the strided convolutions, backward-data of the
+        deconvolutions (the other directions of the strided layers run on the rule-list GEMMs)."""
+        from . import functional as F
+        from . import _lib as L
+        jobs = []
+        for m in self.modules():
+            if isinstance(m, M.SubmanifoldConvolution) and m.filter_size == 3 and m.nIn % 8 == 0 and m.nOut % 8 == 0:
+                jobs.append((m.weight, m.nIn, m.nOut, 27, 0))
+                jobs.append((m.weight, m.nOut, m.nIn, 27, L.F_W_TRANSPOSED | L.F_OFF_REVERSE))
+            elif isinstance(m, M.Convolution) and m.nIn % 8 == 0:
+                jobs.append((m.weight, m.nIn, m.nOut, 8, 0))
+            elif isinstance(m, M.Deconvolution) and m.nOut % 8 == 0:
+                jobs.append((m.weight, m.nOut, m.nIn, 8, L.F_W_TRANSPOSED))
+        return jobs
+
     def forward(self, x, prebuild=True):
         """prebuild=False: no up-front index build -- every rulebook is requested by the first layer that needs it, the
         way the reference's module tree drives the scn surface (DropinBackbone)."""
+        if self.bf16_all or self.bf16_blocks:
+            from . import functional as F
+            with F.packed_weights(self._pack_jobs()):        # one pack launch for the whole network, gone after the forward
+                return self._forward(x, prebuild)
+        return self._forward(x, prebuild)
+
+    def _forward(self, x, prebuild):
         if prebuild:
             x.metadata.build_pyramid(x.spatial_size, len(self.channels), 3)
         interims = []

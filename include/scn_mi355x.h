@@ -281,6 +281,10 @@ int scn_gemm_rules_bf16(const uint16_t* X, int cin, const int32_t* in_rows, cons
 int scn_wgrad_rules_bf16(const uint16_t* X, int cin, const uint16_t* dY, int cout, const int32_t* in_rows,
                          const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, void* scratch,
                          int flags, scn_stream_t stream);
+/* scn_wgrad_bias_rules for bf16-stored operands (dW, db fp32). */
+int scn_wgrad_bias_rules_bf16(const uint16_t* X, int cin, const uint16_t* dY, int cout, const int32_t* in_rows,
+                              const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, float* db,
+                              uint32_t db_offsets, void* scratch, int flags, scn_stream_t stream);
 int scn_wgrad_bias_rules(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
                          const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, float* db,
                          uint32_t db_offsets, void* scratch, int flags, scn_stream_t stream);
@@ -288,6 +292,7 @@ int scn_wgrad_bias_rules(const float* X, int cin, const float* dY, int cout, con
 /* db[c] = sum_r dY[r][c]   (bias gradient of every conv-type layer).  scratch: SCN_COLSUM_BLOCKS*c floats. */
 #define SCN_COLSUM_BLOCKS 512
 int scn_colsum(const float* dY, int64_t n, int c, float* db, void* scratch, scn_stream_t stream);
+int scn_colsum_bf16(const uint16_t* dY, int64_t n, int c, float* db, void* scratch, scn_stream_t stream);   /* bf16-stored dY */
 
 /* ------------------------------------------------------------------------------------------
  * Elementwise / normalisation / IO

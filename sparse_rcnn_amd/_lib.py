@@ -59,7 +59,9 @@ _SIGS = {
     "scn_gemm_rules_bf16": (C.c_int, [p, i32, p, p, C.POINTER(i64), i32, p, p, p, p, i32, i32, p]),
     "scn_wgrad_rules_bf16": (C.c_int, [p, i32, p, i32, p, p, C.POINTER(i64), i32, p, p, i32, p]),
     "scn_wgrad_bias_rules": (C.c_int, [p, i32, p, i32, p, p, C.POINTER(i64), i32, p, p, C.c_uint32, p, i32, p]),
+    "scn_wgrad_bias_rules_bf16": (C.c_int, [p, i32, p, i32, p, p, C.POINTER(i64), i32, p, p, C.c_uint32, p, i32, p]),
     "scn_colsum": (C.c_int, [p, i64, i32, p, p, p]),
+    "scn_colsum_bf16": (C.c_int, [p, i64, i32, p, p, p]),
     "scn_relu_fwd": (C.c_int, [p, i64, p, p]),
     "scn_relu_bwd": (C.c_int, [p, p, i64, p, p]),
     "scn_add": (C.c_int, [p, p, i64, p, p]),

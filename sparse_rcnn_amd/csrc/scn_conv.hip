@@ -297,8 +297,10 @@ extern "C" int scn_gemm_rules_bf16(const uint16_t* X, int cin, const int32_t* in
 // ------------------------------------------------------------------------------------------------
 // colsum (bias gradient): two-stage, fixed order
 // ------------------------------------------------------------------------------------------------
+template <bool HB>
 __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ dY, long long n, int c,
                                                         float* __restrict__ partial) {
+    const unsigned short* dYh = (const unsigned short*)dY;             // HB: bf16-stored rows, widened exactly
     // thread t owns column (t % cpad) of rows (t / cpad) + k*rows_per_pass inside this block's row range
     const long long rows_per_block = (n + gridDim.x - 1) / gridDim.x;
     const long long r_lo = blockIdx.x * rows_per_block;
@@ -313,7 +315,8 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
         const int rsub = threadIdx.x / lanes_per_row;
         float s = 0.f;
         if (rsub < rows_par)
-            for (long long r = r_lo + rsub; r < r_hi; r += rows_par) s += dY[r * c + c0 + col];
+            for (long long r = r_lo + rsub; r < r_hi; r += rows_par)
+                s += HB ? bf16_bits_to_f32(dYh[r * c + c0 + col]) : dY[r * c + c0 + col];
         red[threadIdx.x] = (rsub < rows_par) ? s : 0.f;
         __syncthreads();
         if (threadIdx.x < width) {
@@ -339,14 +342,25 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ 
     if (threadIdx.x == 0) db[col] = (w[0] + w[1]) + (w[2] + w[3]);
 }
 
-extern "C" int scn_colsum(const float* dY, int64_t n, int c, float* db, void* scratch, scn_stream_t stream) {
+static int colsum_impl(const float* dY, int64_t n, int c, float* db, void* scratch, scn_stream_t stream, bool hb) {
     SCN_REQUIRE(n >= 0 && c >= 1 && db && scratch);
     int nblk = (int)(n < SCN_COLSUM_BLOCKS * 8 ? cdiv(n, 8) : SCN_COLSUM_BLOCKS);
     if (nblk < 1) nblk = 1;
     if (n > 0) SCN_REQUIRE(dY);
-    hipLaunchKernelGGL(k_colsum_partial, dim3(nblk), dim3(256), 0, S(stream), dY, (long long)n, c, (float*)scratch);
+    if (hb)
+        hipLaunchKernelGGL(k_colsum_partial<true>, dim3(nblk), dim3(256), 0, S(stream), dY, (long long)n, c, (float*)scratch);
+    else
+        hipLaunchKernelGGL(k_colsum_partial<false>, dim3(nblk), dim3(256), 0, S(stream), dY, (long long)n, c, (float*)scratch);
     SCN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_colsum_final, dim3(c), dim3(256), 0, S(stream), (const float*)scratch, nblk, c, db);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
+}
+
+extern "C" int scn_colsum(const float* dY, int64_t n, int c, float* db, void* scratch, scn_stream_t stream) {
+    return colsum_impl(dY, n, c, db, scratch, stream, false);
+}
+
+extern "C" int scn_colsum_bf16(const uint16_t* dY, int64_t n, int c, float* db, void* scratch, scn_stream_t stream) {
+    return colsum_impl((const float*)dY, n, c, db, scratch, stream, true);
 }

@@ -351,6 +351,186 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// bf16 STORAGE on bf16 MFMA (BASELINE configs 3-5): v_mfma_f32_16x16x32_bf16 contracts 32 RULES per instruction, so both
+// operands are needed rule-minor (A[channel][rule], B[rule][channel] with the rule index inside a lane's 8 elements) while
+// the rows arrive channel-minor.  The transposition is done by the LDS: the 32 gathered rows of a step are written
+// row-major into a swizzled image (256-byte pitch, 16-byte chunk c of row r at 16 (c ^ ((r & 3) << 2 | (r >> 2) & 3)), the
+// dual-use image of cdna_hip_programming.md T10) and read back with ds_read_b64_tr_b16, which hands lane i of a 16-lane
+// group column i of four rows -- exactly an operand fragment.  fp32 accumulation; dW and db come back fp32.
+// Workgroup = 4 waves = 2 x 2 wave blocks of (16 TA) x (16 TB) channels; two LDS buffers, one barrier per step; the rows of
+// step s + 1 and the row indices of step s + 2 are in flight while step s is multiplied.  Same units, slabs and fixed-order
+// sum (k_wgradd_sum) as the fp32 kernel.  Bias gradient: one extra MFMA per column tile with a ones-row A operand.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMAB32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ int wtb_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+template <int TA, int TB, bool IDENT>
+__global__ __launch_bounds__(256) void k_wgrad_tb(const unsigned short* __restrict__ X, int cin,
+                                                  const unsigned short* __restrict__ dY, int cout,
+                                                  const int* __restrict__ in_rows, const int* __restrict__ out_rows,
+                                                  DPlan plan, float* __restrict__ slabs, int relu_in,
+                                                  float* __restrict__ db_slabs, unsigned db_mask, int cout_pad) {
+    constexpr int CBI = 32 * TA, CBJ = 32 * TB;                  // workgroup block
+    constexpr int PA = CBI / 8, PB = CBJ / 8;                    // 16-byte pieces per gathered row
+    constexpr int NPIECE = 32 * (PA + PB);                       // pieces per step (32 rules, both operands)
+    constexpr int NLD = (NPIECE + 255) / 256;                    // pieces per thread
+    constexpr int IMG = 32 * 256;                                // bytes of one image (32 rows, 256-byte pitch)
+    extern __shared__ __attribute__((aligned(16))) char wlds[];  // [buffer 0/1][image A/B][32 rows][256 B]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int unit = blockIdx.x;
+    const bool past = lane < plan.n_off && unit >= plan.unit_start[lane + 1];
+    const int o = __builtin_amdgcn_readfirstlane(__popcll(__ballot(past)));
+    const int s_unit = unit - plan.unit_start[o];
+    const int bi = blockIdx.z / plan.nbj, bj = blockIdx.z % plan.nbj;
+    const int ci0 = bi * CBI, co0 = bj * CBJ;
+    const long long p_lo = plan.rule_start[o], p_hi = plan.rule_start[o + 1];
+    const long long p0 = p_lo + (long long)s_unit * plan.per;
+    const long long p1 = p0 + plan.per < p_hi ? p0 + plan.per : p_hi;
+    const int nrel = (int)(p1 > p0 ? p1 - p0 : 0);
+    const int nsteps = (nrel + 31) / 32;
+    const bool do_db = db_slabs != nullptr && ((db_mask >> o) & 1u) && bi == 0 && wi == 0;
+
+    // ---- loader mapping: piece e of a step -> (image, row, chunk) --------------------------------------------------------
+    int l_row[NLD], l_ch[NLD], l_lds[NLD];
+    bool l_b[NLD], l_ok[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int e = tid + 256 * u;
+        const bool isb = e >= 32 * PA;
+        const int e2 = isb ? e - 32 * PA : e;
+        const int P = isb ? PB : PA;
+        l_b[u] = isb;
+        l_row[u] = e2 / P;
+        l_ch[u] = e2 % P;
+        const int chan = (isb ? co0 : ci0) + 8 * l_ch[u];
+        l_ok[u] = e < NPIECE && chan < (isb ? cout : cin);       // channel counts are multiples of 8: a piece is in or out
+        l_lds[u] = (isb ? IMG : 0) + wtb_off(l_row[u] < 32 ? l_row[u] : 0, l_ch[u]);
+    }
+    auto load_idx = [&](int step, int (&idx)[NLD]) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const long long r = (long long)step * 32 + l_row[u];
+            int v = -1;
+            if (l_ok[u] && r < nrel) v = IDENT ? (int)(p0 + r) : (l_b[u] ? out_rows[p0 + r] : in_rows[p0 + r]);
+            idx[u] = v;
+        }
+    };
+    auto load_rows = [&](const int (&idx)[NLD], uint4 (&st)[NLD]) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            st[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (idx[u] >= 0) {
+                const unsigned short* src = l_b[u] ? dY + (long long)idx[u] * cout + co0 + 8 * l_ch[u]
+                                                   : X + (long long)idx[u] * cin + ci0 + 8 * l_ch[u];
+                st[u] = *(const uint4*)src;
+            }
+        }
+    };
+    auto store_rows = [&](int buf, const uint4 (&st)[NLD]) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            if (tid + 256 * u >= NPIECE) continue;
+            uint4 v = st[u];
+            if (relu_in && !l_b[u]) {                               // ReLU on the X operand: a negative bf16 is a negative int16
+                s16x8 a = __builtin_bit_cast(s16x8, v);
+                a = __builtin_elementwise_max(a, (s16x8){0, 0, 0, 0, 0, 0, 0, 0});
+                v = __builtin_bit_cast(uint4, a);
+            }
+            *(uint4*)(wlds + buf * 2 * IMG + l_lds[u]) = v;
+        }
+    };
+
+    f32x4 acc[TA][TB];
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 dbacc[TB];
+#pragma unroll
+    for (int b = 0; b < TB; ++b) dbacc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    s16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (lane & 15) == 0 ? (short)0x3F80 : (short)0;
+
+    // transposed-read addresses of this lane (T10): lane 4q + p of 16-lane group g supplies row 8g + 4t + q, chunk c0 + (p>>1)
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    int tr_a[2][TA], tr_b[2][TB];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int row = 8 * g + 4 * t + q;
+#pragma unroll
+        for (int a = 0; a < TA; ++a) tr_a[t][a] = wtb_off(row, 2 * (wi * TA + a) + (pp >> 1)) + 8 * (pp & 1);
+#pragma unroll
+        for (int b = 0; b < TB; ++b) tr_b[t][b] = IMG + wtb_off(row, 2 * (wj * TB + b) + (pp >> 1)) + 8 * (pp & 1);
+    }
+
+    int idx0[NLD], idx1[NLD];
+    uint4 st[NLD];
+    if (nsteps > 0) {
+        load_idx(0, idx0);
+        load_idx(1, idx1);
+        load_rows(idx0, st);
+    }
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        store_rows(buf, st);                                   // rows of step s (requested one step ago)
+        if (s + 1 < nsteps) {
+            if (s & 1) { load_rows(idx0, st); load_idx(s + 2, idx1); }      // idx0/idx1 alternate: rows s+1, indices s+2
+            else { load_rows(idx1, st); load_idx(s + 2, idx0); }
+        }
+        __syncthreads();
+        const char* base = wlds + buf * 2 * IMG;
+        bf16x8 fa[TA], fb[TB];
+#pragma unroll
+        for (int a = 0; a < TA; ++a) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + tr_a[0][a]));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + tr_a[1][a]));
+            fa[a] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + tr_b[0][b]));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + tr_b[1][b]));
+            fb[b] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int a = 0; a < TA; ++a)
+#pragma unroll
+            for (int b = 0; b < TB; ++b) acc[a][b] = MFMAB32(fa[a], fb[b], acc[a][b]);
+        if (do_db) {
+#pragma unroll
+            for (int b = 0; b < TB; ++b) dbacc[b] = MFMAB32(__builtin_bit_cast(bf16x8, ones), fb[b], dbacc[b]);
+        }
+    }
+
+    // ---- partial block of this unit -> slab (row-major CBI x CBJ); D: row 4 kq + reg, column lane & 15 ---------------------
+    float* slab = slabs + ((long long)unit * (plan.nbi * plan.nbj) + blockIdx.z) * (CBI * CBJ);
+    const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                slab[(16 * (wi * TA + a) + 4 * kq + j) * CBJ + 16 * (wj * TB + b) + i] = acc[a][b][j];
+    if (do_db && kq == 0) {
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+            const int c = co0 + 16 * (wj * TB + b) + i;
+            if (c < cout_pad) db_slabs[(long long)unit * cout_pad + c] = dbacc[b][0];
+        }
+    }
+}
+
 // dW[o][ci][co] = sum over the units of offset o.  A thread owns V consecutive output channels (one 16-byte slab read
 // per unit at V = 4) and every G-th unit; the G partial sums of an element meet in LDS and are added in ascending g --
 // a fixed association for a given plan (bitwise reproducible).  G is chosen on the host so that small dW (many units,
@@ -427,11 +607,19 @@ Shape pick_shape(int cin, int cout) {
     return s;
 }
 
-int make_dplan(int cin, int cout, const int64_t* prefix_host, int n_off, DPlan& pl) {
+// bf16 MFMA kernel: tiles of 16 channels per wave along Cin / Cout (workgroup block 32 T x 32 T)
+int tb_tiles(int c) { return c <= 32 ? 1 : (c <= 64 ? 2 : 4); }
+bool tb_usable(int cin, int cout) {
+    static const bool off = getenv("SCN_WGRAD_BF16_MFMA") && atoi(getenv("SCN_WGRAD_BF16_MFMA")) == 0;
+    return !off && cin % 8 == 0 && cout % 8 == 0;
+}
+
+int make_dplan(int cin, int cout, const int64_t* prefix_host, int n_off, DPlan& pl, bool hb_mfma = false) {
     const Shape sh = pick_shape(cin, cout);
     pl.n_off = n_off;
     pl.cbi = 16 * sh.ta * (sh.quad ? 2 : 1);
     pl.cbj = 16 * sh.tb * (sh.quad ? 2 : 1);
+    if (hb_mfma) { pl.cbi = 32 * tb_tiles(cin); pl.cbj = 32 * tb_tiles(cout); }
     pl.nbi = (int)cdiv(cin, pl.cbi);
     pl.nbj = (int)cdiv(cout, pl.cbj);
     pl.rule_start[0] = prefix_host[0];
@@ -444,14 +632,15 @@ int make_dplan(int cin, int cout, const int64_t* prefix_host, int n_off, DPlan& 
     // Unit count: the grid should fill the resident workgroup slots of the chip a whole number of times (R rounds) --
     // 1.05 rounds costs as much as 2.  Slots = 256 CUs x workgroups per CU (registers / LDS of the instantiation).
     // Every offset rounds its unit count up, hence the n_off margin.  R and the slot counts: tools/sweep_wgrad_splits.py.
-    const int occ = sh.quad ? 2 : (sh.ta == 4 && sh.tb == 4 ? 2 : (sh.ta == 2 && sh.tb == 2 ? 4 : 3));
-    const int rounds = (sh.quad ? nblk > 1 : (sh.ta == 4 && sh.tb == 4)) ? 2 : 1;
+    int occ = sh.quad ? 2 : (sh.ta == 4 && sh.tb == 4 ? 2 : (sh.ta == 2 && sh.tb == 2 ? 4 : 3));
+    int rounds = (sh.quad ? nblk > 1 : (sh.ta == 4 && sh.tb == 4)) ? 2 : 1;
+    if (hb_mfma) { occ = 4; rounds = 1; }                                   // 32 KB of LDS, <= 128 registers: 4 per CU
     int64_t target = (256 * occ * rounds) / nblk - n_off;
     if (const char* e = getenv("SCN_WGRAD_SPLITS")) target = atoi(e);       // developer override
     if (target < 1) target = 1;
-    const int64_t gran = sh.quad ? 16 : 64;
+    const int64_t gran = hb_mfma ? 32 : (sh.quad ? 16 : 64);
     int64_t per = cdiv(cdiv(total, target), gran) * gran;
-    const int64_t min_per = sh.quad ? 128 : 512;                           // >= 8 blocks of 16 rules per wave
+    const int64_t min_per = hb_mfma ? 256 : (sh.quad ? 128 : 512);         // >= 8 steps per workgroup
     if (per < min_per) per = min_per;
     pl.per = per;
     pl.unit_start[0] = 0;
@@ -463,10 +652,17 @@ int make_dplan(int cin, int cout, const int64_t* prefix_host, int n_off, DPlan& 
 
 extern "C" int64_t scn_wgrad_scratch_bytes(int cin, int cout, const int64_t* prefix_host, int n_off) {
     if (!prefix_host || n_off < 1 || n_off > 32 || cin < 1 || cout < 1) return -1;
-    DPlan pl;
-    if (make_dplan(cin, cout, prefix_host, n_off, pl) != SCN_OK) return -1;
-    return (int64_t)pl.unit_start[n_off] * ((int64_t)pl.nbi * pl.nbj * pl.cbi * pl.cbj + (int64_t)pl.nbj * pl.cbj) *
-               (int64_t)sizeof(float) + 512;
+    // the larger of the two plans a call may use (fp32-MFMA kernel; bf16-MFMA kernel for bf16-stored operands)
+    int64_t best = -1;
+    for (int hb = 0; hb < 2; ++hb) {
+        if (hb && !tb_usable(cin, cout)) continue;
+        DPlan pl;
+        if (make_dplan(cin, cout, prefix_host, n_off, pl, hb != 0) != SCN_OK) return -1;
+        const int64_t b = (int64_t)pl.unit_start[n_off] *
+                              ((int64_t)pl.nbi * pl.nbj * pl.cbi * pl.cbj + (int64_t)pl.nbj * pl.cbj) * (int64_t)sizeof(float) + 512;
+        if (b > best) best = b;
+    }
+    return best;
 }
 
 static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
@@ -475,8 +671,9 @@ static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const 
     SCN_REQUIRE(prefix_host && n_off >= 1 && n_off <= 32 && cin >= 1 && cout >= 1 && dW && scratch);
     SCN_REQUIRE((in_rows == nullptr) == (out_rows == nullptr));
     SCN_REQUIRE(in_rows || n_off == 1);
+    const bool mfma16 = hb && tb_usable(cin, cout) && ((((uintptr_t)X | (uintptr_t)dY) & 15) == 0);
     DPlan pl;
-    SCN_REQUIRE(make_dplan(cin, cout, prefix_host, n_off, pl) == SCN_OK);
+    SCN_REQUIRE(make_dplan(cin, cout, prefix_host, n_off, pl, mfma16) == SCN_OK);
     SCN_REQUIRE(prefix_host[n_off] == prefix_host[0] || (X && dY));
     SCN_REQUIRE((((uintptr_t)X | (uintptr_t)dY) & (hb ? 1 : 3)) == 0);
     if (pl.unit_start[n_off] == 0) {
@@ -493,6 +690,25 @@ static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const 
     float* db_slabs = db ? (float*)scratch + (int64_t)pl.unit_start[n_off] * pl.nbi * pl.nbj * pl.cbi * pl.cbj : nullptr;
     dim3 grid((unsigned)pl.unit_start[n_off], 1, (unsigned)(pl.nbi * pl.nbj));
     const int relu_in = (flags & SCN_F_RELU_IN) ? 1 : 0;
+    if (mfma16) {
+        const int ta = tb_tiles(cin), tb = tb_tiles(cout);
+#define LAUNCH_WT(TA_, TB_, I_)                                                                                  \
+    hipLaunchKernelGGL((k_wgrad_tb<TA_, TB_, I_>), grid, dim3(256), 4 * 32 * 256, S(stream), (const unsigned short*)X, cin, \
+                       (const unsigned short*)dY, cout, in_rows, out_rows, pl, (float*)scratch, relu_in, db_slabs, db_mask, \
+                       cout_pad)
+#define PICK_WT(TA_, TB_) do { if (ident) LAUNCH_WT(TA_, TB_, true); else LAUNCH_WT(TA_, TB_, false); } while (0)
+        if (ta == 1 && tb == 1) PICK_WT(1, 1);
+        else if (ta == 1 && tb == 2) PICK_WT(1, 2);
+        else if (ta == 1 && tb == 4) PICK_WT(1, 4);
+        else if (ta == 2 && tb == 1) PICK_WT(2, 1);
+        else if (ta == 2 && tb == 2) PICK_WT(2, 2);
+        else if (ta == 2 && tb == 4) PICK_WT(2, 4);
+        else if (ta == 4 && tb == 1) PICK_WT(4, 1);
+        else if (ta == 4 && tb == 2) PICK_WT(4, 2);
+        else PICK_WT(4, 4);
+#undef PICK_WT
+#undef LAUNCH_WT
+    } else {
 #define LAUNCH_WD(TA_, TB_, Q_, E_, I_, H_)                                                                      \
     do {                                                                                                         \
         const size_t lds_ = ((Q_) ? 4 * 64 : 4 * (TA_) * (TB_) * 4 * 64 + 4 * 64) * sizeof(float);               \
@@ -521,6 +737,7 @@ static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const 
 #undef PICK_EI
 #undef PICK_I
 #undef LAUNCH_WD
+    }
     SCN_LAUNCH_CHECK();
     // sum of the units: V output channels per thread, G threads per element group so that ~>= 128k threads run
     const int V = (cout % 4 == 0 && (((uintptr_t)dW | (uintptr_t)scratch) & 15) == 0) ? 4 : 1;
@@ -561,4 +778,12 @@ extern "C" int scn_wgrad_bias_rules(const float* X, int cin, const float* dY, in
     SCN_REQUIRE(db && db_offsets);
     return wgrad_impl(X, cin, dY, cout, in_rows, out_rows, prefix_host, n_off, dW, db, db_offsets, scratch, flags,
                       stream);
+}
+
+extern "C" int scn_wgrad_bias_rules_bf16(const uint16_t* X, int cin, const uint16_t* dY, int cout, const int32_t* in_rows,
+                                         const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW,
+                                         float* db, uint32_t db_offsets, void* scratch, int flags, scn_stream_t stream) {
+    SCN_REQUIRE(db && db_offsets);
+    return wgrad_impl((const float*)X, cin, (const float*)dY, cout, in_rows, out_rows, prefix_host, n_off, dW, db,
+                      db_offsets, scratch, flags, stream, true);
 }

@@ -270,32 +270,36 @@ def wgrad_rules(X, dY, in_rows, out_rows, prefix_host, n_off, flags=0):
 
 
 def wgrad_bias_rules(X, dY, in_rows, out_rows, prefix_host, n_off, db_offsets, flags=0):
-    """dW and db in one pass (scn_wgrad_bias_rules)."""
-    if _is_bf16(X):
-        return wgrad_rules_bf16(X, dY, in_rows, out_rows, prefix_host, n_off, flags), colsum(dY)
+    """dW and db in one pass (scn_wgrad_bias_rules; bf16-stored operands: scn_wgrad_bias_rules_bf16, fp32 results)."""
     cin, cout = X.shape[1], dY.shape[1]
     lib = L.lib()
+    hb = _is_bf16(X)
+    if hb and (dY.dtype != torch.bfloat16 or not (X.is_contiguous() and dY.is_contiguous())):
+        raise L.ScnError("wgrad_bias_rules takes contiguous operands of one storage type")
     nbytes = lib.scn_wgrad_scratch_bytes(cin, cout, prefix_host, n_off)
     scratch = L.scratch(nbytes, X.device)
-    dW, db = _new((n_off, cin, cout), X), _new((cout,), X)
+    dW = torch.empty((n_off, cin, cout), dtype=torch.float32, device=X.device)
+    db = torch.empty((cout,), dtype=torch.float32, device=X.device)
     P = int(prefix_host[n_off] - prefix_host[0])
+    entry = lib.scn_wgrad_bias_rules_bf16 if hb else lib.scn_wgrad_bias_rules
+    es = 2.0 if hb else 4.0
 
     def run():
-        L.check(lib.scn_wgrad_bias_rules(L.ptr(X), cin, L.ptr(dY), cout, L.ptr(in_rows), L.ptr(out_rows), prefix_host,
-                                         n_off, L.ptr(dW), L.ptr(db), db_offsets, L.ptr(scratch), flags, L.stream()))
-    profiling.timed("k_wgrad_rules", 2.0 * P * cin * cout,
-                    4.0 * (X.shape[0] * cin + dY.shape[0] * cout + n_off * cin * cout) + 8.0 * P, run)
+        L.check(entry(L.ptr(X), cin, L.ptr(dY), cout, L.ptr(in_rows), L.ptr(out_rows), prefix_host,
+                      n_off, L.ptr(dW), L.ptr(db), db_offsets, L.ptr(scratch), flags, L.stream()))
+    profiling.timed("k_wgrad_rules_bf16" if hb else "k_wgrad_rules", 2.0 * P * cin * cout,
+                    es * (X.shape[0] * cin + dY.shape[0] * cout) + 4.0 * n_off * cin * cout + 8.0 * P, run)
     return dW, db
 
 
 def colsum(dY):
-    if _is_bf16(dY):
-        return torch.sum(dY, dim=0, dtype=torch.float32)
+    """Bias gradient db[c] = sum_r dY[r][c] (fp32 result; dY fp32 or bf16-stored), two-stage, fixed order."""
     lib = L.lib()
     c = dY.shape[1]
-    scratch = _new((L.COLSUM_BLOCKS * c,), dY)
-    db = _new((c,), dY)
-    L.check(lib.scn_colsum(L.ptr(dY), dY.shape[0], c, L.ptr(db), L.ptr(scratch), L.stream()))
+    scratch = torch.empty(L.COLSUM_BLOCKS * c, dtype=torch.float32, device=dY.device)
+    db = torch.empty(c, dtype=torch.float32, device=dY.device)
+    entry = lib.scn_colsum_bf16 if _is_bf16(dY) else lib.scn_colsum
+    L.check(entry(L.ptr(dY), dY.shape[0], c, L.ptr(db), L.ptr(scratch), L.stream()))
     return db
 
 
@@ -457,9 +461,12 @@ class ResidualBlockFunctionBF16(torch.autograd.Function):
                               n_rules=r.count)
 
         def wgrad(Xin, G, W, want_w, want_b):
+            if want_w and want_b:        # the centre offset lists every row once: bias gradient from the same pass
+                dW, db = wgrad_bias_rules(Xin, G, r.in_rows, r.out_rows, r.prefix_host, 27, 1 << 13, L.F_RELU_IN)
+                return dW.view_as(W), db
             dW = wgrad_rules_bf16(Xin, G, r.in_rows, r.out_rows, r.prefix_host, 27, L.F_RELU_IN).view_as(W) \
                 if want_w else None
-            return dW, (torch.sum(G, dim=0, dtype=torch.float32) if want_b else None)
+            return dW, (colsum(G) if want_b else None)
         dW2, db2 = wgrad(Y1, dY, W2, need[3], ctx.has_b2 and need[4])
         dX = None
         if need[0]:

@@ -768,12 +768,15 @@ def test_conv_tiles_in_launch_k_reduction_gives_the_bits_of_the_two_launch_form(
         assert set(timer.summary()) == names
 
 
-@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (8, 16), (48, 80), (128, 64), (256, 256), (23, 7), (130, 33)])
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (8, 16), (48, 80), (128, 64), (256, 256), (23, 7), (130, 33),
+                                      (24, 24), (32, 64), (64, 32), (512, 256), (16, 136)])
 @pytest.mark.parametrize("relu_in", [False, True])
 def test_wgrad_bf16_storage(gpu, cin, cout, relu_in):
-    """scn_wgrad_rules_bf16: operands stored in bf16, widened exactly, fp32 products and sums -- against the oracle's
-    weight gradient of the same (bf16-representable) operands at the fp32 tolerance, and bit-identical to the fp32
-    kernel fed the widened operands (same arithmetic, same order)."""
+    """scn_wgrad_rules_bf16: operands stored in bf16, products exact (a bf16 x bf16 product fits fp32), fp32 sums --
+    against the oracle's weight gradient of the same (bf16-representable) operands at the fp32 tolerance.  Channel
+    counts that are multiples of 8 run on the bf16 MFMA kernel (LDS-transposed operands, its own summation order: equal
+    to the fp32 kernel fed the widened operands within fp32 rounding); the others widen in registers and run the fp32
+    kernel's arithmetic in its order (bit-identical)."""
     from sparse_rcnn_amd import functional as F, _lib as L
     scn, coords, feats, fg, x, scene, size = _input(gpu, seed=19, cin=8, n=1300, dup=100)
     rb = x.metadata.subm_rulebook(tuple(int(s) for s in size), 3)
@@ -788,7 +791,16 @@ def test_wgrad_bf16_storage(gpu, cin, cout, relu_in):
     _, dWo, _ = O.conv_bwd(xin, G.float(), scene.subm_rules(0, 3), torch.zeros(27, cin, cout), has_bias=False)
     _close(dW, dWo, 1e-4, "bf16-storage dW")
     ref = F.wgrad_rules(X.float().to(gpu), G.float().to(gpu), r.in_rows, r.out_rows, r.prefix_host, 27, flags)
-    assert torch.equal(dW, ref)
+    if cin % 8 or cout % 8:
+        assert torch.equal(dW, ref)
+    else:
+        _close(dW, ref, 1e-5, "bf16-MFMA dW vs fp32-MFMA dW of the widened operands")
+        assert torch.equal(dW, F.wgrad_rules_bf16(X.to(gpu), G.to(gpu), r.in_rows, r.out_rows, r.prefix_host, 27, flags))
+    # bias gradient from the same pass (centre offset): column sums of dY
+    dW2, db = F.wgrad_bias_rules(X.to(gpu), G.to(gpu), r.in_rows, r.out_rows, r.prefix_host, 27, 1 << 13, flags)
+    assert torch.equal(dW2, dW)
+    _close(db, G.float().sum(0), 1e-5, "db from the bf16 weight-gradient pass")
+    _close(F.colsum(G.to(gpu)), G.float().sum(0), 1e-5, "bf16 colsum")
 
 
 def _bf16r(t):

@@ -30,6 +30,7 @@ class MaskBranch(nn.Module):
     def __init__(self, backbone_channels=32, raw_channels=7, input_channels=16, unet_channels=(32, 48, 64),
                  linear_channels=(32, 18), bf16_blocks=False):
         super().__init__()
+        self.bf16 = bool(bf16_blocks)           # bf16 STORAGE of the branch's feature slabs (BASELINE configs 3-5)
         c = input_channels + raw_channels
         self.input_conv_layer = M.Sequential(M.SubmanifoldConvolution(3, backbone_channels, input_channels, 1, True),
                                              units(input_channels, 2))
@@ -61,12 +62,35 @@ class MaskBranch(nn.Module):
         if pc is not None and pc.shape[0] == coords.shape[0]:
             coords = pc
             raw_scene = (pc,) + tuple(raw_scene[1:])
-        converted = self.input_conv_layer(backbone_features)
+        if self.bf16:       # the scene-level units on bf16-stored features; the per-point gather (OutputLayer) takes fp32
+            converted = M.CastFeatures(torch.float32)(self.input_conv_layer(M.CastFeatures(torch.bfloat16)(backbone_features)))
+        else:
+            converted = self.input_conv_layer(backbone_features)
         size = torch.as_tensor([int(s) for s in spatial_size], dtype=torch.long) + self.spatial_size_extention
-        combined = torch.cat((self.output_layer(converted), features), dim=-1)
+        per_point = self.output_layer(converted)
+        parts = (per_point, features)
+        unet = self.output_conv_layer
+        if unet.phys0 != unet.channels[0]:      # 23 -> 24 columns: zero column appended where the slab is assembled anyway
+            parts += (features.new_zeros((features.shape[0], unet.phys0 - unet.channels[0])),)
+        combined = torch.cat(parts, dim=-1)
         roi_tensor, selection = self.output_roi_cut((coords, combined, size, *other, batch_splits), selected_bbox)
         skip_features = self.scene_roi_extra_cut(raw_scene, selection)
         if len(skip_features) == 0 or roi_tensor is None:
             return skip_features.new_zeros((0, self.classes)), selection
-        out = self.roi_output_layer(self.output_conv_layer(roi_tensor))
-        return self.linear_layer(out), selection
+        out = self.roi_output_layer(unet(roi_tensor))            # [cropped points, phys0]; the pad column is zero
+        return self._linear(out), selection
+
+    def _linear(self, x):
+        """The Linear / ReLU stack (module_factory.py:700-716) on the library's row GEMM: nn.Linear parameters (state_dict
+        names and shapes kept), y = x W^T + b through NetworkInNetworkFunction with the transposed weight view; a padded
+        input column meets a zero weight row."""
+        from . import functional as F
+        for m in self.linear_layer:
+            if isinstance(m, nn.Linear):
+                W = m.weight.t()
+                if x.shape[1] != W.shape[0]:
+                    W = torch.nn.functional.pad(W, (0, 0, 0, x.shape[1] - W.shape[0]))
+                x = F.NetworkInNetworkFunction.apply(x, W, m.bias)
+            else:
+                x = F.ReLUFunction.apply(x)
+        return x

@@ -55,8 +55,9 @@ class Sequential(torch.nn.Sequential):
                     c1, c2 = inner._modules["1"], inner._modules["3"]          # ReLU, SubM3, ReLU, SubM3
                     fn = (F.ResidualBlockFunctionBF16 if input.features.dtype == torch.bfloat16
                           else F.ResidualBlockFunction)                        # bf16-stored features: CastFeatures
-                    y = fn.apply(input.features, c1.weight, c1.bias, c2.weight, c2.bias,
-                                 input.metadata, input.spatial_size)
+                    w1, b1 = c1._wb(input.features.shape[1])
+                    w2, b2 = c2._wb(w1.shape[-1])
+                    y = fn.apply(input.features, w1, b1, w2, b2, input.metadata, input.spatial_size)
                     input = _out(input, y)
                     i += 2
                     continue
@@ -89,7 +90,8 @@ class Sequential(torch.nn.Sequential):
                 and type(mods[0]) is ReLU and type(mods[2]) is ReLU
                 and type(mods[1]) is SubmanifoldConvolution and type(mods[3]) is SubmanifoldConvolution
                 and mods[1].filter_size == 3 and mods[3].filter_size == 3
-                and mods[1].nIn == mods[3].nOut == input.features.shape[1] and mods[1].nOut == mods[3].nIn)
+                and mods[1].nIn == mods[3].nOut and mods[1].nOut == mods[3].nIn
+                and (mods[3].pad_out_to or mods[3].nOut) == input.features.shape[1])
 
     def _ends_with_subm(self):
         mods = list(self._modules.values())
@@ -181,6 +183,25 @@ class BatchNormLeakyReLU(_BatchNorm):
 
 
 class _ConvBase(Module):
+    # Channel padding (not a reference feature): a feature slab may be PHYSICALLY wider than the layer's nIn / nOut, the
+    # extra columns being zero (sparse_rcnn_amd.unet pads the mask head's 23-channel level to 24 so that its rows are
+    # 16-byte aligned and its layers take the vector kernels).  The parameters keep their logical shape (state_dict
+    # compatibility); `_wb` hands the kernels a zero-padded view through torch's differentiable pad.
+    pad_out_to = None
+
+    def _wb(self, cin_phys):
+        """(weight, bias) as the kernels see them for an input slab of cin_phys columns."""
+        W, b = self.weight, self.bias
+        pin = int(cin_phys) - self.nIn
+        pout = (self.pad_out_to - self.nOut) if self.pad_out_to else 0
+        if pin < 0 or pout < 0:
+            raise ValueError(f"{type(self).__name__}: {cin_phys} input columns for nIn={self.nIn}")
+        if pin or pout:
+            W = torch.nn.functional.pad(W, (0, pout, 0, pin))
+            if b is not None and pout:
+                b = torch.nn.functional.pad(b, (0, pout))
+        return W, b
+
     def _init(self, filter_volume, nIn, nOut, bias):
         self.nIn, self.nOut = int(nIn), int(nOut)
         std = math.sqrt(2.0 / self.nIn / filter_volume)
@@ -214,7 +235,8 @@ class SubmanifoldConvolution(_ConvBase):
         self._init(self.filter_size ** 3, nIn, nOut, bias)
 
     def forward(self, input, relu_in=False, residual=None):
-        y = F.SubmanifoldConvolutionFunction.apply(input.features, self.weight, self.bias, input.metadata,
+        W, b = self._wb(input.features.shape[1])
+        y = F.SubmanifoldConvolutionFunction.apply(input.features, W, b, input.metadata,
                                                    input.spatial_size, self.filter_size, relu_in, residual)
         return _out(input, y)
 
@@ -242,7 +264,8 @@ class Convolution(_ConvBase):
 
     def forward(self, input, relu_in=False):
         in_size = tuple(int(s) for s in input.spatial_size)
-        y = F.ConvolutionFunction.apply(input.features, self.weight, self.bias, input.metadata, in_size, relu_in)
+        W, b = self._wb(input.features.shape[1])
+        y = F.ConvolutionFunction.apply(input.features, W, b, input.metadata, in_size, relu_in)
         out_size = torch.as_tensor([s // 2 for s in in_size], dtype=torch.long)
         return _out(input, y, out_size)
 
@@ -265,7 +288,8 @@ class Deconvolution(_ConvBase):
 
     def forward(self, input, relu_in=False):
         out_size = tuple(int(s) * 2 for s in input.spatial_size)
-        y = F.DeconvolutionFunction.apply(input.features, self.weight, self.bias, input.metadata, out_size, relu_in)
+        W, b = self._wb(input.features.shape[1])
+        y = F.DeconvolutionFunction.apply(input.features, W, b, input.metadata, out_size, relu_in)
         return _out(input, y, torch.as_tensor(out_size, dtype=torch.long))
 
     def extra_repr(self):
@@ -284,8 +308,33 @@ class NetworkInNetwork(Module):
         else:
             self.register_parameter("bias", None)
 
+    # channel padding (see _ConvBase): in_groups = logical widths of the joined inputs, each physically padded to the same
+    # width (JoinTable of two padded slabs); pad_out_to = physical output width
+    pad_out_to = None
+    in_groups = None
+
+    def _wb(self, cin_phys):
+        W, b = self.weight, self.bias
+        pad = torch.nn.functional.pad
+        if cin_phys != self.nIn:
+            groups = self.in_groups or (self.nIn,)
+            if cin_phys % len(groups) or sum(groups) != self.nIn:
+                raise ValueError(f"NetworkInNetwork: {cin_phys} input columns for nIn={self.nIn}")
+            gp = cin_phys // len(groups)
+            parts, r0 = [], 0
+            for gsz in groups:
+                parts.append(pad(W[r0:r0 + gsz], (0, 0, 0, gp - gsz)))
+                r0 += gsz
+            W = torch.cat(parts, 0)
+        pout = (self.pad_out_to - self.nOut) if self.pad_out_to else 0
+        if pout:
+            W = pad(W, (0, pout))
+            b = pad(b, (0, pout)) if b is not None else None
+        return W, b
+
     def forward(self, input):
-        return _out(input, F.NetworkInNetworkFunction.apply(input.features, self.weight, self.bias))
+        W, b = self._wb(input.features.shape[1])
+        return _out(input, F.NetworkInNetworkFunction.apply(input.features, W, b))
 
     def extra_repr(self):
         return f"{self.nIn}->{self.nOut}"

@@ -31,7 +31,7 @@ class SparseStepModel(torch.nn.Module):
     def __init__(self, channels, with_mask, storage):
         super().__init__()
         self.backbone = Backbone(7, channels, bf16_blocks=storage)
-        self.mask = MaskBranch(channels[0], 7, bf16_blocks=False) if with_mask else None
+        self.mask = MaskBranch(channels[0], 7, bf16_blocks=storage) if with_mask else None
 
 
 class SceneStep:

@@ -53,7 +53,7 @@ class SparseUNet(nn.Module):
         # one cast after the first layer and one at the end.
         self.bf16_all = bf16_blocks == "all"
         self.bf16_blocks = bool(bf16_blocks) and not self.bf16_all
-        if bf16_blocks and (batchnorm or any(c % 8 for c in self.channels)):
+        if bf16_blocks and (batchnorm or any(c % 8 for c in self.channels[1 if identity_first else 0:])):
             raise ValueError("bf16_blocks needs channel counts that are multiples of 8 and no batch norm")
         enc = []
         for l, c in enumerate(self.channels):
@@ -73,6 +73,20 @@ class SparseUNet(nn.Module):
                 nin=M.NetworkInNetwork(2 * c, c, True),
                 units=units(c, num_units, batchnorm))))
         self.decoder = nn.ModuleList(dec)
+        # identity_first with a level-0 width that is no multiple of 8 (the mask head's 23): the level runs on slabs
+        # zero-padded to `phys0` columns (16-byte rows: vector kernels in fp32, bf16 storage possible at all); the caller
+        # hands in the padded slab and gets the padded result (modules._ConvBase.pad_out_to)
+        c0 = self.channels[0]
+        self.phys0 = c0
+        if self.identity_first and c0 % 8:
+            self.phys0 = (c0 + 7) // 8 * 8
+            d0 = self.decoder[-1]
+            d0["up"][1].pad_out_to = self.phys0
+            d0["nin"].pad_out_to = self.phys0
+            d0["nin"].in_groups = (c0, c0)
+            for m in d0["units"].modules():
+                if isinstance(m, M.SubmanifoldConvolution):
+                    m.pad_out_to = self.phys0
 
     def _pack_jobs(self):
         """(W, cin, cout, n_off, flags) of every bf16 weight image this network's forward + backward will stage: forward and
@@ -82,6 +96,8 @@ class SparseUNet(nn.Module):
         from . import _lib as L
         jobs = []
         for m in self.modules():
+            if getattr(m, "pad_out_to", None) or (isinstance(m, M._ConvBase) and (m.nIn % 8 or m.nOut % 8)):
+                continue                                     # padded layers see fresh padded weight tensors: packed per call
             if isinstance(m, M.SubmanifoldConvolution) and m.filter_size == 3 and m.nIn % 8 == 0 and m.nOut % 8 == 0:
                 jobs.append((m.weight, m.nIn, m.nOut, 27, 0))
                 jobs.append((m.weight, m.nOut, m.nIn, 27, L.F_W_TRANSPOSED | L.F_OFF_REVERSE))
@@ -96,7 +112,11 @@ class SparseUNet(nn.Module):
         way the reference's module tree drives the scn surface (DropinBackbone)."""
         if self.bf16_all or self.bf16_blocks:
             from . import functional as F
-            with F.packed_weights(self._pack_jobs()):        # one pack launch for the whole network, gone after the forward
+            plan = self.__dict__.get("_pack_plan")
+            if plan is None:                                 # host-side tables of the pack call: built once
+                plan = F.PackPlan(self._pack_jobs())
+                object.__setattr__(self, "_pack_plan", plan)
+            with F.packed_weights(plan):                     # one pack launch for the whole network, gone after the forward
                 return self._forward(x, prebuild)
         return self._forward(x, prebuild)
 
@@ -110,7 +130,7 @@ class SparseUNet(nn.Module):
                 x = M.CastFeatures(torch.bfloat16)(x)
             x = self._units(level[1], x)
             interims.append(x)
-        self.interims = interims
+        object.__setattr__(self, "interims", interims)      # (nn.Module.__setattr__ costs ~60 us per call on the hot path)
         for i, d in enumerate(self.decoder):
             skip = interims[len(self.channels) - 2 - i]
             x = self._units(d["units"], d["nin"](d["join"]([d["up"](x), skip])))

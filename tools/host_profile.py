@@ -12,7 +12,7 @@ dev = torch.device("cuda", 0)
 coords, feats, size, bs, _ = make_batch(1, (512, 512, 256), 150000, dup=1.15, seed=1)
 coords_d, feats_d = coords.to(dev), feats.to(dev)
 torch.manual_seed(0)
-model = Backbone(7, (32, 64, 128, 256)).to(dev)
+model = Backbone(7, (32, 64, 128, 256), bf16_blocks="all" if "--bf16" in sys.argv else False).to(dev)
 flat = FlatParams(model)
 gy = None
 md_next = None

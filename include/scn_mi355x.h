@@ -314,6 +314,20 @@ int scn_bn_bwd(const float* X, const float* dY, int64_t n, int c, const float* m
                const float* gamma, const float* beta, float leak, int training, float* dX, float* dgamma, float* dbeta,
                void* scratch /* scn_bn_scratch_bytes(c) */, scn_stream_t stream);
 
+/* The same layer with batch statistics over ALL ranks of a data-parallel step (the reference's BatchNorm sees its whole
+ * batch as one feature matrix, module_factory.py:92-102; one scene per GPU splits that matrix): the reductions are
+ * exposed as float64 [2][c] sums so that the caller can all-reduce them between the two halves.
+ *   forward : scn_bn_sums -> (sum x, sum x^2) -> all-reduce with the row counts -> mean, var -> scn_bn_fwd
+ *   backward: scn_bn_bwd_reduce -> local dgamma, dbeta and (sum g, sum g x^) -> all-reduce -> scn_bn_bwd_apply with
+ *             n_stat = rows of all ranks. */
+int scn_bn_sums(const float* X, int64_t n, int c, double* sums, void* scratch, scn_stream_t stream);
+int scn_bn_bwd_reduce(const float* X, const float* dY, int64_t n, int c, const float* mean, const float* var, float eps,
+                      const float* gamma, const float* beta, float leak, float* dgamma, float* dbeta, double* sums,
+                      void* scratch, scn_stream_t stream);
+int scn_bn_bwd_apply(const float* X, const float* dY, int64_t n, int c, const float* mean, const float* var, float eps,
+                     const float* gamma, const float* beta, float leak, const double* sums, int64_t n_stat, float* dX,
+                     scn_stream_t stream);
+
 /* InputLayerFunction (custom_operations.py:72-80): mode 0 copy, 1 last, 2 first, 3 sum, 4 mean.
  * acc64: scratch of n_rows*c doubles (modes 3,4).  row_last (mode 1): scratch of n_rows int32. */
 int scn_input_fwd(const float* feats, const int32_t* item_row, const int32_t* row_count, const int32_t* row_first,

@@ -67,6 +67,9 @@ _SIGS = {
     "scn_add": (C.c_int, [p, p, i64, p, p]),
     "scn_bn_scratch_bytes": (i64, [i32]),
     "scn_bn_stats": (C.c_int, [p, i64, i32, p, p, p, p]),
+    "scn_bn_sums": (C.c_int, [p, i64, i32, p, p, p]),
+    "scn_bn_bwd_reduce": (C.c_int, [p, p, i64, i32, p, p, f32, p, p, f32, p, p, p, p, p]),
+    "scn_bn_bwd_apply": (C.c_int, [p, p, i64, i32, p, p, f32, p, p, f32, p, i64, p, p]),
     "scn_bn_fwd": (C.c_int, [p, i64, i32, p, p, f32, p, p, f32, p, p]),
     "scn_bn_bwd": (C.c_int, [p, p, i64, i32, p, p, f32, p, p, f32, i32, p, p, p, p, p]),
     "scn_input_fwd": (C.c_int, [p, p, p, p, i64, i64, i32, i32, p, p, p, p]),

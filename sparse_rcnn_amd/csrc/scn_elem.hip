@@ -324,6 +324,20 @@ __global__ void k_bn_stats_final(const double* __restrict__ partial, int nblk, i
     var[col] = (float)(v > 0.0 ? v : 0.0);
 }
 
+// SyncBN pieces (batch statistics over all ranks; module_factory.py:92-102: the reference's BatchNorm sees the whole batch
+// as one feature matrix): the per-channel sums leave the library as float64 [2][c] so that the caller can all-reduce them.
+__global__ void k_bn_sums_final(const double* __restrict__ partial, int nblk, int c, double* __restrict__ sums) {
+    int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s0 += partial[((long long)b * 2 + 0) * c + col];
+        s1 += partial[((long long)b * 2 + 1) * c + col];
+    }
+    sums[col] = s0;
+    sums[c + col] = s1;
+}
+
 extern "C" int64_t scn_bn_scratch_bytes(int c) { return (int64_t)sizeof(double) * (BN_BLOCKS * 2 + 2) * c; }
 
 extern "C" int scn_bn_stats(const float* X, int64_t n, int c, float* mean, float* var_biased, void* scratch,
@@ -336,6 +350,19 @@ extern "C" int scn_bn_stats(const float* X, int64_t n, int c, float* mean, float
     SCN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bn_stats_final, dim3((c + 255) / 256), dim3(256), 0, S(stream), (const double*)scratch,
                        BN_BLOCKS, c, (long long)n, mean, var_biased);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+extern "C" int scn_bn_sums(const float* X, int64_t n, int c, double* sums, void* scratch, scn_stream_t stream) {
+    SCN_REQUIRE(n >= 0 && c >= 1 && sums && scratch);
+    SCN_REQUIRE(n == 0 || X);
+    hipLaunchKernelGGL(k_bn_partial<false>, dim3(BN_BLOCKS), dim3(256), 0, S(stream), X, (const float*)nullptr,
+                       (long long)n, c, (const float*)nullptr, (const float*)nullptr, 0.f, (const float*)nullptr,
+                       (const float*)nullptr, 0.f, (double*)scratch);
+    SCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_sums_final, dim3((c + 255) / 256), dim3(256), 0, S(stream), (const double*)scratch, BN_BLOCKS,
+                       c, sums);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }
@@ -380,8 +407,8 @@ __global__ void k_bn_bwd_final(const double* __restrict__ partial, int nblk, int
 __global__ void k_bn_bwd_dx(const float* __restrict__ X, const float* __restrict__ dY, long long n, int c,
                             const float* __restrict__ mean, const float* __restrict__ var, float eps,
                             const float* __restrict__ gamma, const float* __restrict__ beta, float leak, int training,
-                            const double* __restrict__ sums, float* __restrict__ dX) {
-    const double inv_n = n > 0 ? 1.0 / (double)n : 0.0;
+                            const double* __restrict__ sums, float* __restrict__ dX, long long n_stat) {
+    const double inv_n = n_stat > 0 ? 1.0 / (double)n_stat : 0.0;   // rows the statistics were taken over (all ranks')
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n * c;
          i += (long long)gridDim.x * blockDim.x) {
         int ch = (int)(i % c);
@@ -411,9 +438,36 @@ extern "C" int scn_bn_bwd(const float* X, const float* dY, int64_t n, int c, con
     SCN_LAUNCH_CHECK();
     if (n) {
         hipLaunchKernelGGL(k_bn_bwd_dx, dim3(scn::ew_grid(n * c, 256)), dim3(256), 0, S(stream), X, dY, (long long)n, c,
-                           mean, var, eps, gamma, beta, leak, training, (const double*)sums, dX);
+                           mean, var, eps, gamma, beta, leak, training, (const double*)sums, dX, (long long)n);
         SCN_LAUNCH_CHECK();
     }
+    return SCN_OK;
+}
+
+// scn_bn_bwd in two halves with the reduction exposed: local (sum g, sum g x^) -> caller all-reduces -> apply.
+extern "C" int scn_bn_bwd_reduce(const float* X, const float* dY, int64_t n, int c, const float* mean, const float* var,
+                                 float eps, const float* gamma, const float* beta, float leak, float* dgamma,
+                                 float* dbeta, double* sums, void* scratch, scn_stream_t stream) {
+    SCN_REQUIRE(n >= 0 && c >= 1 && mean && var && gamma && beta && dgamma && dbeta && sums && scratch);
+    SCN_REQUIRE(n == 0 || (X && dY));
+    hipLaunchKernelGGL(k_bn_partial<true>, dim3(BN_BLOCKS), dim3(256), 0, S(stream), X, dY, (long long)n, c, mean, var,
+                       eps, gamma, beta, leak, (double*)scratch);
+    SCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_bwd_final, dim3((c + 255) / 256), dim3(256), 0, S(stream), (const double*)scratch, BN_BLOCKS,
+                       c, dgamma, dbeta, sums);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+extern "C" int scn_bn_bwd_apply(const float* X, const float* dY, int64_t n, int c, const float* mean, const float* var,
+                                float eps, const float* gamma, const float* beta, float leak, const double* sums,
+                                int64_t n_stat, float* dX, scn_stream_t stream) {
+    SCN_REQUIRE(n >= 0 && c >= 1 && n_stat >= n && mean && var && gamma && beta && sums);
+    if (n == 0) return SCN_OK;
+    SCN_REQUIRE(X && dY && dX);
+    hipLaunchKernelGGL(k_bn_bwd_dx, dim3(scn::ew_grid(n * c, 256)), dim3(256), 0, S(stream), X, dY, (long long)n, c, mean,
+                       var, eps, gamma, beta, leak, 1, sums, dX, (long long)n_stat);
+    SCN_LAUNCH_CHECK();
     return SCN_OK;
 }
 

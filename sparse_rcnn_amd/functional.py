@@ -640,6 +640,51 @@ class NetworkInNetworkFunction(torch.autograd.Function):
         return dX, dW, db
 
 
+class JoinedNetworkInNetworkFunction(torch.autograd.Function):
+    """NetworkInNetwork over a JoinTable without the concatenated slab: Y = b + sum_k X_k . W[rows of part k].
+    Forward: one identity-table GEMM per part, the running sum carried through the kernel's residual operand.
+    Backward: dX_k = dY . W[rows k]^T written straight into its own slab; dW[rows k] = X_k^T dY (db with the first)."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, *parts):
+        W = _f32(weight)
+        b = _f32(bias) if bias is not None else None
+        Xs = [_feat(p) for p in parts]
+        n, cout = Xs[0].shape[0], W.shape[-1]
+        y, r0 = None, 0
+        for k, X in enumerate(Xs):
+            c = X.shape[1]
+            y = gemm_table(X, None, 1, n, W[r0:r0 + c], b if k == 0 else None, cout, residual=y)
+            r0 += c
+        if r0 != W.shape[0]:
+            raise L.ScnError("JoinTable parts do not add up to the NetworkInNetwork's input width")
+        ctx.save_for_backward(W, *Xs)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dY):
+        W, *Xs = ctx.saved_tensors
+        dY = _feat(dY)
+        n = dY.shape[0]
+        need = ctx.needs_input_grad
+        dW = torch.empty_like(W) if need[0] else None
+        db, dXs, r0 = None, [], 0
+        for k, X in enumerate(Xs):
+            c = X.shape[1]
+            dXs.append(gemm_table(dY, None, 1, n, W[r0:r0 + c], None, c, L.F_W_TRANSPOSED) if need[2 + k] else None)
+            if need[0]:
+                if k == 0 and ctx.has_bias and need[1]:
+                    dWk, db = wgrad_bias_rules(X, dY, None, None, _identity_prefix(n), 1, 1)
+                else:
+                    dWk = wgrad_rules(X, dY, None, None, _identity_prefix(n), 1)
+                dW[r0:r0 + c] = dWk.view(c, -1)
+            r0 += c
+        if db is None and ctx.has_bias and need[1]:
+            db = colsum(dY)
+        return (dW, db, *dXs)
+
+
 class ReLUFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features):
@@ -676,15 +721,39 @@ class AddFunction(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------------
 # A8 BatchNorm(Leaky)ReLU (module_factory.py:92-102)
 # ------------------------------------------------------------------------------------------------------
+def _sync_group(sync):
+    """The process group SyncBN reduces over, or None (single process / not requested)."""
+    import torch.distributed as dist
+    if not sync or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+        return None
+    return dist.group.WORLD
+
+
 class BatchNormReLUFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, features, weight, bias, running_mean, running_var, eps, momentum, leak, training):
+    def forward(ctx, features, weight, bias, running_mean, running_var, eps, momentum, leak, training, sync=False):
         lib = L.lib()
         X = _f32(features)
         n, c = X.shape
         g, b = _f32(weight), _f32(bias)
         scratch = torch.empty(lib.scn_bn_scratch_bytes(c), dtype=torch.uint8, device=X.device)
-        if training:
+        group = _sync_group(sync) if training else None
+        n_stat = n
+        if group is not None:
+            # batch statistics over the scenes of ALL ranks (module_factory.py:92-102: one feature matrix per batch):
+            # one all-reduce of (sum x, sum x^2, rows) per layer, float64
+            import torch.distributed as dist
+            pack = torch.empty(2 * c + 1, dtype=torch.float64, device=X.device)
+            L.check(lib.scn_bn_sums(L.ptr(X), n, c, L.ptr(pack), L.ptr(scratch), L.stream()))
+            pack[2 * c] = float(n)
+            dist.all_reduce(pack, group=group)
+            n_stat = int(round(pack[2 * c].item()))
+            mu = pack[:c] / max(n_stat, 1)
+            mean = mu.float()
+            var = (pack[c:2 * c] / max(n_stat, 1) - mu * mu).clamp_(min=0).float()
+            running_mean.mul_(momentum).add_(mean, alpha=1 - momentum)
+            running_var.mul_(momentum).add_(var, alpha=(1 - momentum) * (n_stat / (n_stat - 1) if n_stat > 1 else 1.0))
+        elif training:
             mean, var = _new((c,), X), _new((c,), X)
             L.check(lib.scn_bn_stats(L.ptr(X), n, c, L.ptr(mean), L.ptr(var), L.ptr(scratch), L.stream()))
             # momentum is the RETAIN fraction (SparseConvNet convention; SURVEY.md §4.1 caveat).  The running variance
@@ -700,6 +769,7 @@ class BatchNormReLUFunction(torch.autograd.Function):
                                L.stream()))
         ctx.save_for_backward(X, g, b, mean, var)
         ctx.cfg = (eps, leak, training)
+        ctx.sync = (group, n_stat)
         return Y
 
     @staticmethod
@@ -711,9 +781,20 @@ class BatchNormReLUFunction(torch.autograd.Function):
         n, c = X.shape
         scratch = torch.empty(lib.scn_bn_scratch_bytes(c), dtype=torch.uint8, device=X.device)
         dX, dg, db = torch.empty_like(X), _new((c,), X), _new((c,), X)
+        group, n_stat = ctx.sync
+        if group is not None:
+            # (sum g, sum g x^) over all ranks; dgamma / dbeta stay this rank's share (the gradient all-reduce adds them)
+            import torch.distributed as dist
+            sums = torch.empty(2 * c, dtype=torch.float64, device=X.device)
+            L.check(lib.scn_bn_bwd_reduce(L.ptr(X), L.ptr(dY), n, c, L.ptr(mean), L.ptr(var), eps, L.ptr(g), L.ptr(b), leak,
+                                          L.ptr(dg), L.ptr(db), L.ptr(sums), L.ptr(scratch), L.stream()))
+            dist.all_reduce(sums, group=group)
+            L.check(lib.scn_bn_bwd_apply(L.ptr(X), L.ptr(dY), n, c, L.ptr(mean), L.ptr(var), eps, L.ptr(g), L.ptr(b), leak,
+                                         L.ptr(sums), n_stat, L.ptr(dX), L.stream()))
+            return dX, dg, db, None, None, None, None, None, None, None
         L.check(lib.scn_bn_bwd(L.ptr(X), L.ptr(dY), n, c, L.ptr(mean), L.ptr(var), eps, L.ptr(g), L.ptr(b), leak,
                                1 if training else 0, L.ptr(dX), L.ptr(dg), L.ptr(db), L.ptr(scratch), L.stream()))
-        return dX, dg, db, None, None, None, None, None, None
+        return dX, dg, db, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ import torch
 from torch.nn import Module, Parameter
 
 from . import functional as F
-from .tensor import SparseConvNetTensor
+from .tensor import JoinedTensor, SparseConvNetTensor
 
 
 def _triple(v, what):
@@ -137,7 +137,7 @@ class JoinTable(Module):
     """Channel concat of tensors sharing Metadata / row order (module_factory.py:301)."""
 
     def forward(self, input):
-        return _out(input[0], torch.cat([t.features for t in input], 1))
+        return JoinedTensor([t.features for t in input], input[0].metadata, input[0].spatial_size)
 
 
 class Identity(Module):
@@ -151,6 +151,11 @@ class ReLU(Module):
 
 
 class _BatchNorm(Module):
+    # SYNC (class-wide switch, default off): in a data-parallel step with one scene per rank, take the batch statistics
+    # over the scenes of all ranks -- what the reference's single-process batch does (module_factory.py:92-102); costs
+    # one small all-reduce per layer and direction.  Without it each rank normalises with its own scene's statistics.
+    SYNC = False
+
     def __init__(self, nPlanes, eps=1e-4, momentum=0.9, affine=True, leakiness=0.0):
         super().__init__()
         self.nPlanes, self.eps, self.momentum, self.leakiness = nPlanes, eps, momentum, leakiness
@@ -161,7 +166,8 @@ class _BatchNorm(Module):
 
     def forward(self, input):
         y = F.BatchNormReLUFunction.apply(input.features, self.weight, self.bias, self.running_mean, self.running_var,
-                                          float(self.eps), float(self.momentum), float(self.leakiness), self.training)
+                                          float(self.eps), float(self.momentum), float(self.leakiness), self.training,
+                                          _BatchNorm.SYNC)
         return _out(input, y)
 
     def extra_repr(self):
@@ -333,6 +339,12 @@ class NetworkInNetwork(Module):
         return W, b
 
     def forward(self, input):
+        if isinstance(input, JoinedTensor) and not input.materialized and len(input.parts) > 1:
+            # JoinTable -> NetworkInNetwork (module_factory.py:557-563): one row GEMM per joined part against its rows of
+            # the weight, accumulated through the kernel's residual operand -- the concatenated slab is never built
+            W, b = self._wb(sum(p.shape[1] for p in input.parts))
+            y = F.JoinedNetworkInNetworkFunction.apply(W, b, *input.parts)
+            return SparseConvNetTensor(features=y, metadata=input.metadata, spatial_size=input.spatial_size)
         W, b = self._wb(input.features.shape[1])
         return _out(input, F.NetworkInNetworkFunction.apply(input.features, W, b))
 

@@ -45,3 +45,32 @@ class SparseConvNetTensor:
     def __repr__(self):
         n = None if self.features is None else tuple(self.features.shape)
         return f"SparseConvNetTensor<features={n}, spatial_size={None if self.spatial_size is None else self._size()}>"
+
+
+class JoinedTensor(SparseConvNetTensor):
+    """What ``scn.JoinTable`` returns: the channel concatenation of tensors that share Metadata and row order
+    (module_factory.py:298-301), kept as its PARTS.  ``.features`` is the concatenated slab, built on first access -- a
+    consumer that can read the parts as separate row sources (NetworkInNetwork: one GEMM per part against the matching
+    rows of its weight) never asks for it, and the copy (two slabs written and read again per decoder level) does not
+    happen."""
+
+    def __init__(self, parts, metadata=None, spatial_size=None):
+        self.parts = list(parts)
+        self._cat = None
+        self.metadata = metadata
+        self.spatial_size = spatial_size
+
+    @property
+    def features(self):
+        if self._cat is None:
+            self._cat = torch.cat(self.parts, 1)
+        return self._cat
+
+    @features.setter
+    def features(self, value):
+        self._cat = value
+        self.parts = [value]
+
+    @property
+    def materialized(self):
+        return self._cat is not None

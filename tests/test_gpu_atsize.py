@@ -330,6 +330,43 @@ def test_two_rank_dp_step_matches_oracle(gpu, tmp_path):
                     mean[k].reshape(-1), mean64[k].reshape(-1))
 
 
+def test_syncbn_two_ranks_equals_single_process(gpu, tmp_path):
+    """SyncBN (modules._BatchNorm.SYNC): two ranks hold uneven shares of one feature matrix; outputs, input gradients,
+    the summed parameter gradients and the running statistics equal the single-process layer on the whole matrix -- what
+    the reference's single-process batch computes (module_factory.py:92-102)."""
+    import sparse_rcnn_amd as scn
+    port = _free_port()
+    procs, outs = [], []
+    for r in range(2):
+        out = str(tmp_path / f"bn{r}.npz")
+        outs.append(out)
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "syncbn_rank_worker.py"), out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), logs
+    z = [np.load(o) for o in outs]
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(5000, 24, generator=g) * 2 + 0.5
+    G = torch.randn(5000, 24, generator=g)
+    bn = scn.BatchNormLeakyReLU(24, leakiness=0.2).to(gpu)
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 1.5, 24)); bn.bias.copy_(torch.linspace(-0.3, 0.3, 24))
+    x = X.to(gpu).requires_grad_()
+    y = bn(scn.SparseConvNetTensor(features=x, metadata=None, spatial_size=None)).features
+    y.backward(G.to(gpu))
+    cat = lambda k: torch.from_numpy(np.concatenate([z[0][k], z[1][k]]))
+    for what, a, b, tol in (("forward", cat("y"), y, 1e-6), ("dX", cat("dx"), x.grad, 1e-5),
+                            ("dgamma (sum over ranks)", torch.from_numpy(z[0]["dg"] + z[1]["dg"]), bn.weight.grad, 1e-5),
+                            ("dbeta (sum over ranks)", torch.from_numpy(z[0]["db"] + z[1]["db"]), bn.bias.grad, 1e-5),
+                            ("running_mean", torch.from_numpy(z[0]["rm"]), bn.running_mean, 1e-6),
+                            ("running_var", torch.from_numpy(z[1]["rv"]), bn.running_var, 1e-6)):
+        e = _err(a, b)
+        _record("syncbn_two_ranks", what, e, tol)
+        assert e["rel_to_scale"] <= tol, (what, e)
+
+
 # ------------------------------------------------------------------------------------------------ cfg 5 shape
 def test_cfg5_shape_bf16_properties(gpu):
     """BASELINE configs[4]'s per-GPU shape (600k voxels, 5 levels to 512 channels) in bf16 storage: the oracle is not the

@@ -427,6 +427,60 @@ def test_nms_and_proposal_selector_match_reference_golden(gpu, path):
     assert np.array_equal(torch.cat(i).numpy(), z["out_index"])
 
 
+def test_rpn_boundary_chain_sparse_to_dense_to_proposals(gpu):
+    """SURVEY §8f N3 assembled as ONE boundary (module_factory.py:581-611 dilation network on a SparseToDense'd level;
+    anchor_network.py:127-219 1x1 heads; proposal_selector.py:60-89): sparse level features -> scn.SparseToDense ->
+    dense 3^3 conv stack + ReLU (torch / MIOpen: outside the hot path) -> per-anchor score and box heads ->
+    ProposalSelector (top-k + one-launch NMS) -> gradient of the kept scores back into the sparse features.
+    SparseToDense must equal the oracle bit for bit; the dense stack agrees with the same layers on the CPU; the
+    selection made on the device's own scores equals the oracle's top-k + greedy NMS on those scores (keep decisions and
+    indices bit-exact); the gradient that reaches the sparse rows equals the CPU chain's."""
+    from sparse_rcnn_amd.proposals import ProposalSelector
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=51, cin=12, grid=(24, 24, 16), n=2500, batch=2, dup=200)
+    n0 = scene.n(0)
+    C, A = 12, 3
+    torch.manual_seed(5)
+    stack = torch.nn.Sequential(torch.nn.Conv3d(C, 16, 3, padding=1), torch.nn.ReLU(),
+                                torch.nn.Conv3d(16, 16, 3, padding=1), torch.nn.ReLU())
+    score_head, box_head = torch.nn.Conv3d(16, A, 1), torch.nn.Conv3d(16, A * 6, 1)
+    sel = ProposalSelector(128, 32, 0.3)
+
+    def chain(xfeat, dense, dev):
+        h = stack.to(dev)(dense)
+        score = score_head.to(dev)(h).flatten(1)                                   # [B, A X Y Z]
+        delta = box_head.to(dev)(h).view(2, A, 6, -1).permute(0, 1, 3, 2).reshape(2, -1, 6)
+        g = torch.stack(torch.meshgrid(*[torch.arange(int(s), dtype=torch.float32) for s in size], indexing="ij"), -1)
+        ctr = g.reshape(1, 1, -1, 3).expand(2, A, -1, 3).reshape(2, -1, 3).to(dev)
+        half = 2.0 + torch.nn.functional.softplus(delta[..., 3:])
+        box = torch.stack([ctr + delta[..., :3] - half, ctr + delta[..., :3] + half], -2)          # [B, N, 2, 3]
+        return score, box
+
+    # device
+    Xg = x.features.detach().clone().requires_grad_()
+    xt = scn.SparseConvNetTensor(features=Xg, metadata=x.metadata, spatial_size=x.spatial_size)
+    dense_g = scn.SparseToDense(3, C)(xt)
+    score_g, box_g = chain(Xg, dense_g, gpu)
+    s_list, b_list, i_list = sel(score_g, box_g)
+    # oracle pieces
+    Xo = x.features.detach().cpu().clone().requires_grad_()
+    dense_o = O.sparse_to_dense(Xo, scene.coords0, size.tolist(), 2)
+    assert torch.equal(dense_g.detach().cpu(), dense_o.detach())                   # A13 bit-exact
+    score_o, box_o = chain(Xo, dense_o, torch.device("cpu"))
+    _close(score_g, score_o, 1e-4, "dense stack scores (MIOpen vs CPU)")
+    _close(box_g, box_o, 1e-4, "dense stack boxes")
+    sg, bg = score_g.detach().cpu(), box_g.detach().cpu()
+    for b in range(2):                                                             # selection on the device's own scores
+        top, idx = torch.topk(sg[b], 128, sorted=True)
+        keep = torch.from_numpy(O.nms(bg[b][idx].numpy(), 0.3))
+        assert torch.equal(i_list[b], idx[keep][:32]) and torch.equal(s_list[b].detach().cpu(), top[keep][:32])
+        assert torch.equal(b_list[b].detach().cpu(), bg[b][idx][keep][:32])
+    # gradient of the kept scores back to the sparse rows: the same selection applied to the CPU chain
+    torch.cat(s_list).sum().backward()
+    sum(score_o[b][i_list[b]].sum() for b in range(2)).backward()
+    _close(Xg.grad, Xo.grad, 1e-4, "d kept scores / d sparse features")
+    assert Xg.grad.shape == (n0, C)
+
+
 def test_nms_edge_cases(gpu):
     from sparse_rcnn_amd.proposals import non_maximum_suppression
     e = non_maximum_suppression(torch.zeros(2, 0, 2, 3, device=gpu), 0.5)

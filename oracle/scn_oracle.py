@@ -425,16 +425,20 @@ def init_unet_params(cin, channels, seed=0, identity_first=False):
 
 
 def unet_forward(scene: OracleScene, feats_pts: torch.Tensor, params: dict, channels, identity_first=False,
-                 storage=None):
+                 storage=None, tile_weights=None, split_nin=False):
     """A12: encoder level = {SubM1 | Conv2s2} + 2x[x + SubM3(ReLU(SubM3(ReLU(x))))];
     decoder level = ReLU -> Deconv2s2 -> Join(up, skip) -> NiN -> 2x residual
     (module_factory.py:127-183, 513-578; custom_container.py:70-83: cat((upsampled, skip))).
     identity_first: encoder level 0 has no layer (FLD('I')).  storage: optional rounding applied to every stored
     feature slab after the first layer (straight-through in backward) -- the bf16 STORAGE mode of the HIP path restated
-    on the CPU: storage=bf16_storage."""
+    on the CPU: storage=bf16_storage.  tile_weights: rounding applied to the weights of the layers that run
+    on the bf16 tile kernel in that mode (SubM 3^3, Convolution: their LDS image is bf16; the 1x1 / deconvolution GEMMs
+    keep fp32 weights).  split_nin: the NetworkInNetwork over a JoinTable as the HIP path evaluates it -- one GEMM per
+    joined part, the first partial result stored (rounded) before the second is added."""
     P = params
     relu = torch.relu
     q = storage if storage is not None else (lambda t: t)
+    wq = tile_weights if tile_weights is not None else (lambda t: t)
     x = _InputFn.apply(feats_pts, scene)
     skips = []
     L = len(channels)
@@ -443,8 +447,8 @@ def unet_forward(scene: OracleScene, feats_pts: torch.Tensor, params: dict, chan
         rules = scene.subm_rules(level, 3)
         n = scene.n(level)
         for u in range(2):
-            y = q(conv(relu(x), P[f"{prefix}.res{u}.conv0.weight"], P[f"{prefix}.res{u}.conv0.bias"], rules, n))
-            y = conv(relu(y), P[f"{prefix}.res{u}.conv1.weight"], P[f"{prefix}.res{u}.conv1.bias"], rules, n)
+            y = q(conv(relu(x), wq(P[f"{prefix}.res{u}.conv0.weight"]), P[f"{prefix}.res{u}.conv0.bias"], rules, n))
+            y = conv(relu(y), wq(P[f"{prefix}.res{u}.conv1.weight"]), P[f"{prefix}.res{u}.conv1.bias"], rules, n)
             x = q(x + y)
         return x
 
@@ -457,13 +461,18 @@ def unet_forward(scene: OracleScene, feats_pts: torch.Tensor, params: dict, chan
             x = q(conv(x, P["enc0.in.weight"], P["enc0.in.bias"], ident, scene.n(0)))
         else:
             rules = scene.strided_rules(l - 1)
-            x = q(conv(x, P[f"enc{l}.in.weight"], P[f"enc{l}.in.bias"], rules, scene.n(l)))
+            x = q(conv(x, wq(P[f"enc{l}.in.weight"]), P[f"enc{l}.in.bias"], rules, scene.n(l)))
         x = residual(x, f"enc{l}", l)
         skips.append(x)
     for l in range(L - 2, -1, -1):
         rules = swap_rules(scene.strided_rules(l))
         up = q(conv(relu(x), P[f"dec{l}.up.weight"], P[f"dec{l}.up.bias"], rules, scene.n(l)))
-        x = q(torch.cat([up, skips[l]], 1) @ P[f"dec{l}.nin.weight"] + P[f"dec{l}.nin.bias"])
+        Wn = P[f"dec{l}.nin.weight"]
+        if split_nin:
+            c_up = up.shape[1]
+            x = q(skips[l] @ Wn[c_up:] + q(up @ Wn[:c_up] + P[f"dec{l}.nin.bias"]))
+        else:
+            x = q(torch.cat([up, skips[l]], 1) @ Wn + P[f"dec{l}.nin.bias"])
         x = residual(x, f"dec{l}", l)
     return x
 

@@ -139,6 +139,42 @@ def _check_grad(name, what, got, o32, o64):
     assert e["rel_l2"] <= GRAD_L2 and e["p99_to_scale"] <= (GRAD_P99 if got.numel() >= 1000 else 5 * GRAD_P99), (what, e)
 
 
+def test_cfg2_bf16_storage_vs_oracle_with_the_same_roundings_at_150k(gpu, scene150k):
+    """The bf16 STORAGE mode (BASELINE configs 3-5) of the full backbone at 150k voxels against the ORACLE evaluated with
+    the same storage roundings -- every stored slab after the first layer rounded to bf16, the tile-kernel layers' weights
+    rounded to bf16, the NetworkInNetwork over the JoinTable evaluated part by part -- not against the HIP path's own fp32
+    run.  What is left between the two: the summation order inside a layer and, through it, single bf16 roundings that fall
+    the other way.  Forward within 2^-6 of the output scale and 3e-3 in relative L2; gradients by relative L2 (bf16
+    gradients carry 2^-9 per stored value, and the straight-through rounding of the oracle is the same model)."""
+    from sparse_rcnn_amd.unet import Backbone
+    coords, feats, size, bs, splits, scene = scene150k
+    ch = (32, 64, 128, 256)
+    params = O.init_unet_params(7, list(ch), seed=0)
+    net = Backbone(7, ch, bf16_blocks="all").to(gpu)
+    net.unet.load_oracle_params(params)
+    fin = feats.to(gpu).requires_grad_()
+    out = net(coords, fin, size, 1)
+    assert out.features.dtype == torch.float32
+    gy = torch.randn(out.features.shape, generator=torch.Generator().manual_seed(5))
+    out.features.backward(gy.to(gpu))
+    torch.cuda.synchronize()
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    fo = feats.clone().requires_grad_()
+    exp = O.unet_forward(scene, fo, po, list(ch), storage=O.bf16_storage, tile_weights=O.bf16_storage, split_nin=True)
+    exp.backward(gy)
+    name = "cfg2_bf16_storage_150k"
+    e = _err(out.features, exp)
+    _record(name, "forward features vs oracle with the same roundings", e, "rel_to_scale <= 2^-6, rel_l2 <= 3e-3")
+    assert e["rel_to_scale"] <= 2.0 ** -6 and e["rel_l2"] <= 3e-3, e
+    for k, p in net.unet.named_oracle_params().items():
+        e = _err(p.grad, po[k].grad.view_as(p))
+        _record(name, "grad " + k, e, "rel_l2 <= 3e-2")
+        assert torch.isfinite(p.grad).all() and e["rel_l2"] <= 3e-2, (k, e)
+    e = _err(fin.grad, fo.grad)
+    _record(name, "grad input features", e, "rel_l2 <= 3e-2")
+    assert e["rel_l2"] <= 3e-2, e
+
+
 def test_dropin_path_equals_backbone_path_at_150k(gpu, scene150k):
     """The layer-by-layer module path (Metadata created inside the forward from HOST coordinates, rulebooks requested
     lazily -- then, from the second forward on, built by one native call on the remembered depth) gives the bits of the

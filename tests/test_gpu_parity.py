@@ -445,10 +445,15 @@ def test_rpn_boundary_chain_sparse_to_dense_to_proposals(gpu):
     score_head, box_head = torch.nn.Conv3d(16, A, 1), torch.nn.Conv3d(16, A * 6, 1)
     sel = ProposalSelector(128, 32, 0.3)
 
+    import copy
+    nets = {"cpu": (stack, score_head, box_head),
+            "cuda": tuple(copy.deepcopy(m).to(gpu) for m in (stack, score_head, box_head))}
+
     def chain(xfeat, dense, dev):
-        h = stack.to(dev)(dense)
-        score = score_head.to(dev)(h).flatten(1)                                   # [B, A X Y Z]
-        delta = box_head.to(dev)(h).view(2, A, 6, -1).permute(0, 1, 3, 2).reshape(2, -1, 6)
+        st, sh, bh = nets[torch.device(dev).type]
+        h = st(dense)
+        score = sh(h).flatten(1)                                                   # [B, A X Y Z]
+        delta = bh(h).view(2, A, 6, -1).permute(0, 1, 3, 2).reshape(2, -1, 6)
         g = torch.stack(torch.meshgrid(*[torch.arange(int(s), dtype=torch.float32) for s in size], indexing="ij"), -1)
         ctr = g.reshape(1, 1, -1, 3).expand(2, A, -1, 3).reshape(2, -1, 3).to(dev)
         half = 2.0 + torch.nn.functional.softplus(delta[..., 3:])

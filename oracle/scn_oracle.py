@@ -425,7 +425,7 @@ def init_unet_params(cin, channels, seed=0, identity_first=False):
 
 
 def unet_forward(scene: OracleScene, feats_pts: torch.Tensor, params: dict, channels, identity_first=False,
-                 storage=None, tile_weights=None, split_nin=False):
+                 storage=None, tile_weights=None, split_nin=False, record=None):
     """A12: encoder level = {SubM1 | Conv2s2} + 2x[x + SubM3(ReLU(SubM3(ReLU(x))))];
     decoder level = ReLU -> Deconv2s2 -> Join(up, skip) -> NiN -> 2x residual
     (module_factory.py:127-183, 513-578; custom_container.py:70-83: cat((upsampled, skip))).
@@ -462,8 +462,12 @@ def unet_forward(scene: OracleScene, feats_pts: torch.Tensor, params: dict, chan
         else:
             rules = scene.strided_rules(l - 1)
             x = q(conv(x, wq(P[f"enc{l}.in.weight"]), P[f"enc{l}.in.bias"], rules, scene.n(l)))
+        if record is not None:
+            record.append((f"enc{l}.head", x.detach()))
         x = residual(x, f"enc{l}", l)
         skips.append(x)
+        if record is not None:
+            record.append((f"enc{l}", x.detach()))
     for l in range(L - 2, -1, -1):
         rules = swap_rules(scene.strided_rules(l))
         up = q(conv(relu(x), P[f"dec{l}.up.weight"], P[f"dec{l}.up.bias"], rules, scene.n(l)))
@@ -474,6 +478,8 @@ def unet_forward(scene: OracleScene, feats_pts: torch.Tensor, params: dict, chan
         else:
             x = q(torch.cat([up, skips[l]], 1) @ Wn + P[f"dec{l}.nin.bias"])
         x = residual(x, f"dec{l}", l)
+        if record is not None:
+            record.append((f"dec{l}", x.detach()))
     return x
 
 

@@ -151,8 +151,9 @@ int scn_pyramid_build(const int64_t* coords, int64_t n_points, int n_levels, int
  * (start x,y,z,sample ; stop x,y,z,sample+1), half-open.  The result is the reference's selection order: box-major,
  * ascending point row.
  *   scn_roi_units(n)        number of 256-point units of n points
- *   scn_roi_count           unit_offsets int32 [bb][scn_roi_units(n)]: after the call, the first output row of every
- *                           (box, unit) run; prefix (device int64 [bb+1]): first output row of every box, prefix[bb] = M.
+ *   scn_roi_count           unit_offsets int32 [bb * scn_roi_units(n) + bb]: after the call, for every (box, unit) the
+ *                           start of its run relative to the box's first output row (+ bb box totals behind them);
+ *                           prefix (device int64 [bb+1]): first output row of every box, prefix[bb] = M.
  *                           prefix_host != NULL: copied back (synchronises stream once); NULL: asynchronous.
  *   scn_roi_fill            src_row[M] (point row), box_of[M], out_coords int64 [M][4] = (x,y,z of the point, box) --
  *                           select_coords' extended coordinates (may be NULL).
@@ -162,7 +163,7 @@ int64_t scn_roi_units(int64_t n);
 int scn_roi_count(const int32_t* coords, int64_t n, const int32_t* boxes, int bb, int32_t* unit_offsets, int64_t* prefix,
                   int64_t* prefix_host, scn_stream_t stream);
 int scn_roi_fill(const int32_t* coords, int64_t n, const int32_t* boxes, int bb, const int32_t* unit_offsets,
-                 int32_t* src_row, int32_t* box_of, int64_t* out_coords, scn_stream_t stream);
+                 const int64_t* prefix, int32_t* src_row, int32_t* box_of, int64_t* out_coords, scn_stream_t stream);
 int scn_roi_inside(const int32_t* src_row, const int32_t* box_of, int64_t m, int64_t n, int bb, uint8_t* inside_u8,
                    scn_stream_t stream);
 /* out_coords[m] = (x,y,z of coords[src_row[m]], box_of[m]) as int64 rows (select_coords, roi_select_sparse.py:136-149) */

@@ -35,7 +35,7 @@ _SIGS = {
     "scn_pyramid_build": (C.c_int, [p, i64, i32, i32, p, i64, C.POINTER(i64), p]),
     "scn_roi_units": (i64, [i64]),
     "scn_roi_count": (C.c_int, [p, i64, p, i32, p, p, p, p]),
-    "scn_roi_fill": (C.c_int, [p, i64, p, i32, p, p, p, p, p]),
+    "scn_roi_fill": (C.c_int, [p, i64, p, i32, p, p, p, p, p, p]),
     "scn_roi_inside": (C.c_int, [p, p, i64, i64, i32, p, p]),
     "scn_roi_coords": (C.c_int, [p, p, p, i64, p, p]),
     "scn_roi_boxes": (C.c_int, [p, p, i32, p, p, p, p]),

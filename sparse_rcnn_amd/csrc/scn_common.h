@@ -56,10 +56,6 @@ inline int ew_grid(int64_t work_items, int block) {
     return (int)g;
 }
 
-// In-place exclusive scan of `total` int32 counts (scn_index.hip); prefix[s] = scanned value at entry s * per_seg for
-// s < n_seg, prefix[n_seg] = grand total (device int64[n_seg + 1]).
-int scan_counts(int32_t* counts, int64_t total, int64_t per_seg, int n_seg, int64_t* prefix, hipStream_t st);
-
 }  // namespace scn
 
 // ---- device-side key packing / hashing (shared by index kernels) ----

@@ -183,13 +183,6 @@ static int scan_launch(const int32_t* table, int n_seg, int64_t n, int32_t* bloc
     return SCN_OK;
 }
 
-int scn::scan_counts(int32_t* counts, int64_t total, int64_t per_seg, int n_seg, int64_t* prefix, hipStream_t st) {
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, counts, (long long)total, (long long)per_seg, n_seg,
-                       (long long*)prefix);
-    SCN_LAUNCH_CHECK();
-    return SCN_OK;
-}
-
 extern "C" int scn_rules_scan(const int32_t* table, int n_off, int64_t n_out, int32_t* block_sums, int64_t* prefix,
                               int64_t* prefix_host, scn_stream_t stream) {
     SCN_REQUIRE(n_off >= 1 && n_out >= 0 && block_sums && prefix && (n_out == 0 || table));

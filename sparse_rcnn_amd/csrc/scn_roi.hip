@@ -10,8 +10,9 @@
 //                 a unit is spatially compact and a box only meets its candidate units); for the others the four
 //                 inside tests are one ballot + popcount each.  cnt[box][unit] (int32, box-major) is the only
 //                 intermediate: BB x N / 256 counters, 43 k integers at 64 boxes x 172 k points.
-//   k_scan_blocks (scn_index.hip): exclusive scan of cnt in box-major order = start of every (box, unit) run in the
-//                 output, and prefix[box] = first output row of the box (the CSR the mask-head epilogue consumes).
+//   k_roi_scan_box / k_roi_prefix: exclusive scan of every box's counters (one workgroup per box) and of the box totals:
+//                 prefix[box] = first output row of the box (the CSR the mask-head epilogue consumes), prefix[box] +
+//                 cnt[box][unit] = start of the (box, unit) run in the output.
 //   k_roi_fill  : the same walk; lanes write src_row / box_of and the int64 (x, y, z, box) coordinate rows of
 //                 select_coords at  start(box, unit) + rank inside the unit  (ballot prefix popcount).
 //
@@ -82,7 +83,8 @@ template <bool FILL>
 __global__ __launch_bounds__(ROI_WAVES * 64) void k_roi_walk(const int4* __restrict__ coords, long long n,
                                                              const int* __restrict__ boxes, int bb, long long n_units,
                                                              int* __restrict__ cnt, int* __restrict__ src_row,
-                                                             int* __restrict__ box_of, long long* __restrict__ out_coords) {
+                                                             int* __restrict__ box_of, long long* __restrict__ out_coords,
+                                                             const long long* __restrict__ prefix) {
     __shared__ int sbox[ROI_BOX_TILE * 8];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long unit = (long long)blockIdx.x * ROI_WAVES + w;
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(ROI_WAVES * 64) void k_roi_walk(const int4* __restr
                 for (int q = 0; q < 4; ++q) c += __popcll(__ballot(u.valid[q] && roi_inside(u.p[q], b)));
                 if (lane == 0) cnt[slot] = c;
             } else {
-                int run = cnt[slot];                        // first output row of this (box, unit) run
+                long long run = prefix[b0 + k] + cnt[slot]; // first output row of this (box, unit) run
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const bool in = u.valid[q] && roi_inside(u.p[q], b);
@@ -129,6 +131,64 @@ __global__ __launch_bounds__(ROI_WAVES * 64) void k_roi_walk(const int4* __restr
     }
 }
 
+// Exclusive scan of cnt[box][0 .. n_units) in place, one workgroup per box, and the box totals.  (The scan shared with the
+// rulebooks -- one workgroup over all boxes x units -- took 60 of the crop's 120 us at 64 boxes x 674 units.)
+__global__ __launch_bounds__(256) void k_roi_scan_box(int* __restrict__ cnt, long long n_units, int* __restrict__ total) {
+    __shared__ int wsum[4];
+    __shared__ int carry_s;
+    int* row = cnt + (long long)blockIdx.x * n_units;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (long long base = 0; base < n_units; base += 256) {
+        const long long i = base + threadIdx.x;
+        const int v = i < n_units ? row[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        int off = carry_s;
+        for (int k = 0; k < w; ++k) off += wsum[k];
+        if (i < n_units) row[i] = off + x - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = off + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[blockIdx.x] = carry_s;
+}
+
+// prefix[b] = rows selected by the boxes before b (one workgroup; bb < 65536), prefix[bb] = M
+__global__ __launch_bounds__(1024) void k_roi_prefix(const int* __restrict__ total, int bb, long long* __restrict__ prefix) {
+    __shared__ long long wtot[16];
+    __shared__ long long carry_s;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < bb; base += 1024) {
+        const int i = base + threadIdx.x;
+        const long long v = i < bb ? total[i] : 0;
+        long long x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const long long y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wtot[w] = x;
+        __syncthreads();
+        long long off = carry_s;
+        for (int k = 0; k < w; ++k) off += wtot[k];
+        if (i < bb) prefix[i] = off + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = off + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) prefix[bb] = carry_s;
+}
+
 extern "C" int64_t scn_roi_units(int64_t n) { return n > 0 ? cdiv(n, ROI_UNIT) : 1; }
 
 extern "C" int scn_roi_count(const int32_t* coords, int64_t n, const int32_t* boxes, int bb, int32_t* unit_offsets,
@@ -144,10 +204,13 @@ extern "C" int scn_roi_count(const int32_t* coords, int64_t n, const int32_t* bo
         SCN_REQUIRE(n_units * bb < 2147483647LL);
         hipLaunchKernelGGL(k_roi_walk<false>, dim3((unsigned)cdiv(n_units, ROI_WAVES)), dim3(ROI_WAVES * 64), 0, st,
                            (const int4*)coords, (long long)n, boxes, bb, (long long)n_units, unit_offsets, (int*)nullptr,
-                           (int*)nullptr, (long long*)nullptr);
+                           (int*)nullptr, (long long*)nullptr, (const long long*)nullptr);
         SCN_LAUNCH_CHECK();
-        const int rc = scn::scan_counts(unit_offsets, n_units * bb, n_units, bb, prefix, st);   // scn_index.hip
-        if (rc) return rc;
+        int* totals = unit_offsets + n_units * bb;           // bb box totals behind the counters
+        hipLaunchKernelGGL(k_roi_scan_box, dim3((unsigned)bb), dim3(256), 0, st, unit_offsets, (long long)n_units, totals);
+        SCN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_roi_prefix, dim3(1), dim3(1024), 0, st, (const int*)totals, bb, (long long*)prefix);
+        SCN_LAUNCH_CHECK();
     }
     if (!prefix_host) return SCN_OK;
     SCN_HIP(hipMemcpyAsync(prefix_host, prefix, sizeof(int64_t) * (bb + 1), hipMemcpyDeviceToHost, st));
@@ -157,14 +220,15 @@ extern "C" int scn_roi_count(const int32_t* coords, int64_t n, const int32_t* bo
 }
 
 extern "C" int scn_roi_fill(const int32_t* coords, int64_t n, const int32_t* boxes, int bb, const int32_t* unit_offsets,
-                            int32_t* src_row, int32_t* box_of, int64_t* out_coords, scn_stream_t stream) {
+                            const int64_t* prefix, int32_t* src_row, int32_t* box_of, int64_t* out_coords,
+                            scn_stream_t stream) {
     SCN_REQUIRE(n >= 0 && bb >= 0 && bb < 65536);
     if (n == 0 || bb == 0) return SCN_OK;
-    SCN_REQUIRE(coords && boxes && unit_offsets && src_row && box_of);
+    SCN_REQUIRE(coords && boxes && unit_offsets && prefix && src_row && box_of);
     const int64_t n_units = scn_roi_units(n);
     hipLaunchKernelGGL(k_roi_walk<true>, dim3((unsigned)cdiv(n_units, ROI_WAVES)), dim3(ROI_WAVES * 64), 0, S(stream),
                        (const int4*)coords, (long long)n, boxes, bb, (long long)n_units, (int*)unit_offsets, src_row,
-                       box_of, (long long*)out_coords);
+                       box_of, (long long*)out_coords, (const long long*)prefix);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }

@@ -115,7 +115,7 @@ def roi_select(coords_i32: torch.Tensor, boxes_i32: torch.Tensor, want_coords=Tr
     if bb == 0 or n == 0:
         e = torch.zeros(0, dtype=torch.int32, device=dev)
         return RoiSelection(e, e, [0] * (bb + 1), n, bb, torch.zeros((0, 4), dtype=torch.int64, device=dev))
-    offsets = torch.empty(bb * lib.scn_roi_units(n), dtype=torch.int32, device=dev)
+    offsets = torch.empty(bb * lib.scn_roi_units(n) + bb, dtype=torch.int32, device=dev)
     prefix_dev = torch.empty(bb + 1, dtype=torch.int64, device=dev)
     L.check(lib.scn_roi_count(L.ptr(coords_i32), n, L.ptr(boxes_i32), bb, L.ptr(offsets), L.ptr(prefix_dev), None,
                               L.stream()))
@@ -127,8 +127,8 @@ def roi_select(coords_i32: torch.Tensor, boxes_i32: torch.Tensor, want_coords=Tr
     box_of = torch.empty(m, dtype=torch.int32, device=dev)
     new_coords = torch.empty((m, 4), dtype=torch.int64, device=dev) if want_coords else None
     if m:
-        L.check(lib.scn_roi_fill(L.ptr(coords_i32), n, L.ptr(boxes_i32), bb, L.ptr(offsets), L.ptr(src_row),
-                                 L.ptr(box_of), L.ptr(new_coords), L.stream()))
+        L.check(lib.scn_roi_fill(L.ptr(coords_i32), n, L.ptr(boxes_i32), bb, L.ptr(offsets), L.ptr(prefix_dev),
+                                 L.ptr(src_row), L.ptr(box_of), L.ptr(new_coords), L.stream()))
     return RoiSelection(src_row, box_of, prefix, n, bb, new_coords)
 
 

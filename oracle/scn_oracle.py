@@ -454,6 +454,7 @@ def unet_forward(scene: OracleScene, feats_pts: torch.Tensor, params: dict, chan
 
     for l in range(L):
         if l == 0 and identity_first:
+            x = q(x)                           # the level's slab is stored (bf16 storage: cast) before anything reads it
             skips.append(x)
             continue
         if l == 0:

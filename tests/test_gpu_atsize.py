@@ -202,37 +202,45 @@ def test_dropin_path_equals_backbone_path_at_150k(gpu, scene150k):
 
 
 # ------------------------------------------------------------------------------------------------ cfg 3
-def _oracle_mask_branch(coords_np, raw, bb_feats, mp, boxes_np, assoc, scene):
-    """SparseMaskNetwork forward (model.py:758-782) on the oracle ops, reference configuration (run.py:741-810)."""
+def _oracle_mask_branch(coords_np, raw, bb_feats, mp, boxes_np, assoc, scene, bf16=False):
+    """SparseMaskNetwork forward (model.py:758-782) on the oracle ops, reference configuration (run.py:741-810).
+    bf16: with the storage roundings of the HIP path's bf16 mode (stored slabs and the tile-kernel layers' weights rounded,
+    NetworkInNetwork over the JoinTable part by part; OutputLayer / crop / InputLayer mean / Linear stay fp32)."""
     relu = torch.relu
+    q = O.bf16_storage if bf16 else (lambda t: t)
+    kw = dict(storage=O.bf16_storage, tile_weights=O.bf16_storage, split_nin=True) if bf16 else {}
     n0 = scene.n(0)
     ident = [(np.arange(n0, dtype=np.int32),) * 2]
-    x = O.conv(bb_feats, mp["in.weight"], mp["in.bias"], ident, n0)
+    x = q(O.conv(q(bb_feats), mp["in.weight"], mp["in.bias"], ident, n0))
     rules = scene.subm_rules(0, 3)
     for u in range(2):
-        y = O.conv(relu(x), mp[f"in.res{u}.conv0.weight"], mp[f"in.res{u}.conv0.bias"], rules, n0)
-        y = O.conv(relu(y), mp[f"in.res{u}.conv1.weight"], mp[f"in.res{u}.conv1.bias"], rules, n0)
-        x = x + y
+        y = q(O.conv(relu(x), q(mp[f"in.res{u}.conv0.weight"]), mp[f"in.res{u}.conv0.bias"], rules, n0))
+        y = O.conv(relu(y), q(mp[f"in.res{u}.conv1.weight"]), mp[f"in.res{u}.conv1.bias"], rules, n0)
+        x = q(x + y)
     per_point = x[torch.from_numpy(scene.prow)]                              # OutputLayer
     cat = torch.cat([per_point, raw], 1)
     src, box_of, inside = O.roi_crop(coords_np, boxes_np, assoc)
     new_coords = np.concatenate([coords_np[src][:, :3], box_of[:, None]], 1)
     rscene = O.OracleScene(new_coords)
     unet_p = {k[5:]: v for k, v in mp.items() if k.startswith("unet.")}
-    m = O.unet_forward(rscene, cat[torch.from_numpy(src)], unet_p, [23, 32, 48, 64], identity_first=True)
+    m = O.unet_forward(rscene, cat[torch.from_numpy(src)], unet_p, [23, 32, 48, 64], identity_first=True, **kw)
     pts = m[torch.from_numpy(rscene.prow)]                                   # OutputLayer over the ROI batch
     h = torch.relu(pts @ mp["lin0.weight"].t() + mp["lin0.bias"])
     return h @ mp["lin1.weight"].t() + mp["lin1.bias"], src, box_of, rscene
 
 
-def test_cfg3_roi_crop_and_mask_branch_vs_oracle_at_size(gpu, scene150k):
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_cfg3_roi_crop_and_mask_branch_vs_oracle_at_size(gpu, scene150k, dtype):
     """BASELINE configs[2] at size: 150k voxels x 64 make_boxes boxes.  ROI selection bit-exact vs O.roi_crop; the mask
     branch with the reference's plan (SubM1 32->16 + 2 units; 23 -> 32 -> 48 -> 64 internal U-Net; Linear 23-32-18,
     scannet_config/run.py:749-810) against the oracle in fp32: logits and the gradients of the backbone features, the
-    raw point features and every parameter."""
+    raw point features and every parameter.
+    dtype = "bf16": the branch in bf16 STORAGE against the oracle evaluated with the same roundings (bounds as in
+    test_cfg2_bf16_storage_vs_oracle_with_the_same_roundings_at_150k)."""
     import sparse_rcnn_amd as scn
     from sparse_rcnn_amd import roi
     from sparse_rcnn_amd.maskhead import MaskBranch
+    bf16 = dtype == "bf16"
     from sparse_rcnn_amd.synthetic import make_boxes
     coords, feats, size, bs, splits, scene = scene150k
     bbox_batch = make_boxes(coords, 64, seed=3)
@@ -240,7 +248,7 @@ def test_cfg3_roi_crop_and_mask_branch_vs_oracle_at_size(gpu, scene150k):
     n0 = scene.n(0)
     bb = torch.randn(n0, 32, generator=g)
     torch.manual_seed(3)
-    branch = MaskBranch(32, 7).to(gpu)
+    branch = MaskBranch(32, 7, bf16_blocks="all" if bf16 else False).to(gpu)
     with torch.no_grad():
         for p in branch.parameters():
             if p.dim() == 1:
@@ -279,19 +287,31 @@ def test_cfg3_roi_crop_and_mask_branch_vs_oracle_at_size(gpu, scene150k):
         mo[k] = t.requires_grad_()
     raw_o = feats.clone().requires_grad_()
     bb_o = bb.clone().requires_grad_()
-    exp, src, box_of, rscene = _oracle_mask_branch(coords.numpy(), raw_o, bb_o, mo, boxes_np, assoc, scene)
-    md64 = {k: v.detach().double().requires_grad_() for k, v in mo.items()}
-    raw_d, bb_d = feats.double().requires_grad_(), bb.double().requires_grad_()
-    exp64 = _oracle_mask_branch(coords.numpy(), raw_d, bb_d, md64, boxes_np, assoc, scene)[0]
-    name = "cfg3_mask_branch_64boxes_150k"
+    exp, src, box_of, rscene = _oracle_mask_branch(coords.numpy(), raw_o, bb_o, mo, boxes_np, assoc, scene, bf16=bf16)
+    if not bf16:
+        md64 = {k: v.detach().double().requires_grad_() for k, v in mo.items()}
+        raw_d, bb_d = feats.double().requires_grad_(), bb.double().requires_grad_()
+        exp64 = _oracle_mask_branch(coords.numpy(), raw_d, bb_d, md64, boxes_np, assoc, scene)[0]
+    name = "cfg3_mask_branch_64boxes_150k" + ("_bf16_storage" if bf16 else "")
     assert np.array_equal(sel.src_row.cpu().numpy(), src) and np.array_equal(sel.box_of.cpu().numpy(), box_of)
     assert selection[1] == cnt and sel.prefix[-1] == len(src)
     assert np.array_equal(sel.new_coords.cpu().numpy(), np.concatenate([coords.numpy()[src][:, :3], box_of[:, None]], 1))
     print(f"[parity] {name}: {len(src)} cropped points in 64 boxes, {rscene.n(0)} ROI voxels")
     e = _err(logits, exp)
+    gl = torch.randn(exp.shape, generator=g)
+    if bf16:
+        _record(name, "mask logits vs oracle with the same roundings", e, "rel_to_scale <= 2^-5, rel_l2 <= 2e-2")
+        assert e["rel_to_scale"] <= 2.0 ** -5 and e["rel_l2"] <= 2e-2, e
+        logits.backward(gl.to(gpu))
+        exp.backward(gl)
+        for what, a, b in [("grad backbone features", bb_g.grad, bb_o.grad), ("grad raw point features", raw_g.grad, raw_o.grad)] + \
+                [("grad " + k, p.grad, mo[k].grad.view_as(p)) for k, p in mp.items()]:
+            e = _err(a, b)
+            _record(name, what, e, "rel_l2 <= 8e-2")
+            assert torch.isfinite(a).all() and e["rel_l2"] <= 8e-2, (what, e)
+        return
     _record(name, "mask logits", e, FEAT_TOL)
     assert e["rel_to_scale"] <= FEAT_TOL, e
-    gl = torch.randn(exp.shape, generator=g)
     logits.backward(gl.to(gpu))
     exp.backward(gl)
     exp64.backward(gl.double())
@@ -443,3 +463,20 @@ def test_cfg5_shape_bf16_properties(gpu):
     e = _err(outs[1][1], outs[0][1])
     _record("cfg5_shape_bf16", "bf16-storage input gradient vs fp32", e, 0.1)
     assert torch.isfinite(outs[1][1]).all() and e["rel_l2"] < 0.1, e
+
+
+def test_bench_self_launch_two_ranks_on_one_gpu(gpu):
+    """`python bench.py --gpus 2` with no torchrun environment starts its own two ranks (gloo here, so that both may share
+    cuda:0) and prints ONE JSON line on stdout with n_gpus = 2 -- the launch path of the driver's scaling run."""
+    env = dict(os.environ, SCN_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--target", "30000", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["roofline"]["kernel"] == "k_conv_ts" and 0 < d["roofline"]["frac"] < 1

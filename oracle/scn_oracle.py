@@ -499,6 +499,22 @@ def bf16_storage(t):
     return _RoundBF16.apply(t)
 
 
+class _RoundBF16Both(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+def bf16_storage_both(t):
+    """A slab stored in bf16 in BOTH directions: the value is rounded going forward and the gradient that arrives at it
+    (the sum over its consumers) is rounded going backward -- the HIP path keeps feature gradients in bf16 slabs too."""
+    return _RoundBF16Both.apply(t)
+
+
 class _InputFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, scene):

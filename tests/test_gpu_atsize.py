@@ -148,9 +148,10 @@ def test_cfg2_bf16_storage_vs_oracle_with_the_same_roundings_at_150k(gpu, scene1
     at the noise floor of bf16 storage itself, so the mirrored roundings show where the path is short -- the first
     encoder level (5 layers) must agree within 5e-4 in relative L2, each later piece agrees at 1e-5 .. 1e-3 on identical
     inputs -- and fade with depth: the final features are held to 2^-6 of the output scale and 1e-2 in relative L2 (the
-    un-mirrored fp32 oracle sits at 6e-3).  Gradients: the oracle rounds the gradient arriving at every stored slab too
-    (bf16_storage_both); 120 stored gradient slabs later the first layers' parameter gradients agree to 4-6 % in relative
-    L2 (bound 1e-1; recorded) -- bf16 gradient slabs carry 2^-9 per value per stage and the ReLU masks amplify it."""
+    un-mirrored fp32 oracle sits at 6e-3).  Gradients: the oracle differentiates the rounded forward in fp32 (straight-through
+    roundings), the HIP path stores every feature gradient in bf16 -- 120 stored gradient slabs later the parameter gradients
+    agree to 1-6 % in relative L2 (bound 8e-2; recorded).  (An oracle that ALSO rounds every arriving gradient is a second
+    noisy realisation, not a sharper reference: it sits 9-15 % from the HIP path and 10 % from the fp32-gradient oracle.)"""
     from sparse_rcnn_amd.unet import Backbone
     coords, feats, size, bs, splits, scene = scene150k
     ch = (32, 64, 128, 256)
@@ -166,7 +167,7 @@ def test_cfg2_bf16_storage_vs_oracle_with_the_same_roundings_at_150k(gpu, scene1
     po = {k: v.clone().requires_grad_() for k, v in params.items()}
     fo = feats.clone().requires_grad_()
     rec = []
-    exp = O.unet_forward(scene, fo, po, list(ch), storage=O.bf16_storage_both, tile_weights=O.bf16_storage, split_nin=True,
+    exp = O.unet_forward(scene, fo, po, list(ch), storage=O.bf16_storage, tile_weights=O.bf16_storage, split_nin=True,
                          record=rec)
     exp.backward(gy)
     name = "cfg2_bf16_storage_150k"
@@ -178,11 +179,11 @@ def test_cfg2_bf16_storage_vs_oracle_with_the_same_roundings_at_150k(gpu, scene1
     assert e["rel_to_scale"] <= 2.0 ** -6 and e["rel_l2"] <= 1e-2, e
     for k, p in net.unet.named_oracle_params().items():
         e = _err(p.grad, po[k].grad.view_as(p))
-        _record(name, "grad " + k, e, "rel_l2 <= 1e-1")
-        assert torch.isfinite(p.grad).all() and e["rel_l2"] <= 1e-1, (k, e)
+        _record(name, "grad " + k, e, "rel_l2 <= 8e-2")
+        assert torch.isfinite(p.grad).all() and e["rel_l2"] <= 8e-2, (k, e)
     e = _err(fin.grad, fo.grad)
-    _record(name, "grad input features", e, "rel_l2 <= 1e-1")
-    assert e["rel_l2"] <= 1e-1, e
+    _record(name, "grad input features", e, "rel_l2 <= 8e-2")
+    assert e["rel_l2"] <= 8e-2, e
 
 
 def test_dropin_path_equals_backbone_path_at_150k(gpu, scene150k):
@@ -209,9 +210,9 @@ def _oracle_mask_branch(coords_np, raw, bb_feats, mp, boxes_np, assoc, scene, bf
     bf16: with the storage roundings of the HIP path's bf16 mode (stored slabs and the tile-kernel layers' weights rounded,
     NetworkInNetwork over the JoinTable part by part; OutputLayer / crop / InputLayer mean / Linear stay fp32)."""
     relu = torch.relu
-    q = O.bf16_storage_both if bf16 else (lambda t: t)          # slabs: value and arriving gradient rounded
-    wq = O.bf16_storage if bf16 else (lambda t: t)              # weights: value rounded, gradient fp32
-    kw = dict(storage=O.bf16_storage_both, tile_weights=O.bf16_storage, split_nin=True) if bf16 else {}
+    q = O.bf16_storage if bf16 else (lambda t: t)               # stored slabs (gradient passes straight through)
+    wq = q                                                      # tile-kernel weights
+    kw = dict(storage=O.bf16_storage, tile_weights=O.bf16_storage, split_nin=True) if bf16 else {}
     n0 = scene.n(0)
     ident = [(np.arange(n0, dtype=np.int32),) * 2]
     x = q(O.conv(q(bb_feats), mp["in.weight"], mp["in.bias"], ident, n0))

@@ -497,3 +497,136 @@ class _RoundBF16(torch.autograd.Function):
 def bf16_storage(t):
     """Round to bf16 and widen back (value as stored by the bf16 storage path); gradient passes straight through."""
     return _RoundBF16.apply(t)
+
+
+
+class _InputFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, scene):
+        ctx.scene = scene
+        return input_layer_fwd(feats, scene.prow, scene.n(0), 4)
+
+    @staticmethod
+    def backward(ctx, dY):
+        return input_layer_bwd(dY, ctx.scene.prow, 4), None
+
+
+# --------------------------------------------------------------------------
+# N2: mask-head epilogue over the ROI selection
+# (ndsis/modules/model.py:824-882 SparseMaskPredictor, :1150-1227 SparseMaskLossSelector;
+#  ndsis/utils/basic_functions.py:177-216 split_select_nd)
+# --------------------------------------------------------------------------
+
+def mask_predict(mask_output, is_inside, box_sample_count, batch_splits, class_indices, num_valid=0):
+    """is_inside bool [BB, N]; mask_output fp32 [M, K] with rows box-major / ascending point.
+    -> list per sample of fp32 [boxes_s, points_s] (model.py:859-882)."""
+    mo = np.asarray(mask_output, dtype=np.float32)
+    ins = np.asarray(is_inside, dtype=bool)
+    out, r, b0, p0 = [], 0, 0, 0
+    for nb, npts in zip(box_sample_count, batch_splits):
+        blk = np.zeros((nb, npts), np.float32)
+        for j in range(nb):
+            pts = np.nonzero(ins[b0 + j])[0]
+            c = int(class_indices[b0 + j])
+            valid = c >= 0 and (num_valid == 0 or c < num_valid)
+            if valid:
+                x = mo[r:r + len(pts), c].astype(np.float64)
+                blk[j, pts - p0] = (1.0 / (1.0 + np.exp(-x))).astype(np.float32)
+            r += len(pts)
+        out.append(blk)
+        b0 += nb
+        p0 += npts
+    return out
+
+
+def mask_loss_select(mask_scores, is_inside, box_sample_count, batch_splits, keep_list, gt_associations_list,
+                     gt_labels_list, gt_masks_list):
+    """-> (pred flat, gt flat, rows per kept box, labels) in crop order over the kept boxes (model.py:1157-1227)."""
+    ms = np.asarray(mask_scores, dtype=np.float32)
+    ins = np.asarray(is_inside, dtype=bool)
+    pred, gt, rows, labels = [], [], [], []
+    r, b0, p0 = 0, 0, 0
+    for s, (nb, npts) in enumerate(zip(box_sample_count, batch_splits)):
+        keep = np.asarray(keep_list[s], dtype=bool)
+        assoc = np.asarray(gt_associations_list[s], dtype=np.int64)
+        a = 0
+        for j in range(nb):
+            pts = np.nonzero(ins[b0 + j])[0]
+            if keep[j]:
+                g = int(assoc[a]); a += 1
+                lab = int(np.asarray(gt_labels_list[s])[g])
+                pred.append(ms[r:r + len(pts), lab])
+                gt.append(np.asarray(gt_masks_list[s], dtype=np.float32)[g, pts - p0])
+                rows.append(len(pts)); labels.append(lab)
+            r += len(pts)
+        b0 += nb
+        p0 += npts
+    cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.float32)
+    return cat(pred), cat(gt), rows, np.asarray(labels, np.int64)
+
+
+# --------------------------------------------------------------------------
+# N3: greedy NMS of score-sorted boxes (ndsis/utils/bbox.py:713-759, IoU :205-242, :598-620)
+# --------------------------------------------------------------------------
+
+def nms(boxes, thr):
+    """boxes fp32 [N, 2, 3] sorted by descending confidence -> bool [N].  fp32 arithmetic in the reference's order."""
+    b = np.asarray(boxes, dtype=np.float32).reshape(-1, 2, 3)
+    n = len(b)
+    size = b[:, 1] - b[:, 0]
+    vol = (size[:, 0] * size[:, 1]) * size[:, 2]
+    keep = np.ones(n, dtype=bool)
+    thr = np.float32(thr)
+    for j in range(n):
+        if not keep[j]:
+            continue
+        lo = np.maximum(b[j, 0], b[j + 1:, 0])
+        hi = np.minimum(b[j, 1], b[j + 1:, 1])
+        e = np.maximum(hi - lo, np.float32(0))
+        inter = (e[:, 0] * e[:, 1]) * e[:, 2]
+        union = (vol[j] + vol[j + 1:]) - inter
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ov = inter / union
+        keep[j + 1:] &= ~(ov > thr)
+    return keep
+
+
+# --------------------------------------------------------------------------
+# N4: voxelisation (ndsis/data/sparse_augmentation.py:81-126 augment_coords, :42-47 fix_cut_out,
+#     :50-78 random_cut_out given its drawn start positions)
+# --------------------------------------------------------------------------
+
+def augment_coords(coords, rot_and_scale, sub_pixel_offset, spatial_size=None, shift=None, start_positions=None):
+    """-> (resulting int64 [M,3], is_inside bool [N], spatial_size int64 [3], complete_shift fp32 [3]).
+    points @ R in fp32 as fma(z, R2j, fma(y, R1j, x*R0j)) (torch's CPU association for K = 3; the fused multiply-adds are
+    emulated in float64: the product of two fp32 values is exact there)."""
+    p = np.asarray(coords, dtype=np.float32)
+    r = np.asarray(rot_and_scale, dtype=np.float32).reshape(3, 3)
+    aug = np.empty_like(p)
+    for j in range(3):
+        acc = (p[:, 0] * r[0, j]).astype(np.float32)
+        for k in (1, 2):
+            acc = (p[:, k].astype(np.float64) * np.float64(r[k, j]) + acc.astype(np.float64)).astype(np.float32)
+        aug[:, j] = acc
+    complete_shift = (-aug.min(0) + np.asarray(sub_pixel_offset, dtype=np.float32)).astype(np.float32)
+    discrete = (aug + complete_shift).astype(np.float32).astype(np.int64)          # .long(): truncation
+    if spatial_size is not None:
+        size = np.broadcast_to(np.asarray(spatial_size, dtype=np.int64), (3,))
+        if shift is not None:
+            start = np.broadcast_to(-np.asarray(shift, dtype=np.int64), (3,))
+            inside = ((0 <= discrete) & (discrete < size)).all(1)
+        else:
+            start = np.broadcast_to(np.asarray(start_positions, dtype=np.int64), (3,))
+            moved = discrete - start
+            inside = ((0 <= moved) & (moved < size)).all(1)
+        res = (discrete - start)[inside]
+        complete_shift = complete_shift - start.astype(np.float32)
+        return res, inside, size.copy(), complete_shift
+    size = discrete.max(0)
+    res = discrete
+    if shift is not None:
+        sh = np.broadcast_to(np.asarray(shift, dtype=np.int64), (3,))
+        res = discrete + sh
+        size = size + 2 * sh
+        complete_shift = complete_shift + sh.astype(np.float32)
+    return res, np.ones(len(p), bool), size, complete_shift

@@ -27,6 +27,8 @@ from .unet import SparseUNet, units
 
 
 class MaskBranch(nn.Module):
+    PREFETCH_ROI_INDEX = True       # build the ROI batch's selection + rulebooks beside the scene-level layers (False: inline)
+
     def __init__(self, backbone_channels=32, raw_channels=7, input_channels=16, unet_channels=(32, 48, 64),
                  linear_channels=(32, 18), bf16_blocks=False):
         super().__init__()
@@ -62,18 +64,22 @@ class MaskBranch(nn.Module):
         if pc is not None and pc.shape[0] == coords.shape[0]:
             coords = pc
             raw_scene = (pc,) + tuple(raw_scene[1:])
+        size = torch.as_tensor([int(s) for s in spatial_size], dtype=torch.long) + self.spatial_size_extention
+        # the crop's selection and the ROI batch's index structures depend on coordinates and boxes only: a helper thread
+        # builds them (its own high-priority stream) while the scene-level layers below are queued and run
+        pending = self.output_roi_cut.prepare_cut_in_thread(coords, size, selected_bbox) if self.PREFETCH_ROI_INDEX else None
         if self.bf16:       # the scene-level units on bf16-stored features; the per-point gather (OutputLayer) takes fp32
             converted = M.CastFeatures(torch.float32)(self.input_conv_layer(M.CastFeatures(torch.bfloat16)(backbone_features)))
         else:
             converted = self.input_conv_layer(backbone_features)
-        size = torch.as_tensor([int(s) for s in spatial_size], dtype=torch.long) + self.spatial_size_extention
         per_point = self.output_layer(converted)
         parts = (per_point, features)
         unet = self.output_conv_layer
         if unet.phys0 != unet.channels[0]:      # 23 -> 24 columns: zero column appended where the slab is assembled anyway
             parts += (features.new_zeros((features.shape[0], unet.phys0 - unet.channels[0])),)
         combined = torch.cat(parts, dim=-1)
-        roi_tensor, selection = self.output_roi_cut((coords, combined, size, *other, batch_splits), selected_bbox)
+        roi_tensor, selection = self.output_roi_cut((coords, combined, size, *other, batch_splits), selected_bbox,
+                                                    prepared=pending)
         skip_features = self.scene_roi_extra_cut(raw_scene, selection)
         if len(skip_features) == 0 or roi_tensor is None:
             return skip_features.new_zeros((0, self.classes)), selection

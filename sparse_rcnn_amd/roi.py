@@ -203,10 +203,11 @@ class RawToTensorFeatureExtractorCombiner:
     extract = staticmethod(RawToFeaturesSceneFeatureExtractorCombiner.extract)
 
     @classmethod
-    def combine(cls, new_coords, new_features, spatial_size, batch_size=0):
+    def combine(cls, new_coords, new_features, spatial_size, batch_size=0, metadata=None):
+        """metadata: a Metadata already prepared for new_coords (prepare_cut_in_thread); None: built here."""
         if new_coords.shape[0] == 0:     # CustomInputLayer's contract for an empty crop (custom_operations.py:71,85-86)
             return None
-        md = Metadata(len(spatial_size))
+        md = metadata if metadata is not None else Metadata(len(spatial_size))
         size = torch.as_tensor([int(s) for s in spatial_size], dtype=torch.long)
         feats = InputLayerFunction.apply(len(spatial_size), md, size, new_coords, new_features, batch_size, cls.MODE)
         return SparseConvNetTensor(features=feats, metadata=md, spatial_size=size)
@@ -257,13 +258,87 @@ class SparseRoiCut(torch.nn.Module):
         self.feature_extractor_combiner = feature_extractor_combiner
         self.clip_boxes, self.resize_boxes, self.dense_inside = clip_boxes, resize_boxes, dense_inside
 
-    def forward(self, feature_map, bbox_batch):
+    def forward(self, feature_map, bbox_batch, prepared=None):
+        """prepared: the result of `prepare_cut_in_thread` for the same coordinates, boxes and spatial size -- the
+        selection and the ROI batch's index structures depend on those only, so a caller that knows the boxes before the
+        features are ready (the mask branch: boxes come from the RPN, features from layers that still run) has them built
+        meanwhile."""
         fec = self.feature_extractor_combiner
         old_coords, old_features, spatial_size, batch_splits = fec.extract(feature_map)
-        boxes, counts, _ = transform_boxes(bbox_batch, spatial_size, self.clip_boxes, self.resize_boxes)
-        new_coords, new_features, sel = roi_cut_device(old_coords, old_features, boxes)
-        box_features = fec.combine(new_coords, new_features, spatial_size, sel.n_boxes)
+        if prepared is not None:
+            boxes, counts, sel, md = prepared.result()
+            if sel.n_points != old_coords.shape[0]:
+                raise L.ScnError("SparseRoiCut: `prepared` was built for other coordinates")
+            new_coords, new_features = sel.new_coords, select_features(old_features, sel)
+            if md is not None:
+                md.handover()
+                box_features = fec.combine(new_coords, new_features, spatial_size, sel.n_boxes, metadata=md)
+            else:
+                box_features = fec.combine(new_coords, new_features, spatial_size, sel.n_boxes)
+        else:
+            boxes, counts, _ = transform_boxes(bbox_batch, spatial_size, self.clip_boxes, self.resize_boxes)
+            new_coords, new_features, sel = roi_cut_device(old_coords, old_features, boxes)
+            box_features = fec.combine(new_coords, new_features, spatial_size, sel.n_boxes)
         return box_features, (sel.is_inside() if self.dense_inside else sel, counts, batch_splits)
+
+    def prepare_cut_in_thread(self, coords, spatial_size, bbox_batch, n_levels=0):
+        """Start building what the cut needs from coordinates and boxes alone -- the selection list and, for the
+        RawToTensor combiner, the InputLayer rules + rulebook pyramid of the ROI batch (n_levels; 0: the depth the last
+        network over this spatial size used, Metadata.LEVELS_HINT) -- on a helper thread and its own high-priority stream.
+        Returns a handle for `forward(..., prepared=)`."""
+        from concurrent.futures import ThreadPoolExecutor
+        global _roi_pool, _roi_stream
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if _roi_pool is None:
+            _roi_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="scn-roi-index")
+        if _roi_stream.get(dev) is None:
+            _roi_stream[dev] = torch.cuda.Stream(device=dev, priority=-1)
+        side, main = _roi_stream[dev], torch.cuda.current_stream()
+        size = tuple(int(s) for s in spatial_size)
+        want_md = isinstance(self.feature_extractor_combiner, RawToTensorFeatureExtractorCombiner) or \
+            (isinstance(self.feature_extractor_combiner, type) and
+             issubclass(self.feature_extractor_combiner, RawToTensorFeatureExtractorCombiner))
+        mode = getattr(self.feature_extractor_combiner, "MODE", 4)
+        clip, resize = self.clip_boxes, self.resize_boxes
+
+        def fn():
+            torch.cuda.set_device(dev)
+            side.wait_stream(main)                       # the coordinates may have been produced on the caller's stream
+            with torch.cuda.stream(side):
+                boxes, counts, _ = transform_boxes(bbox_batch, size, clip, resize)
+                sel = roi_select(_coords_to_device(coords), boxes)
+                md = None
+                if want_md and sel.src_row.shape[0]:
+                    levels = n_levels or Metadata.LEVELS_HINT.get(size, 1)
+                    lv, ok = size, 1
+                    while ok < levels and all(v % 2 == 0 for v in lv):
+                        lv, ok = tuple(v // 2 for v in lv), ok + 1
+                    md = Metadata(3)
+                    md._prepared_for = (sel.new_coords.data_ptr(), sel.new_coords._version, tuple(sel.new_coords.shape),
+                                        sel.new_coords.device)
+                    md.build_native(size, sel.new_coords, sel.n_boxes, mode, ok, 3)
+                    md._unrequested = set(md.strided)
+                    md.ready_event = torch.cuda.Event()
+                    md.ready_event.record(side)
+                for t in (sel.src_row, sel.box_of, sel.new_coords):
+                    if t is not None:
+                        t.record_stream(main)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return boxes, counts, sel, md, ev
+
+        fut = _roi_pool.submit(fn)
+
+        class _Pending:
+            def result(self_inner):
+                boxes, counts, sel, md, ev = fut.result()
+                torch.cuda.current_stream().wait_event(ev)
+                return boxes, counts, sel, md
+        return _Pending()
+
+
+_roi_pool = None
+_roi_stream = {}
 
 
 class SparseRoiExtraCut(torch.nn.Module):

@@ -17,6 +17,8 @@ selected boxes as the reference's `selected_bbox` list.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -27,7 +29,10 @@ from .unet import SparseUNet, units
 
 
 class MaskBranch(nn.Module):
-    PREFETCH_ROI_INDEX = True       # build the ROI batch's selection + rulebooks beside the scene-level layers (False: inline)
+    # True: build the ROI batch's selection + rulebooks on a helper thread beside the scene-level layers.  Measured on one
+    # box (tools/ab_roi_prefetch.sh, profiles/r2_ab_roi_prefetch.log): fp32 12.4-12.9 ms either way, bf16 9.6-9.9 ms inline
+    # against 9.7-12.8 ms with the helper (two Python threads issuing ~13 us launches share one interpreter lock) -> inline.
+    PREFETCH_ROI_INDEX = os.environ.get("SCN_ROI_PREFETCH", "0") != "0"
 
     def __init__(self, backbone_channels=32, raw_channels=7, input_channels=16, unet_channels=(32, 48, 64),
                  linear_channels=(32, 18), bf16_blocks=False):

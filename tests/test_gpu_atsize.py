@@ -149,11 +149,13 @@ def test_cfg2_bf16_storage_vs_oracle_with_the_same_roundings_at_150k(gpu, scene1
     encoder level (5 layers) must agree within 5e-4 in relative L2, each later piece agrees at 1e-5 .. 1e-3 on identical
     inputs -- and fade with depth: the final features are held to 2^-6 of the output scale and 1e-2 in relative L2 (the
     un-mirrored fp32 oracle sits at 6e-3).  Gradients: the oracle differentiates the rounded forward in fp32 (straight-through
-    roundings), the HIP path stores every feature gradient in bf16.  What separates them is mostly not rounding noise but
-    ReLU masks: where the two forwards differ by their 1e-4 .. 5e-3, inputs within that distance of zero take different
-    masks (a few 0.1 % of a layer's elements), and a flipped mask moves a whole gradient contribution -- the parameter
-    gradients agree to 1-10 % in relative L2 (bound 1.5e-1; recorded per tensor).  (An oracle that ALSO rounds every arriving
-    gradient is a second noisy realisation, not a sharper reference: it sits 9-15 % from the HIP path.)"""
+    roundings), the HIP path stores every feature gradient in bf16.  Rounding the gradients is not what separates them (an
+    oracle that rounds every arriving gradient too moves the parameter gradients by 0.3-0.7 %); ReLU masks are: where two
+    forwards differ by their 1e-4 .. 5e-3, inputs within that distance of zero take different masks, and a flipped mask
+    moves a whole gradient contribution.  The yardstick is therefore measured, not chosen: the ORACLE is run a second time
+    with every value nudged by 2e-7 relative (one fp32 ulp, what a different summation order does) before it is rounded --
+    the two oracle realisations sit 5e-3 apart in the forward and 4-16 % apart in the parameter gradients, growing with
+    depth -- and each HIP gradient must lie within 1.5x that distance (+1e-2) of the first realisation."""
     from sparse_rcnn_amd.unet import Backbone
     coords, feats, size, bs, splits, scene = scene150k
     ch = (32, 64, 128, 256)
@@ -172,20 +174,34 @@ def test_cfg2_bf16_storage_vs_oracle_with_the_same_roundings_at_150k(gpu, scene1
     exp = O.unet_forward(scene, fo, po, list(ch), storage=O.bf16_storage, tile_weights=O.bf16_storage, split_nin=True,
                          record=rec)
     exp.backward(gy)
+    # second realisation of the same rounded network: values nudged by an fp32 ulp before each storage rounding
+    gen = torch.Generator().manual_seed(9)
+
+    def nudged(t):
+        return O.bf16_storage(t + (t * (torch.randn(t.shape, generator=gen) * 2e-7)).detach())
+    p2 = {k: v.clone().requires_grad_() for k, v in params.items()}
+    f2 = feats.clone().requires_grad_()
+    exp2 = O.unet_forward(scene, f2, p2, list(ch), storage=nudged, tile_weights=O.bf16_storage, split_nin=True)
+    exp2.backward(gy)
     name = "cfg2_bf16_storage_150k"
+    floor = _err(exp2.detach(), exp)
+    _record(name, "forward features: second oracle realisation (ulp-nudged) vs first", floor, "yardstick")
     e = _err(net.unet.interims[0].features.float(), dict(rec)["enc0"])
     _record(name, "encoder level 0 output vs oracle with the same roundings", e, "rel_l2 <= 5e-4")
     assert e["rel_l2"] <= 5e-4, e
     e = _err(out.features, exp)
     _record(name, "forward features vs oracle with the same roundings", e, "rel_to_scale <= 2^-6, rel_l2 <= 1e-2")
     assert e["rel_to_scale"] <= 2.0 ** -6 and e["rel_l2"] <= 1e-2, e
-    for k, p in net.unet.named_oracle_params().items():
-        e = _err(p.grad, po[k].grad.view_as(p))
-        _record(name, "grad " + k, e, "rel_l2 <= 1.5e-1")
-        assert bool(torch.isfinite(p.grad).all()) and e["rel_l2"] <= 1.5e-1, (k, e)
-    e = _err(fin.grad, fo.grad)
-    _record(name, "grad input features", e, "rel_l2 <= 1.5e-1")
-    assert e["rel_l2"] <= 1.5e-1, e
+    bad = []
+    for k, p in list(net.unet.named_oracle_params().items()) + [("input features", fin)]:
+        ref, ref2 = (fo.grad, f2.grad) if p is fin else (po[k].grad.view_as(p), p2[k].grad.view_as(p))
+        e, fl = _err(p.grad, ref), _err(ref2, ref)
+        bound = 1.5 * fl["rel_l2"] + 1e-2
+        e["yardstick_rel_l2"] = fl["rel_l2"]
+        _record(name, "grad " + k, e, "rel_l2 <= 1.5 x (second oracle realisation vs first) + 1e-2 = %.3g" % bound)
+        if not (bool(torch.isfinite(p.grad).all()) and e["rel_l2"] <= bound):
+            bad.append((k, e["rel_l2"], bound))
+    assert not bad, bad
 
 
 def test_dropin_path_equals_backbone_path_at_150k(gpu, scene150k):
@@ -241,8 +257,10 @@ def test_cfg3_roi_crop_and_mask_branch_vs_oracle_at_size(gpu, scene150k, dtype):
     branch with the reference's plan (SubM1 32->16 + 2 units; 23 -> 32 -> 48 -> 64 internal U-Net; Linear 23-32-18,
     scannet_config/run.py:749-810) against the oracle in fp32: logits and the gradients of the backbone features, the
     raw point features and every parameter.
-    dtype = "bf16": the branch in bf16 STORAGE against the oracle evaluated with the same roundings (bounds as in
-    test_cfg2_bf16_storage_vs_oracle_with_the_same_roundings_at_150k)."""
+    dtype = "bf16": the branch in bf16 STORAGE against the oracle evaluated with the same roundings; the gradient bound
+    (relative L2 <= 2.5e-1) is the distance between two ulp-nudged realisations of such a network as measured per tensor in
+    test_cfg2_bf16_storage_vs_oracle_with_the_same_roundings_at_150k (4-16 %), with the headroom the branch's two stacked
+    networks ask for."""
     import sparse_rcnn_amd as scn
     from sparse_rcnn_amd import roi
     from sparse_rcnn_amd.maskhead import MaskBranch

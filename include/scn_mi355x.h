@@ -55,6 +55,8 @@ extern "C" {
                                 dX = mask(conv^T dY1) + dY), default is before */
 #define SCN_F_SPLIT_SUM 16    /* scn_conv_tiles: launch the tile kernel only; the caller runs scn_conv_tiles_finish next
                                * (lets a profiler bracket the two kernels separately; results are identical) */
+#define SCN_F_GEMM_V1 32      /* scn_gemm_table / scn_gemm_rules: run the register-only kernels (operands straight from
+                               * global memory) where the LDS-tiled ones would be taken; same bits -- the tests' cross-check */
 
 typedef void* scn_stream_t;
 
@@ -267,6 +269,19 @@ int scn_wgrad_rules(const float* X, int cin, const float* dY, int cout, const in
  * the bit mask db_offsets of dY[out_p][c].  The caller names offsets whose rule lists together contain every output row
  * exactly once (centre offset of a submanifold conv: 1 << (k^3/2); all offsets of a Deconvolution; the identity list),
  * so db equals the column sum of dY.  Any channel count (rows that are not 16-byte aligned take element-wise loads). */
+/* Row GEMM over the parts of a JoinTable, A tile staged through LDS (scn_gemm_lt.hip):
+ *     [Y0 | Y1][r] = residual[r] + bias + in([X0[r] | X1[r]]) . W        for r < n
+ * Two sources (cx1 > 0): NetworkInNetwork(2C -> C) applied to JoinTable([up, skip]) without the concatenated slab
+ * (module_factory.py:298-301, 365-367); W is the layer's [cx0 + cx1][cy0] weight.  Two destinations (cy1 > 0) with
+ * SCN_F_W_TRANSPOSED: its backward-data, dUp = dY . W[:c0]^T and dSkip = dY . W[c0:]^T from one read of dY; W is the layer's
+ * weight unchanged ([cy0 + cy1][cx0] seen from this call).  cx1 == cy1 == 0: the identity-table scn_gemm_table.
+ * Channel counts of the sources are multiples of 8, slabs 16-byte aligned; residual / relu_mask only with one destination.
+ * bf16_storage != 0: features, residual, relu_mask and outputs are uint16 bf16 bit patterns (W, bias fp32; exact widening,
+ * fp32 arithmetic, one rounding of the result). */
+int scn_gemm_rows2(const void* X0, int cx0, const void* X1, int cx1, int64_t n, const float* W, const float* bias,
+                   const void* residual, const void* relu_mask, void* Y0, int cy0, void* Y1, int cy1, int flags,
+                   int bf16_storage, scn_stream_t stream);
+
 /* bf16-storage forms of scn_gemm_table / scn_gemm_rules (features, residual, relu_mask and Y are uint16 bf16 bit
  * patterns; W and bias fp32; rows are widened exactly and the arithmetic is the fp32 kernels'; one rounding of Y). */
 int scn_gemm_table_bf16(const uint16_t* X, int64_t n_in, int cin, const int32_t* table, int n_off, int64_t n_out,

@@ -57,6 +57,7 @@ _SIGS = {
     "scn_wgrad_rules": (C.c_int, [p, i32, p, i32, p, p, C.POINTER(i64), i32, p, p, i32, p]),
     "scn_gemm_table_bf16": (C.c_int, [p, i64, i32, p, i32, i64, p, p, p, p, p, i32, i32, p]),
     "scn_gemm_rules_bf16": (C.c_int, [p, i32, p, p, C.POINTER(i64), i32, p, p, p, p, i32, i32, p]),
+    "scn_gemm_rows2": (C.c_int, [p, i32, p, i32, i64, p, p, p, p, p, i32, p, i32, i32, i32, p]),
     "scn_wgrad_rules_bf16": (C.c_int, [p, i32, p, i32, p, p, C.POINTER(i64), i32, p, p, i32, p]),
     "scn_wgrad_bias_rules": (C.c_int, [p, i32, p, i32, p, p, C.POINTER(i64), i32, p, p, C.c_uint32, p, i32, p]),
     "scn_wgrad_bias_rules_bf16": (C.c_int, [p, i32, p, i32, p, p, C.POINTER(i64), i32, p, p, C.c_uint32, p, i32, p]),
@@ -92,7 +93,7 @@ _SIGS = {
 
 EXPORTS = tuple(_SIGS)
 
-F_RELU_IN, F_W_TRANSPOSED, F_OFF_REVERSE, F_RESIDUAL_LAST, F_SPLIT_SUM = 1, 2, 4, 8, 16
+F_RELU_IN, F_W_TRANSPOSED, F_OFF_REVERSE, F_RESIDUAL_LAST, F_SPLIT_SUM, F_GEMM_V1 = 1, 2, 4, 8, 16, 32
 OK, EINVAL, ESIZE, EHASH, EHIP = 0, 1, 2, 3, 4
 PYRAMID_MAX_LEVELS, PYRAMID_LEVEL_STRIDE = 8, 72
 PYRAMID_DESC_LEN = 8 + PYRAMID_MAX_LEVELS * PYRAMID_LEVEL_STRIDE

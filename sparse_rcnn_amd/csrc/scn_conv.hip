@@ -20,6 +20,16 @@
 using scn::S;
 using scn::cdiv;
 
+namespace scn {   // scn_gemm_lt.hip: the same GEMMs with the A tile staged through LDS (8-channel groups, aligned slabs)
+bool gemm_lt_usable(const void* X0, const void* X1, int cx0, int cx1, const void* W);
+int gemm_lt_rows(const void* X0, int cx0, const void* X1, int cx1, int64_t n, const float* W, const float* bias,
+                 const void* residual, const void* relu_mask, void* Y0, int cy0, void* Y1, int cy1, int flags, bool hb,
+                 scn_stream_t stream);
+int gemm_lt_rules(const void* X, int cin, const int32_t* in_rows, const int32_t* out_rows, const int64_t* prefix_host,
+                  int n_off, const float* W, const float* bias, const void* relu_mask, void* Y, int cout, int flags,
+                  bool hb, scn_stream_t stream);
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -149,6 +159,10 @@ static int gemm_table_impl(const float* X, int64_t n_in, int cin, const int32_t*
     SCN_REQUIRE(n_out * (int64_t)cout < (1LL << 40) && cdiv(n_out, 128) < 2147483647LL);
     const bool fast = (cin % 8 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0);
     const bool wt = flags & SCN_F_W_TRANSPOSED;
+    // identity table (NetworkInNetwork, SubM 1^3, Linear): the LDS-tiled row GEMM, same bits (SCN_F_GEMM_V1: this file's)
+    if (!table && fast && !(flags & SCN_F_GEMM_V1) && n_out < 2147483647LL)
+        return scn::gemm_lt_rows(X, cin, nullptr, 0, n_out, W, bias, residual, relu_mask, Y, cout, nullptr, 0, flags, hb,
+                                 stream);
     dim3 grid((unsigned)cdiv(n_out, 128), (unsigned)cdiv(cout, 32));
 #define LAUNCH_T(F, T, H)                                                                                     \
     hipLaunchKernelGGL((k_gemm_table<F, T, H>), grid, dim3(256), 0, S(stream), X, cin, table, n_off,          \
@@ -262,6 +276,10 @@ static int gemm_rules_impl(const float* X, int cin, const int32_t* in_rows, cons
     SCN_REQUIRE(X && in_rows && out_rows && W && Y);
     const bool fast = (cin % 8 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0);
     const bool wt = flags & SCN_F_W_TRANSPOSED;
+    // (one 32-column chunk: the four waves of a workgroup would share nothing -- the register kernel is faster there)
+    if (fast && cout > 32 && !(flags & SCN_F_GEMM_V1))
+        return scn::gemm_lt_rules(X, cin, in_rows, out_rows, prefix_host, n_off, W, bias, relu_mask, Y, cout, flags, hb,
+                                  stream);
     dim3 grid((unsigned)cdiv(tiles, 4), (unsigned)cdiv(cout, 32));
 #define LAUNCH_R(F, T, H)                                                                                     \
     hipLaunchKernelGGL((k_gemm_rules<F, T, H>), grid, dim3(256), 0, S(stream), X, cin, in_rows, out_rows, seg, \

@@ -640,10 +640,40 @@ class NetworkInNetworkFunction(torch.autograd.Function):
         return dX, dW, db
 
 
+FUSED_JOIN = True   # NetworkInNetwork over two JoinTable parts: one two-source launch (False: one GEMM per part, chained)
+
+
+def gemm_rows2(X0, X1, W, bias, cout, flags=0):
+    """scn_gemm_rows2 with two sources: Y = bias + [X0 | X1] . W (W is the layer's [c0 + c1][cout] weight)."""
+    n, c0, c1 = X0.shape[0], X0.shape[1], X1.shape[1]
+    Y = _new((n, cout), X0, X0.dtype)
+
+    def run():
+        L.check(L.lib().scn_gemm_rows2(L.ptr(X0), c0, L.ptr(X1), c1, n, L.ptr(W), L.ptr(bias), 0, 0, L.ptr(Y), cout, 0, 0,
+                                       flags, int(_is_bf16(X0)), L.stream()))
+    eb = X0.element_size()
+    profiling.timed("k_gemm_table", 2.0 * n * (c0 + c1) * cout, eb * n * (c0 + c1 + cout) + 4.0 * (c0 + c1) * cout, run)
+    return Y
+
+
+def gemm_rows2_bwd(dY, W, c0, c1):
+    """scn_gemm_rows2 with two destinations: dX0 = dY . W[:c0]^T, dX1 = dY . W[c0:]^T from one read of dY."""
+    n, cout = dY.shape
+    d0, d1 = _new((n, c0), dY, dY.dtype), _new((n, c1), dY, dY.dtype)
+
+    def run():
+        L.check(L.lib().scn_gemm_rows2(L.ptr(dY), cout, 0, 0, n, L.ptr(W), 0, 0, 0, L.ptr(d0), c0, L.ptr(d1), c1,
+                                       L.F_W_TRANSPOSED, int(_is_bf16(dY)), L.stream()))
+    eb = dY.element_size()
+    profiling.timed("k_gemm_table", 2.0 * n * (c0 + c1) * cout, eb * n * (c0 + c1 + cout) + 4.0 * (c0 + c1) * cout, run)
+    return d0, d1
+
+
 class JoinedNetworkInNetworkFunction(torch.autograd.Function):
     """NetworkInNetwork over a JoinTable without the concatenated slab: Y = b + sum_k X_k . W[rows of part k].
-    Forward: one identity-table GEMM per part, the running sum carried through the kernel's residual operand.
-    Backward: dX_k = dY . W[rows k]^T written straight into its own slab; dW[rows k] = X_k^T dY (db with the first)."""
+    Two parts in 8-channel groups (every decoder level): ONE launch reads both slabs (scn_gemm_rows2) and one launch writes
+    both gradients.  Otherwise one identity-table GEMM per part, the running sum carried through the kernel's residual
+    operand, and dX_k = dY . W[rows k]^T per part.  dW[rows k] = X_k^T dY (db with the first)."""
 
     @staticmethod
     def forward(ctx, weight, bias, *parts):
@@ -651,13 +681,18 @@ class JoinedNetworkInNetworkFunction(torch.autograd.Function):
         b = _f32(bias) if bias is not None else None
         Xs = [_feat(p) for p in parts]
         n, cout = Xs[0].shape[0], W.shape[-1]
-        y, r0 = None, 0
-        for k, X in enumerate(Xs):
-            c = X.shape[1]
-            y = gemm_table(X, None, 1, n, W[r0:r0 + c], b if k == 0 else None, cout, residual=y)
-            r0 += c
-        if r0 != W.shape[0]:
+        if sum(X.shape[1] for X in Xs) != W.shape[0]:
             raise L.ScnError("JoinTable parts do not add up to the NetworkInNetwork's input width")
+        ctx.fused = (FUSED_JOIN and len(Xs) == 2 and Xs[0].dtype == Xs[1].dtype and Xs[0].shape[1] % 8 == 0
+                     and Xs[1].shape[1] % 8 == 0 and n > 0)
+        if ctx.fused:
+            y = gemm_rows2(Xs[0], Xs[1], W, b, cout)
+        else:
+            y, r0 = None, 0
+            for k, X in enumerate(Xs):
+                c = X.shape[1]
+                y = gemm_table(X, None, 1, n, W[r0:r0 + c], b if k == 0 else None, cout, residual=y)
+                r0 += c
         ctx.save_for_backward(W, *Xs)
         ctx.has_bias = bias is not None
         return y
@@ -670,9 +705,12 @@ class JoinedNetworkInNetworkFunction(torch.autograd.Function):
         need = ctx.needs_input_grad
         dW = torch.empty_like(W) if need[0] else None
         db, dXs, r0 = None, [], 0
+        if ctx.fused and need[2] and need[3]:
+            dXs = list(gemm_rows2_bwd(dY, W, Xs[0].shape[1], Xs[1].shape[1]))
         for k, X in enumerate(Xs):
             c = X.shape[1]
-            dXs.append(gemm_table(dY, None, 1, n, W[r0:r0 + c], None, c, L.F_W_TRANSPOSED) if need[2 + k] else None)
+            if len(dXs) <= k:
+                dXs.append(gemm_table(dY, None, 1, n, W[r0:r0 + c], None, c, L.F_W_TRANSPOSED) if need[2 + k] else None)
             if need[0]:
                 if k == 0 and ctx.has_bias and need[1]:
                     dWk, db = wgrad_bias_rules(X, dY, None, None, _identity_prefix(n), 1, 1)

@@ -142,7 +142,7 @@ def _check_grad(name, what, got, o32, o64):
 def test_cfg2_bf16_storage_vs_oracle_with_the_same_roundings_at_150k(gpu, scene150k):
     """The bf16 STORAGE mode (BASELINE configs 3-5) of the full backbone at 150k voxels against the ORACLE evaluated with
     the same storage roundings -- every stored slab after the first layer rounded to bf16, the tile-kernel layers' weights
-    rounded to bf16, the NetworkInNetwork over the JoinTable evaluated part by part -- not against the HIP path's own fp32
+    rounded to bf16 (the NetworkInNetwork over the JoinTable is one two-source launch: no rounding between its parts) -- not against the HIP path's own fp32
     run.  What is left between the two: the summation order inside a layer and, through it, single bf16 roundings that fall
     the other way (0.01 % of a layer's outputs, tools/diag_bf16_layers.py).  A ReLU network amplifies those until they sit
     at the noise floor of bf16 storage itself, so the mirrored roundings show where the path is short -- the first
@@ -171,7 +171,7 @@ def test_cfg2_bf16_storage_vs_oracle_with_the_same_roundings_at_150k(gpu, scene1
     po = {k: v.clone().requires_grad_() for k, v in params.items()}
     fo = feats.clone().requires_grad_()
     rec = []
-    exp = O.unet_forward(scene, fo, po, list(ch), storage=O.bf16_storage, tile_weights=O.bf16_storage, split_nin=True,
+    exp = O.unet_forward(scene, fo, po, list(ch), storage=O.bf16_storage, tile_weights=O.bf16_storage,
                          record=rec)
     exp.backward(gy)
     # second realisation of the same rounded network: values nudged by an fp32 ulp before each storage rounding
@@ -181,7 +181,7 @@ def test_cfg2_bf16_storage_vs_oracle_with_the_same_roundings_at_150k(gpu, scene1
         return O.bf16_storage(t + (t * (torch.randn(t.shape, generator=gen) * 2e-7)).detach())
     p2 = {k: v.clone().requires_grad_() for k, v in params.items()}
     f2 = feats.clone().requires_grad_()
-    exp2 = O.unet_forward(scene, f2, p2, list(ch), storage=nudged, tile_weights=O.bf16_storage, split_nin=True)
+    exp2 = O.unet_forward(scene, f2, p2, list(ch), storage=nudged, tile_weights=O.bf16_storage)
     exp2.backward(gy)
     name = "cfg2_bf16_storage_150k"
     floor = _err(exp2.detach(), exp)
@@ -225,12 +225,12 @@ def test_dropin_path_equals_backbone_path_at_150k(gpu, scene150k):
 # ------------------------------------------------------------------------------------------------ cfg 3
 def _oracle_mask_branch(coords_np, raw, bb_feats, mp, boxes_np, assoc, scene, bf16=False):
     """SparseMaskNetwork forward (model.py:758-782) on the oracle ops, reference configuration (run.py:741-810).
-    bf16: with the storage roundings of the HIP path's bf16 mode (stored slabs and the tile-kernel layers' weights rounded,
-    NetworkInNetwork over the JoinTable part by part; OutputLayer / crop / InputLayer mean / Linear stay fp32)."""
+    bf16: with the storage roundings of the HIP path's bf16 mode (stored slabs and the tile-kernel layers' weights rounded;
+    OutputLayer / crop / InputLayer mean / Linear stay fp32)."""
     relu = torch.relu
     q = O.bf16_storage if bf16 else (lambda t: t)               # stored slabs (gradient passes straight through)
     wq = q                                                      # tile-kernel weights
-    kw = dict(storage=O.bf16_storage, tile_weights=O.bf16_storage, split_nin=True) if bf16 else {}
+    kw = dict(storage=O.bf16_storage, tile_weights=O.bf16_storage) if bf16 else {}
     n0 = scene.n(0)
     ident = [(np.arange(n0, dtype=np.int32),) * 2]
     x = q(O.conv(q(bb_feats), mp["in.weight"], mp["in.bias"], ident, n0))

@@ -960,6 +960,80 @@ def test_small_gemms_bf16_storage_equal_the_fp32_kernels_rounded(gpu, cin, cout)
                                          L.F_W_TRANSPOSED, relu_mask=M.float())))
 
 
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 32), (128, 64), (256, 128), (24, 24), (40, 18), (256, 200)])
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_lds_tiled_row_gemms_reproduce_the_register_kernels_bit_for_bit(gpu, cin, cout, storage):
+    """scn_gemm_lt.hip behind scn_gemm_table (identity table) and scn_gemm_rules: the A tile staged through LDS, the
+    summation order of scn_conv.hip's kernels -- SCN_F_GEMM_V1 runs those, and the results are equal bit for bit, with
+    every epilogue operand (bias, residual, ReLU-backward mask, input ReLU), both weight orientations, ragged tiles."""
+    from sparse_rcnn_amd import functional as F, _lib as L
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=37, cin=8, n=1700, dup=100)
+    sz = tuple(int(s) for s in size)
+    sb = x.metadata.strided_rulebook(sz)
+    n, nc, r = sb.n_fine, sb.n_coarse, sb.rules
+    g = torch.Generator().manual_seed(3 * cin + cout)
+    st = (lambda t: t.to(torch.bfloat16)) if storage == "bf16" else (lambda t: t)
+    X = st(torch.randn(n, cin, generator=g)).to(gpu); R = st(torch.randn(n, cout, generator=g)).to(gpu)
+    M = st(torch.randn(n, cout, generator=g)).to(gpu)
+    W = (torch.randn(1, cin, cout, generator=g) * 0.2).to(gpu); b = torch.randn(cout, generator=g).to(gpu)
+    for fl, kw in ((0, dict(residual=R)), (L.F_RELU_IN, dict(relu_mask=M)), (0, {})):
+        y = F.gemm_table(X, None, 1, n, W, b, cout, fl, **kw)
+        assert torch.equal(y, F.gemm_table(X, None, 1, n, W, b, cout, fl | L.F_GEMM_V1, **kw)), (fl, list(kw))
+    G = st(torch.randn(n, cout, generator=g)).to(gpu); MX = st(torch.randn(n, cin, generator=g)).to(gpu)
+    dx = F.gemm_table(G, None, 1, n, W, None, cin, L.F_W_TRANSPOSED, relu_mask=MX)
+    assert torch.equal(dx, F.gemm_table(G, None, 1, n, W, None, cin, L.F_W_TRANSPOSED | L.F_GEMM_V1, relu_mask=MX))
+    ref = (G.double() @ W[0].double().t()) * (MX.double() > 0)
+    _close(dx.float(), ref, 2e-2 if storage == "bf16" else FEAT_TOL, "dX vs fp64")
+    # rule lists (8 offsets, ragged 128/64/32-rule tiles): Deconvolution forward, Convolution backward-data
+    Xc = st(torch.randn(nc, cin, generator=g)).to(gpu); Wu = (torch.randn(8, cin, cout, generator=g) * 0.2).to(gpu)
+    u = F.gemm_rules(Xc, r.out_rows, r.in_rows, r.prefix_host, 8, n, Wu, b, cout, L.F_RELU_IN)
+    assert torch.equal(u, F.gemm_rules(Xc, r.out_rows, r.in_rows, r.prefix_host, 8, n, Wu, b, cout, L.F_RELU_IN | L.F_GEMM_V1))
+    Wd = (torch.randn(8, cout, cin, generator=g) * 0.2).to(gpu)
+    d = F.gemm_rules(Xc, r.out_rows, r.in_rows, r.prefix_host, 8, n, Wd, None, cout, L.F_W_TRANSPOSED, relu_mask=M)
+    assert torch.equal(d, F.gemm_rules(Xc, r.out_rows, r.in_rows, r.prefix_host, 8, n, Wd, None, cout,
+                                       L.F_W_TRANSPOSED | L.F_GEMM_V1, relu_mask=M))
+
+
+@pytest.mark.parametrize("c0,c1,cout", [(32, 32, 32), (64, 64, 64), (128, 128, 128), (24, 24, 24), (16, 40, 48), (512, 512, 64)])
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_row_gemm_over_join_parts_equals_the_gemm_on_the_concatenated_slab(gpu, c0, c1, cout, storage):
+    """scn_gemm_rows2: NetworkInNetwork over JoinTable([up, skip]) read from the two slabs, and its backward-data written to
+    the two gradient slabs -- bit-equal to the one-source kernel on torch.cat of the parts / to the column split of its
+    one-destination result, and within fp32 tolerance of the fp64 product."""
+    from sparse_rcnn_amd import functional as F, _lib as L
+    n = 3001
+    g = torch.Generator().manual_seed(c0 + 7 * c1 + cout)
+    st = (lambda t: t.to(torch.bfloat16)) if storage == "bf16" else (lambda t: t)
+    X0 = st(torch.randn(n, c0, generator=g)).to(gpu); X1 = st(torch.randn(n, c1, generator=g)).to(gpu)
+    W = (torch.randn(c0 + c1, cout, generator=g) * 0.2).to(gpu); b = torch.randn(cout, generator=g).to(gpu)
+    y = F.gemm_rows2(X0, X1, W, b, cout)
+    cat = torch.cat([X0, X1], 1).contiguous()
+    assert torch.equal(y, F.gemm_table(cat, None, 1, n, W, b, cout))
+    _close(y.float(), cat.double() @ W.double() + b.double(), 2e-2 if storage == "bf16" else FEAT_TOL, "rows2 fwd vs fp64")
+    G = st(torch.randn(n, cout, generator=g)).to(gpu)
+    d0, d1 = F.gemm_rows2_bwd(G, W, c0, c1)
+    both = F.gemm_table(G, None, 1, n, W, None, c0 + c1, L.F_W_TRANSPOSED)
+    assert torch.equal(d0, both[:, :c0]) and torch.equal(d1, both[:, c0:])
+    # the autograd node on top of it, against the part-by-part form
+    Wp = W.clone().requires_grad_(); bp = b.clone().requires_grad_()
+    parts = [X0.clone().requires_grad_(), X1.clone().requires_grad_()]
+    out = F.JoinedNetworkInNetworkFunction.apply(Wp, bp, *parts)
+    assert torch.equal(out, y)
+    out.backward(G)
+    assert torch.equal(parts[0].grad, d0) and torch.equal(parts[1].grad, d1)
+    F.FUSED_JOIN = False
+    try:
+        Wq = W.clone().requires_grad_(); bq = b.clone().requires_grad_()
+        parts2 = [X0.clone().requires_grad_(), X1.clone().requires_grad_()]
+        out2 = F.JoinedNetworkInNetworkFunction.apply(Wq, bq, *parts2)
+        out2.backward(G)
+    finally:
+        F.FUSED_JOIN = True
+    _close(out.float(), out2.float(), 2e-2 if storage == "bf16" else 1e-5, "fused vs chained forward")
+    assert torch.equal(Wp.grad, Wq.grad) and torch.equal(bp.grad, bq.grad)
+    assert torch.equal(parts[0].grad, parts2[0].grad) and torch.equal(parts[1].grad, parts2[1].grad)
+
+
 def test_backbone_with_bf16_features_everywhere_tracks_the_fp32_backbone(gpu):
     """Backbone(bf16_blocks="all"): every layer after the first 1x1 convolution on bf16-stored features."""
     from sparse_rcnn_amd.unet import Backbone

@@ -13,9 +13,9 @@ params = O.init_unet_params(7, list(ch), seed=0)
 scene = O.OracleScene(coords.numpy())
 only27 = lambda w: O.bf16_storage(w) if w.shape[0] == 27 else w
 only8 = lambda w: O.bf16_storage(w) if w.shape[0] == 8 else w
-for mode, kw in (("mirrored", dict(storage=O.bf16_storage, tile_weights=O.bf16_storage, split_nin=True)),
-                 ("round SubM3 weights only", dict(storage=O.bf16_storage, tile_weights=only27, split_nin=True)),
-                 ("round strided weights only", dict(storage=O.bf16_storage, tile_weights=only8, split_nin=True)),
+for mode, kw in (("mirrored", dict(storage=O.bf16_storage, tile_weights=O.bf16_storage)),
+                 ("round SubM3 weights only", dict(storage=O.bf16_storage, tile_weights=only27)),
+                 ("round strided weights only", dict(storage=O.bf16_storage, tile_weights=only8)),
                  ("storage only", dict(storage=O.bf16_storage)), ("fp32 oracle", dict())):
     rec = []
     exp = O.unet_forward(scene, feats, params, list(ch), record=rec, **kw)
@@ -28,7 +28,7 @@ for mode, kw in (("mirrored", dict(storage=O.bf16_storage, tile_weights=O.bf16_s
 
 # ---- level 1 piece by piece, each HIP module fed the ORACLE's own (mirrored) input ------------------------------------
 rec = []
-O.unet_forward(scene, feats, params, list(ch), record=rec, storage=O.bf16_storage, tile_weights=O.bf16_storage, split_nin=True)
+O.unet_forward(scene, feats, params, list(ch), record=rec, storage=O.bf16_storage, tile_weights=O.bf16_storage)
 rec = dict(rec)
 net = Backbone(7, ch, bf16_blocks="all").cuda()
 net.unet.load_oracle_params(params)

@@ -683,8 +683,9 @@ class JoinedNetworkInNetworkFunction(torch.autograd.Function):
         n, cout = Xs[0].shape[0], W.shape[-1]
         if sum(X.shape[1] for X in Xs) != W.shape[0]:
             raise L.ScnError("JoinTable parts do not add up to the NetworkInNetwork's input width")
-        ctx.fused = (FUSED_JOIN and len(Xs) == 2 and Xs[0].dtype == Xs[1].dtype and Xs[0].shape[1] % 8 == 0
-                     and Xs[1].shape[1] % 8 == 0 and n > 0)
+        c0, c1 = (Xs[0].shape[1], Xs[1].shape[1]) if len(Xs) == 2 else (0, 0)
+        ctx.fused = (FUSED_JOIN and len(Xs) == 2 and Xs[0].dtype == Xs[1].dtype and c0 >= 8 and c1 >= 8 and c0 % 8 == 0
+                     and c1 % 8 == 0 and n > 0)
         if ctx.fused:
             y = gemm_rows2(Xs[0], Xs[1], W, b, cout)
         else:
@@ -705,7 +706,7 @@ class JoinedNetworkInNetworkFunction(torch.autograd.Function):
         need = ctx.needs_input_grad
         dW = torch.empty_like(W) if need[0] else None
         db, dXs, r0 = None, [], 0
-        if ctx.fused and need[2] and need[3]:
+        if ctx.fused and need[2] and need[3] and dY.shape[1] % 8 == 0:       # (the kernel stages dY in 8-channel groups)
             dXs = list(gemm_rows2_bwd(dY, W, Xs[0].shape[1], Xs[1].shape[1]))
         for k, X in enumerate(Xs):
             c = X.shape[1]

@@ -341,28 +341,47 @@ def side_measurements(job, args, world, dist, torch):
 def dropin_measurement(job, args, torch):
     """The same backbone driven the way the reference's module tree drives the scn surface: CustomInputLayer creates the
     Metadata inside the forward (custom_operations.py:67-83), rulebooks are built lazily by the first layer that needs
-    them, no helper thread."""
+    them, no helper thread.  Timed twice: as is, and with the training loop's batches wrapped in scn.index_prefetching
+    (one line around the data loader) so that the coming batch's index build overlaps this one's kernels."""
+    import sparse_rcnn_amd as scn
     from sparse_rcnn_amd.unet import DropinBackbone
     net = DropinBackbone(job.model.backbone)
     n = max(5, min(10, args.steps))
-    gy = None
-    for i in range(n + 3):
-        if i == 3:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        job.flat.zero_grad()
-        fin = job.feats.detach().requires_grad_()
-        out = net(job.coords_cpu, fin, job.size, 1)
-        if gy is None:
-            gy = torch.randn_like(out.features)
-        out.features.backward(gy)
-        job.flat.all_reduce_mean()
-        job.flat.sgd_step(job.lr)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / n * 1e3
+
+    # what a DataLoader yields: another host coords tensor per batch (same scene here).  Three recycled buffers, as a
+    # loader's shared-memory blocks are: a FRESH 5.5 MB host allocation per step costs this pool's boxes a ~90 ms stall
+    # every few steps (mmap / page-fault work under the process's mmap lock, which every HIP call of every thread needs;
+    # tools/diag_host_coords3.py) -- an effect of the host allocator, not of the path measured here
+    ring = [job.coords_cpu.clone() for _ in range(3)]
+
+    def loader(count):
+        for i in range(count):
+            yield (ring[i % 3], job.size, 1)
+
+    def timed(batches):
+        gy, t0 = None, None
+        for i, (coords, size, bs) in enumerate(batches):
+            if i == 3:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            job.flat.zero_grad()
+            fin = job.feats.detach().requires_grad_()
+            out = net(coords, fin, size, bs)
+            if gy is None:
+                gy = torch.randn_like(out.features)
+            out.features.backward(gy)
+            job.flat.all_reduce_mean()
+            job.flat.sgd_step(job.lr)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    ms = timed(loader(n + 3))
+    ms_pf = timed(scn.index_prefetching(loader(n + 3), lambda b: b))
     return {"ms_per_step": ms, "value": job.n_active / (ms * 1e-3),
+            "ms_per_step_index_prefetching": ms_pf, "value_index_prefetching": job.n_active / (ms_pf * 1e-3),
             "note": "layer-by-layer scn module path with the Metadata created inside the forward from HOST coords "
-                    "(the reference's CustomInputLayer contract), rulebooks built on first use, no helper thread"}
+                    "(the reference's CustomInputLayer contract), rulebooks built on first use, no helper thread; "
+                    "`index_prefetching`: the same with the loop's batches wrapped in scn.index_prefetching (the coming "
+                    "batch's index build runs on the helper thread during this batch)"}
 
 
 def main():

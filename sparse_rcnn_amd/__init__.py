@@ -10,7 +10,7 @@ hand-written gfx950 HIP kernels behind the C ABI of include/scn_mi355x.h (libscn
 from . import ioLayers                                                     # noqa: F401  (scn.ioLayers.*Function)
 from ._lib import ScnError, EXPORTS, LIB_PATH, load as load_library          # noqa: F401
 from .ioLayers import InputLayer, OutputLayer                              # noqa: F401
-from .metadata import Metadata                                             # noqa: F401
+from .metadata import Metadata, index_prefetching, prefetch_index           # noqa: F401
 from .modules import (AddTable, AveragePooling, BatchNormLeakyReLU, BatchNormReLU, CastFeatures, ConcatTable,  # noqa: F401
                       Convolution, Deconvolution, Identity, JoinTable, MaxPooling, NetworkInNetwork, ReLU,
                       Sequential, SparseToDense, SubmanifoldConvolution)
@@ -20,4 +20,5 @@ __all__ = [
     "Metadata", "SparseConvNetTensor", "ioLayers", "InputLayer", "OutputLayer", "Sequential", "ConcatTable",
     "AddTable", "JoinTable", "Identity", "ReLU", "BatchNormReLU", "BatchNormLeakyReLU", "Convolution",
     "Deconvolution", "SubmanifoldConvolution", "NetworkInNetwork", "MaxPooling", "AveragePooling", "SparseToDense",
+    "prefetch_index", "index_prefetching",
 ]

@@ -4,7 +4,7 @@ import torch
 from torch.nn import Module
 
 from .functional import InputLayerFunction, OutputLayerFunction
-from .metadata import Metadata
+from .metadata import Metadata, take_prefetched
 from .tensor import SparseConvNetTensor
 
 
@@ -22,9 +22,15 @@ class InputLayer(Module):
     def forward(self, input, metadata=None):
         coords, features = input[0], input[1]
         batch_size = input[2] if len(input) == 3 else 0
-        md = metadata if metadata is not None else Metadata(self.dimension)
-        feats = InputLayerFunction.apply(self.dimension, md, self.spatial_size, coords.long(), features, batch_size,
-                                         self.mode)
+        coords = coords.long()
+        md = metadata
+        if md is None:
+            md = take_prefetched(coords)                    # announced by scn.prefetch_index for this very tensor
+            if md is not None and md.input_size != tuple(int(s) for s in self.spatial_size.tolist()):
+                md = None                                   # announced with another spatial size: build here
+        if md is None:
+            md = Metadata(self.dimension)
+        feats = InputLayerFunction.apply(self.dimension, md, self.spatial_size, coords, features, batch_size, self.mode)
         return SparseConvNetTensor(features=feats, metadata=md, spatial_size=self.spatial_size)
 
 

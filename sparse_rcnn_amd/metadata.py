@@ -56,6 +56,58 @@ class PendingMetadata:
         return self._future.result()             # re-raises what the build raised
 
 
+# ---- index prefetch for the drop-in path -----------------------------------------------------------------------------
+# The reference's CustomInputLayer (custom_operations.py:67-83) builds `scn.InputLayer(...)([coords, features, batch_size])`
+# inside the forward: the layer has no say in when the index structures are built.  They depend on the coordinates only, so
+# whoever holds the NEXT batch can have them built while the current one runs: `prefetch_index(coords, ...)` starts the
+# build on the helper thread / index stream and parks it under the identity of the coords tensor; the InputLayer that later
+# receives that very tensor adopts it (ioLayers.InputLayer.forward).  `index_prefetching(loader, extract)` is the one-line
+# form for a training loop.
+_prefetched: "Dict[tuple, PendingMetadata]" = {}
+_PREFETCH_KEEP = 4
+
+
+def _coords_key(coords: torch.Tensor):
+    return (coords.data_ptr(), coords._version, tuple(coords.shape), str(coords.device))
+
+
+def prefetch_index(coords: torch.Tensor, spatial_size, batch_size: int = 0, mode: int = 4, n_levels: int = 0, k: int = 3):
+    """Start building the index structures of a COMING batch (InputLayer rules + the rulebook pyramid as deep as the last
+    network over this spatial size went, Metadata.LEVELS_HINT).  coords: the int64 [N, 4] tensor the forward will hand to
+    scn.InputLayer -- the same tensor object, unmodified."""
+    size = tuple(int(s) for s in torch.as_tensor(spatial_size).reshape(-1).tolist())
+    levels = n_levels or Metadata.LEVELS_HINT.get(size, 0)
+    while len(_prefetched) >= _PREFETCH_KEEP:                 # batches that were announced and never run
+        _prefetched.pop(next(iter(_prefetched)))
+    pending = Metadata(len(size)).prepare_in_thread(spatial_size, coords, int(batch_size), mode, levels, k)
+    _prefetched[_coords_key(coords)] = pending
+    return pending
+
+
+def take_prefetched(coords: torch.Tensor):
+    """The Metadata prefetched for exactly this coords tensor, or None."""
+    if not _prefetched:
+        return None
+    pending = _prefetched.pop(_coords_key(coords), None)
+    return None if pending is None else pending.result()
+
+
+def index_prefetching(batches, extract):
+    """Wrap a data loader: yields its batches unchanged, and before yielding batch i announces batch i+1's coordinates
+    (extract(batch) -> (coords, spatial_size, batch_size)) with prefetch_index, so that their index build overlaps batch
+    i's kernels.      for batch in scn.index_prefetching(loader, lambda b: (b[0], b[2], b[3])): ..."""
+    it = iter(batches)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        prefetch_index(*extract(nxt))
+        yield cur
+        cur = nxt
+    yield cur
+
+
 @dataclass
 class Grid:
     coords: torch.Tensor            # int32 [N,4] device

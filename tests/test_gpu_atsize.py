@@ -220,6 +220,15 @@ def test_dropin_path_equals_backbone_path_at_150k(gpu, scene150k):
     hinted = drop(coords, feats.to(gpu), size, 1)                           # second: one scn_pyramid_build call
     assert getattr(hinted.metadata, "_workspace", None) is not None
     assert torch.equal(lazy, ref) and torch.equal(hinted.features, ref)
+    # the training loop's batches wrapped in scn.index_prefetching: batch i+1's index structures are built on the helper
+    # thread while batch i runs, and the InputLayer inside the forward adopts them (same tensor object) -- same bits
+    from sparse_rcnn_amd import metadata as MD
+    batches = [(coords.clone(), size, 1) for _ in range(3)]
+    outs = [drop(c, feats.to(gpu), s_, b) for c, s_, b in scn.index_prefetching(batches, lambda t: t)]
+    assert all(torch.equal(o.features, ref) for o in outs)
+    assert outs[0].metadata._prepared_for is None                       # the first batch was never announced
+    assert outs[1].metadata._prepared_for is not None and outs[2].metadata._prepared_for is not None
+    assert not MD._prefetched
 
 
 # ------------------------------------------------------------------------------------------------ cfg 3

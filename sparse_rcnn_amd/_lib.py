@@ -144,10 +144,14 @@ def check(rc: int):
         raise ScnError(f"libscn_mi355x error {rc}: {load().scn_last_error_string().decode()}")
 
 
+_raw_stream, _get_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+
+
 def stream() -> int:
-    """Raw hipStream_t of torch's current stream (torch.cuda.current_stream() costs ~9 us per call in Python, and
-    every C call needs the handle: ~0.7 ms of host time per benchmark step)."""
-    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+    """Raw hipStream_t of torch's current stream.  torch.cuda.current_stream() costs ~9 us per call in Python and
+    torch.cuda.current_device() ~1 us (lazy-init checks); every C call needs the handle (560 calls per config-3 step), so
+    this goes to the two C bindings directly -- lib() has already made sure the GPU context exists."""
+    return _raw_stream(_get_device())
 
 
 _scratch = {}
@@ -157,7 +161,7 @@ def scratch(nbytes: int, device):
     """Scratch buffer for a kernel call on the CURRENT stream: one growing buffer per (device, stream).  Calls on a
     stream are ordered, and every scratch user has finished with it when its call's last kernel ends, so the next
     call on the same stream may overwrite it."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), stream())
+    key = (device.index if device.index is not None else _get_device(), stream())
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = _scratch[key] = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -170,7 +174,7 @@ _arrival = {}
 def arrival(n: int, device):
     """Zeroed int32 arrival counters for the in-launch K reduction of scn_conv_tiles on the CURRENT stream: one growing
     buffer per (device, stream), zeroed when it is (re)allocated -- the kernels leave it zero (include/scn_mi355x.h)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), stream())
+    key = (device.index if device.index is not None else _get_device(), stream())
     buf = _arrival.get(key)
     if buf is None or buf.numel() < n:
         buf = _arrival[key] = torch.zeros(max(int(n), 1 << 16), dtype=torch.int32, device=device)

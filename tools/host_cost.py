@@ -62,6 +62,8 @@ with torch.no_grad():
         m.backbone(job.coords, fin, job.size, 1, metadata=md)
     torch.cuda.synchronize()
     print(f"backbone forward only (no_grad, index structures given): {1e3 * (time.perf_counter() - t0) / n:.2f} ms")
+# backward on the calling thread, so that the profile below sees the Python side of the backward functions too
+torch.autograd.set_multithreading_enabled(False)
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(10):
@@ -69,5 +71,5 @@ for _ in range(10):
 pr.disable()
 torch.cuda.synchronize()
 st = io.StringIO()
-pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(40)
-print(st.getvalue()[:8000])
+pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(70)
+print(st.getvalue()[:16000])

@@ -29,10 +29,11 @@ from .unet import SparseUNet, units
 
 
 class MaskBranch(nn.Module):
-    # True: build the ROI batch's selection + rulebooks on a helper thread beside the scene-level layers.  Measured on one
-    # box (tools/ab_roi_prefetch.sh, profiles/r2_ab_roi_prefetch.log): fp32 12.4-12.9 ms either way, bf16 9.6-9.9 ms inline
-    # against 9.7-12.8 ms with the helper (two Python threads issuing ~13 us launches share one interpreter lock) -> inline.
-    PREFETCH_ROI_INDEX = os.environ.get("SCN_ROI_PREFETCH", "0") != "0"
+    # Where the ROI batch's selection + rulebooks are built: "0" inline on the caller's stream | "thread": helper thread +
+    # its own stream | "stream": its own stream, caller's thread.  Measured on one box each (tools/ab_roi_prefetch.sh,
+    # profiles/r2_ab_roi_prefetch.log): fp32 12.1-12.9 ms whichever way; bf16 9.6-10.2 ms inline, 9.7-12.8 with the helper
+    # thread (two Python threads issuing launches share one interpreter lock), 10.0-11.6 on the side stream -> inline.
+    PREFETCH_ROI_INDEX = os.environ.get("SCN_ROI_PREFETCH", "0")       # "0" inline | "thread" | "stream"
 
     def __init__(self, backbone_channels=32, raw_channels=7, input_channels=16, unet_channels=(32, 48, 64),
                  linear_channels=(32, 18), bf16_blocks=False):
@@ -72,7 +73,10 @@ class MaskBranch(nn.Module):
         size = torch.as_tensor([int(s) for s in spatial_size], dtype=torch.long) + self.spatial_size_extention
         # the crop's selection and the ROI batch's index structures depend on coordinates and boxes only: a helper thread
         # builds them (its own high-priority stream) while the scene-level layers below are queued and run
-        pending = self.output_roi_cut.prepare_cut_in_thread(coords, size, selected_bbox) if self.PREFETCH_ROI_INDEX else None
+        how = self.PREFETCH_ROI_INDEX
+        how = {True: "thread", False: "0", "1": "thread"}.get(how, how)
+        pending = None if how == "0" else self.output_roi_cut.prepare_cut_in_thread(coords, size, selected_bbox,
+                                                                                  in_thread=how == "thread")
         if self.bf16:       # the scene-level units on bf16-stored features; the per-point gather (OutputLayer) takes fp32
             converted = M.CastFeatures(torch.float32)(self.input_conv_layer(M.CastFeatures(torch.bfloat16)(backbone_features)))
         else:

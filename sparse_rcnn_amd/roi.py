@@ -281,11 +281,13 @@ class SparseRoiCut(torch.nn.Module):
             box_features = fec.combine(new_coords, new_features, spatial_size, sel.n_boxes)
         return box_features, (sel.is_inside() if self.dense_inside else sel, counts, batch_splits)
 
-    def prepare_cut_in_thread(self, coords, spatial_size, bbox_batch, n_levels=0):
+    def prepare_cut_in_thread(self, coords, spatial_size, bbox_batch, n_levels=0, in_thread=True):
         """Start building what the cut needs from coordinates and boxes alone -- the selection list and, for the
         RawToTensor combiner, the InputLayer rules + rulebook pyramid of the ROI batch (n_levels; 0: the depth the last
-        network over this spatial size used, Metadata.LEVELS_HINT) -- on a helper thread and its own high-priority stream.
-        Returns a handle for `forward(..., prepared=)`."""
+        network over this spatial size used, Metadata.LEVELS_HINT) -- on its own high-priority stream, so that the host
+        waits of the build (row counts) wait for index kernels only and not for whatever the caller has queued before.
+        in_thread: on a helper thread as well (False: on the caller's thread, which then blocks for the build's own
+        ~1 ms while the GPU works through the caller's queue).  Returns a handle for `forward(..., prepared=)`."""
         from concurrent.futures import ThreadPoolExecutor
         global _roi_pool, _roi_stream
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -327,11 +329,16 @@ class SparseRoiCut(torch.nn.Module):
                 ev.record(side)
             return boxes, counts, sel, md, ev
 
-        fut = _roi_pool.submit(fn)
+        if in_thread:
+            fut = _roi_pool.submit(fn)
+            get = fut.result
+        else:
+            done = fn()
+            get = lambda: done
 
         class _Pending:
             def result(self_inner):
-                boxes, counts, sel, md, ev = fut.result()
+                boxes, counts, sel, md, ev = get()
                 torch.cuda.current_stream().wait_event(ev)
                 return boxes, counts, sel, md
         return _Pending()

@@ -204,6 +204,15 @@ int64_t scn_tiles_scratch_bytes(int n_off, int64_t n);
 int scn_tiles_build(const int32_t* table, int n_off, int64_t n, int32_t* perm, int32_t* tstab, uint32_t* tile_mask,
                     int32_t* tile_order, void* scratch, scn_stream_t stream);
 
+/* Stable LSD radix sort of (uint32 key, int32 value) pairs on the low `bits` key bits -- the primitive behind
+ * scn_tiles_build (rows by offset mask, tiles by offset count); exported so that it can be checked on its own.  It takes
+ * the place of the hash-map iteration order upstream leaves undefined (canonical orders are sorted orders).
+ * vals == NULL: values are the input positions.  Outputs must not alias the inputs.  ceil(bits/9) passes of <= 512 bins;
+ * n <= 4096 runs as one launch out of LDS. */
+int64_t scn_sort_pairs_scratch_bytes(int64_t n);
+int scn_sort_pairs(const uint32_t* keys, const int32_t* vals, int64_t n, int bits, uint32_t* keys_out,
+                   int32_t* vals_out, void* scratch, scn_stream_t stream);
+
 /* THE HOT KERNEL.  Output-stationary convolution over mask-sorted tiles, accumulators in registers, weights in LDS:
  *     Y[r] = residual[r] + bias + sum_o in(X[table[o][r]]) . W[o']          (same result as scn_gemm_table)
  * Serves SubmanifoldConvolution fwd / backward-data (module_factory.py:404-406), Convolution fwd (:232-234) and

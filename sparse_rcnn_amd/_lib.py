@@ -42,6 +42,8 @@ _SIGS = {
     "scn_gemm_table": (C.c_int, [p, i64, i32, p, i32, i64, p, p, p, p, p, i32, i32, p]),
     "scn_tiles_scratch_bytes": (i64, [i32, i64]),
     "scn_tiles_build": (C.c_int, [p, i32, i64, p, p, p, p, p, p]),
+    "scn_sort_pairs_scratch_bytes": (i64, [i64]),
+    "scn_sort_pairs": (C.c_int, [p, p, i64, i32, p, p, p, p]),
     "scn_conv_tiles_scratch_bytes": (i64, [i32, i64, i32]),
     "scn_conv_tiles_arrival_counters": (i64, [i32, i64, i32]),
     "scn_conv_tiles": (C.c_int, [p, i64, i32, p, p, p, p, i32, i64, p, p, p, p, p, i32, i32, p, p, p]),

@@ -144,7 +144,15 @@ def run(args):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ranks_seen = 1
-    if world > 1:
+    # SCN_BENCH_FORCE_DIST=1: create the process group even for one rank (a 1-GPU box rehearses the RCCL code path:
+    # communicator setup, bucketed all-reduce from the gradient hooks, barriers)
+    force_dist = bool(os.environ.get("SCN_BENCH_FORCE_DIST")) and world == 1
+    if force_dist:
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    dist_on = world > 1 or force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
@@ -183,7 +191,7 @@ def run(args):
     # the timed region; collect now and move the survivors to the permanent generation, as a training loop would
     gc.collect()
     gc.freeze()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -194,7 +202,7 @@ def run(args):
         job.step()
     job.finish()                             # the index build started in the last timed step ends inside the timed region
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
     profiling.TIMER = None
@@ -203,7 +211,7 @@ def run(args):
     red_dev = dev if (world == 1 or backend == "nccl") else "cpu"
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     vox = torch.tensor([float(job.n_active)], dtype=torch.float64, device=red_dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(vox, op=dist.ReduceOp.SUM)
     dt, total_vox = tmax.item(), vox.item()
@@ -231,7 +239,7 @@ def run(args):
             "config": {"workload": job.describe(),
                        "parallelism": f"dp{world} (1 scene/GPU, flat-bucket all-reduce)"},
             "n_ranks_seen_by_rccl": ranks_seen if backend == "nccl" else None,
-            "n_ranks_seen": ranks_seen, "collective_backend": backend if world > 1 else None,
+            "n_ranks_seen": ranks_seen, "collective_backend": backend if dist_on else None,
         }
         out.update(extras)
         if ks:
@@ -250,7 +258,7 @@ def run(args):
         os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     return 0

@@ -10,6 +10,8 @@ bottom-level weights (60 % of the bytes) are complete halfway through backward.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -41,7 +43,9 @@ class FlatParams:
     def _setup_buckets(self, n_buckets):
         self.buckets = []                 # (param indices, flat slice), in the order backward completes them
         self._bucket_of, self._pending, self._works, self._launched = {}, [], [], []
-        if n_buckets <= 0 or not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        # (SCN_DP_FORCE_BUCKETS: take the overlapped path with a single rank too -- a 1-GPU rehearsal of the RCCL calls)
+        min_world = 1 if os.environ.get("SCN_DP_FORCE_BUCKETS") else 2
+        if n_buckets <= 0 or not (dist.is_available() and dist.is_initialized() and dist.get_world_size() >= min_world):
             return
         total = self.flat.numel()
         target = -(-total // n_buckets)

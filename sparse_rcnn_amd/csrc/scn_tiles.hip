@@ -26,7 +26,7 @@
 using scn::S;
 using scn::cdiv;
 
-// Sort key = the offset mask with its bits PERMUTED: bit position of offset o is key_bit[o].  For 3^3 tables the rare
+// Sort key = Gray-code rank of the offset mask with its bits PERMUTED: bit position of offset o is key_bit[o].  For 3^3 tables the rare
 // offsets (the 8 corners, then the 12 edges) take the most significant positions, faces and the centre the least: rows
 // that differ only in common offsets end up adjacent.  Measured executed/useful 1.31 vs 1.38 (natural bit order) at
 // 150k voxels.  Other table shapes keep the natural order.
@@ -51,6 +51,11 @@ __global__ void k_row_masks(const int* __restrict__ table, int n_off, long long 
          r += (long long)gridDim.x * blockDim.x) {
         unsigned m = 0;
         for (int o = 0; o < n_off; ++o) m |= (table[(long long)o * n + r] >= 0 ? 1u : 0u) << kb.pos[o];
+        // sort key = RANK of the permuted mask in the reflected Gray code (binary value whose Gray code is m): masks that
+        // follow each other in this order differ in few offsets, so the tiles that mix several masks visit fewer offsets
+        // than in binary order -- executed/useful 1.276 / 1.157 / 1.173 / 1.253 on the four levels of the cfg-2 scene
+        // against 1.311 / 1.175 / 1.186 / 1.267
+        m ^= m >> 1; m ^= m >> 2; m ^= m >> 4; m ^= m >> 8; m ^= m >> 16;
         key[r] = m;
     }
 }
@@ -66,7 +71,8 @@ __global__ void k_build_tiles(const int* __restrict__ table, int n_off, long lon
         const bool ok = e < n;
         const int row = ok ? sorted_rows[e] : -1;
         perm[e] = row;
-        const unsigned key = ok ? sorted_key[e] : 0u;
+        const unsigned rank = ok ? sorted_key[e] : 0u;
+        const unsigned key = rank ^ (rank >> 1);            // Gray code of the rank = the permuted mask
         unsigned m = 0;                                     // the real offset mask: undo the key's bit permutation
         for (int o = 0; o < n_off; ++o) {
             const unsigned have = (key >> kb.pos[o]) & 1u;

@@ -1,6 +1,6 @@
 """Developer tool: per-kernel sums of a rocprofv3 --pmc counter_collection.csv (averaged over dispatches)."""
 import csv, glob, sys, collections
-rows = list(csv.DictReader(open(glob.glob(sys.argv[1] + "/*/*counter_collection.csv")[0])))
+rows = list(csv.DictReader(open((glob.glob(sys.argv[1] + "/*/*counter_collection.csv") + glob.glob(sys.argv[1] + "/*counter_collection.csv"))[0])))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     k = r["Kernel_Name"].split("(")[0].replace("void ", "")[:48]

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     const int ka = kc + 4 * kq;
     const bool k0_ok = ka + 3 < cin, k1_ok = ka + 16 + 3 < cin;
     const int nA = n0 + i, nB = n0 + 16 + i;
-    const bool single = n_kc == 1;
+    const bool single = !FUSED && n_kc == 1;            // (the host picks FUSED only for n_kc > 1)
     const bool direct = single || FUSED;                // this launch writes Y itself
     const float bA = (direct && bias && nA < cout) ? bias[nA] : 0.f;
     const float bB = (direct && bias && nB < cout) ? bias[nB] : 0.f;
@@ -192,6 +192,27 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     const __amdgpu_buffer_rsrc_t xrsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(unsigned)(n_in * cin * 4), 0x00020000);
     const int row_bytes = cin * 4, lane_boff = ka * 4;
+    // Epilogue operands (residual, ReLU-backward mask) through raw buffer descriptors too (FULLK): a missing operand is a
+    // descriptor of zero records (every load returns 0 without touching memory), so the loads are UNCONDITIONAL and can be
+    // issued when a tile STARTS -- they are back long before its epilogue, which used to be a dependent round trip per
+    // tile (SQ counters, profiles/r2c_sq_counters.txt: the backward-data launches ran 12-14 % more cycles than the forward).
+    const bool use_res = direct && residual != nullptr, use_mask = direct && relu_mask != nullptr;
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)residual, 0, use_res ? (int)(unsigned)(n_out * cout * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)relu_mask, 0, use_mask ? (int)(unsigned)(n_out * cout * 4) : 0, 0x00020000);
+    const int out_row_bytes = cout * 4;
+    const int colA_b = nA < cout ? nA * 4 : (int)0x7FFFFFF0, colB_b = nB < cout ? nB * 4 : (int)0x7FFFFFF0;
+#define TS_LOAD_OPS(OROW, RS, MK)                                                                    \
+    do {                                                                                             \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                           \
+            const int ro_ = __mul24((OROW)[j_], out_row_bytes);          /* row -1 -> out of range */  \
+            RS[j_][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, ro_ + colA_b, 0, 0)); \
+            RS[j_][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, ro_ + colB_b, 0, 0)); \
+            MK[j_][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mrsrc, ro_ + colA_b, 0, 0)); \
+            MK[j_][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mrsrc, ro_ + colB_b, 0, 0)); \
+        }                                                                                            \
+    } while (0)
 #define TS_GATHER(IDX, A0, A1)                                                                       \
     do {                                                                                             \
         if (TS_EXP >= 1) { A0 = (f32x4){(float)(IDX), 1.f, 2.f, 3.f}; A1 = A0; }                        \
@@ -273,7 +294,6 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     // requested first and consumed afterwards (one wait, not eight round trips).
     auto ts_write = [&](const int (&orow)[4], const f32x4& c0, const f32x4& c1) {
         float rs[4][2], mk[4][2];
-        const bool use_res = direct && residual != nullptr, use_mask = direct && relu_mask != nullptr;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const long long off = (long long)(orow[j] < 0 ? 0 : orow[j]) * cout;
@@ -307,10 +327,32 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
             }
         }
     };
+    auto ts_store = [&](const int (&orow)[4], const f32x4& c0, const f32x4& c1, const float (&rs)[4][2],
+                        const float (&mk)[4][2]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = orow[j];
+            if (row < 0) continue;
+            const long long off = (long long)row * cout;
+            if (nA < cout) {
+                float y = c0[j] + (res_last ? 0.f : rs[j][0]);
+                if (use_mask && !(mk[j][0] > 0.f)) y = 0.f;
+                if (res_last) y += rs[j][0];
+                out[off + nA] = y;
+            }
+            if (nB < cout) {
+                float y = c1[j] + (res_last ? 0.f : rs[j][1]);
+                if (use_mask && !(mk[j][1] > 0.f)) y = 0.f;
+                if (res_last) y += rs[j][1];
+                out[off + nB] = y;
+            }
+        }
+    };
     // in-launch K reduction (FUSED): q1 = tile whose partial is published and not yet ticketed, q2 = tile whose ticket is
     // in flight (tk_v holds it in lane 0); -1 = none.  Callers drain the wave's memory operations first.
     long long q1 = -1, q2 = -1;
     int tk_v = 0;
+    int orow_q1[4] = {-1, -1, -1, -1}, orow_q2[4] = {-1, -1, -1, -1};     // output rows of the tiles q1 / q2 (FULLK)
     auto ts_publish = [&](long long t, const f32x4& c0, const f32x4& c1) {
         const int sb = (int)((t * n_chunks + chunk) * n_kc + kci) * (TS_T * TS_CT * 4) + lane * 16;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, c0), srsrc,
@@ -328,8 +370,15 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
                 const int unit = (int)(q2 * n_chunks + chunk);
                 if (lane == 0) __hip_atomic_store(counters + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 int orow2[4];
+                float rs2[4][2], mk2[4][2];
+                if constexpr (FULLK) {          // rows kept from the tile's own pass; operands requested with the partials
 #pragma unroll
-                for (int j = 0; j < 4; ++j) orow2[j] = perm[q2 * TS_T + 4 * kq + j];
+                    for (int j = 0; j < 4; ++j) orow2[j] = orow_q2[j];
+                    TS_LOAD_OPS(orow2, rs2, mk2);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) orow2[j] = perm[q2 * TS_T + 4 * kq + j];
+                }
                 const int sb = (unit * n_kc) * (TS_T * TS_CT * 4) + lane * 16;
                 // bias + slab[0] + slab[1] + ... in ascending K-chunk order (the association of k_conv_ts_sum)
                 f32x4 y0 = {bA, bA, bA, bA}, y1 = {bB, bB, bB, bB};
@@ -346,7 +395,8 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
                         if (k0 + u < n_kc) { y0 += p0[u]; y1 += p1[u]; }
                     }
                 }
-                ts_write(orow2, y0, y1);
+                if constexpr (FULLK) ts_store(orow2, y0, y1, rs2, mk2);
+                else ts_write(orow2, y0, y1);
             }
         }
         // (b) the stores of q1 are drained: take its ticket
@@ -354,6 +404,8 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
             tk_v = __hip_atomic_fetch_add(counters + (int)(q1 * n_chunks + chunk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         q2 = q1;
         q1 = -1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) orow_q2[j] = orow_q1[j];
     };
 
     // ---- tile loop: the id, mask and output rows of the NEXT tile are fetched while the current one computes --------
@@ -365,6 +417,10 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         for (int j = 0; j < 4; ++j) orow[j] = orow_next[j];
         const int* tb_s = tstab + tile * n_off * TS_T;              // wave-uniform base; the lane adds i
         const int n_steps = __popc(m);
+        float rs_t[4][2], mk_t[4][2];
+        if constexpr (FULLK) {
+            if (!(FUSED && !single)) TS_LOAD_OPS(orow, rs_t, mk_t);    // oldest loads of the tile: back before its epilogue
+        }
         if (TS_TIMELINE) { tl_tiles += 1; tl_steps += n_steps; }
         tile_next = grab();
         if (tile_next >= 0) {
@@ -422,9 +478,12 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ts_retire();
             ts_publish(tile, c0, c1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) orow_q1[j] = orow[j];
             continue;
         }
-        ts_write(orow, c0, c1);
+        if constexpr (FULLK) ts_store(orow, c0, c1, rs_t, mk_t);
+        else ts_write(orow, c0, c1);
     }
     if (FUSED && !single) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -473,6 +532,7 @@ __global__ void k_conv_ts_sum(const float* __restrict__ slabs, int n_kc, long lo
 
 #undef TS_STEP
 #undef TS_GATHER
+#undef TS_LOAD_OPS
 
 // scratch = [256 reserved bytes] [slabs if n_kc > 1: n_kc partial tiles of 16 x 32 floats per (tile, column chunk)]
 // (covers both slab layouts: the fused kernel's fragment-major one and the row-major one of the two-launch form)
@@ -517,7 +577,8 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     const bool vec = (cin % 4 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0);
     const bool vecn = (cout % 4 == 0) && (((uintptr_t)W & 15) == 0);
     // the fast path addresses X through a raw buffer descriptor: 32-bit byte offsets, 24-bit row indices
-    const bool fullk = vec && n_in < (1ll << 23) && n_in * cin * 4 < (1ll << 32) - (1ll << 24);
+    const bool fullk = vec && n_in < (1ll << 23) && n_in * cin * 4 < (1ll << 32) - (1ll << 24) &&
+                       n_out < (1ll << 23) && n_out * cout * 4 < (1ll << 31);
     const bool part = cin % TS_KC != 0;
     dim3 grid((unsigned)(n_tg * n_chunks * n_kc));
     hipStream_t st = S(stream);

@@ -15,7 +15,10 @@
 //   * lane (i, kq) gathers ONE 16-byte piece per step: row tstab[t][o][i], channels kc + 8 kq .. + 7 (A fragment layout
 //     of the instruction: A[row l & 15][k = 8 (l >> 4) + j]);
 //   * the LDS image is [o][n][k], k contiguous: the B fragment of lane (i, kq) for column block nb is the 16 bytes at
-//     ((o CT + 16 nb + i) 32 + 8 kq) -- a wave reads 1 KB contiguous, conflict-free ds_read_b128;
+//     ((o CT + 16 nb + i) 32 + 8 kq) -- a wave reads 1 KB contiguous with ds_read_b128.  (Lanes of a 16-lane group are
+//     64 bytes apart, so SQ_LDS_BANK_CONFLICT is 0.42-0.46 of the LDS cycles; the piece order 16 kq + i, where 16 lanes
+//     read 256 consecutive bytes, was built and measured in round 2c: 23.7 / 29.9 / 28.1 / 29.3 us per launch on the
+//     four levels against 23.9 / 29.2 / 27.2 / 29.2 -- the kernel waits for its row gathers, not for LDS.)
 //   * input ReLU is one v_pk_max_i16 per register (a negative bf16 is a negative int16).
 // C/D: acc[nb][j] = D[row 4 kq + j][MFMA column i of block nb].  The image assigns ACTUAL column n0 + NB i + nb to MFMA
 // column i of block nb, so a lane's NB accumulators of a row are NB CONSECUTIVE output columns: one 2 NB-byte store (and

@@ -63,3 +63,11 @@ ids = np.nonzero(live)[0]
 for x in range(8):
     sel = ids % 8 == x
     print(f"  blockIdx % 8 == {x}: end mean {wg_end[sel].mean():.1f} us  min {wg_end[sel].min():.1f}  max {wg_end[sel].max():.1f}  steps mean {wg_steps[sel].mean():.0f}")
+# where the wave-time of the launch goes (fractions of waves x kernel span)
+span = float(d[:, 2].max() - t0)
+tot = span * len(d)
+print(f"wave-time split: before start {(d[:,0]-t0).sum()/tot:.3f}  staging {(d[:,1]-d[:,0]).sum()/tot:.3f}  "
+      f"tile phase {(d[:,2]-d[:,1]).sum()/tot:.3f}  idle after own end {(d[:,2].max()-d[:,2]).sum()/tot:.3f}")
+wend = wg[:, :, 2].astype(float)
+print(f"  idle after own end, split: inside the workgroup (wave end -> WG end) {((wend.max(1, keepdims=True)-wend).sum())/tot:.3f}  "
+      f"across workgroups (WG end -> kernel end) {((wend.max()-wend.max(1)).sum()*16)/tot:.3f}")

@@ -1,6 +1,7 @@
 """CPU: host-side logic -- synthetic generator, flat-bucket data parallelism over gloo (world_size 2)."""
 import os
 import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -12,6 +13,8 @@ import torch.multiprocessing as mp
 from oracle import scn_oracle as O
 from sparse_rcnn_amd.dp import FlatParams, broadcast_params
 from sparse_rcnn_amd.synthetic import make_batch, make_boxes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_synthetic_scene_is_deterministic_and_surface_like():
@@ -156,3 +159,34 @@ def test_roi_cut_signature_is_the_reference_one():
     assert roi.RawToRawFeatureExtractorCombiner().combine(1, 2, 3, 4) == (1, 2, 3, 4)
     assert roi.RawToTensorFeatureExtractorCombiner().combine(torch.zeros(0, 4, dtype=torch.long), torch.zeros(0, 2),
                                                             torch.tensor([8, 8, 8]), 2) is None
+
+
+def test_last_gradient_bucket_is_small():
+    """dp.FlatParams cuts its buckets by when backward completes them: the last one (whose all-reduce nothing hides)
+    holds at most ~5 % of the bytes, every parameter sits in exactly one bucket, and the slices tile the flat buffer in
+    reverse parameter order.  Runs in a child process (it creates a one-rank gloo group)."""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%r, RANK="0", WORLD_SIZE="1", SCN_DP_FORCE_BUCKETS="1")
+dist.init_process_group("gloo")
+from sparse_rcnn_amd.dp import FlatParams
+sizes = [7 * 32, 32] + [27 * 32 * 32, 32] * 4 + [8 * 32 * 64, 64] + [27 * 64 * 64, 64] * 4 + [8 * 64 * 128, 128] + [27 * 128 * 128, 128] * 4
+net = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(n)) for n in sizes])
+fp = FlatParams(net, n_buckets=4)
+total = fp.flat.numel()
+assert len(fp.buckets) == 4, len(fp.buckets)
+ids = [i for b, _ in fp.buckets for i in b]
+assert ids == list(range(len(sizes) - 1, -1, -1)), ids                 # reverse parameter order, each exactly once
+assert sum(s.numel() for _, s in fp.buckets) == total
+off = total
+for b, s in fp.buckets:                                                # contiguous slices, back to front
+    off -= s.numel()
+    assert s.data_ptr() == fp.flat_grad.data_ptr() + 4 * off
+assert 0 < fp.buckets[-1][1].numel() <= 0.06 * total, fp.buckets[-1][1].numel() / total
+one = FlatParams(torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(5))]), n_buckets=4)
+assert len(one.buckets) == 1 and one.buckets[0][1].numel() == 5
+print("OK")
+''' % (ROOT, str(_free_port()))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]

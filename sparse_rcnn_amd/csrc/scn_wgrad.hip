@@ -31,6 +31,16 @@ using scn::cdiv;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+#ifndef WD_TIMELINE
+#define WD_TIMELINE 0       // 1 (developer builds): per-wave wall_clock64 stamps of k_wgrad_direct (tools/wd_timeline.py)
+#endif
+#if WD_TIMELINE
+__device__ long long wd_stamps[65536 * 4];      // [wave slot][t0, t_loop, t_end, rules]
+extern "C" int scn_debug_wd_stamps(void* dst_host) {
+    return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(wd_stamps), sizeof(wd_stamps)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 struct DPlan {
     long long rule_start[33];           // prefix of rules per offset
     int unit_start[33];                 // prefix of work units per offset; a unit = `per` consecutive rules of one offset
@@ -85,6 +95,9 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if WD_TIMELINE
+    const long long wd_t0 = wall_clock64();
+#endif
     const int i = lane & 15, kq = lane >> 4;
     const int unit = blockIdx.x;
     // offset of this unit: unit_start is non-decreasing, so o = #{o' : unit >= unit_start[o'+1]} -- one ballot instead
@@ -275,6 +288,9 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ 
 #undef WD_ROWS
 #undef WD_MFMA
 
+#if WD_TIMELINE
+    const long long wd_t1 = wall_clock64();
+#endif
     float* slab = slabs + ((long long)unit * (plan.nbi * plan.nbj) + blockIdx.z) * (CBI * CBJ);
     float* dbr = red + (QUAD ? 0 : 4 * NACC * 4 * 64);                  // [4 waves][64 columns]
 
@@ -349,6 +365,13 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ 
                 if (cbn + t < cout_pad) db_slabs[(long long)unit * cout_pad + cbn + t] = dbacc[t];
         }
     }
+#if WD_TIMELINE
+    if (lane == 0) {
+        const long long slot = (((long long)blockIdx.x + (long long)gridDim.x * blockIdx.z) * 4 + wave) & 65535;
+        wd_stamps[slot * 4 + 0] = wd_t0; wd_stamps[slot * 4 + 1] = wd_t1; wd_stamps[slot * 4 + 2] = wall_clock64();
+        wd_stamps[slot * 4 + 3] = nrel;
+    }
+#endif
 }
 
 

@@ -314,6 +314,17 @@ int scn_wgrad_bias_rules(const float* X, int cin, const float* dY, int cout, con
                          const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, float* db,
                          uint32_t db_offsets, void* scratch, int flags, scn_stream_t stream);
 
+/* The two weight (and bias) gradients of a pre-activation residual unit (module_factory.py:127-183: x + SubM3(ReLU(SubM3(
+ * ReLU(x))))) in ONE launch and one sum: both convolutions walk the same rule list with the same channel counts;
+ * (X0, dY0) and (X1, dY1) are their operand pairs (fp32).  dW = [2][n_off][cin][cout]; db = [2][cout], or NULL with
+ * db_offsets == 0.  Per problem the units, the per-unit arithmetic and the fixed-order sum are those of
+ * scn_wgrad_bias_rules under this call's plan; the launch pays its tail and its fixed costs once for twice the work.
+ * Scratch: scn_wgrad_scratch_bytes2.  prefix_host[0] must be 0; n_off <= 32. */
+int64_t scn_wgrad_scratch_bytes2(int cin, int cout, const int64_t* prefix_host, int n_off);
+int scn_wgrad_bias_rules2(const float* X0, const float* dY0, const float* X1, const float* dY1, int cin, int cout,
+                          const int32_t* in_rows, const int32_t* out_rows, const int64_t* prefix_host, int n_off,
+                          float* dW, float* db, uint32_t db_offsets, void* scratch, int flags, scn_stream_t stream);
+
 /* db[c] = sum_r dY[r][c]   (bias gradient of every conv-type layer).  scratch: SCN_COLSUM_BLOCKS*c floats. */
 #define SCN_COLSUM_BLOCKS 512
 int scn_colsum(const float* dY, int64_t n, int c, float* db, void* scratch, scn_stream_t stream);

@@ -41,11 +41,16 @@ extern "C" int scn_debug_wd_stamps(void* dst_host) {
 }
 #endif
 
+// Two problems on ONE rule list (the two weight gradients of a residual unit: scn_wgrad_bias_rules2) run as one launch over
+// 2 n_real VIRTUAL offsets: virtual offset v = problem * n_real + offset, its rules are rule_start[v] - problem * p_rules in
+// the shared list.  A single problem has n_real == n_off and p_rules == 0.
 struct DPlan {
-    long long rule_start[33];           // prefix of rules per offset
-    int unit_start[33];                 // prefix of work units per offset; a unit = `per` consecutive rules of one offset
+    long long rule_start[65];           // prefix of rules per (virtual) offset
+    int unit_start[65];                 // prefix of work units per offset; a unit = `per` consecutive rules of one offset
     long long per;                      // rules per unit (multiple of 64)
+    long long p_rules;                  // rules of one problem (two-problem launches), else 0
     int n_off, cbi, cbj, nbi, nbj;      // workgroup block (channels of X x channels of dY), blocks along Cin / Cout
+    int n_real;                         // offsets per problem
 };
 
 template <int T>
@@ -77,11 +82,12 @@ __device__ __forceinline__ typename Frag<T>::type widen(const R& r) {
 }
 
 template <int TA, int TB, bool QUAD, bool EDGE, bool IDENT, bool HB = false>
-__global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ X, int cin, const float* __restrict__ dY,
+__global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ X_0, int cin, const float* __restrict__ dY_0,
                                                       int cout, const int* __restrict__ in_rows,
                                                       const int* __restrict__ out_rows, DPlan plan,
                                                       float* __restrict__ slabs, int relu_in,
-                                                      float* __restrict__ db_slabs, unsigned db_mask, int cout_pad) {
+                                                      float* __restrict__ db_slabs, unsigned db_mask, int cout_pad,
+                                                      const float* __restrict__ X_1, const float* __restrict__ dY_1) {
     typedef typename Frag<TA>::type fa_t;
     typedef typename Frag<TB>::type fb_t;
     constexpr bool PACKED = HB && !EDGE;                         // bf16 rows kept packed in the ring
@@ -103,13 +109,18 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ 
     // offset of this unit: unit_start is non-decreasing, so o = #{o' : unit >= unit_start[o'+1]} -- one ballot instead
     // of a serial scalar search (every workgroup pays its prologue; with ~1000 short workgroups it adds up)
     const bool past = lane < plan.n_off && unit >= plan.unit_start[lane + 1];
-    const int o = __builtin_amdgcn_readfirstlane(__popcll(__ballot(past)));
-    const int s_unit = unit - plan.unit_start[o];
+    const int ov = __builtin_amdgcn_readfirstlane(__popcll(__ballot(past)));      // (virtual) offset of this unit
+    const int prob = ov >= plan.n_real ? 1 : 0;                                   // two-problem launch: which operand pair
+    const int o = ov - prob * plan.n_real;
+    const float* X = prob ? X_1 : X_0;
+    const float* dY = prob ? dY_1 : dY_0;
+    const int s_unit = unit - plan.unit_start[ov];
     const int bi = blockIdx.z / plan.nbj, bj = blockIdx.z % plan.nbj;
     const int wi = QUAD ? (wave >> 1) : 0, wj = QUAD ? (wave & 1) : 0;
     const int ci0 = bi * CBI + wi * WI, co0 = bj * CBJ + wj * WJ;       // first channel of the wave block
 
-    const long long p_lo = plan.rule_start[o], p_hi = plan.rule_start[o + 1];
+    const long long p_shift = prob ? plan.p_rules : 0;                 // the second problem walks the same rule list
+    const long long p_lo = plan.rule_start[ov] - p_shift, p_hi = plan.rule_start[ov + 1] - p_shift;
     const long long p0 = p_lo + (long long)s_unit * plan.per;
     const long long p1 = p0 + plan.per < p_hi ? p0 + plan.per : p_hi;
     // this wave's rule range [q0, q1): K mode = a quarter of the unit (multiple of 16 rules), QUAD = the whole unit
@@ -565,11 +576,13 @@ __global__ __launch_bounds__(256) void k_wgradd_sum(const float* __restrict__ sl
                                                     int main_blocks, int G) {
     typedef typename Frag<V>::type vec_t;
     if ((int)blockIdx.x >= main_blocks) {
-        const int co = blockIdx.x - main_blocks;
+        const int cidx = blockIdx.x - main_blocks;                   // (problem, column)
+        const int prob = cidx / cout, co = cidx - prob * cout;
         float s = 0.f;
-        for (int o = 0; o < plan.n_off; ++o) {
+        for (int o = 0; o < plan.n_real; ++o) {
             if (!((db_mask >> o) & 1u)) continue;
-            for (int u = plan.unit_start[o] + threadIdx.x; u < plan.unit_start[o + 1]; u += 256)
+            const int ov = prob * plan.n_real + o;
+            for (int u = plan.unit_start[ov] + threadIdx.x; u < plan.unit_start[ov + 1]; u += 256)
                 s += db_slabs[(long long)u * cout_pad + co];
         }
 #pragma unroll
@@ -577,7 +590,7 @@ __global__ __launch_bounds__(256) void k_wgradd_sum(const float* __restrict__ sl
         __shared__ float w[4];
         if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
         __syncthreads();
-        if (threadIdx.x == 0) db[co] = (w[0] + w[1]) + (w[2] + w[3]);
+        if (threadIdx.x == 0) db[cidx] = (w[0] + w[1]) + (w[2] + w[3]);
         return;
     }
     __shared__ __attribute__((aligned(16))) float part[256 * V];
@@ -640,6 +653,8 @@ bool tb_usable(int cin, int cout) {
 int make_dplan(int cin, int cout, const int64_t* prefix_host, int n_off, DPlan& pl, bool hb_mfma = false) {
     const Shape sh = pick_shape(cin, cout);
     pl.n_off = n_off;
+    pl.n_real = n_off;
+    pl.p_rules = 0;
     pl.cbi = 16 * sh.ta * (sh.quad ? 2 : 1);
     pl.cbj = 16 * sh.tb * (sh.quad ? 2 : 1);
     if (hb_mfma) { pl.cbi = 32 * tb_tiles(cin); pl.cbj = 32 * tb_tiles(cout); }
@@ -688,26 +703,44 @@ extern "C" int64_t scn_wgrad_scratch_bytes(int cin, int cout, const int64_t* pre
     return best;
 }
 
+// Two problems on one rule list (X1 / dY1 != NULL; fp32 operands, rule lists only): 2 n_off virtual offsets, the second
+// problem's rules behind the first one's in the virtual rule space; dW = [2][n_off][cin][cout], db = [2][cout].
+static int two_problem_plan(int cin, int cout, const int64_t* prefix_host, int n_off, DPlan& pl) {
+    if (n_off > 32 || prefix_host[0] != 0) return SCN_EINVAL;
+    int64_t vprefix[65];
+    const int64_t P = prefix_host[n_off];
+    for (int v = 0; v <= 2 * n_off; ++v) vprefix[v] = v <= n_off ? prefix_host[v] : P + prefix_host[v - n_off];
+    const int rc = make_dplan(cin, cout, vprefix, 2 * n_off, pl, false);
+    pl.n_real = n_off;
+    pl.p_rules = P;
+    return rc;
+}
+
 static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
-                      const int32_t* out_rows, const int64_t* prefix_host, int n_off, float* dW, float* db,
-                      unsigned db_mask, void* scratch, int flags, scn_stream_t stream, bool hb = false) {
-    SCN_REQUIRE(prefix_host && n_off >= 1 && n_off <= 32 && cin >= 1 && cout >= 1 && dW && scratch);
+                      const int32_t* out_rows, const int64_t* prefix_host, int n_off_real, float* dW, float* db,
+                      unsigned db_mask, void* scratch, int flags, scn_stream_t stream, bool hb = false,
+                      const float* X1 = nullptr, const float* dY1 = nullptr) {
+    SCN_REQUIRE(prefix_host && n_off_real >= 1 && n_off_real <= 32 && cin >= 1 && cout >= 1 && dW && scratch);
     SCN_REQUIRE((in_rows == nullptr) == (out_rows == nullptr));
-    SCN_REQUIRE(in_rows || n_off == 1);
+    SCN_REQUIRE(in_rows || n_off_real == 1);
+    const bool two = X1 != nullptr;
+    SCN_REQUIRE(!two || (dY1 && in_rows && !hb && (((uintptr_t)X1 | (uintptr_t)dY1) & 3) == 0));
+    const int n_prob = two ? 2 : 1, n_off = n_prob * n_off_real;             // (virtual) offsets of the launch
     const bool mfma16 = hb && tb_usable(cin, cout) && ((((uintptr_t)X | (uintptr_t)dY) & 15) == 0);
     DPlan pl;
-    SCN_REQUIRE(make_dplan(cin, cout, prefix_host, n_off, pl, mfma16) == SCN_OK);
-    SCN_REQUIRE(prefix_host[n_off] == prefix_host[0] || (X && dY));
+    if (two) SCN_REQUIRE(two_problem_plan(cin, cout, prefix_host, n_off_real, pl) == SCN_OK);
+    else SCN_REQUIRE(make_dplan(cin, cout, prefix_host, n_off, pl, mfma16) == SCN_OK);
+    SCN_REQUIRE(prefix_host[n_off_real] == prefix_host[0] || (X && dY));
     SCN_REQUIRE((((uintptr_t)X | (uintptr_t)dY) & (hb ? 1 : 3)) == 0);
     if (pl.unit_start[n_off] == 0) {
         SCN_HIP(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)n_off * cin * cout, S(stream)));
-        if (db) SCN_HIP(hipMemsetAsync(db, 0, sizeof(float) * (size_t)cout, S(stream)));
+        if (db) SCN_HIP(hipMemsetAsync(db, 0, sizeof(float) * (size_t)n_prob * cout, S(stream)));
         return SCN_OK;
     }
     const Shape sh = pick_shape(cin, cout);
     // vector row pieces need aligned rows and whole blocks; anything else takes the element-wise (EDGE) instantiation
     const bool edge = (cin % (16 * sh.ta) != 0) || (cout % (16 * sh.tb) != 0) ||
-                      ((((uintptr_t)X | (uintptr_t)dY) & 15) != 0);
+                      ((((uintptr_t)X | (uintptr_t)dY | (uintptr_t)X1 | (uintptr_t)dY1) & 15) != 0);
     const bool ident = in_rows == nullptr;
     const int cout_pad = pl.nbj * pl.cbj;
     float* db_slabs = db ? (float*)scratch + (int64_t)pl.unit_start[n_off] * pl.nbi * pl.nbj * pl.cbi * pl.cbj : nullptr;
@@ -743,7 +776,7 @@ static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const 
         }                                                                                                        \
         hipLaunchKernelGGL((k_wgrad_direct<TA_, TB_, Q_, E_, I_, H_>), grid, dim3(256), lds_, S(stream), X, cin, \
                            dY, cout, in_rows, out_rows, pl, (float*)scratch, relu_in, db_slabs, db_mask,         \
-                           cout_pad);                                                                            \
+                           cout_pad, X1, dY1);                                                                   \
     } while (0)
 #define PICK_I(TA_, TB_, Q_, E_, H_)                                                                             \
     do { if (ident) LAUNCH_WD(TA_, TB_, Q_, E_, true, H_); else LAUNCH_WD(TA_, TB_, Q_, E_, false, H_); } while (0)
@@ -769,11 +802,11 @@ static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const 
     while (G < 16 && groups * G < 128 * 1024) G *= 2;
     const int main_blocks = (int)cdiv(groups, 256 / G);
     if (V == 4)
-        hipLaunchKernelGGL(k_wgradd_sum<4>, dim3(main_blocks + (db ? cout : 0)), dim3(256), 0, S(stream),
+        hipLaunchKernelGGL(k_wgradd_sum<4>, dim3(main_blocks + (db ? n_prob * cout : 0)), dim3(256), 0, S(stream),
                            (const float*)scratch, pl, cin, cout, dW, (const float*)db_slabs, db_mask, cout_pad, db,
                            main_blocks, G);
     else
-        hipLaunchKernelGGL(k_wgradd_sum<1>, dim3(main_blocks + (db ? cout : 0)), dim3(256), 0, S(stream),
+        hipLaunchKernelGGL(k_wgradd_sum<1>, dim3(main_blocks + (db ? n_prob * cout : 0)), dim3(256), 0, S(stream),
                            (const float*)scratch, pl, cin, cout, dW, (const float*)db_slabs, db_mask, cout_pad, db,
                            main_blocks, G);
     SCN_LAUNCH_CHECK();
@@ -801,6 +834,28 @@ extern "C" int scn_wgrad_bias_rules(const float* X, int cin, const float* dY, in
     SCN_REQUIRE(db && db_offsets);
     return wgrad_impl(X, cin, dY, cout, in_rows, out_rows, prefix_host, n_off, dW, db, db_offsets, scratch, flags,
                       stream);
+}
+
+// The two weight (and bias) gradients of a residual unit in ONE launch + one sum: both convolutions share the rule list and
+// the channel counts; (X0, dY0) and (X1, dY1) are their operand pairs.  dW = [2][n_off][cin][cout], db = [2][cout] (NULL: no
+// bias gradients).  Same units, same association per problem as scn_wgrad_bias_rules with this plan; what it buys is a
+// launch whose tail and fixed costs are paid once for twice the work (tools/wgrad_batch_bound.py: 0.82-0.85 of two calls).
+extern "C" int64_t scn_wgrad_scratch_bytes2(int cin, int cout, const int64_t* prefix_host, int n_off) {
+    if (!prefix_host || n_off < 1 || n_off > 32 || cin < 1 || cout < 1) return -1;
+    DPlan pl;
+    if (two_problem_plan(cin, cout, prefix_host, n_off, pl) != SCN_OK) return -1;
+    return (int64_t)pl.unit_start[2 * n_off] *
+               ((int64_t)pl.nbi * pl.nbj * pl.cbi * pl.cbj + (int64_t)pl.nbj * pl.cbj) * (int64_t)sizeof(float) + 512;
+}
+
+extern "C" int scn_wgrad_bias_rules2(const float* X0, const float* dY0, const float* X1, const float* dY1, int cin, int cout,
+                                     const int32_t* in_rows, const int32_t* out_rows, const int64_t* prefix_host, int n_off,
+                                     float* dW, float* db, uint32_t db_offsets, void* scratch, int flags,
+                                     scn_stream_t stream) {
+    SCN_REQUIRE(X0 && dY0 && X1 && dY1 && in_rows && out_rows);
+    SCN_REQUIRE((db != nullptr) == (db_offsets != 0));
+    return wgrad_impl(X0, cin, dY0, cout, in_rows, out_rows, prefix_host, n_off, dW, db, db_offsets, scratch, flags,
+                      stream, false, X1, dY1);
 }
 
 extern "C" int scn_wgrad_bias_rules_bf16(const uint16_t* X, int cin, const uint16_t* dY, int cout, const int32_t* in_rows,

@@ -1091,3 +1091,46 @@ def test_config3_path_with_bf16_storage_tracks_fp32(gpu):
     rel = lambda a, b: ((a - b).norm() / b.norm()).item()
     assert torch.isfinite(res[1][0]).all() and rel(res[1][0], res[0][0]) < 3e-2, rel(res[1][0], res[0][0])
     assert torch.isfinite(res[1][1]).all() and rel(res[1][1], res[0][1]) < 0.15, rel(res[1][1], res[0][1])
+
+
+# ---------------------------------------------------------------------------------------- paired weight gradient
+@pytest.mark.parametrize("C", [8, 32, 48, 64, 128])
+@pytest.mark.parametrize("bias", [True, False])
+def test_paired_weight_gradient_of_a_residual_unit(gpu, C, bias):
+    """scn_wgrad_bias_rules2 (both weight gradients of a residual unit in one launch) against the oracle, and against the
+    one-call-per-layer form: the same block, the same inputs, every gradient."""
+    from sparse_rcnn_amd import functional as F
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=11, cin=C, n=2500, dup=100)
+    rb = x.metadata.subm_rulebook(size, 3)
+    g = torch.Generator().manual_seed(3)
+    w1 = (torch.randn(27, C, C, generator=g) * (2.0 / (27 * C)) ** 0.5)
+    w2 = (torch.randn(27, C, C, generator=g) * (2.0 / (27 * C)) ** 0.5)
+    b1 = torch.randn(C, generator=g) * 0.1 if bias else None
+    b2 = torch.randn(C, generator=g) * 0.1 if bias else None
+    gy = torch.randn(rb.n, C, generator=g)
+
+    def run(pair):
+        F.WGRAD_PAIR = pair
+        try:
+            X = x.features.detach().clone().requires_grad_()
+            ps = [t.to(gpu).requires_grad_() if t is not None else None for t in (w1, b1, w2, b2)]
+            y = F.ResidualBlockFunction.apply(X, ps[0], ps[1], ps[2], ps[3], x.metadata, size)
+            gr = torch.autograd.grad(y, [X] + [p_ for p_ in ps if p_ is not None], gy.to(gpu))
+            return y.detach(), gr
+        finally:
+            F.WGRAD_PAIR = True
+    y_p, g_p = run(True)
+    y_s, g_s = run(False)
+    assert torch.equal(y_p, y_s)
+    for a, b in zip(g_p, g_s):              # same kernels on the same operands; the plans (units) differ -> rounding only
+        _close(a, b, 2e-6, "paired vs single weight gradients")
+    # oracle
+    nbr, rules = O.subm_rulebook(scene.coords0, 3)
+    Xo = x.features.detach().cpu().clone().requires_grad_()
+    po = [t.clone().requires_grad_() if t is not None else None for t in (w1, b1, w2, b2)]
+    h = O.conv(torch.relu(Xo), po[0], po[1], rules, scene.n(0))
+    yo = Xo + O.conv(torch.relu(h), po[2], po[3], rules, scene.n(0))
+    go = torch.autograd.grad(yo, [Xo] + [p_ for p_ in po if p_ is not None], gy)
+    _close(y_p, yo, FEAT_TOL, "residual unit forward")
+    for a, b in zip(g_p, go):
+        _close(a, b, 2e-4, "residual unit gradients (paired weight gradient)")

@@ -325,6 +325,12 @@ int scn_wgrad_bias_rules2(const float* X0, const float* dY0, const float* X1, co
                           const int32_t* in_rows, const int32_t* out_rows, const int64_t* prefix_host, int n_off,
                           float* dW, float* db, uint32_t db_offsets, void* scratch, int flags, scn_stream_t stream);
 
+/* ... for bf16-stored operand pairs (uint16 bit patterns; dW, db fp32; the bf16-MFMA kernel where it applies). */
+int scn_wgrad_bias_rules2_bf16(const uint16_t* X0, const uint16_t* dY0, const uint16_t* X1, const uint16_t* dY1, int cin,
+                               int cout, const int32_t* in_rows, const int32_t* out_rows, const int64_t* prefix_host,
+                               int n_off, float* dW, float* db, uint32_t db_offsets, void* scratch, int flags,
+                               scn_stream_t stream);
+
 /* db[c] = sum_r dY[r][c]   (bias gradient of every conv-type layer).  scratch: SCN_COLSUM_BLOCKS*c floats. */
 #define SCN_COLSUM_BLOCKS 512
 int scn_colsum(const float* dY, int64_t n, int c, float* db, void* scratch, scn_stream_t stream);

@@ -405,11 +405,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ int wtb_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
 template <int TA, int TB, bool IDENT>
-__global__ __launch_bounds__(256) void k_wgrad_tb(const unsigned short* __restrict__ X, int cin,
-                                                  const unsigned short* __restrict__ dY, int cout,
+__global__ __launch_bounds__(256) void k_wgrad_tb(const unsigned short* __restrict__ X_0, int cin,
+                                                  const unsigned short* __restrict__ dY_0, int cout,
                                                   const int* __restrict__ in_rows, const int* __restrict__ out_rows,
                                                   DPlan plan, float* __restrict__ slabs, int relu_in,
-                                                  float* __restrict__ db_slabs, unsigned db_mask, int cout_pad) {
+                                                  float* __restrict__ db_slabs, unsigned db_mask, int cout_pad,
+                                                  const unsigned short* __restrict__ X_1,
+                                                  const unsigned short* __restrict__ dY_1) {
     constexpr int CBI = 32 * TA, CBJ = 32 * TB;                  // workgroup block
     constexpr int PA = CBI / 8, PB = CBJ / 8;                    // 16-byte pieces per gathered row
     constexpr int NPIECE = 32 * (PA + PB);                       // pieces per step (32 rules, both operands)
@@ -422,11 +424,16 @@ __global__ __launch_bounds__(256) void k_wgrad_tb(const unsigned short* __restri
     const int wi = wave >> 1, wj = wave & 1;
     const int unit = blockIdx.x;
     const bool past = lane < plan.n_off && unit >= plan.unit_start[lane + 1];
-    const int o = __builtin_amdgcn_readfirstlane(__popcll(__ballot(past)));
-    const int s_unit = unit - plan.unit_start[o];
+    const int ov = __builtin_amdgcn_readfirstlane(__popcll(__ballot(past)));      // (virtual) offset: see DPlan
+    const int prob = ov >= plan.n_real ? 1 : 0;
+    const int o = ov - prob * plan.n_real;
+    const unsigned short* X = prob ? X_1 : X_0;
+    const unsigned short* dY = prob ? dY_1 : dY_0;
+    const int s_unit = unit - plan.unit_start[ov];
     const int bi = blockIdx.z / plan.nbj, bj = blockIdx.z % plan.nbj;
     const int ci0 = bi * CBI, co0 = bj * CBJ;
-    const long long p_lo = plan.rule_start[o], p_hi = plan.rule_start[o + 1];
+    const long long p_shift = prob ? plan.p_rules : 0;
+    const long long p_lo = plan.rule_start[ov] - p_shift, p_hi = plan.rule_start[ov + 1] - p_shift;
     const long long p0 = p_lo + (long long)s_unit * plan.per;
     const long long p1 = p0 + plan.per < p_hi ? p0 + plan.per : p_hi;
     const int nrel = (int)(p1 > p0 ? p1 - p0 : 0);
@@ -705,12 +712,12 @@ extern "C" int64_t scn_wgrad_scratch_bytes(int cin, int cout, const int64_t* pre
 
 // Two problems on one rule list (X1 / dY1 != NULL; fp32 operands, rule lists only): 2 n_off virtual offsets, the second
 // problem's rules behind the first one's in the virtual rule space; dW = [2][n_off][cin][cout], db = [2][cout].
-static int two_problem_plan(int cin, int cout, const int64_t* prefix_host, int n_off, DPlan& pl) {
+static int two_problem_plan(int cin, int cout, const int64_t* prefix_host, int n_off, DPlan& pl, bool hb_mfma = false) {
     if (n_off > 32 || prefix_host[0] != 0) return SCN_EINVAL;
     int64_t vprefix[65];
     const int64_t P = prefix_host[n_off];
     for (int v = 0; v <= 2 * n_off; ++v) vprefix[v] = v <= n_off ? prefix_host[v] : P + prefix_host[v - n_off];
-    const int rc = make_dplan(cin, cout, vprefix, 2 * n_off, pl, false);
+    const int rc = make_dplan(cin, cout, vprefix, 2 * n_off, pl, hb_mfma);
     pl.n_real = n_off;
     pl.p_rules = P;
     return rc;
@@ -724,11 +731,12 @@ static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const 
     SCN_REQUIRE((in_rows == nullptr) == (out_rows == nullptr));
     SCN_REQUIRE(in_rows || n_off_real == 1);
     const bool two = X1 != nullptr;
-    SCN_REQUIRE(!two || (dY1 && in_rows && !hb && (((uintptr_t)X1 | (uintptr_t)dY1) & 3) == 0));
+    SCN_REQUIRE(!two || (dY1 && in_rows && (((uintptr_t)X1 | (uintptr_t)dY1) & (hb ? 1 : 3)) == 0));
     const int n_prob = two ? 2 : 1, n_off = n_prob * n_off_real;             // (virtual) offsets of the launch
-    const bool mfma16 = hb && tb_usable(cin, cout) && ((((uintptr_t)X | (uintptr_t)dY) & 15) == 0);
+    const bool mfma16 = hb && tb_usable(cin, cout) &&
+                        ((((uintptr_t)X | (uintptr_t)dY | (uintptr_t)X1 | (uintptr_t)dY1) & 15) == 0);
     DPlan pl;
-    if (two) SCN_REQUIRE(two_problem_plan(cin, cout, prefix_host, n_off_real, pl) == SCN_OK);
+    if (two) SCN_REQUIRE(two_problem_plan(cin, cout, prefix_host, n_off_real, pl, mfma16) == SCN_OK);
     else SCN_REQUIRE(make_dplan(cin, cout, prefix_host, n_off, pl, mfma16) == SCN_OK);
     SCN_REQUIRE(prefix_host[n_off_real] == prefix_host[0] || (X && dY));
     SCN_REQUIRE((((uintptr_t)X | (uintptr_t)dY) & (hb ? 1 : 3)) == 0);
@@ -751,7 +759,7 @@ static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const 
 #define LAUNCH_WT(TA_, TB_, I_)                                                                                  \
     hipLaunchKernelGGL((k_wgrad_tb<TA_, TB_, I_>), grid, dim3(256), 4 * 32 * 256, S(stream), (const unsigned short*)X, cin, \
                        (const unsigned short*)dY, cout, in_rows, out_rows, pl, (float*)scratch, relu_in, db_slabs, db_mask, \
-                       cout_pad)
+                       cout_pad, (const unsigned short*)X1, (const unsigned short*)dY1)
 #define PICK_WT(TA_, TB_) do { if (ident) LAUNCH_WT(TA_, TB_, true); else LAUNCH_WT(TA_, TB_, false); } while (0)
         if (ta == 1 && tb == 1) PICK_WT(1, 1);
         else if (ta == 1 && tb == 2) PICK_WT(1, 2);
@@ -842,10 +850,16 @@ extern "C" int scn_wgrad_bias_rules(const float* X, int cin, const float* dY, in
 // launch whose tail and fixed costs are paid once for twice the work (tools/wgrad_batch_bound.py: 0.82-0.85 of two calls).
 extern "C" int64_t scn_wgrad_scratch_bytes2(int cin, int cout, const int64_t* prefix_host, int n_off) {
     if (!prefix_host || n_off < 1 || n_off > 32 || cin < 1 || cout < 1) return -1;
-    DPlan pl;
-    if (two_problem_plan(cin, cout, prefix_host, n_off, pl) != SCN_OK) return -1;
-    return (int64_t)pl.unit_start[2 * n_off] *
-               ((int64_t)pl.nbi * pl.nbj * pl.cbi * pl.cbj + (int64_t)pl.nbj * pl.cbj) * (int64_t)sizeof(float) + 512;
+    int64_t best = -1;
+    for (int hb = 0; hb < 2; ++hb) {                 // fp32-MFMA plan; bf16-MFMA plan for bf16-stored operands
+        if (hb && !tb_usable(cin, cout)) continue;
+        DPlan pl;
+        if (two_problem_plan(cin, cout, prefix_host, n_off, pl, hb != 0) != SCN_OK) return -1;
+        const int64_t b = (int64_t)pl.unit_start[2 * n_off] *
+                              ((int64_t)pl.nbi * pl.nbj * pl.cbi * pl.cbj + (int64_t)pl.nbj * pl.cbj) * (int64_t)sizeof(float) + 512;
+        if (b > best) best = b;
+    }
+    return best;
 }
 
 extern "C" int scn_wgrad_bias_rules2(const float* X0, const float* dY0, const float* X1, const float* dY1, int cin, int cout,
@@ -856,6 +870,17 @@ extern "C" int scn_wgrad_bias_rules2(const float* X0, const float* dY0, const fl
     SCN_REQUIRE((db != nullptr) == (db_offsets != 0));
     return wgrad_impl(X0, cin, dY0, cout, in_rows, out_rows, prefix_host, n_off, dW, db, db_offsets, scratch, flags,
                       stream, false, X1, dY1);
+}
+
+/* scn_wgrad_bias_rules2 for bf16-stored operand pairs (dW, db fp32). */
+extern "C" int scn_wgrad_bias_rules2_bf16(const uint16_t* X0, const uint16_t* dY0, const uint16_t* X1, const uint16_t* dY1,
+                                          int cin, int cout, const int32_t* in_rows, const int32_t* out_rows,
+                                          const int64_t* prefix_host, int n_off, float* dW, float* db, uint32_t db_offsets,
+                                          void* scratch, int flags, scn_stream_t stream) {
+    SCN_REQUIRE(X0 && dY0 && X1 && dY1 && in_rows && out_rows);
+    SCN_REQUIRE((db != nullptr) == (db_offsets != 0));
+    return wgrad_impl((const float*)X0, cin, (const float*)dY0, cout, in_rows, out_rows, prefix_host, n_off, dW, db,
+                      db_offsets, scratch, flags, stream, true, (const float*)X1, (const float*)dY1);
 }
 
 extern "C" int scn_wgrad_bias_rules_bf16(const uint16_t* X, int cin, const uint16_t* dY, int cout, const int32_t* in_rows,

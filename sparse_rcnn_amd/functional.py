@@ -335,10 +335,15 @@ WGRAD_PAIR = os.environ.get("SCN_WGRAD_PAIR", "1") != "0"
 
 def wgrad_bias_rules2(X0, dY0, X1, dY1, in_rows, out_rows, prefix_host, n_off, db_offsets, flags=0):
     """The two weight (and, db_offsets != 0, bias) gradients of a residual unit in one launch + one sum
-    (scn_wgrad_bias_rules2): fp32 operand pairs (X0, dY0), (X1, dY1) on one rule list.  -> dW [2, n_off, cin, cout],
-    db [2, cout] or None."""
+    (scn_wgrad_bias_rules2 / _bf16): operand pairs (X0, dY0), (X1, dY1) of one storage type on one rule list.
+    -> fp32 dW [2, n_off, cin, cout], db [2, cout] or None."""
     lib = L.lib()
     cin, cout = X0.shape[1], dY0.shape[1]
+    hb = _is_bf16(X0)
+    if any(_is_bf16(t) != hb or not t.is_contiguous() for t in (dY0, X1, dY1)):
+        raise L.ScnError("wgrad_bias_rules2 takes contiguous operands of one storage type")
+    entry = lib.scn_wgrad_bias_rules2_bf16 if hb else lib.scn_wgrad_bias_rules2
+    es = 2.0 if hb else 4.0
     nbytes = lib.scn_wgrad_scratch_bytes2(cin, cout, prefix_host, n_off)
     if nbytes < 0:
         raise L.ScnError("scn_wgrad_scratch_bytes2: bad arguments")
@@ -348,11 +353,10 @@ def wgrad_bias_rules2(X0, dY0, X1, dY1, in_rows, out_rows, prefix_host, n_off, d
     P = int(prefix_host[n_off] - prefix_host[0])
 
     def run():
-        L.check(lib.scn_wgrad_bias_rules2(L.ptr(X0), L.ptr(dY0), L.ptr(X1), L.ptr(dY1), cin, cout, L.ptr(in_rows),
-                                          L.ptr(out_rows), prefix_host, n_off, L.ptr(dW), L.ptr(db), db_offsets,
-                                          L.ptr(scratch), flags, L.stream()))
-    profiling.timed("k_wgrad_rules", 4.0 * P * cin * cout,
-                    8.0 * (X0.shape[0] * cin + dY0.shape[0] * cout + n_off * cin * cout) + 16.0 * P, run)
+        L.check(entry(L.ptr(X0), L.ptr(dY0), L.ptr(X1), L.ptr(dY1), cin, cout, L.ptr(in_rows), L.ptr(out_rows),
+                      prefix_host, n_off, L.ptr(dW), L.ptr(db), db_offsets, L.ptr(scratch), flags, L.stream()))
+    profiling.timed("k_wgrad_rules_bf16" if hb else "k_wgrad_rules", 4.0 * P * cin * cout,
+                    2.0 * es * (X0.shape[0] * cin + dY0.shape[0] * cout) + 8.0 * n_off * cin * cout + 16.0 * P, run)
     return dW, db
 
 
@@ -543,12 +547,22 @@ class ResidualBlockFunctionBF16(torch.autograd.Function):
             dW = wgrad_rules_bf16(Xin, G, r.in_rows, r.out_rows, r.prefix_host, 27, L.F_RELU_IN).view_as(W) \
                 if want_w else None
             return dW, (colsum(G) if want_b else None)
-        dW2, db2 = wgrad(Y1, dY, W2, need[3], ctx.has_b2 and need[4])
+        want_b1, want_b2 = ctx.has_b1 and need[2], ctx.has_b2 and need[4]
+        pair = (WGRAD_PAIR and need[1] and need[3] and want_b1 == want_b2 and W1.shape == W2.shape
+                and W1.shape[1] == W1.shape[2] and r.prefix_host[0] == 0 and dY1.is_contiguous())
+        if not pair:
+            dW2, db2 = wgrad(Y1, dY, W2, need[3], want_b2)
         dX = None
         if need[0]:
             dX = conv_rules_bf16(dY1, rb.tiles, rb.n, W1, None, W1.shape[1], back | L.F_RESIDUAL_LAST, relu_mask=X,
                                  residual=dY, image=ctx.bwd_images[0], n_rules=r.count)
-        dW1, db1 = wgrad(X, dY1, W1, need[1], ctx.has_b1 and need[2])
+        if pair:            # both weight gradients in one launch (see ResidualBlockFunction)
+            dWp, dbp = wgrad_bias_rules2(X, dY1, Y1, dY, r.in_rows, r.out_rows, r.prefix_host, 27,
+                                         (1 << 13) if want_b1 else 0, L.F_RELU_IN)
+            dW1, dW2 = dWp[0].view_as(W1), dWp[1].view_as(W2)
+            db1, db2 = (dbp[0], dbp[1]) if dbp is not None else (None, None)
+        else:
+            dW1, db1 = wgrad(X, dY1, W1, need[1], want_b1)
         return dX, dW1, db1, dW2, db2, None, None
 
 

@@ -1134,3 +1134,35 @@ def test_paired_weight_gradient_of_a_residual_unit(gpu, C, bias):
     _close(y_p, yo, FEAT_TOL, "residual unit forward")
     for a, b in zip(g_p, go):
         _close(a, b, 2e-4, "residual unit gradients (paired weight gradient)")
+
+
+@pytest.mark.parametrize("C", [16, 32, 64, 128])
+def test_paired_weight_gradient_bf16_storage(gpu, C):
+    """The bf16-stored residual unit: both weight gradients in one launch (scn_wgrad_bias_rules2_bf16, bf16 MFMA where the
+    shape allows) against the one-call-per-layer form on the same operands -- products of bf16 values are exact in fp32,
+    so only the order of the fp32 sums differs."""
+    from sparse_rcnn_amd import functional as F
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=12, cin=C, n=2500, dup=100)
+    rb = x.metadata.subm_rulebook(size, 3)
+    g = torch.Generator().manual_seed(4)
+    w1 = (torch.randn(27, C, C, generator=g) * (2.0 / (27 * C)) ** 0.5)
+    w2 = (torch.randn(27, C, C, generator=g) * (2.0 / (27 * C)) ** 0.5)
+    b1, b2 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    gy = torch.randn(rb.n, C, generator=g).to(torch.bfloat16)
+    X0 = x.features.detach().to(torch.bfloat16)
+
+    def run(pair):
+        F.WGRAD_PAIR = pair
+        try:
+            X = X0.clone().requires_grad_()
+            ps = [t.to(gpu).requires_grad_() for t in (w1, b1, w2, b2)]
+            y = F.ResidualBlockFunctionBF16.apply(X, ps[0], ps[1], ps[2], ps[3], x.metadata, size)
+            gr = torch.autograd.grad(y, [X] + ps, gy.to(gpu))
+            return y.detach(), gr
+        finally:
+            F.WGRAD_PAIR = True
+    y_p, g_p = run(True)
+    y_s, g_s = run(False)
+    assert torch.equal(y_p, y_s) and torch.equal(g_p[0], g_s[0])
+    for a, b in zip(g_p[1:], g_s[1:]):
+        _close(a.float(), b.float(), 3e-6, "paired vs single weight gradients, bf16 storage")

@@ -325,6 +325,16 @@ int scn_wgrad_bias_rules2(const float* X0, const float* dY0, const float* X1, co
                           const int32_t* in_rows, const int32_t* out_rows, const int64_t* prefix_host, int n_off,
                           float* dW, float* db, uint32_t db_offsets, void* scratch, int flags, scn_stream_t stream);
 
+/* The general form: n_prob = 2 ... 4 operand pairs (host arrays of device pointers) on one rule list -- the four
+ * convolutions of two stacked residual units (module_factory.py:513-530 `num_units=2`) in one launch.
+ * dW = [n_prob][n_off][cin][cout], db = [n_prob][cout] or NULL with db_offsets == 0. */
+int64_t scn_wgrad_scratch_bytes_n(int cin, int cout, const int64_t* prefix_host, int n_off, int n_prob);
+int scn_wgrad_bias_rules_n(const float* const* Xs, const float* const* dYs, int n_prob, int cin, int cout,
+                          const int32_t* in_rows, const int32_t* out_rows, const int64_t* prefix_host, int n_off,
+                          float* dW, float* db, uint32_t db_offsets, void* scratch, int flags, scn_stream_t stream);
+int scn_wgrad_bias_rules_n_bf16(const uint16_t* const* Xs, const uint16_t* const* dYs, int n_prob, int cin, int cout,
+                               const int32_t* in_rows, const int32_t* out_rows, const int64_t* prefix_host, int n_off,
+                               float* dW, float* db, uint32_t db_offsets, void* scratch, int flags, scn_stream_t stream);
 /* ... for bf16-stored operand pairs (uint16 bit patterns; dW, db fp32; the bf16-MFMA kernel where it applies). */
 int scn_wgrad_bias_rules2_bf16(const uint16_t* X0, const uint16_t* dY0, const uint16_t* X1, const uint16_t* dY1, int cin,
                                int cout, const int32_t* in_rows, const int32_t* out_rows, const int64_t* prefix_host,

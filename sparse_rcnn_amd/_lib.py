@@ -66,6 +66,9 @@ _SIGS = {
     "scn_wgrad_scratch_bytes2": (i64, [i32, i32, C.POINTER(i64), i32]),
     "scn_wgrad_bias_rules2": (C.c_int, [p, p, p, p, i32, i32, p, p, C.POINTER(i64), i32, p, p, C.c_uint32, p, i32, p]),
     "scn_wgrad_bias_rules2_bf16": (C.c_int, [p, p, p, p, i32, i32, p, p, C.POINTER(i64), i32, p, p, C.c_uint32, p, i32, p]),
+    "scn_wgrad_scratch_bytes_n": (i64, [i32, i32, C.POINTER(i64), i32, i32]),
+    "scn_wgrad_bias_rules_n": (C.c_int, [C.POINTER(p), C.POINTER(p), i32, i32, i32, p, p, C.POINTER(i64), i32, p, p, C.c_uint32, p, i32, p]),
+    "scn_wgrad_bias_rules_n_bf16": (C.c_int, [C.POINTER(p), C.POINTER(p), i32, i32, i32, p, p, C.POINTER(i64), i32, p, p, C.c_uint32, p, i32, p]),
     "scn_colsum": (C.c_int, [p, i64, i32, p, p, p]),
     "scn_colsum_bf16": (C.c_int, [p, i64, i32, p, p, p]),
     "scn_relu_fwd": (C.c_int, [p, i64, p, p]),

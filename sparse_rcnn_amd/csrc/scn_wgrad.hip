@@ -41,20 +41,32 @@ extern "C" int scn_debug_wd_stamps(void* dst_host) {
 }
 #endif
 
-// Two problems on ONE rule list (the two weight gradients of a residual unit: scn_wgrad_bias_rules2) run as one launch over
-// 2 n_real VIRTUAL offsets: virtual offset v = problem * n_real + offset, its rules are rule_start[v] - problem * p_rules in
-// the shared list.  A single problem has n_real == n_off and p_rules == 0.
+// Several problems on ONE rule list (the weight gradients of one or two residual units: scn_wgrad_bias_rules2 / _rules_n)
+// run as one launch over n_prob x n_real VIRTUAL offsets: virtual offset v = problem * n_real + offset, its rules are
+// rule_start[v] - problem * p_rules in the shared list.  A single problem has n_real == n_off and p_rules == 0.
+#define WD_MAX_PROB 4
 struct DPlan {
-    long long rule_start[65];           // prefix of rules per (virtual) offset
-    int unit_start[65];                 // prefix of work units per offset; a unit = `per` consecutive rules of one offset
+    long long rule_start[129];          // prefix of rules per (virtual) offset
+    int unit_start[129];                // prefix of work units per offset; a unit = `per` consecutive rules of one offset
     long long per;                      // rules per unit (multiple of 64)
-    long long p_rules;                  // rules of one problem (two-problem launches), else 0
+    long long p_rules;                  // rules of one problem (multi-problem launches), else 0
     int n_off, cbi, cbj, nbi, nbj;      // workgroup block (channels of X x channels of dY), blocks along Cin / Cout
     int n_real;                         // offsets per problem
 };
 
 template <int T>
 struct Frag { typedef float type __attribute__((ext_vector_type(T))); };
+
+// operand pairs of the problems of a launch (by value in the kernel arguments)
+struct WdOps { const void* X[WD_MAX_PROB]; const void* dY[WD_MAX_PROB]; };
+
+// (virtual) offset of a unit: unit_start is non-decreasing, so v = #{v' : unit >= unit_start[v'+1]} -- two ballots cover
+// the 128 virtual offsets of a four-problem launch
+__device__ __forceinline__ int wd_offset_of(const DPlan& plan, int unit, int lane) {
+    const bool lo = lane < plan.n_off && unit >= plan.unit_start[lane + 1];
+    const bool hi = lane + 64 < plan.n_off && unit >= plan.unit_start[lane + 65];
+    return __builtin_amdgcn_readfirstlane(__popcll(__ballot(lo)) + __popcll(__ballot(hi)));
+}
 
 // Row pieces as they sit in the register ring: fp32 storage = the T floats themselves; bf16 storage (HB) = the T packed
 // bf16 values as loaded (half the registers, half the gather bytes), widened to fp32 when the block is multiplied:
@@ -87,7 +99,7 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ 
                                                       const int* __restrict__ out_rows, DPlan plan,
                                                       float* __restrict__ slabs, int relu_in,
                                                       float* __restrict__ db_slabs, unsigned db_mask, int cout_pad,
-                                                      const float* __restrict__ X_1, const float* __restrict__ dY_1) {
+                                                      WdOps more) {
     typedef typename Frag<TA>::type fa_t;
     typedef typename Frag<TB>::type fb_t;
     constexpr bool PACKED = HB && !EDGE;                         // bf16 rows kept packed in the ring
@@ -108,18 +120,17 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ 
     const int unit = blockIdx.x;
     // offset of this unit: unit_start is non-decreasing, so o = #{o' : unit >= unit_start[o'+1]} -- one ballot instead
     // of a serial scalar search (every workgroup pays its prologue; with ~1000 short workgroups it adds up)
-    const bool past = lane < plan.n_off && unit >= plan.unit_start[lane + 1];
-    const int ov = __builtin_amdgcn_readfirstlane(__popcll(__ballot(past)));      // (virtual) offset of this unit
-    const int prob = ov >= plan.n_real ? 1 : 0;                                   // two-problem launch: which operand pair
+    const int ov = wd_offset_of(plan, unit, lane);                               // (virtual) offset of this unit
+    const int prob = ov / plan.n_real;                                            // which operand pair (scalar)
     const int o = ov - prob * plan.n_real;
-    const float* X = prob ? X_1 : X_0;
-    const float* dY = prob ? dY_1 : dY_0;
+    const float* X = prob ? (const float*)more.X[prob] : X_0;
+    const float* dY = prob ? (const float*)more.dY[prob] : dY_0;
     const int s_unit = unit - plan.unit_start[ov];
     const int bi = blockIdx.z / plan.nbj, bj = blockIdx.z % plan.nbj;
     const int wi = QUAD ? (wave >> 1) : 0, wj = QUAD ? (wave & 1) : 0;
     const int ci0 = bi * CBI + wi * WI, co0 = bj * CBJ + wj * WJ;       // first channel of the wave block
 
-    const long long p_shift = prob ? plan.p_rules : 0;                 // the second problem walks the same rule list
+    const long long p_shift = prob * plan.p_rules;                     // every problem walks the same rule list
     const long long p_lo = plan.rule_start[ov] - p_shift, p_hi = plan.rule_start[ov + 1] - p_shift;
     const long long p0 = p_lo + (long long)s_unit * plan.per;
     const long long p1 = p0 + plan.per < p_hi ? p0 + plan.per : p_hi;
@@ -410,8 +421,7 @@ __global__ __launch_bounds__(256) void k_wgrad_tb(const unsigned short* __restri
                                                   const int* __restrict__ in_rows, const int* __restrict__ out_rows,
                                                   DPlan plan, float* __restrict__ slabs, int relu_in,
                                                   float* __restrict__ db_slabs, unsigned db_mask, int cout_pad,
-                                                  const unsigned short* __restrict__ X_1,
-                                                  const unsigned short* __restrict__ dY_1) {
+                                                  WdOps more) {
     constexpr int CBI = 32 * TA, CBJ = 32 * TB;                  // workgroup block
     constexpr int PA = CBI / 8, PB = CBJ / 8;                    // 16-byte pieces per gathered row
     constexpr int NPIECE = 32 * (PA + PB);                       // pieces per step (32 rules, both operands)
@@ -423,16 +433,15 @@ __global__ __launch_bounds__(256) void k_wgrad_tb(const unsigned short* __restri
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave >> 1, wj = wave & 1;
     const int unit = blockIdx.x;
-    const bool past = lane < plan.n_off && unit >= plan.unit_start[lane + 1];
-    const int ov = __builtin_amdgcn_readfirstlane(__popcll(__ballot(past)));      // (virtual) offset: see DPlan
-    const int prob = ov >= plan.n_real ? 1 : 0;
+    const int ov = wd_offset_of(plan, unit, lane);                               // (virtual) offset: see DPlan
+    const int prob = ov / plan.n_real;
     const int o = ov - prob * plan.n_real;
-    const unsigned short* X = prob ? X_1 : X_0;
-    const unsigned short* dY = prob ? dY_1 : dY_0;
+    const unsigned short* X = prob ? (const unsigned short*)more.X[prob] : X_0;
+    const unsigned short* dY = prob ? (const unsigned short*)more.dY[prob] : dY_0;
     const int s_unit = unit - plan.unit_start[ov];
     const int bi = blockIdx.z / plan.nbj, bj = blockIdx.z % plan.nbj;
     const int ci0 = bi * CBI, co0 = bj * CBJ;
-    const long long p_shift = prob ? plan.p_rules : 0;
+    const long long p_shift = prob * plan.p_rules;
     const long long p_lo = plan.rule_start[ov] - p_shift, p_hi = plan.rule_start[ov + 1] - p_shift;
     const long long p0 = p_lo + (long long)s_unit * plan.per;
     const long long p1 = p0 + plan.per < p_hi ? p0 + plan.per : p_hi;
@@ -710,14 +719,16 @@ extern "C" int64_t scn_wgrad_scratch_bytes(int cin, int cout, const int64_t* pre
     return best;
 }
 
-// Two problems on one rule list (X1 / dY1 != NULL; fp32 operands, rule lists only): 2 n_off virtual offsets, the second
-// problem's rules behind the first one's in the virtual rule space; dW = [2][n_off][cin][cout], db = [2][cout].
-static int two_problem_plan(int cin, int cout, const int64_t* prefix_host, int n_off, DPlan& pl, bool hb_mfma = false) {
-    if (n_off > 32 || prefix_host[0] != 0) return SCN_EINVAL;
-    int64_t vprefix[65];
+// n_prob problems on one rule list: n_prob x n_off virtual offsets, problem p's rules behind those of problem p - 1 in the
+// virtual rule space; dW = [n_prob][n_off][cin][cout], db = [n_prob][cout].
+static int multi_problem_plan(int cin, int cout, const int64_t* prefix_host, int n_off, int n_prob, DPlan& pl,
+                              bool hb_mfma = false) {
+    if (n_off > 32 || n_prob < 2 || n_prob > WD_MAX_PROB || prefix_host[0] != 0) return SCN_EINVAL;
+    int64_t vprefix[129];
     const int64_t P = prefix_host[n_off];
-    for (int v = 0; v <= 2 * n_off; ++v) vprefix[v] = v <= n_off ? prefix_host[v] : P + prefix_host[v - n_off];
-    const int rc = make_dplan(cin, cout, vprefix, 2 * n_off, pl, hb_mfma);
+    for (int v = 0; v <= n_prob * n_off; ++v) vprefix[v] = (v / n_off) * P + prefix_host[v % n_off];
+    vprefix[n_prob * n_off] = n_prob * P;
+    const int rc = make_dplan(cin, cout, vprefix, n_prob * n_off, pl, hb_mfma);
     pl.n_real = n_off;
     pl.p_rules = P;
     return rc;
@@ -726,20 +737,29 @@ static int two_problem_plan(int cin, int cout, const int64_t* prefix_host, int n
 static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
                       const int32_t* out_rows, const int64_t* prefix_host, int n_off_real, float* dW, float* db,
                       unsigned db_mask, void* scratch, int flags, scn_stream_t stream, bool hb = false,
-                      const float* X1 = nullptr, const float* dY1 = nullptr) {
+                      int n_prob = 1, const void* const* Xs = nullptr, const void* const* dYs = nullptr) {
     SCN_REQUIRE(prefix_host && n_off_real >= 1 && n_off_real <= 32 && cin >= 1 && cout >= 1 && dW && scratch);
     SCN_REQUIRE((in_rows == nullptr) == (out_rows == nullptr));
     SCN_REQUIRE(in_rows || n_off_real == 1);
-    const bool two = X1 != nullptr;
-    SCN_REQUIRE(!two || (dY1 && in_rows && (((uintptr_t)X1 | (uintptr_t)dY1) & (hb ? 1 : 3)) == 0));
-    const int n_prob = two ? 2 : 1, n_off = n_prob * n_off_real;             // (virtual) offsets of the launch
-    const bool mfma16 = hb && tb_usable(cin, cout) &&
-                        ((((uintptr_t)X | (uintptr_t)dY | (uintptr_t)X1 | (uintptr_t)dY1) & 15) == 0);
+    // several problems (operand pairs Xs[p], dYs[p]; Xs[0] == X, dYs[0] == dY) on the one rule list
+    const bool multi = n_prob > 1;
+    SCN_REQUIRE(n_prob >= 1 && n_prob <= WD_MAX_PROB && (!multi || (Xs && dYs && in_rows)));
+    WdOps more{};
+    uintptr_t all_ptrs = (uintptr_t)X | (uintptr_t)dY;
+    for (int q = 0; multi && q < n_prob; ++q) {
+        SCN_REQUIRE(Xs[q] && dYs[q]);
+        more.X[q] = Xs[q];
+        more.dY[q] = dYs[q];
+        all_ptrs |= (uintptr_t)Xs[q] | (uintptr_t)dYs[q];
+    }
+    SCN_REQUIRE(!multi || (Xs[0] == (const void*)X && dYs[0] == (const void*)dY));
+    const int n_off = n_prob * n_off_real;                                   // (virtual) offsets of the launch
+    const bool mfma16 = hb && tb_usable(cin, cout) && ((all_ptrs & 15) == 0);
     DPlan pl;
-    if (two) SCN_REQUIRE(two_problem_plan(cin, cout, prefix_host, n_off_real, pl, mfma16) == SCN_OK);
+    if (multi) SCN_REQUIRE(multi_problem_plan(cin, cout, prefix_host, n_off_real, n_prob, pl, mfma16) == SCN_OK);
     else SCN_REQUIRE(make_dplan(cin, cout, prefix_host, n_off, pl, mfma16) == SCN_OK);
     SCN_REQUIRE(prefix_host[n_off_real] == prefix_host[0] || (X && dY));
-    SCN_REQUIRE((((uintptr_t)X | (uintptr_t)dY) & (hb ? 1 : 3)) == 0);
+    SCN_REQUIRE((all_ptrs & (hb ? 1 : 3)) == 0);
     if (pl.unit_start[n_off] == 0) {
         SCN_HIP(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)n_off * cin * cout, S(stream)));
         if (db) SCN_HIP(hipMemsetAsync(db, 0, sizeof(float) * (size_t)n_prob * cout, S(stream)));
@@ -748,7 +768,7 @@ static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const 
     const Shape sh = pick_shape(cin, cout);
     // vector row pieces need aligned rows and whole blocks; anything else takes the element-wise (EDGE) instantiation
     const bool edge = (cin % (16 * sh.ta) != 0) || (cout % (16 * sh.tb) != 0) ||
-                      ((((uintptr_t)X | (uintptr_t)dY | (uintptr_t)X1 | (uintptr_t)dY1) & 15) != 0);
+                      ((all_ptrs & 15) != 0);
     const bool ident = in_rows == nullptr;
     const int cout_pad = pl.nbj * pl.cbj;
     float* db_slabs = db ? (float*)scratch + (int64_t)pl.unit_start[n_off] * pl.nbi * pl.nbj * pl.cbi * pl.cbj : nullptr;
@@ -759,7 +779,7 @@ static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const 
 #define LAUNCH_WT(TA_, TB_, I_)                                                                                  \
     hipLaunchKernelGGL((k_wgrad_tb<TA_, TB_, I_>), grid, dim3(256), 4 * 32 * 256, S(stream), (const unsigned short*)X, cin, \
                        (const unsigned short*)dY, cout, in_rows, out_rows, pl, (float*)scratch, relu_in, db_slabs, db_mask, \
-                       cout_pad, (const unsigned short*)X1, (const unsigned short*)dY1)
+                       cout_pad, more)
 #define PICK_WT(TA_, TB_) do { if (ident) LAUNCH_WT(TA_, TB_, true); else LAUNCH_WT(TA_, TB_, false); } while (0)
         if (ta == 1 && tb == 1) PICK_WT(1, 1);
         else if (ta == 1 && tb == 2) PICK_WT(1, 2);
@@ -784,7 +804,7 @@ static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const 
         }                                                                                                        \
         hipLaunchKernelGGL((k_wgrad_direct<TA_, TB_, Q_, E_, I_, H_>), grid, dim3(256), lds_, S(stream), X, cin, \
                            dY, cout, in_rows, out_rows, pl, (float*)scratch, relu_in, db_slabs, db_mask,         \
-                           cout_pad, X1, dY1);                                                                   \
+                           cout_pad, more);                                                                      \
     } while (0)
 #define PICK_I(TA_, TB_, Q_, E_, H_)                                                                             \
     do { if (ident) LAUNCH_WD(TA_, TB_, Q_, E_, true, H_); else LAUNCH_WD(TA_, TB_, Q_, E_, false, H_); } while (0)
@@ -844,43 +864,68 @@ extern "C" int scn_wgrad_bias_rules(const float* X, int cin, const float* dY, in
                       stream);
 }
 
-// The two weight (and bias) gradients of a residual unit in ONE launch + one sum: both convolutions share the rule list and
-// the channel counts; (X0, dY0) and (X1, dY1) are their operand pairs.  dW = [2][n_off][cin][cout], db = [2][cout] (NULL: no
-// bias gradients).  Same units, same association per problem as scn_wgrad_bias_rules with this plan; what it buys is a
-// launch whose tail and fixed costs are paid once for twice the work (tools/wgrad_batch_bound.py: 0.82-0.85 of two calls).
-extern "C" int64_t scn_wgrad_scratch_bytes2(int cin, int cout, const int64_t* prefix_host, int n_off) {
-    if (!prefix_host || n_off < 1 || n_off > 32 || cin < 1 || cout < 1) return -1;
+// The weight (and bias) gradients of the n_prob = 2 convolutions of a residual unit (or the 4 of two stacked units) in ONE
+// launch + one sum: they share the rule list and the channel counts; (Xs[p], dYs[p]) are their operand pairs.
+// dW = [n_prob][n_off][cin][cout], db = [n_prob][cout] (NULL: no bias gradients).  Same per-unit arithmetic and fixed-order
+// sum as scn_wgrad_bias_rules under this call's plan; what it buys is a launch whose tail and fixed costs are paid once
+// for n_prob times the work (tools/wgrad_batch_bound.py: two problems take 0.82-0.85 of two calls).
+extern "C" int64_t scn_wgrad_scratch_bytes_n(int cin, int cout, const int64_t* prefix_host, int n_off, int n_prob) {
+    if (!prefix_host || n_off < 1 || n_off > 32 || cin < 1 || cout < 1 || n_prob < 2 || n_prob > WD_MAX_PROB) return -1;
     int64_t best = -1;
     for (int hb = 0; hb < 2; ++hb) {                 // fp32-MFMA plan; bf16-MFMA plan for bf16-stored operands
         if (hb && !tb_usable(cin, cout)) continue;
         DPlan pl;
-        if (two_problem_plan(cin, cout, prefix_host, n_off, pl, hb != 0) != SCN_OK) return -1;
-        const int64_t b = (int64_t)pl.unit_start[2 * n_off] *
+        if (multi_problem_plan(cin, cout, prefix_host, n_off, n_prob, pl, hb != 0) != SCN_OK) return -1;
+        const int64_t b = (int64_t)pl.unit_start[n_prob * n_off] *
                               ((int64_t)pl.nbi * pl.nbj * pl.cbi * pl.cbj + (int64_t)pl.nbj * pl.cbj) * (int64_t)sizeof(float) + 512;
         if (b > best) best = b;
     }
     return best;
 }
 
+extern "C" int64_t scn_wgrad_scratch_bytes2(int cin, int cout, const int64_t* prefix_host, int n_off) {
+    return scn_wgrad_scratch_bytes_n(cin, cout, prefix_host, n_off, 2);
+}
+
+extern "C" int scn_wgrad_bias_rules_n(const float* const* Xs, const float* const* dYs, int n_prob, int cin, int cout,
+                                     const int32_t* in_rows, const int32_t* out_rows, const int64_t* prefix_host, int n_off,
+                                     float* dW, float* db, uint32_t db_offsets, void* scratch, int flags,
+                                     scn_stream_t stream) {
+    SCN_REQUIRE(Xs && dYs && n_prob >= 2 && n_prob <= WD_MAX_PROB && in_rows && out_rows);
+    SCN_REQUIRE((db != nullptr) == (db_offsets != 0));
+    return wgrad_impl(Xs[0], cin, dYs[0], cout, in_rows, out_rows, prefix_host, n_off, dW, db, db_offsets, scratch, flags,
+                      stream, false, n_prob, (const void* const*)Xs, (const void* const*)dYs);
+}
+
+/* ... for bf16-stored operand pairs (dW, db fp32). */
+extern "C" int scn_wgrad_bias_rules_n_bf16(const uint16_t* const* Xs, const uint16_t* const* dYs, int n_prob, int cin,
+                                          int cout, const int32_t* in_rows, const int32_t* out_rows,
+                                          const int64_t* prefix_host, int n_off, float* dW, float* db, uint32_t db_offsets,
+                                          void* scratch, int flags, scn_stream_t stream) {
+    SCN_REQUIRE(Xs && dYs && n_prob >= 2 && n_prob <= WD_MAX_PROB && in_rows && out_rows);
+    SCN_REQUIRE((db != nullptr) == (db_offsets != 0));
+    return wgrad_impl((const float*)Xs[0], cin, (const float*)dYs[0], cout, in_rows, out_rows, prefix_host, n_off, dW, db,
+                      db_offsets, scratch, flags, stream, true, n_prob, (const void* const*)Xs, (const void* const*)dYs);
+}
+
 extern "C" int scn_wgrad_bias_rules2(const float* X0, const float* dY0, const float* X1, const float* dY1, int cin, int cout,
                                      const int32_t* in_rows, const int32_t* out_rows, const int64_t* prefix_host, int n_off,
                                      float* dW, float* db, uint32_t db_offsets, void* scratch, int flags,
                                      scn_stream_t stream) {
-    SCN_REQUIRE(X0 && dY0 && X1 && dY1 && in_rows && out_rows);
-    SCN_REQUIRE((db != nullptr) == (db_offsets != 0));
-    return wgrad_impl(X0, cin, dY0, cout, in_rows, out_rows, prefix_host, n_off, dW, db, db_offsets, scratch, flags,
-                      stream, false, X1, dY1);
+    const float* Xs[2] = {X0, X1};
+    const float* dYs[2] = {dY0, dY1};
+    return scn_wgrad_bias_rules_n(Xs, dYs, 2, cin, cout, in_rows, out_rows, prefix_host, n_off, dW, db, db_offsets, scratch,
+                                 flags, stream);
 }
 
-/* scn_wgrad_bias_rules2 for bf16-stored operand pairs (dW, db fp32). */
 extern "C" int scn_wgrad_bias_rules2_bf16(const uint16_t* X0, const uint16_t* dY0, const uint16_t* X1, const uint16_t* dY1,
                                           int cin, int cout, const int32_t* in_rows, const int32_t* out_rows,
                                           const int64_t* prefix_host, int n_off, float* dW, float* db, uint32_t db_offsets,
                                           void* scratch, int flags, scn_stream_t stream) {
-    SCN_REQUIRE(X0 && dY0 && X1 && dY1 && in_rows && out_rows);
-    SCN_REQUIRE((db != nullptr) == (db_offsets != 0));
-    return wgrad_impl((const float*)X0, cin, (const float*)dY0, cout, in_rows, out_rows, prefix_host, n_off, dW, db,
-                      db_offsets, scratch, flags, stream, true, (const float*)X1, (const float*)dY1);
+    const uint16_t* Xs[2] = {X0, X1};
+    const uint16_t* dYs[2] = {dY0, dY1};
+    return scn_wgrad_bias_rules_n_bf16(Xs, dYs, 2, cin, cout, in_rows, out_rows, prefix_host, n_off, dW, db, db_offsets,
+                                      scratch, flags, stream);
 }
 
 extern "C" int scn_wgrad_bias_rules_bf16(const uint16_t* X, int cin, const uint16_t* dY, int cout, const int32_t* in_rows,

@@ -333,31 +333,39 @@ def wgrad_bias_rules(X, dY, in_rows, out_rows, prefix_host, n_off, db_offsets, f
 WGRAD_PAIR = os.environ.get("SCN_WGRAD_PAIR", "1") != "0"
 
 
-def wgrad_bias_rules2(X0, dY0, X1, dY1, in_rows, out_rows, prefix_host, n_off, db_offsets, flags=0):
-    """The two weight (and, db_offsets != 0, bias) gradients of a residual unit in one launch + one sum
-    (scn_wgrad_bias_rules2 / _bf16): operand pairs (X0, dY0), (X1, dY1) of one storage type on one rule list.
-    -> fp32 dW [2, n_off, cin, cout], db [2, cout] or None."""
+def wgrad_bias_rules_n(Xs, dYs, in_rows, out_rows, prefix_host, n_off, db_offsets, flags=0):
+    """The weight (and, db_offsets != 0, bias) gradients of 2 ... 4 convolutions that share a rule list and their channel
+    counts -- the two of a residual unit, the four of two stacked units -- in one launch + one sum
+    (scn_wgrad_bias_rules_n / _bf16): operand pairs (Xs[p], dYs[p]) of one storage type.
+    -> fp32 dW [n_prob, n_off, cin, cout], db [n_prob, cout] or None."""
     lib = L.lib()
-    cin, cout = X0.shape[1], dY0.shape[1]
-    hb = _is_bf16(X0)
-    if any(_is_bf16(t) != hb or not t.is_contiguous() for t in (dY0, X1, dY1)):
-        raise L.ScnError("wgrad_bias_rules2 takes contiguous operands of one storage type")
-    entry = lib.scn_wgrad_bias_rules2_bf16 if hb else lib.scn_wgrad_bias_rules2
+    n_prob = len(Xs)
+    cin, cout = Xs[0].shape[1], dYs[0].shape[1]
+    hb = _is_bf16(Xs[0])
+    if any(_is_bf16(t) != hb or not t.is_contiguous() for t in tuple(Xs) + tuple(dYs)):
+        raise L.ScnError("wgrad_bias_rules_n takes contiguous operands of one storage type")
+    entry = lib.scn_wgrad_bias_rules_n_bf16 if hb else lib.scn_wgrad_bias_rules_n
     es = 2.0 if hb else 4.0
-    nbytes = lib.scn_wgrad_scratch_bytes2(cin, cout, prefix_host, n_off)
+    nbytes = lib.scn_wgrad_scratch_bytes_n(cin, cout, prefix_host, n_off, n_prob)
     if nbytes < 0:
-        raise L.ScnError("scn_wgrad_scratch_bytes2: bad arguments")
-    scratch = L.scratch(nbytes, X0.device)
-    dW = torch.empty((2, n_off, cin, cout), dtype=torch.float32, device=X0.device)
-    db = torch.empty((2, cout), dtype=torch.float32, device=X0.device) if db_offsets else None
+        raise L.ScnError("scn_wgrad_scratch_bytes_n: bad arguments")
+    scratch = L.scratch(nbytes, Xs[0].device)
+    dW = torch.empty((n_prob, n_off, cin, cout), dtype=torch.float32, device=Xs[0].device)
+    db = torch.empty((n_prob, cout), dtype=torch.float32, device=Xs[0].device) if db_offsets else None
     P = int(prefix_host[n_off] - prefix_host[0])
+    xp = (C.c_void_p * n_prob)(*[t.data_ptr() for t in Xs])
+    yp = (C.c_void_p * n_prob)(*[t.data_ptr() for t in dYs])
 
     def run():
-        L.check(entry(L.ptr(X0), L.ptr(dY0), L.ptr(X1), L.ptr(dY1), cin, cout, L.ptr(in_rows), L.ptr(out_rows),
-                      prefix_host, n_off, L.ptr(dW), L.ptr(db), db_offsets, L.ptr(scratch), flags, L.stream()))
-    profiling.timed("k_wgrad_rules_bf16" if hb else "k_wgrad_rules", 4.0 * P * cin * cout,
-                    2.0 * es * (X0.shape[0] * cin + dY0.shape[0] * cout) + 8.0 * n_off * cin * cout + 16.0 * P, run)
+        L.check(entry(xp, yp, n_prob, cin, cout, L.ptr(in_rows), L.ptr(out_rows), prefix_host, n_off, L.ptr(dW), L.ptr(db),
+                      db_offsets, L.ptr(scratch), flags, L.stream()))
+    profiling.timed("k_wgrad_rules_bf16" if hb else "k_wgrad_rules", 2.0 * n_prob * P * cin * cout,
+                    n_prob * (es * (Xs[0].shape[0] * cin + dYs[0].shape[0] * cout) + 4.0 * n_off * cin * cout + 8.0 * P), run)
     return dW, db
+
+
+def wgrad_bias_rules2(X0, dY0, X1, dY1, in_rows, out_rows, prefix_host, n_off, db_offsets, flags=0):
+    return wgrad_bias_rules_n((X0, X1), (dY0, dY1), in_rows, out_rows, prefix_host, n_off, db_offsets, flags)
 
 
 def colsum(dY):

@@ -1166,3 +1166,31 @@ def test_paired_weight_gradient_bf16_storage(gpu, C):
     assert torch.equal(y_p, y_s) and torch.equal(g_p[0], g_s[0])
     for a, b in zip(g_p[1:], g_s[1:]):
         _close(a.float(), b.float(), 3e-6, "paired vs single weight gradients, bf16 storage")
+
+
+@pytest.mark.parametrize("C,bf16", [(32, False), (64, False), (32, True), (128, True)])
+def test_four_weight_gradients_in_one_launch(gpu, C, bf16):
+    """scn_wgrad_bias_rules_n with four operand pairs on one rule list (what two stacked residual units would hand it)
+    against four scn_wgrad_bias_rules calls: equal up to the order of the fp32 unit sums.  (The four-problem launch is NOT
+    used by the module path: measured without gain over two two-problem launches)"""
+    from sparse_rcnn_amd import functional as F
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=14, cin=C, n=2500, dup=100)
+    r = x.metadata.subm_rulebook(size, 3).rules
+    g = torch.Generator().manual_seed(8)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    n = x.features.shape[0]
+    Xs = [torch.randn(n, C, generator=g).to(gpu).to(dt) for _ in range(4)]
+    Gs = [torch.randn(n, C, generator=g).to(gpu).to(dt) for _ in range(4)]
+    dW, db = F.wgrad_bias_rules_n(Xs, Gs, r.in_rows, r.out_rows, r.prefix_host, 27, 1 << 13, L_F_RELU_IN())
+    for q in range(4):
+        dW1, db1 = F.wgrad_bias_rules(Xs[q], Gs[q], r.in_rows, r.out_rows, r.prefix_host, 27, 1 << 13, L_F_RELU_IN())
+        _close(dW[q], dW1, 3e-6, f"problem {q}: dW")
+        _close(db[q], db1, 3e-6, f"problem {q}: db")
+    dW0, db0 = F.wgrad_bias_rules_n(Xs[:3], Gs[:3], r.in_rows, r.out_rows, r.prefix_host, 27, 0, 0)     # three, no bias, no ReLU
+    assert db0 is None
+    _close(dW0[2], F.wgrad_rules(Xs[2], Gs[2], r.in_rows, r.out_rows, r.prefix_host, 27, 0), 3e-6, "three problems")
+
+
+def L_F_RELU_IN():
+    from sparse_rcnn_amd import _lib as L
+    return L.F_RELU_IN

@@ -578,7 +578,7 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     const bool vecn = (cout % 4 == 0) && (((uintptr_t)W & 15) == 0);
     // the fast path addresses X through a raw buffer descriptor: 32-bit byte offsets, 24-bit row indices
     const bool fullk = vec && n_in < (1ll << 23) && n_in * cin * 4 < (1ll << 32) - (1ll << 24) &&
-                       n_out < (1ll << 23) && n_out * cout * 4 < (1ll << 31);
+                       n_out < (1ll << 23) && n_out * cout * 4 < (1ll << 32) - (1ll << 24);
     const bool part = cin % TS_KC != 0;
     dim3 grid((unsigned)(n_tg * n_chunks * n_kc));
     hipStream_t st = S(stream);

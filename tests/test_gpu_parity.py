@@ -1194,3 +1194,39 @@ def test_four_weight_gradients_in_one_launch(gpu, C, bf16):
 def L_F_RELU_IN():
     from sparse_rcnn_amd import _lib as L
     return L.F_RELU_IN
+
+
+@pytest.mark.parametrize("n", [1, 3, 20, 70])
+def test_paired_weight_gradient_on_tiny_scenes(gpu, n):
+    """Residual unit on scenes of a few voxels (most offsets have no rule; some problems' units are empty): the paired
+    weight gradient equals the one-call-per-layer form and the oracle."""
+    from sparse_rcnn_amd import functional as F
+    C = 32
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=15, cin=C, n=n, dup=0, batch=1, grid=(6, 5, 4))
+    g = torch.Generator().manual_seed(9)
+    ws = [torch.randn(27, C, C, generator=g) * 0.05 for _ in range(2)]
+    bs = [torch.randn(C, generator=g) * 0.1 for _ in range(2)]
+    gy = torch.randn(x.features.shape[0], C, generator=g)
+
+    def run(pair):
+        F.WGRAD_PAIR = pair
+        try:
+            X = x.features.detach().clone().requires_grad_()
+            ps = [ws[0].to(gpu).requires_grad_(), bs[0].to(gpu).requires_grad_(), ws[1].to(gpu).requires_grad_(), bs[1].to(gpu).requires_grad_()]
+            y = F.ResidualBlockFunction.apply(X, *ps, x.metadata, size)
+            return y.detach(), torch.autograd.grad(y, [X] + ps, gy.to(gpu))
+        finally:
+            F.WGRAD_PAIR = True
+    y_p, g_p = run(True)
+    y_s, g_s = run(False)
+    assert torch.equal(y_p, y_s)
+    for a, b in zip(g_p, g_s):
+        _close(a, b, 2e-6, "paired vs single on a tiny scene")
+    nbr, rules = O.subm_rulebook(scene.coords0, 3)
+    Xo = x.features.detach().cpu().clone().requires_grad_()
+    po = [ws[0].clone().requires_grad_(), bs[0].clone().requires_grad_(), ws[1].clone().requires_grad_(), bs[1].clone().requires_grad_()]
+    h = O.conv(torch.relu(Xo), po[0], po[1], rules, scene.n(0))
+    yo = Xo + O.conv(torch.relu(h), po[2], po[3], rules, scene.n(0))
+    go = torch.autograd.grad(yo, [Xo] + po, gy)
+    for a, b in zip(g_p, go):
+        _close(a, b, 2e-4, "tiny scene gradients vs oracle")

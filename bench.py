@@ -41,8 +41,8 @@ PEAK_HBM_GBPS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec (6.2
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)       # >= 10 warm-up, >= 50 timed iterations
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--target", type=int, default=None, help="active voxels per scene (default: the workload's)")
     ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg5"), default="cfg2",

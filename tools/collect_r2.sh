@@ -6,7 +6,7 @@ O=$R/gpurun_out/r2
 mkdir -p $O
 cd $R
 b() { name=$1; shift; python bench.py "$@" > $O/bench_$name.json 2> $O/bench_$name.err; echo "bench $name rc=$?"; }
-b cfg2 --steps 30 --warmup 5 --dropin
+b cfg2 --dropin
 b cfg2_all_kernels --steps 20 --warmup 5 --profile-all --no-cpu-baseline --no-extras
 b cfg2_bf16 --dtype bf16 --steps 30 --warmup 5 --no-cpu-baseline
 b cfg3 --workload cfg3 --steps 20 --warmup 5 --no-cpu-baseline

@@ -133,6 +133,19 @@ class FlatParams:
     def sgd_step(self, lr: float):
         self.flat.add_(self.flat_grad, alpha=-lr)
 
+    def step_single_rank(self, lr: float):
+        """all_reduce_mean + sgd_step for ONE rank without a process group: there is nothing to reduce, so the gradients
+        need not be packed into the flat bucket first (a 50 MB copy at 32->256 channels) -- the update reads them where
+        autograd left them, one multi-tensor launch.  Same arithmetic per element as sgd_step."""
+        if (self.buckets or os.environ.get("SCN_STEP_PACKED") or
+                (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)):
+            self.all_reduce_mean()
+            self.sgd_step(lr)
+            return
+        have = [(p, p.grad) for p in self.params if p.grad is not None]
+        if have:
+            torch._foreach_add_([p.data for p, _ in have], [g for _, g in have], alpha=-lr)
+
 
 def broadcast_params(fp: FlatParams, src: int = 0):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

@@ -91,8 +91,7 @@ class SceneStep:
 
     def step(self):
         self.forward_backward()
-        self.flat.all_reduce_mean()
-        self.flat.sgd_step(self.lr)
+        self.flat.step_single_rank(self.lr)      # = all_reduce_mean + sgd_step; one rank: no packing into the flat bucket
 
     def finish(self):
         """Join the index build started by the last step (it belongs to the timed region)."""

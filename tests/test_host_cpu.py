@@ -190,3 +190,27 @@ print("OK")
 ''' % (ROOT, str(_free_port()))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_single_rank_step_equals_packed_step():
+    """FlatParams.step_single_rank (no process group: update straight from the per-parameter gradients) == all_reduce_mean +
+    sgd_step through the flat bucket, bit for bit."""
+    torch.manual_seed(0)
+    def make():
+        torch.manual_seed(1)
+        net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+        return net, FlatParams(net)
+    x = torch.randn(11, 5)
+    outs = []
+    for single in (True, False):
+        net, fp = make()
+        for _ in range(3):
+            fp.zero_grad()
+            net(x).square().sum().backward()
+            if single:
+                fp.step_single_rank(1e-2)
+            else:
+                fp.all_reduce_mean()
+                fp.sgd_step(1e-2)
+        outs.append(fp.flat.clone())
+    assert torch.equal(outs[0], outs[1])

@@ -315,6 +315,7 @@ def test_fuzz_native_index_build(gpu, seed):
     size = torch.tensor(grid)
     cfg = dict(seed=seed, grid=grid, levels=levels, batch=batch, points=len(coords))
     cg = coords.to(gpu)
+    Metadata.LEVELS_HINT.pop(tuple(int(g_) for g_ in grid), None)      # an earlier case on this grid may have gone deeper
     a = Metadata(3); a.set_input(size, cg, batch, 4); a.build_pyramid(size, levels, 3)
     b = Metadata(3).build_native(size, cg, batch, 4, levels, 3)
     eq = torch.equal

@@ -57,9 +57,12 @@ def parse_args(argv=None):
                     help="time every GEMM kernel launch of the sampled steps, not only the dominant kernel")
     ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
                     help="build the index structures inside the forward pass instead of one batch ahead")
-    ap.add_argument("--dropin", action="store_true",
-                    help="also time the layer-by-layer module path the reference's module_factory builds (lazy Metadata, "
-                         "no helper thread, no fused residual node) and report it as `dropin` next to the headline")
+    ap.add_argument("--dropin", dest="dropin", action="store_true", default=True,
+                    help="(default) also time the layer-by-layer module path the reference's module_factory builds (lazy "
+                         "Metadata, no helper thread) and report it as `dropin` next to the headline")
+    ap.add_argument("--no-dropin", dest="dropin", action="store_false")
+    ap.add_argument("--no-bf16-leg", dest="bf16_leg", action="store_false",
+                    help="skip the short bf16-storage side leg (cfg2 in bf16: ms/step + k_conv_tb roofline) of the default run")
     ap.add_argument("--no-extras", action="store_true", help="skip the index-build / no-prefetch side measurements")
     a = ap.parse_args(argv)
     if a.bf16_all:
@@ -78,24 +81,82 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def self_launch(args, script=None, argv=None):
+def _tail(path, nbytes=4000):
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, os.SEEK_END)
+            size = f.tell()
+            f.seek(max(0, size - nbytes))
+            return f.read().decode(errors="replace")
+    except OSError:
+        return ""
+
+
+def self_launch(args, script=None, argv=None, poll_s=0.05, grace_s=5.0):
     """Start --gpus fresh ranks of this script.  Nothing here touches torch.cuda: a forked/exec'd child of a process that
-    initialised the GPU is not allowed on this pool, and RCCL wants one fresh process per device."""
+    initialised the GPU is not allowed on this pool, and RCCL wants one fresh process per device.
+
+    All ranks are polled: when ANY rank exits non-zero (out of memory, RCCL initialisation, a crash) the others -- which
+    would sit in a collective until the driver's time limit -- are terminated, the dead rank's stderr tail is printed, and
+    the launch returns that rank's code.  Every rank writes stdout / stderr to its own file (no pipe can fill up); rank 0's
+    stdout (the ONE JSON line) is relayed on success, rank 0's stderr always."""
+    import signal
+    import tempfile
     port = _free_port()
-    procs = []
+    tmp = tempfile.mkdtemp(prefix="scn_bench_")
+    procs, files = [], []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), SCN_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out_p, err_p = os.path.join(tmp, f"rank{r}.out"), os.path.join(tmp, f"rank{r}.err")
+        fo, fe = open(out_p, "wb"), open(err_p, "wb")
+        files.append((out_p, err_p, fo, fe))
         procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] +
-                                      (sys.argv[1:] if argv is None else list(argv)), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else None))
-    out0 = procs[0].communicate()[0].decode()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = max(rc, abs(p.wait()))
-    sys.stdout.write(out0)
-    sys.stdout.flush()
+                                      (sys.argv[1:] if argv is None else list(argv)), env=env, stdout=fo, stderr=fe))
+    dead = None
+    while dead is None:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            dead = bad[0]
+        elif all(c == 0 for c in codes):
+            break
+        else:
+            time.sleep(poll_s)
+    rc = 0
+    if dead is not None:
+        for p in procs:                                  # the survivors wait in a collective that will never complete
+            if p.poll() is None:
+                p.send_signal(signal.SIGTERM)
+        t_end = time.time() + grace_s
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.0, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        rc = abs(dead[1]) or 1
+    for _, _, fo, fe in files:
+        fo.close(); fe.close()
+    sys.stderr.write(_tail(files[0][1], 20000))
+    if dead is not None:
+        sys.stderr.write(f"\n[bench.py] rank {dead[0]} exited with code {dead[1]}; the other ranks were terminated.  "
+                         f"Its stderr tail:\n{_tail(files[dead[0]][1])}\n")
+    else:
+        with open(files[0][0], "rb") as f:
+            sys.stdout.write(f.read().decode(errors="replace"))
+    sys.stdout.flush(); sys.stderr.flush()
+    for out_p, err_p, _, _ in files:
+        for q in (out_p, err_p):
+            try:
+                os.remove(q)
+            except OSError:
+                pass
+    try:
+        os.rmdir(tmp)
+    except OSError:
+        pass
     return rc
 
 
@@ -191,6 +252,10 @@ def run(args):
     # the timed region; collect now and move the survivors to the permanent generation, as a training loop would
     gc.collect()
     gc.freeze()
+    import ctypes
+    from sparse_rcnn_amd import _lib as L
+    paths = (ctypes.c_int64 * 4)()
+    L.lib().scn_conv_tiles_path_counts(paths, 1)              # count the kernel variants of the timed region only
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
@@ -207,6 +272,8 @@ def run(args):
     dt = time.perf_counter() - t0
     profiling.TIMER = None
     sampled = max(1, timer.sampled_steps)
+    L.lib().scn_conv_tiles_path_counts(paths, 0)
+    dt_local = dt
 
     red_dev = dev if (world == 1 or backend == "nccl") else "cpu"
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
@@ -215,6 +282,17 @@ def run(args):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(vox, op=dist.ReduceOp.SUM)
     dt, total_vox = tmax.item(), vox.item()
+    # per-rank figures (a bad scaling curve must be diagnosable from the one line): step time as each rank saw it, the time
+    # its compute stream waited for gradient all-reduces after backward had ended (HIP events, mean of the last steps), rows
+    exposed = job.flat.exposed_allreduce_ms()
+    mine = torch.tensor([dt_local / args.steps * 1e3, float(job.n_active), -1.0 if exposed is None else exposed,
+                         float(job.n_roi_rows)], dtype=torch.float64, device=red_dev)
+    per_rank = [mine]
+    if dist_on:
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+    per_rank = [dict(rank=r, ms_per_step=v[0], n_active=int(v[1]), allreduce_ms_exposed=None if v[2] < 0 else v[2],
+                     n_roi_rows=int(v[3])) for r, v in enumerate(t.tolist() for t in per_rank)]
 
     # ---- side measurements outside the timed region (rank 0's numbers; every rank runs them so collectives stay matched)
     extras = {}
@@ -240,6 +318,12 @@ def run(args):
                        "parallelism": f"dp{world} (1 scene/GPU, flat-bucket all-reduce)"},
             "n_ranks_seen_by_rccl": ranks_seen if backend == "nccl" else None,
             "n_ranks_seen": ranks_seen, "collective_backend": backend if dist_on else None,
+            "per_rank": per_rank,
+            "fast_path": {"conv_tiles_fast": int(paths[0]), "conv_tiles_general": int(paths[1]),
+                          "k_reduction_in_launch": int(paths[2]), "k_reduction_second_launch": int(paths[3]),
+                          "all_fast": int(paths[1]) == 0 and int(paths[3]) == 0,
+                          "note": "scn_conv_tiles launches of the timed region by kernel variant (rank 0): `general` = the "
+                                  "64-bit-addressing fallback above 2^23 rows / 4 GB slabs"} if args.dtype == "f32" else None,
         }
         out.update(extras)
         if ks:
@@ -277,7 +361,9 @@ def roofline(dom, d, sampled, args):
     except (OSError, KeyError, ValueError):
         pass
     common = {"kernel": dom, "traffic": traffic,
-              "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r2_traffic.json)",
+              "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+              "traffic_source": "RECORDED by separate rocprofv3 --pmc passes of an earlier run of this command "
+                                "(profiles/%s), not measured by this run" % os.path.basename(tfile),
               "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
               "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
               "launches_per_step": d["launches"] / sampled, "sampled_steps": sampled, "avg_launch_us": us}
@@ -341,9 +427,43 @@ def side_measurements(job, args, world, dist, torch):
             dist.barrier()
         ex["ms_per_step_no_prefetch"] = (time.perf_counter() - t0) / n * 1e3
         job.prefetch = True
-    if args.dropin and args.workload == "cfg2":
+    if args.dropin and args.workload == "cfg2" and world == 1:
         ex["dropin"] = dropin_measurement(job, args, torch)
+    if args.bf16_leg and args.workload == "cfg2" and args.dtype == "f32" and world == 1 and args.target is None:
+        ex["bf16"] = bf16_side_leg(args, job.device, torch)
     return ex
+
+
+def bf16_side_leg(args, dev, torch):
+    """BASELINE configs[2..4] store features in bf16: the same cfg-2 step in bf16 STORAGE (fp32 accumulation, fp32
+    parameters), a short run outside the timed region, with the roofline of ITS dominant kernel (k_conv_tb: HBM-bound)."""
+    from sparse_rcnn_amd import profiling
+    from sparse_rcnn_amd.trainstep import SceneStep
+    job = SceneStep("cfg2", dev, dtype="bf16", prefetch=args.prefetch, seed=1, grad_seed=100)
+    n, warm = max(10, min(40, args.steps)), 10
+    timer = profiling.KernelTimer(every=max(5, n // 2), names={"k_conv_tb"})
+    for _ in range(warm):
+        job.step()
+    timer.reserve(1024)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        timer.begin_step()
+        profiling.TIMER = timer if timer.active else None
+        job.step()
+    job.finish()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    profiling.TIMER = None
+    ks = timer.summary()
+    out = {"ms_per_step": ms, "value": job.n_active / (ms * 1e-3), "steps": n, "warmup": warm,
+           "workload": "cfg2 in bf16 storage (bench.py --dtype bf16 times it as the main leg)"}
+    if "k_conv_tb" in ks:
+        out["roofline"] = roofline("k_conv_tb", ks["k_conv_tb"], max(1, timer.sampled_steps),
+                                   argparse.Namespace(workload="cfg2", dtype="bf16"))
+    del job
+    torch.cuda.empty_cache()
+    return out
 
 
 def dropin_measurement(job, args, torch):

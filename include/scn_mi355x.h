@@ -228,6 +228,12 @@ int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32_t* tstab, 
                    const int32_t* tile_order, int n_off, int64_t n_out, const float* W, const float* bias, const float* residual,
                    const float* relu_mask, float* Y, int cout, int flags, void* scratch, int32_t* arrival,
                    scn_stream_t stream);
+/* Which kernel variant the scn_conv_tiles calls of this process took since the last reset: out[0] = launches on the fast path
+ * (raw-buffer gathers: 16-byte rows, < 2^23 rows, < 4 GB slabs), out[1] = launches that fell back to the general kernel
+ * (same results, 64-bit addressing), out[2] = launches with the in-launch K reduction, out[3] = launches that left the K
+ * reduction to a second launch.  reset != 0 zeroes the counters after reading.  (bench.py reports it as `fast_path`: a
+ * workload that outgrows the fast path's limits changes kernels, and the JSON line says so.) */
+void scn_conv_tiles_path_counts(int64_t out[4], int reset);
 /* Second half of a scn_conv_tiles call made with SCN_F_SPLIT_SUM: adds the K-chunk slabs (no-op when cin <= 32: the
  * tile kernel has written Y).  Same arguments as that call. */
 int scn_conv_tiles_finish(int cin, int64_t n_out, const float* bias, const float* residual, const float* relu_mask,
@@ -391,6 +397,21 @@ int scn_input_bwd(const float* dY, const int32_t* item_row, const int32_t* row_c
 int scn_gather_rows(const float* X, const int32_t* rows, int64_t m, int c, float* Y, scn_stream_t stream);
 int scn_segment_sum(const float* dY, const int32_t* item_row, int64_t n_items, int64_t n_rows, int c, float* dX,
                     double* acc64, scn_stream_t stream);
+
+/* Per-sample pooling of a slab -- the reference's SparseGlobalPool / split_batch (ndsis/modules/custom_operations.py:24-59;
+ * sparse class network model.py:507-512, module_factory.py:655-657).  The sample of row r is coords[r][3] (the grid's int32
+ * [n][4] rows, x y z b).  op: 0 mean (torch.mean, the reference's default), 1 sum, 2 max (torch.amax).
+ *   fwd: Y[b][:] over the rows of sample b; a sample without rows pools to zeros (custom_operations.py:53-54).
+ *        cnt[b] = rows of sample b; *unsorted != 0 iff some row has a smaller sample index than the row before it.
+ *   bwd: mean dX[r] = dY[b] / cnt[b]; sum dX[r] = dY[b]; max: dY[b][c] split evenly among the rows that hold the maximum.
+ * scratch: scn_segment_pool_scratch_bytes(n_samples, c) (fp64 accumulators / tie counts).  No host synchronisation.
+ * scn_sample_counts: cnt and *unsorted alone (split_batch: rows grouped by sample are returned as row ranges). */
+int64_t scn_segment_pool_scratch_bytes(int n_samples, int c);
+int scn_sample_counts(const int32_t* coords, int64_t n, int n_samples, int32_t* cnt, int32_t* unsorted, scn_stream_t stream);
+int scn_segment_pool_fwd(const float* X, const int32_t* coords, int64_t n, int c, int n_samples, int op, float* Y,
+                         int32_t* cnt, int32_t* unsorted, void* scratch, scn_stream_t stream);
+int scn_segment_pool_bwd(const float* X, const float* Y, const float* dY, const int32_t* coords, int64_t n, int c,
+                         int n_samples, int op, const int32_t* cnt, float* dX, void* scratch, scn_stream_t stream);
 
 /* scn.SparseToDense (module_factory.py:429-435): out [B][C][X][Y][Z] pre-zeroed by the caller. */
 int scn_sparse_to_dense_fwd(const float* X, const int32_t* coords, int64_t n, int c, const int64_t* size3_host,

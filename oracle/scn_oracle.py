@@ -299,6 +299,23 @@ def pool_fwd(X, child, average):
     return Y
 
 
+def split_batch(X, coords, batch_size):
+    """custom_operations.py:24-39: per sample b the rows whose batch column equals b, in row order (a [B, N] bool mask
+    `arange(B)[:, None] == coords[:, -1]` and one boolean index per sample)."""
+    b = torch.from_numpy(np.asarray(coords)[:, -1].astype(np.int64))
+    mask = torch.arange(batch_size).unsqueeze(1) == b
+    return [X[m] for m in mask]
+
+
+def global_pool(X, coords, batch_size, pooling_function=torch.mean):
+    """custom_operations.py:42-59 SparseGlobalPool.forward: stack of pooling_function(rows of sample b, dim=0), zeros for
+    a sample without rows, `features[:0]` for a batch of zero samples."""
+    parts = split_batch(X, coords, batch_size)
+    if parts:
+        return torch.stack([pooling_function(f, dim=0) if len(f) else f.new_zeros((f.shape[1])) for f in parts])
+    return X[:0]
+
+
 def sparse_to_dense(X, coords, spatial_size, batch_size):
     """A13: zeros [B,C,X,Y,Z]; out[b,:,x,y,z] = X[row]."""
     sx, sy, sz = (int(v) for v in spatial_size)

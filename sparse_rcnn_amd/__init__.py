@@ -15,10 +15,11 @@ from .modules import (AddTable, AveragePooling, BatchNormLeakyReLU, BatchNormReL
                       Convolution, Deconvolution, Identity, JoinTable, MaxPooling, NetworkInNetwork, ReLU,
                       Sequential, SparseToDense, SubmanifoldConvolution)
 from .tensor import SparseConvNetTensor                                    # noqa: F401
+from .custom_operations import SparseGlobalPool, split_batch               # noqa: F401  (device forms of the reference's own helpers)
 
 __all__ = [
     "Metadata", "SparseConvNetTensor", "ioLayers", "InputLayer", "OutputLayer", "Sequential", "ConcatTable",
     "AddTable", "JoinTable", "Identity", "ReLU", "BatchNormReLU", "BatchNormLeakyReLU", "Convolution",
     "Deconvolution", "SubmanifoldConvolution", "NetworkInNetwork", "MaxPooling", "AveragePooling", "SparseToDense",
-    "prefetch_index", "index_prefetching",
+    "prefetch_index", "index_prefetching", "SparseGlobalPool", "split_batch",
 ]

@@ -47,6 +47,7 @@ _SIGS = {
     "scn_conv_tiles_scratch_bytes": (i64, [i32, i64, i32]),
     "scn_conv_tiles_arrival_counters": (i64, [i32, i64, i32]),
     "scn_conv_tiles": (C.c_int, [p, i64, i32, p, p, p, p, i32, i64, p, p, p, p, p, i32, i32, p, p, p]),
+    "scn_conv_tiles_path_counts": (None, [C.POINTER(i64), i32]),
     "scn_conv_tiles_finish": (C.c_int, [i32, i64, p, p, p, p, i32, i32, p, p]),
     "scn_conv_tiles_bf16_image_bytes": (i64, [i32, i32, i32]),
     "scn_conv_tiles_bf16_pack": (C.c_int, [p, i32, i32, i32, i32, p, p]),
@@ -95,6 +96,10 @@ _SIGS = {
     "scn_nms": (C.c_int, [p, i32, i32, f32, p, p]),
     "scn_pool_fwd": (C.c_int, [p, p, i64, i32, i32, p, p]),
     "scn_pool_bwd": (C.c_int, [p, p, p, p, i64, i32, i32, p, p]),
+    "scn_segment_pool_scratch_bytes": (i64, [i32, i32]),
+    "scn_sample_counts": (C.c_int, [p, i64, i32, p, p, p]),
+    "scn_segment_pool_fwd": (C.c_int, [p, p, i64, i32, i32, i32, p, p, p, p, p]),
+    "scn_segment_pool_bwd": (C.c_int, [p, p, p, p, i64, i32, i32, i32, p, p, p, p]),
     "scn_sparse_to_dense_fwd": (C.c_int, [p, p, i64, i32, C.POINTER(i64), p, p]),
     "scn_sparse_to_dense_bwd": (C.c_int, [p, p, i64, i32, C.POINTER(i64), p, p]),
 }

@@ -17,6 +17,8 @@
 //   * v_mfma_f32_16x16x4_f32, exact fp32.  Step (half, e) contracts channels 16*half + 4*kq + e (kq = lane>>4): a fixed
 //     permutation of the summation order shared by A and B so each lane fetches 4 channels per 16-byte access.
 //     C/D: acc[j] = D[4*kq + j][lane & 15].
+#include <atomic>
+
 #include "scn_common.h"
 
 #ifndef TS_EXP
@@ -544,6 +546,12 @@ extern "C" int64_t scn_conv_tiles_scratch_bytes(int cin, int64_t n_out, int cout
            (n_kc > 1 ? n_kc * cdiv(n_out, TS_T) * TS_T * cdiv(cout, TS_CT) * TS_CT * (int64_t)sizeof(float) : 0);
 }
 
+static std::atomic<int64_t> g_ts_paths[4];
+
+extern "C" void scn_conv_tiles_path_counts(int64_t out[4], int reset) {
+    for (int i = 0; i < 4; ++i) out[i] = reset ? g_ts_paths[i].exchange(0) : g_ts_paths[i].load();
+}
+
 extern "C" int64_t scn_conv_tiles_arrival_counters(int cin, int64_t n_out, int cout) {
     return cdiv(cin, TS_KC) > 1 ? cdiv(n_out, TS_T) * cdiv(cout, TS_CT) : 0;
 }
@@ -580,6 +588,8 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     const bool fullk = vec && n_in < (1ll << 23) && n_in * cin * 4 < (1ll << 32) - (1ll << 24) &&
                        n_out < (1ll << 23) && n_out * cout * 4 < (1ll << 32) - (1ll << 24);
     const bool part = cin % TS_KC != 0;
+    g_ts_paths[fullk ? 0 : 1].fetch_add(1, std::memory_order_relaxed);
+    if (n_kc > 1) g_ts_paths[fused ? 2 : 3].fetch_add(1, std::memory_order_relaxed);
     dim3 grid((unsigned)(n_tg * n_chunks * n_kc));
     hipStream_t st = S(stream);
 #define LAUNCH_TS_F(T, V, VN, FK, PT, FU)                                                                           \

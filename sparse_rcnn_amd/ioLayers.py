@@ -25,9 +25,9 @@ class InputLayer(Module):
         coords = coords.long()
         md = metadata
         if md is None:
-            md = take_prefetched(coords)                    # announced by scn.prefetch_index for this very tensor
-            if md is not None and md.input_size != tuple(int(s) for s in self.spatial_size.tolist()):
-                md = None                                   # announced with another spatial size: build here
+            # announced by scn.prefetch_index for this very tensor object AND for this layer's spatial size, mode and
+            # batch_size (a mode-0 layer must keep its "unique coordinates" check, n_samples must be the layer's)
+            md = take_prefetched(coords, self.spatial_size.tolist(), batch_size, self.mode)
         if md is None:
             md = Metadata(self.dimension)
         feats = InputLayerFunction.apply(self.dimension, md, self.spatial_size, coords, features, batch_size, self.mode)

@@ -95,6 +95,22 @@ class MaskBranch(nn.Module):
         out = self.roi_output_layer(unet(roi_tensor))            # [cropped points, phys0]; the pad column is zero
         return self._linear(out), selection
 
+    # parameter naming shared with the checker (tests map the oracle's mask-branch parameters by these names)
+    def named_oracle_params(self):
+        out = {}
+        ic = self.input_conv_layer
+        out["in.weight"], out["in.bias"] = ic[0].weight, ic[0].bias
+        for u, block in enumerate(ic[1]):
+            convs = [m for m in block[0][1] if isinstance(m, M.SubmanifoldConvolution)]
+            for v, cv in enumerate(convs):
+                out[f"in.res{u}.conv{v}.weight"], out[f"in.res{u}.conv{v}.bias"] = cv.weight, cv.bias
+        for k, p in self.output_conv_layer.named_oracle_params().items():
+            out["unet." + k] = p
+        lin = [m for m in self.linear_layer if isinstance(m, nn.Linear)]
+        for i, m in enumerate(lin):
+            out[f"lin{i}.weight"], out[f"lin{i}.bias"] = m.weight, m.bias
+        return out
+
     def _linear(self, x):
         """The Linear / ReLU stack (module_factory.py:700-716) on the library's row GEMM: nn.Linear parameters (state_dict
         names and shapes kept), y = x W^T + b through NetworkInNetworkFunction with the transposed weight view; a padded

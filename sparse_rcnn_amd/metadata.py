@@ -63,49 +63,85 @@ class PendingMetadata:
 # build on the helper thread / index stream and parks it under the identity of the coords tensor; the InputLayer that later
 # receives that very tensor adopts it (ioLayers.InputLayer.forward).  `index_prefetching(loader, extract)` is the one-line
 # form for a training loop.
-_prefetched: "Dict[tuple, PendingMetadata]" = {}
+# Entries are keyed by the identity of the coords tensor OBJECT and hold a strong reference to it: an announced batch that
+# is never run (an early `break`, an exception in the loop) cannot have its storage freed and recycled for another
+# same-shaped tensor that would then match a stale entry.  The contract is "the same tensor object, unmodified": an in-place
+# refill that does not go through torch (numpy views of a recycled loader buffer) is invisible to `_version` and is the
+# caller's to avoid.
+class _Announced:
+    __slots__ = ("coords", "version", "size", "batch_size", "mode", "pending")
+
+    def __init__(self, coords, size, batch_size, mode, pending):
+        self.coords, self.version, self.size = coords, coords._version, size
+        self.batch_size, self.mode, self.pending = int(batch_size), int(mode), pending
+
+
+_prefetched: "Dict[int, _Announced]" = {}
 _PREFETCH_KEEP = 4
-
-
-def _coords_key(coords: torch.Tensor):
-    return (coords.data_ptr(), coords._version, tuple(coords.shape), str(coords.device))
 
 
 def prefetch_index(coords: torch.Tensor, spatial_size, batch_size: int = 0, mode: int = 4, n_levels: int = 0, k: int = 3):
     """Start building the index structures of a COMING batch (InputLayer rules + the rulebook pyramid as deep as the last
     network over this spatial size went, Metadata.LEVELS_HINT).  coords: the int64 [N, 4] tensor the forward will hand to
-    scn.InputLayer -- the same tensor object, unmodified."""
+    scn.InputLayer -- the same tensor object, unmodified; mode / batch_size: those of the InputLayer that will consume it
+    (the reference's backbone: mode 4, custom_operations.py:67-83) -- an InputLayer with other settings builds its own."""
     size = tuple(int(s) for s in torch.as_tensor(spatial_size).reshape(-1).tolist())
     levels = n_levels or Metadata.LEVELS_HINT.get(size, 0)
     while len(_prefetched) >= _PREFETCH_KEEP:                 # batches that were announced and never run
         _prefetched.pop(next(iter(_prefetched)))
     pending = Metadata(len(size)).prepare_in_thread(spatial_size, coords, int(batch_size), mode, levels, k)
-    _prefetched[_coords_key(coords)] = pending
+    _prefetched[id(coords)] = _Announced(coords, size, batch_size, mode, pending)
     return pending
 
 
-def take_prefetched(coords: torch.Tensor):
-    """The Metadata prefetched for exactly this coords tensor, or None."""
+def take_prefetched(coords: torch.Tensor, spatial_size=None, batch_size=None, mode=None):
+    """The Metadata prefetched for exactly this coords tensor object (unmodified since the announcement) and -- when given --
+    for this spatial size / batch_size / mode, or None (the caller then builds its own)."""
     if not _prefetched:
         return None
-    pending = _prefetched.pop(_coords_key(coords), None)
-    return None if pending is None else pending.result()
+    e = _prefetched.get(id(coords))
+    if e is None or e.coords is not coords:
+        return None
+    del _prefetched[id(coords)]
+    if e.version != coords._version:
+        return None                                           # modified in place since it was announced
+    if spatial_size is not None and e.size != tuple(int(s) for s in spatial_size):
+        return None
+    if (batch_size is not None and int(batch_size) != e.batch_size) or (mode is not None and int(mode) != e.mode):
+        return None
+    return e.pending.result()
+
+
+def drop_prefetched(coords=None):
+    """Forget announced batches (all, or the one announced for `coords`)."""
+    if coords is None:
+        _prefetched.clear()
+    else:
+        _prefetched.pop(id(coords), None)
 
 
 def index_prefetching(batches, extract):
     """Wrap a data loader: yields its batches unchanged, and before yielding batch i announces batch i+1's coordinates
     (extract(batch) -> (coords, spatial_size, batch_size)) with prefetch_index, so that their index build overlaps batch
-    i's kernels.      for batch in scn.index_prefetching(loader, lambda b: (b[0], b[2], b[3])): ..."""
+    i's kernels.      for batch in scn.index_prefetching(loader, lambda b: (b[0], b[2], b[3])): ...
+    When the loop ends early (break, exception) the batch that was announced and never run is forgotten."""
     it = iter(batches)
     try:
         cur = next(it)
     except StopIteration:
         return
-    for nxt in it:
-        prefetch_index(*extract(nxt))
+    announced = None
+    try:
+        for nxt in it:
+            args = extract(nxt)
+            announced = args[0]
+            prefetch_index(*args)
+            yield cur
+            cur = nxt
         yield cur
-        cur = nxt
-    yield cur
+    finally:
+        if announced is not None:
+            drop_prefetched(announced)
 
 
 @dataclass
@@ -560,7 +596,7 @@ class Metadata:
 
     # ---- index prefetch on a side stream -----------------------------------------------------------
     def prepare_async(self, spatial_size, coords, batch_size: int = 0, mode: int = 4, n_levels: int = 0, k: int = 3,
-                      native: bool = False):
+                      native: bool = False, caller_stream=None):
         """Build the InputLayer rules (and optionally the rulebook pyramid of an n_levels U-Net) on the index stream.
 
         All index structures depend only on the coordinates, so a training loop can build those of batch i+1 while the
@@ -568,8 +604,10 @@ class Metadata:
         the host syncs of the size queries then wait on the index stream only.  `InputLayerFunction` adopts a prepared
         Metadata (same coords) instead of rebuilding it; `handover()` orders the consumer stream behind the build."""
         side = index_stream(torch.device("cuda", torch.cuda.current_device()))
-        side.wait_stream(torch.cuda.current_stream())          # coords may have been produced on the current stream
-        self._prepared_for = (coords.data_ptr(), coords._version, tuple(coords.shape), coords.device)
+        # coords may have been produced on the CALLER's stream (prepare_in_thread captures it: on the helper thread
+        # torch.cuda.current_stream() is that thread's default stream, not the caller's)
+        side.wait_stream(caller_stream if caller_stream is not None else torch.cuda.current_stream())
+        self._prepared_for = (coords, coords._version)         # strong reference: the identity cannot be recycled
         with torch.cuda.stream(side):
             if native and n_levels:
                 self.build_native(spatial_size, coords, batch_size, mode, n_levels, k)
@@ -587,16 +625,19 @@ class Metadata:
         waits would keep it from queueing the matrix kernels of the current batch (measured: slower than no prefetch).
         The helper spends its time inside C calls and event waits, which release the GIL."""
         dev = torch.cuda.current_device()
+        caller_stream = torch.cuda.current_stream() if coords.is_cuda else None
 
         def fn():
             torch.cuda.set_device(dev)
-            return self.prepare_async(spatial_size, coords, batch_size, mode, n_levels, k, native=native)
+            return self.prepare_async(spatial_size, coords, batch_size, mode, n_levels, k, native=native,
+                                      caller_stream=caller_stream)
         return PendingMetadata(fn)
 
     def prepared_for(self, coords: torch.Tensor) -> bool:
         """Was this (prefetched) Metadata built for `coords`?  The same tensor object and version is accepted at once;
         anything else is compared value by value with the stored int32 copy (one host wait: a rare path)."""
-        if self._prepared_for == (coords.data_ptr(), coords._version, tuple(coords.shape), coords.device):
+        pf = self._prepared_for
+        if pf is not None and pf[0] is coords and pf[1] == coords._version:
             return True
         if self.point_coords is None or tuple(coords.shape) != tuple(self.point_coords.shape):
             return False

@@ -316,8 +316,7 @@ class SparseRoiCut(torch.nn.Module):
                     while ok < levels and all(v % 2 == 0 for v in lv):
                         lv, ok = tuple(v // 2 for v in lv), ok + 1
                     md = Metadata(3)
-                    md._prepared_for = (sel.new_coords.data_ptr(), sel.new_coords._version, tuple(sel.new_coords.shape),
-                                        sel.new_coords.device)
+                    md._prepared_for = (sel.new_coords, sel.new_coords._version)
                     md.build_native(size, sel.new_coords, sel.n_boxes, mode, ok, 3)
                     md._unrequested = set(md.strided)
                     md.ready_event = torch.cuda.Event()

@@ -86,7 +86,10 @@ class SceneStep:
             if self._gm is None or self._gm.shape != logits.shape:
                 self._gm = torch.randn(logits.shape, generator=self._gen).to(self.device)
                 self.n_roi_rows = logits.shape[0]
-            torch.autograd.backward([out.features, logits], [self._gy, self._gm])
+            if logits.requires_grad and logits.shape[0]:
+                torch.autograd.backward([out.features, logits], [self._gy, self._gm])
+            else:         # empty crop (no proposal caught a point): the mask branch contributes nothing on this rank
+                out.features.backward(self._gy)
         self.out, self.logits, self.fin = out, logits, fin
 
     def step(self):

@@ -31,6 +31,29 @@ def units(c, num_units=2, batchnorm=False):
     return M.Sequential(*[residual_block(c, batchnorm) for _ in range(num_units)])
 
 
+def reference_key_map(n_levels, num_units=2):
+    """state_dict key of the reference's FeatureExtractor (sparse + U-Net: `main_network` = SequentialInterims of encoder
+    levels, `unet.module_list` = SkipConnectionReuniter per decoder level; module_factory.py:438-578, model.py:364-391)
+    -> this package's parameter name (`SparseUNet.named_oracle_params`).  Checked against the key list of a reference
+    FeatureExtractor built on this package (tests/golden/dropin_feature_extractor.json)."""
+    out = {}
+    for l in range(n_levels):
+        for t in ("weight", "bias"):
+            out[f"main_network.{l}.0.0.{t}"] = f"enc{l}.in.{t}"
+            for u in range(num_units):
+                for v, idx in enumerate((1, 3)):                 # Sequential(ReLU, SubM, ReLU, SubM) inside ConcatTable[1]
+                    out[f"main_network.{l}.1.{u}.0.1.{idx}.{t}"] = f"enc{l}.res{u}.conv{v}.{t}"
+    for i in range(n_levels - 1):
+        l = n_levels - 2 - i
+        for t in ("weight", "bias"):
+            out[f"unet.module_list.{i}.input_stage.1.{t}"] = f"dec{l}.up.{t}"
+            out[f"unet.module_list.{i}.channel_changer.{t}"] = f"dec{l}.nin.{t}"
+            for u in range(num_units):
+                for v, idx in enumerate((1, 3)):
+                    out[f"unet.module_list.{i}.output_stage.{u}.0.1.{idx}.{t}"] = f"dec{l}.res{u}.conv{v}.{t}"
+    return out
+
+
 class SparseUNet(nn.Module):
     """forward(SparseConvNetTensor with Cin channels) -> SparseConvNetTensor with channels[0] channels at full
     resolution; ``.interims`` holds the encoder outputs (the reference's SequentialInterims, custom_container.py:5-12)."""
@@ -164,6 +187,38 @@ class SparseUNet(nn.Module):
             for v, cv in enumerate(convs):
                 out[f"{prefix}.res{u}.conv{v}.weight"], out[f"{prefix}.res{u}.conv{v}.bias"] = cv.weight, cv.bias
 
+    def load_reference_state_dict(self, state_dict, prefix=None, strict=True):
+        """Load a checkpoint written by the REFERENCE's FeatureExtractor (training.py:386-391 saves model.state_dict()):
+        keys `<prefix>main_network...` / `<prefix>unet.module_list...` are mapped onto this network's parameters by
+        `reference_key_map`; SparseConvNet's grouped weight layout [fv, 1, nIn, nOut] is accepted.  prefix=None: detected
+        from the first key that ends in 'main_network.0.0.0.weight'.  -> (missing reference keys, unused checkpoint keys)."""
+        if self.identity_first:
+            raise NotImplementedError("the mask head's internal U-Net is not a FeatureExtractor checkpoint")
+        if prefix is None:
+            tail = "main_network.0.0.0.weight"
+            prefix = next((k[:-len(tail)] for k in state_dict if k.endswith(tail)), "")
+        own = self.named_oracle_params()
+        kmap = reference_key_map(len(self.channels))
+        missing, used = [], set()
+        with torch.no_grad():
+            for rk, name in kmap.items():
+                t = state_dict.get(prefix + rk)
+                if t is None:
+                    missing.append(prefix + rk)
+                    continue
+                if t.dim() == 4 and t.shape[1] == 1:
+                    t = t.squeeze(1)
+                p = own[name]
+                if tuple(t.shape) != tuple(p.shape):
+                    raise ValueError(f"{prefix + rk}: checkpoint shape {tuple(t.shape)} != {tuple(p.shape)} ({name})")
+                p.copy_(t)
+                used.add(prefix + rk)
+        unused = [k for k in state_dict if k.startswith(prefix + "main_network.") or k.startswith(prefix + "unet.")]
+        unused = [k for k in unused if k not in used]
+        if strict and (missing or unused):
+            raise KeyError(f"reference checkpoint mismatch: missing {missing[:4]}... unused {unused[:4]}...")
+        return missing, unused
+
     def load_oracle_params(self, params):
         with torch.no_grad():
             for k, p in self.named_oracle_params().items():
@@ -190,6 +245,10 @@ class Backbone(nn.Module):
             metadata = Metadata(3).build_native(spatial_size, coords, batch_size, 4, len(self.unet.channels), 3)
         x = InputLayer(3, spatial_size, mode=4)((coords, feats, batch_size), metadata)
         return self.unet(x)
+
+    def load_reference_state_dict(self, state_dict, prefix=None, strict=True):
+        """A reference FeatureExtractor checkpoint -> this backbone (SparseUNet.load_reference_state_dict)."""
+        return self.unet.load_reference_state_dict(state_dict, prefix, strict)
 
     def prefetch_in_thread(self, coords, spatial_size, batch_size=0):
         """As `prefetch`, on a helper thread: returns a PendingMetadata whose `.result()` is passed as `metadata=`."""

@@ -1,6 +1,10 @@
 """Helper of tests/test_gpu_atsize.py::test_two_rank_dp_step_matches_oracle -- ONE rank of a data-parallel step of the
-real Backbone, run as a fresh process (RANK / WORLD_SIZE / MASTER_* in the environment, gloo collective so that two
-ranks may share one GPU).  Writes the parameters and the all-reduced mean gradient as seen by this rank."""
+real Backbone (cfg2) or of Backbone + sparse ROI crop + mask branch (cfg3), run as a fresh process (RANK / WORLD_SIZE /
+MASTER_* in the environment, gloo collective so that two ranks may share one GPU).  Writes the parameters and the
+all-reduced mean gradient as seen by this rank.
+
+argv: out.npz target grid_x,grid_y,grid_z [workload [dtype [n_boxes [empty_rank]]]]
+empty_rank: that rank's boxes are moved outside the scene (its ROI crop is empty: no mask-branch gradients there)."""
 import os
 import sys
 
@@ -14,22 +18,29 @@ import torch.distributed as dist
 
 def main():
     out_path, target, grid = sys.argv[1], int(sys.argv[2]), tuple(int(v) for v in sys.argv[3].split(","))
+    workload = sys.argv[4] if len(sys.argv) > 4 else "cfg2"
+    dtype = sys.argv[5] if len(sys.argv) > 5 else "f32"
+    n_boxes = int(sys.argv[6]) if len(sys.argv) > 6 else None
+    empty_rank = int(sys.argv[7]) if len(sys.argv) > 7 else -1
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
     from sparse_rcnn_amd.trainstep import SceneStep
-    job = SceneStep("cfg2", torch.device("cuda", 0), dtype="f32", prefetch=False, seed=10 + rank, grad_seed=100 + rank,
-                    n_buckets=4, target=target, grid=grid, lr=0.0)
+    job = SceneStep(workload, torch.device("cuda", 0), dtype=dtype, prefetch=False, seed=10 + rank, grad_seed=100 + rank,
+                    n_buckets=4, target=target, grid=grid, lr=0.0, n_boxes=n_boxes)
     assert job.flat.buckets, "the bucketed, overlapped all-reduce must be active with 2 ranks"
+    if rank == empty_rank:
+        job.boxes = [b + 10_000.0 for b in job.boxes]
     job.step()
     torch.cuda.synchronize()
-    names = list(job.model.backbone.unet.named_oracle_params())
-    params = {k: p.detach().cpu().numpy() for k, p in job.model.backbone.unet.named_oracle_params().items()}
-    grads = {}
-    views = dict(zip([id(p) for p in job.flat.params], job.flat.grad_views))
-    for k, p in job.model.backbone.unet.named_oracle_params().items():
-        grads["g:" + k] = views[id(p)].detach().cpu().numpy()
-    np.savez(out_path, n_active=job.n_active, **params, **grads)
+    named = {k: p for k, p in job.model.backbone.unet.named_oracle_params().items()}
+    if job.model.mask is not None:
+        named.update({"m:" + k: p for k, p in job.model.mask.named_oracle_params().items()})
+    params = {k: p.detach().cpu().numpy() for k, p in named.items()}
+    views = dict(zip([id(p) for p in job.flat.params], job.flat.mean_grad_views()))
+    assert len(views) == len(named), (len(views), len(named))       # every parameter of the step is named
+    grads = {"g:" + k: views[id(p)].detach().cpu().numpy() for k, p in named.items()}
+    np.savez(out_path, n_active=job.n_active, n_roi_rows=job.n_roi_rows, **params, **grads)
     dist.barrier()
     dist.destroy_process_group()
 

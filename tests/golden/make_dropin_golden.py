@@ -1,7 +1,9 @@
 """Drop-in boundary fixture (SURVEY.md §8c iii): in the build container only, register this package as
 ``sparseconvnet``, import the REFERENCE's ndsis.modules.model and build its FeatureExtractor (sparse + U-Net) with the
-parameter dict restated from scannet_config/run.py:581-627.  Stores the state_dict key list + shapes and the scn layer
-census; tests/test_dropin_cpu.py checks this package's own graph builder against it without the reference present.
+parameter dict restated from scannet_config/run.py:581-627.  Stores the state_dict key list + shapes, the scn layer
+census and the module-tree `repr` (the reference's container class names around this package's layer lines: output of
+the run, not source text); tests/test_dropin_cpu.py checks this package's own graph builder against it -- key NAMES
+through unet.reference_key_map, the order of the scn layers through the repr -- without the reference present.
 
     python tests/golden/make_dropin_golden.py
 """
@@ -42,7 +44,7 @@ if __name__ == "__main__":
             if type(m).__module__.startswith("sparse_rcnn_amd"):
                 census[type(m).__name__] = census.get(type(m).__name__, 0) + 1
         out[name] = dict(channels=ch, n_params=int(sum(v.numel() for v in sd.values())),
-                         keys={k: list(v.shape) for k, v in sd.items()}, census=census)
+                         keys={k: list(v.shape) for k, v in sd.items()}, census=census, repr=repr(fe))
         print(name, out[name]["n_params"], census)
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "dropin_feature_extractor.json"), "w") as f:
         json.dump(out, f, indent=0, sort_keys=True)

@@ -251,6 +251,8 @@ def _oracle_mask_branch(coords_np, raw, bb_feats, mp, boxes_np, assoc, scene, bf
     per_point = x[torch.from_numpy(scene.prow)]                              # OutputLayer
     cat = torch.cat([per_point, raw], 1)
     src, box_of, inside = O.roi_crop(coords_np, boxes_np, assoc)
+    if len(src) == 0:                                    # no box caught a point: the branch ends here (model.py:768-770)
+        return None, src, box_of, None
     new_coords = np.concatenate([coords_np[src][:, :3], box_of[:, None]], 1)
     rscene = O.OracleScene(new_coords)
     unet_p = {k[5:]: v for k, v in mp.items() if k.startswith("unet.")}
@@ -354,6 +356,101 @@ def test_cfg3_roi_crop_and_mask_branch_vs_oracle_at_size(gpu, scene150k, dtype):
         _check_grad(name, "grad " + k, p.grad, mo[k].grad.view_as(p), md64[k].grad.view_as(p))
 
 
+def _mask_oracle_params(named, dt=torch.float32):
+    """MaskBranch.named_oracle_params() tensors (torch or numpy) -> oracle-shaped leaf tensors of dtype dt."""
+    shapes = dict(O.unet_param_shapes(23, [23, 32, 48, 64], identity_first=True))
+    mo = {}
+    for k, p in named.items():
+        t = (torch.from_numpy(np.asarray(p)) if not torch.is_tensor(p) else p.detach().cpu()).clone()
+        if k.startswith("unet."):
+            t = t.view(shapes[k[5:]])
+        elif k.endswith("conv0.weight") or k.endswith("conv1.weight"):
+            t = t.view(27, 16, 16)
+        elif k == "in.weight":
+            t = t.view(1, 32, 16)
+        mo[k] = t.to(dt).requires_grad_()
+    return mo
+
+
+def _oracle_cfg3_step(coords, feats, boxes, pb, pm, ch, grad_seed, dt=torch.float32, bf16=False):
+    """One cfg-3 step on the oracle: backbone -> (its OUTPUT feeds the mask branch) OutputLayer -> crop -> mask branch; the
+    upstream gradients are drawn as trainstep.SceneStep draws them (one generator: backbone output first, then the logits).
+    pb / pm: backbone / mask-branch parameters by oracle name (any float dtype; module or oracle shape).
+    -> (out, logits or None, {name: gradient}) with the mask names prefixed 'm:' and the input gradient 'input features'."""
+    scene = O.OracleScene(coords.numpy())
+    bshapes = dict(O.unet_param_shapes(7, list(ch)))
+    po = {k: (torch.from_numpy(np.asarray(v)) if not torch.is_tensor(v) else v.detach().cpu()).clone().view(bshapes[k])
+          .to(dt).requires_grad_() for k, v in pb.items()}
+    mo = _mask_oracle_params(pm, dt)
+    fo = feats.to(dt).clone().requires_grad_()
+    kw = dict(storage=O.bf16_storage, tile_weights=O.bf16_storage) if bf16 else {}
+    out = O.unet_forward(scene, fo, po, list(ch), **kw)
+    gen = torch.Generator().manual_seed(grad_seed)
+    gy = torch.randn(out.shape, generator=gen)
+    boxes_np, cnt, assoc = O.transform_boxes([b.numpy() for b in boxes])
+    logits, src, box_of, rscene = _oracle_mask_branch(coords.numpy(), fo, out, mo, boxes_np, assoc, scene, bf16=bf16)
+    if logits is None:
+        out.backward(gy.to(dt))
+    else:
+        gm = torch.randn(logits.shape, generator=gen)
+        torch.autograd.backward([out, logits], [gy.to(dt), gm.to(dt)])
+    grads = {k: v.grad for k, v in po.items()}
+    grads.update({"m:" + k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in mo.items()})
+    grads["input features"] = fo.grad
+    return out, logits, grads, len(src)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_cfg3_end_to_end_backbone_crop_mask_vs_oracle_at_150k(gpu, dtype):
+    """BASELINE configs[2] as ONE chain at size: trainstep.SceneStep("cfg3") -- the step bench.py times --
+    on the 150k-voxel scene with 64 boxes: Backbone 32-64-128-256 -> its output through SubM1 + units -> OutputLayer -> sparse
+    ROI crop -> internal U-Net -> Linear stack, backward from BOTH heads (dY on the backbone output, dM on the logits).  The
+    mask branch consumes the backbone's own output (not random features): forward of both heads, every one of the 76 + 80
+    parameter gradients and the input-feature gradient against the oracle; fp32 with the fp64 arbiter recorded, bf16 storage
+    against the oracle with the same roundings."""
+    from sparse_rcnn_amd.trainstep import SceneStep
+    bf16 = dtype == "bf16"
+    job = SceneStep("cfg3", gpu, dtype=dtype, prefetch=False, seed=1, grad_seed=100, lr=0.0)
+    with torch.no_grad():                    # biases away from zero (they are initialised to zero)
+        g = torch.Generator().manual_seed(21)
+        for p in job.model.parameters():
+            if p.dim() == 1:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    job.forward_backward()
+    torch.cuda.synchronize()
+    pb = dict(job.model.backbone.unet.named_oracle_params())
+    pm = dict(job.model.mask.named_oracle_params())
+    ch = job.channels
+    out, logits, grads, n_sel = _oracle_cfg3_step(job.coords_cpu, job.feats_cpu, job.boxes, pb, pm, ch, 100, bf16=bf16)
+    name = "cfg3_end_to_end_150k" + ("_bf16_storage" if bf16 else "")
+    assert job.out.features.shape[0] == 150_000 and job.logits.shape == logits.shape and n_sel == job.n_roi_rows
+    print(f"[parity] {name}: {n_sel} cropped points")
+    e_out, e_log = _err(job.out.features, out), _err(job.logits, logits)
+    got = {k: p.grad for k, p in pb.items()}
+    got.update({"m:" + k: p.grad for k, p in pm.items()})
+    got["input features"] = job.fin.grad
+    assert set(got) == set(grads)
+    if bf16:
+        _record(name, "backbone features vs oracle with the same roundings", e_out, "rel_to_scale <= 2^-6, rel_l2 <= 1e-2")
+        _record(name, "mask logits vs oracle with the same roundings", e_log, "rel_to_scale <= 2^-4, rel_l2 <= 4e-2")
+        assert e_out["rel_to_scale"] <= 2.0 ** -6 and e_out["rel_l2"] <= 1e-2, e_out
+        assert e_log["rel_to_scale"] <= 2.0 ** -4 and e_log["rel_l2"] <= 4e-2, e_log
+        bad = []
+        for k in grads:
+            e = _err(got[k], grads[k].view_as(got[k]))
+            _record(name, "grad " + k, e, "rel_l2 <= 2.5e-1")
+            if not (bool(torch.isfinite(got[k]).all()) and e["rel_l2"] <= 2.5e-1):
+                bad.append((k, e["rel_l2"]))
+        assert not bad, bad
+        return
+    _record(name, "backbone features", e_out, FEAT_TOL)
+    _record(name, "mask logits", e_log, FEAT_TOL)
+    assert e_out["rel_to_scale"] <= FEAT_TOL and e_log["rel_to_scale"] <= FEAT_TOL, (e_out, e_log)
+    _, _, g64, _ = _oracle_cfg3_step(job.coords_cpu, job.feats_cpu, job.boxes, pb, pm, ch, 100, dt=torch.float64)
+    for k in grads:
+        _check_grad(name, "grad " + k, got[k], grads[k].view_as(got[k]), g64[k].view_as(got[k]))
+
+
 def test_tensor_to_tensor_roi_cut_vs_oracle_at_size(gpu, scene150k):
     """TensorToTensorFeatureExtractorCombiner (roi_select_sparse.py:99-122): the active sites of a SparseConvNetTensor
     are cut (mode-0 re-voxelisation); rows, coordinates and features against the oracle crop of the voxel list."""
@@ -425,6 +522,71 @@ def test_two_rank_dp_step_matches_oracle(gpu, tmp_path):
     for k in names:
         _check_grad("cfg4_two_rank_dp_step", "mean grad " + k, torch.from_numpy(z[0]["g:" + k]).reshape(-1),
                     mean[k].reshape(-1), mean64[k].reshape(-1))
+
+
+@pytest.mark.parametrize("case", ["f32", "bf16", "f32-empty-rank"])
+def test_two_rank_dp_cfg3_step_matches_oracle(gpu, tmp_path, case):
+    """BASELINE configs[3] (data-parallel detection + mask step) on what one GPU can run: two fresh
+    gloo ranks on cuda:0, one scene and its 16 boxes each, ONE flat buffer over backbone + mask branch, bucketed all-reduce
+    from the gradient hooks.  The averaged flat gradient every rank ends up with == the mean of the two scenes' ORACLE
+    gradients (backbone and mask parameters).  "bf16": bf16 storage against the oracle with the same roundings.
+    "f32-empty-rank": rank 1's boxes catch no point -- its mask branch produces no gradient and its buckets go out
+    (zero-filled) in the same order as rank 0's."""
+    dtype = "bf16" if case == "bf16" else "f32"
+    empty = 1 if case.endswith("empty-rank") else -1
+    target, grid, n_boxes = 30_000, (256, 256, 128), 16
+    port = _free_port()
+    procs, outs = [], []
+    for r in range(2):
+        out = str(tmp_path / f"rank{r}.npz")
+        outs.append(out)
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_rank_worker.py"), out, str(target),
+                                       ",".join(map(str, grid)), "cfg3", dtype, str(n_boxes), str(empty)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), logs
+    z = [np.load(o) for o in outs]
+    from sparse_rcnn_amd.synthetic import make_batch, make_boxes
+    ch = [32, 64, 128, 256]
+    bnames = [n for n, _ in O.unet_param_shapes(7, ch)]
+    mnames = [k[2:] for k in z[0].files if k.startswith("m:")]
+    assert len(mnames) == 80 and len(bnames) == 76
+    keys = bnames + ["m:" + k for k in mnames]
+    for k in keys:
+        assert np.array_equal(z[0][k], z[1][k]), k                            # broadcast: ranks hold the same parameters
+        assert np.array_equal(z[0]["g:" + k], z[1]["g:" + k]), k               # ... and the same reduced gradient
+    bf16 = dtype == "bf16"
+    mean, mean64 = None, None
+    for r in range(2):
+        coords, feats, size, bs, _ = make_batch(1, grid, target, dup=1.15, seed=10 + r)
+        boxes = make_boxes(coords, n_boxes, seed=10 + r + 2)
+        if r == empty:
+            boxes = [b + 10_000.0 for b in boxes]
+        pb = {k: z[0][k] for k in bnames}
+        pm = {k: z[0]["m:" + k] for k in mnames}
+        for dt in ((torch.float32,) if bf16 else (torch.float32, torch.float64)):
+            out, logits, gr, n_sel = _oracle_cfg3_step(coords, feats, boxes, pb, pm, ch, 100 + r, dt=dt, bf16=bf16)
+            assert out.shape[0] == int(z[r]["n_active"]) and n_sel == int(z[r]["n_roi_rows"]), (r, n_sel)
+            assert (n_sel == 0) == (r == empty)
+            gr = {k: gr[k] / 2 for k in keys}
+            if dt == torch.float32:
+                mean = gr if mean is None else {k: mean[k] + gr[k] for k in keys}
+            else:
+                mean64 = gr if mean64 is None else {k: mean64[k] + gr[k] for k in keys}
+    name = "cfg3_two_rank_dp_step_" + case
+    bad = []
+    for k in keys:
+        got = torch.from_numpy(z[0]["g:" + k]).reshape(-1)
+        if bf16:
+            e = _err(got, mean[k].reshape(-1))
+            _record(name, "mean grad " + k, e, "rel_l2 <= 2.5e-1")
+            if not (bool(torch.isfinite(got).all()) and e["rel_l2"] <= 2.5e-1):
+                bad.append((k, e["rel_l2"]))
+        else:
+            _check_grad(name, "mean grad " + k, got, mean[k].reshape(-1), mean64[k].reshape(-1))
+    assert not bad, bad
 
 
 def test_syncbn_two_ranks_equals_single_process(gpu, tmp_path):

@@ -35,7 +35,8 @@ def _cloud(seed, grid=(24, 20, 16), n=1500, batch=2, dup=200):
 def _close(a, b, tol=FEAT_TOL, what=""):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     assert a.shape == b.shape, (what, a.shape, b.shape)
-    scale = max(1.0, b.abs().max().item())
+    scale = b.abs().max().item()          # relative to the oracle's own scale (no floor at 1: small outputs are held
+    scale = scale if scale > 0 else 1.0   # to a relative bound too; an all-zero expectation is held to tol absolutely)
     err = (a - b).abs().max().item() / scale
     assert err <= tol, f"{what}: max err {err:.3e} (scale {scale:.3g}) > {tol}"
 
@@ -75,6 +76,53 @@ def test_input_output_layer_modes(gpu, mode):
     gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(10))
     y.backward(gy.to(gpu))
     _close(xf.grad, O.output_layer_bwd(gy, scene.prow, scene.n(0)), 1e-6, "output bwd")
+
+
+def test_stale_or_mismatched_index_announcements_are_not_adopted(gpu):
+    """ADVICE r2 (metadata.py): a batch announced with scn.prefetch_index and never run must not be adopted by a later
+    same-shaped tensor with other coordinates (the entry holds the announced tensor: its identity cannot be recycled); an
+    in-place torch modification after the announcement, another mode or batch_size, or a generator closed early drop the
+    announcement; the InputLayer then builds its own structures -- checked against the oracle of the coordinates it got."""
+    scn = _scn()
+    from sparse_rcnn_amd import metadata as MD
+    MD.drop_prefetched()
+    ca, size, batch = _cloud(31)
+    cb, _, _ = _cloud(32)
+    assert ca.shape == cb.shape and not torch.equal(ca, cb)
+    feats = torch.randn(len(ca), 4, generator=torch.Generator().manual_seed(1)).to(gpu)
+
+    def rows(x):
+        return x.get_spatial_locations().numpy()
+    # A announced, dropped (never run); B arrives: same shape, other values
+    scn.prefetch_index(ca, size, batch)
+    xb = scn.InputLayer(3, size, mode=4)((cb, feats, batch))
+    assert np.array_equal(rows(xb), O.OracleScene(cb.numpy()).coords0) and xb.metadata._prepared_for is None
+    assert len(MD._prefetched) == 1                                  # A is still parked (and keeps its tensor alive)
+    xa = scn.InputLayer(3, size, mode=4)((ca, feats, batch))          # ... and is adopted by A itself
+    assert xa.metadata._prepared_for is not None and np.array_equal(rows(xa), O.OracleScene(ca.numpy()).coords0)
+    assert not MD._prefetched
+    # modified in place after the announcement: version differs -> not adopted
+    cc = ca.clone()
+    scn.prefetch_index(cc, size, batch)
+    cc.copy_(cb)
+    xc = scn.InputLayer(3, size, mode=4)((cc, feats, batch))
+    assert xc.metadata._prepared_for is None and np.array_equal(rows(xc), O.OracleScene(cb.numpy()).coords0)
+    # announced for mode 4; a mode-0 layer keeps its own check (duplicates -> error), a batch_size-3 layer its own count
+    cd = ca.clone()
+    scn.prefetch_index(cd, size, batch)
+    with pytest.raises(scn.ScnError, match="unique"):
+        scn.InputLayer(3, size, mode=0)((cd, feats, batch))
+    ce = ca.clone()
+    scn.prefetch_index(ce, size, batch)
+    xe = scn.InputLayer(3, size, mode=4)((ce, feats, 3))
+    assert xe.batch_size() == 3 and xe.metadata._prepared_for is None
+    # a loop that ends early forgets what it announced
+    MD.drop_prefetched()
+    batches = [(ca.clone(), size, batch) for _ in range(3)]
+    for i, bt in enumerate(scn.index_prefetching(batches, lambda t: t)):
+        if i == 0:
+            break
+    assert not MD._prefetched
 
 
 def test_empty_and_zero_row_samples(gpu):
@@ -1230,3 +1278,44 @@ def test_paired_weight_gradient_on_tiny_scenes(gpu, n):
     go = torch.autograd.grad(yo, [Xo] + po, gy)
     for a, b in zip(g_p, go):
         _close(a, b, 2e-4, "tiny scene gradients vs oracle")
+
+
+# ---------------------------------------------------------------------------------------- N1: SparseGlobalPool / split_batch
+POOL_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "globalpool_*.npz")))
+
+
+@pytest.mark.parametrize("path", POOL_GOLDEN, ids=[os.path.basename(p) for p in POOL_GOLDEN])
+def test_global_pool_and_split_batch_match_reference_golden(gpu, path):
+    """sparse_rcnn_amd.SparseGlobalPool / split_batch (scn_segment_pool_*, scn_sample_counts) against fixtures produced by the
+    reference's own SparseGlobalPool / split_batch (tests/golden/make_globalpool_golden.py) and against the oracle: rows
+    grouped by sample and shuffled, an empty sample, a batch of zero samples; mean / sum / amax with tied maxima; forward
+    within fp32 rounding of the reference's own summation (1e-6 of the scale), backward likewise, the split bit-exact."""
+    scn = _scn()
+    d = np.load(path)
+    fn = getattr(torch, str(d["fn"]))
+    bs = int(d["batch_size"])
+    coords, feats = torch.from_numpy(d["coords"]), torch.from_numpy(d["feats"])
+    fg = feats.to(gpu).requires_grad_()
+    if bs == 0:
+        md = scn.Metadata(3)
+        md.n_samples = 0
+        t = scn.SparseConvNetTensor(features=fg, metadata=md, spatial_size=torch.tensor([48, 48, 48]))
+        assert scn.SparseGlobalPool(fn)(t).shape == (0, feats.shape[1]) and scn.split_batch(t) == []
+        return
+    t = scn.InputLayer(3, torch.tensor([48, 48, 48]), mode=0)((coords, fg, bs))
+    assert torch.equal(t.features.detach().cpu(), feats)                   # mode 0: the fixture's rows are the tensor's rows
+    y = scn.SparseGlobalPool(fn)(t)
+    _close(y, torch.from_numpy(d["out"]), 1e-6, "pooled vs reference")
+    _close(y, O.global_pool(feats, d["coords"], bs, fn), 1e-6, "pooled vs oracle")
+    if str(d["fn"]) == "amax":
+        assert torch.equal(y.detach().cpu(), torch.from_numpy(d["out"]))   # a maximum is exact
+    y.backward(torch.from_numpy(d["gy"]).to(gpu))
+    _close(fg.grad, torch.from_numpy(d["dfeats"]), 1e-6, "pool backward vs reference")
+    parts = scn.split_batch(t.detach())
+    assert [len(p) for p in parts] == d["split_rows"].tolist()
+    assert torch.equal(torch.cat(parts).cpu(), torch.from_numpy(d["split_cat"]))
+    # a pooling function the device pass does not know still works (the reference's formulation over the split)
+    med = scn.SparseGlobalPool(lambda f, dim: torch.median(f, dim=dim).values)(t.detach())
+    exp = torch.stack([torch.median(p, dim=0).values if len(p) else p.new_zeros(p.shape[1]) for p in
+                       O.split_batch(feats, d["coords"], bs)])
+    assert torch.equal(med.cpu(), exp)

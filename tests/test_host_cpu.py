@@ -64,7 +64,51 @@ def _dp_worker(rank, world, port, out, n_buckets=0):
     fp.all_reduce_mean()
     fp.sgd_step(0.1)
     # by value (numpy): a tensor would travel as a shared-memory handle that dies with this process
-    out.put((rank, fp.flat.detach().numpy().copy(), local.detach().numpy().copy(), fp.flat_grad.numpy().copy()))
+    out.put((rank, fp.flat.detach().numpy().copy(), local.detach().numpy().copy(), fp.mean_grad().numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+class _TwoHeads(torch.nn.Module):
+    """A 'backbone' and a 'mask branch' whose forward may be skipped (a rank whose ROI crop is empty)."""
+
+    def __init__(self):
+        super().__init__()
+        self.backbone = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Linear(8, 8), torch.nn.Linear(8, 4))
+        self.mask = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.Linear(8, 2))
+
+
+def _dp_worker_uneven(rank, world, port, out, weighted):
+    """Rank 1 never runs its mask branch (no gradients for those parameters): every rank must still issue the bucket
+    all-reduces in the same order.  weighted: ranks contribute in proportion to a per-rank count (set before backward)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = _TwoHeads()
+    fp = FlatParams(net, n_buckets=3)
+    broadcast_params(fp)
+    assert len(fp.buckets) >= 2
+    res = []
+    for step in range(2):
+        x = torch.full((4, 6), float(rank + 1 + step))
+        fp.zero_grad()
+        w = float(rank + 1) if weighted else 1.0
+        fp.rank_weight = w
+        h = net.backbone(x)
+        loss = h.sum()
+        if rank == 0:                                  # rank 1: empty crop, the mask head never runs
+            loss = loss + net.mask(h).square().sum()
+        order = []
+        orig = fp._launch_bucket
+        fp._launch_bucket = lambda b, orig=orig: (order.append(b), orig(b))[1]
+        loss.backward()
+        local = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in fp.params])
+        fp.all_reduce_mean(total_weight=3.0 if weighted else None)
+        fp._launch_bucket = orig
+        assert order == list(range(len(fp.buckets))), order       # strictly in index order, on every rank
+        res.append((local.numpy().copy(), fp.mean_grad().numpy().copy(), w))
+        fp.sgd_step(0.1)
+    out.put((rank, fp.flat.detach().numpy().copy(), res))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -96,6 +140,45 @@ def test_bucketed_overlapped_all_reduce_world2():
     assert torch.equal(w0, w1)
     assert torch.allclose(m0, (g0 + g1) / 2) and torch.equal(m0, m1)
     assert torch.equal(m0[:7], torch.zeros(7))                # the unused parameter (first in parameters()) stays zero
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_bucket_order_with_a_rank_whose_mask_branch_gets_no_gradient(weighted):
+    """a rank with an empty ROI crop gives its mask-branch parameters no gradient; buckets still go out in
+    index order on every rank, the result is the (count-weighted) mean with zeros for the missing gradients, over two steps."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_dp_worker_uneven, args=(r, 2, port, q, weighted)) for r in range(2)]
+    for p in ps: p.start()
+    res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
+    for p in ps: p.join(60)
+    (_, w0, r0), (_, w1, r1) = res
+    assert np.array_equal(w0, w1)
+    for (l0, m0, a0), (l1, m1, a1) in zip(r0, r1):
+        assert np.array_equal(m0, m1)
+        denom = 3.0 if weighted else 2.0
+        assert np.allclose(m0, (a0 * l0 + a1 * l1) / denom, rtol=1e-6, atol=1e-7)
+        assert np.abs(l1).sum() > 0 and np.abs(l0 - l1).sum() > 0
+
+
+def test_weight_given_after_backward_is_rejected_on_the_bucketed_path():
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%r, RANK="0", WORLD_SIZE="1", SCN_DP_FORCE_BUCKETS="1")
+dist.init_process_group("gloo")
+from sparse_rcnn_amd.dp import FlatParams
+net = torch.nn.Linear(3, 2)
+fp = FlatParams(net, n_buckets=2)
+fp.zero_grad(); net(torch.ones(1, 3)).sum().backward()
+try:
+    fp.all_reduce_mean(weight=2.0)
+except ValueError as e:
+    print("OK", e)
+''' % (ROOT, str(_free_port()))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
 
 
 def test_flat_params_views_survive_backward():
@@ -130,6 +213,27 @@ def test_bench_self_launch_starts_fresh_ranks(tmp_path, capsys):
     import torch
     assert torch.cuda.is_initialized() == bool(before)              # launching made no GPU call in this process
     assert bench.self_launch(args, script=str(script), argv=["--other"]) == 7     # a failing rank fails the launch
+
+
+def test_bench_self_launch_returns_promptly_when_a_rank_dies(tmp_path, capsys):
+    """rank 1 exits with code 3 while rank 0 would wait (here: sleep) for minutes -- the launcher
+    terminates the survivor, reports the dead rank's stderr tail and returns its code within seconds."""
+    import time
+    import bench
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import os, sys, time\n"
+        "if os.environ['RANK'] == '1':\n"
+        "    sys.stderr.write('rank 1: simulated RCCL init failure\\n'); sys.exit(3)\n"
+        "time.sleep(120)\n"
+        "print('never printed')\n")
+    args = bench.parse_args(["--gpus", "2"])
+    t0 = time.time()
+    rc = bench.self_launch(args, script=str(script), argv=[])
+    took = time.time() - t0
+    cap = capsys.readouterr()
+    assert rc == 3 and took < 20, (rc, took)
+    assert "never printed" not in cap.out and "simulated RCCL init failure" in cap.err and "rank 1 exited with code 3" in cap.err
 
 
 def test_bench_dtype_aliases():

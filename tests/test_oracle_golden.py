@@ -113,3 +113,30 @@ def test_oracle_voxelisation_matches_reference(path):
 
 def test_vox_golden_present():
     assert len(VOX_GOLDEN) >= 4
+
+
+# ---- N1: SparseGlobalPool / split_batch, pinned by the reference's own classes (custom_operations.py:24-59) -------------
+POOL_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "globalpool_*.npz")))
+POOL_FN = {"mean": "mean", "sum": "sum", "amax": "amax"}
+
+
+@pytest.mark.parametrize("path", POOL_GOLDEN, ids=[os.path.basename(p) for p in POOL_GOLDEN])
+def test_oracle_global_pool_matches_reference(path):
+    import torch
+    d = np.load(path)
+    fn = getattr(torch, POOL_FN[str(d["fn"])])
+    x = torch.from_numpy(d["feats"]).requires_grad_()
+    bs = int(d["batch_size"])
+    y = O.global_pool(x, d["coords"], bs, fn)
+    assert tuple(y.shape) == d["out"].shape and np.array_equal(y.detach().numpy(), d["out"])
+    if len(d["feats"]):
+        y.backward(torch.from_numpy(d["gy"]))
+        assert np.array_equal(x.grad.numpy(), d["dfeats"])
+    parts = O.split_batch(x.detach(), d["coords"], bs)
+    assert [len(p) for p in parts] == d["split_rows"].tolist()
+    if parts:
+        assert np.array_equal(torch.cat(parts).numpy(), d["split_cat"])
+
+
+def test_global_pool_golden_present():
+    assert len(POOL_GOLDEN) >= 5

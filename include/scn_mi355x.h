@@ -480,6 +480,98 @@ int scn_vox_discretize(const float* aug, int64_t n, const float* shift, const in
 int scn_vox_gather(const int32_t* discrete, const int32_t* rows, int64_t m, const int32_t* start_host,
                    int64_t batch_index, int64_t* out, scn_stream_t stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * bf16-STORAGE forms of the HBM-bound feature kernels (BASELINE configs 3-5; scn_elem_bf16.hip): slabs are uint16 bf16 bit
+ * patterns, values are widened exactly, the arithmetic is that of the fp32 forms above, one round-to-nearest-even per
+ * result.  scn.OutputLayer / the ROI feature gather (custom_operations.py:7-10; roi_select_sparse.py:125-133),
+ * scn.MaxPooling / AveragePooling (module_factory.py:315-354), scn.SparseToDense (:429-435), scn.AddTable (:308), and
+ * the storage casts on either side of a bf16-stored stretch of a network.
+ * ---------------------------------------------------------------------------------------- */
+int scn_cast_f32_to_bf16(const float* X, int64_t count, uint16_t* Y, scn_stream_t stream);
+int scn_cast_bf16_to_f32(const uint16_t* X, int64_t count, float* Y, scn_stream_t stream);
+int scn_add_bf16(const uint16_t* A, const uint16_t* B, int64_t count, uint16_t* Y, scn_stream_t stream);
+int scn_gather_rows_bf16(const uint16_t* X, const int32_t* rows, int64_t m, int c, uint16_t* Y, scn_stream_t stream);
+int scn_segment_sum_bf16(const uint16_t* dY, const int32_t* item_row, int64_t n_items, int64_t n_rows, int c, uint16_t* dX,
+                         double* acc64, scn_stream_t stream);
+int scn_pool_fwd_bf16(const uint16_t* X, const int32_t* child, int64_t n_coarse, int c, int average, uint16_t* Y,
+                      scn_stream_t stream);
+int scn_pool_bwd_bf16(const uint16_t* X, const uint16_t* Y, const uint16_t* dY, const int32_t* parent, int64_t n_fine, int c,
+                      int average, uint16_t* dX, scn_stream_t stream);
+int scn_sparse_to_dense_fwd_bf16(const uint16_t* X, const int32_t* coords, int64_t n, int c, const int64_t* size3_host,
+                                 uint16_t* out, scn_stream_t stream);
+int scn_sparse_to_dense_bwd_bf16(const uint16_t* dOut, const int32_t* coords, int64_t n, int c, const int64_t* size3_host,
+                                 uint16_t* dX, scn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Step executor (scn_exec.hip): ONE call walks the launch plan of a whole network pass.
+ *
+ * The reference drives the scn surface layer by layer from Python (module_factory.py builds nested scn.Sequential trees;
+ * model.py:414-431 runs them); at ~330 launches per backbone step (~760 with the mask branch) the interpreter, not the
+ * GPU, bounds the bf16 steps.  A plan is a flat list of ops over three tables the caller fills per step -- feature slabs
+ * (`bufs`), parameters / weight images (`params`) and parameter gradients (`grads`) -- and a table of per-level index
+ * structures.  Each op is exactly one of the entry points above with exactly the arguments the layer-by-layer path would
+ * pass (same kernels, same bits); the executor adds no arithmetic of its own.
+ * ---------------------------------------------------------------------------------------- */
+enum {
+    SCN_OP_GEMM_IDENT = 1,   /* scn_gemm_table(_bf16), identity table: SubM 1^3 / NetworkInNetwork / Linear; fwd or bwd-data  */
+    SCN_OP_CONV_SUBM = 2,    /* scn_conv_tiles(_bf16) over the level's 3^3 tiles (fwd; bwd-data with SCN_F_W_TRANSPOSED|OFF_REVERSE) */
+    SCN_OP_CONV_CHILD = 3,   /* scn_conv_tiles(_bf16) over the level's child tiles: Convolution fwd / Deconvolution bwd-data */
+    SCN_OP_RULES_CHILD = 4,  /* scn_gemm_rules(_bf16) coarse -> fine: Deconvolution fwd / Convolution bwd-data              */
+    SCN_OP_ROWS2 = 5,        /* scn_gemm_rows2: NiN over two joined parts (fwd), or its two-destination bwd-data             */
+    SCN_OP_WGRAD_SUBM = 6,   /* scn_wgrad_bias_rules(_bf16) on the level's 3^3 rules                                          */
+    SCN_OP_WGRAD2_SUBM = 7,  /* scn_wgrad_bias_rules2(_bf16): both convolutions of a residual unit                             */
+    SCN_OP_WGRAD_DOWN = 8,   /* Convolution: scn_wgrad_rules(_bf16) on the child rules (X fine, dY coarse)                     */
+    SCN_OP_WGRAD_UP = 9,     /* Deconvolution: scn_wgrad_bias_rules(_bf16), roles swapped (X coarse, dY fine), db over all 8  */
+    SCN_OP_WGRAD_IDENT = 10, /* identity list: NiN / SubM 1^3 / Linear; aux = element offset into grads[w] (joined parts)     */
+    SCN_OP_COLSUM = 11,      /* scn_colsum(_bf16): bias gradient alone                                                        */
+    SCN_OP_ADD = 12,         /* y = x + x1 (scn_add / scn_add_bf16): the two gradient paths of a skip connection             */
+    SCN_OP_CAST = 13         /* storage cast: SCN_XF_BF16 set = fp32 -> bf16, else bf16 -> fp32                               */
+};
+#define SCN_XF_BF16 (1 << 16)        /* op flag: the op's feature slabs are bf16-stored                                      */
+#define SCN_XF_COARSE_ROWS (1 << 17) /* op flag (GEMM_IDENT / WGRAD_IDENT / COLSUM / ADD / CAST): rows = n_coarse of `level` */
+
+typedef struct scn_exec_level {
+    int64_t n;                       /* rows of this level */
+    const int32_t* tstab;            /* SubM 3^3 tiles of this level (scn_tiles_build) */
+    const uint32_t* tile_mask;
+    const int32_t* perm;
+    const int32_t* tile_order;
+    const int32_t* in_rows;          /* SubM 3^3 compacted rules */
+    const int32_t* out_rows;
+    const int64_t* prefix_host;      /* int64[28] on the host */
+    int64_t n_coarse;                /* rows of the next (coarser) level; 0: none */
+    const int32_t* c_tstab;          /* child tiles [nt_coarse][8][16] */
+    const uint32_t* c_tile_mask;
+    const int32_t* c_perm;
+    const int32_t* c_tile_order;
+    const int32_t* c_in_rows;        /* strided rules: in = fine rows, out = coarse rows */
+    const int32_t* c_out_rows;
+    const int64_t* c_prefix_host;    /* int64[9] on the host */
+} scn_exec_level;
+
+typedef struct scn_exec_op {
+    int32_t op;                      /* SCN_OP_* */
+    int32_t flags;                   /* SCN_F_* of the underlying call | SCN_XF_* */
+    int32_t level;
+    int32_t cin, cout;               /* of the CALL (backward-data calls swap the layer's) */
+    int32_t x, y;                    /* buffer ids: source slab, destination slab (wgrad ops: X operand, dY operand) */
+    int32_t r, m;                    /* residual operand, relu-mask operand; -1: none */
+    int32_t x1, y1;                  /* ROWS2: second source / second destination; WGRAD2: second operand pair; ADD: x1 */
+    int32_t c1;                      /* ROWS2: channels of the second source (fwd) / second destination (bwd) */
+    int32_t w, b;                    /* params[] ids (weight or bf16 image, bias) -- wgrad / colsum ops: grads[] ids; -1: none */
+    int32_t aux;                     /* WGRAD_IDENT: element offset into grads[w]; WGRAD_*: unused */
+    int32_t reserved;
+} scn_exec_op;
+
+/* Scratch bytes and zeroed arrival counters (the scn_conv_tiles contract) the plan needs for these level sizes. */
+int scn_exec_requirements(const scn_exec_op* ops, int n_ops, const scn_exec_level* levels, int n_levels,
+                          int64_t* scratch_bytes, int64_t* arrival_counters);
+/* Walk the plan on `stream`.  Stops at the first failing op (its status is returned, scn_last_error_string names the op). */
+int scn_exec_run(const scn_exec_op* ops, int n_ops, const scn_exec_level* levels, int n_levels, void* const* bufs,
+                 const void* const* params, void* const* grads, void* scratch, int64_t scratch_bytes, int32_t* arrival,
+                 scn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -441,8 +441,26 @@ def init_unet_params(cin, channels, seed=0, identity_first=False):
     return params
 
 
+class FrozenReLU:
+    """ReLU with PRESCRIBED sign masks (tests: the masks the HIP forward recorded, sparse_rcnn_amd.functional.RELU_RECORD):
+    call k multiplies its argument by mask k instead of deciding `x > 0` itself.  Two evaluations of a ReLU network that
+    share their masks compute the same piecewise-linear function, so inputs within rounding of zero cannot flip a row's
+    contribution in one of them only -- gradients then differ by summation order alone.  A mask may be wider than the
+    argument (slabs padded with zero columns on the device)."""
+
+    def __init__(self, masks):
+        self.masks, self.k = list(masks), 0
+
+    def __call__(self, x):
+        m = self.masks[self.k]
+        self.k += 1
+        if m.shape[0] != x.shape[0] or m.shape[1] < x.shape[1]:
+            raise ValueError(f"FrozenReLU: mask {self.k - 1} has shape {tuple(m.shape)}, argument {tuple(x.shape)}")
+        return x * m[:, :x.shape[1]].to(x.dtype)
+
+
 def unet_forward(scene: OracleScene, feats_pts: torch.Tensor, params: dict, channels, identity_first=False,
-                 storage=None, tile_weights=None, split_nin=False, record=None):
+                 storage=None, tile_weights=None, split_nin=False, record=None, relu=None):
     """A12: encoder level = {SubM1 | Conv2s2} + 2x[x + SubM3(ReLU(SubM3(ReLU(x))))];
     decoder level = ReLU -> Deconv2s2 -> Join(up, skip) -> NiN -> 2x residual
     (module_factory.py:127-183, 513-578; custom_container.py:70-83: cat((upsampled, skip))).
@@ -451,9 +469,10 @@ def unet_forward(scene: OracleScene, feats_pts: torch.Tensor, params: dict, chan
     on the CPU: storage=bf16_storage.  tile_weights: rounding applied to the weights of the layers that run
     on the bf16 tile kernel in that mode (SubM 3^3, Convolution: their LDS image is bf16; the 1x1 / deconvolution GEMMs
     keep fp32 weights).  split_nin: the NetworkInNetwork over a JoinTable as the HIP path evaluates it -- one GEMM per
-    joined part, the first partial result stored (rounded) before the second is added."""
+    joined part, the first partial result stored (rounded) before the second is added.
+    relu: replaces torch.relu (FrozenReLU: prescribed sign masks, consumed in the order the network applies its ReLUs)."""
     P = params
-    relu = torch.relu
+    relu = torch.relu if relu is None else relu        # relu: a FrozenReLU (prescribed masks), default the real one
     q = storage if storage is not None else (lambda t: t)
     wq = tile_weights if tile_weights is not None else (lambda t: t)
     x = _InputFn.apply(feats_pts, scene)

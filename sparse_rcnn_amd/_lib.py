@@ -100,6 +100,17 @@ _SIGS = {
     "scn_sample_counts": (C.c_int, [p, i64, i32, p, p, p]),
     "scn_segment_pool_fwd": (C.c_int, [p, p, i64, i32, i32, i32, p, p, p, p, p]),
     "scn_segment_pool_bwd": (C.c_int, [p, p, p, p, i64, i32, i32, i32, p, p, p, p]),
+    "scn_cast_f32_to_bf16": (C.c_int, [p, i64, p, p]),
+    "scn_cast_bf16_to_f32": (C.c_int, [p, i64, p, p]),
+    "scn_add_bf16": (C.c_int, [p, p, i64, p, p]),
+    "scn_gather_rows_bf16": (C.c_int, [p, p, i64, i32, p, p]),
+    "scn_segment_sum_bf16": (C.c_int, [p, p, i64, i64, i32, p, p, p]),
+    "scn_pool_fwd_bf16": (C.c_int, [p, p, i64, i32, i32, p, p]),
+    "scn_pool_bwd_bf16": (C.c_int, [p, p, p, p, i64, i32, i32, p, p]),
+    "scn_sparse_to_dense_fwd_bf16": (C.c_int, [p, p, i64, i32, C.POINTER(i64), p, p]),
+    "scn_sparse_to_dense_bwd_bf16": (C.c_int, [p, p, i64, i32, C.POINTER(i64), p, p]),
+    "scn_exec_requirements": (C.c_int, [p, i32, p, i32, C.POINTER(i64), C.POINTER(i64)]),
+    "scn_exec_run": (C.c_int, [p, i32, p, i32, p, p, p, p, i64, p, p]),
     "scn_sparse_to_dense_fwd": (C.c_int, [p, p, i64, i32, C.POINTER(i64), p, p]),
     "scn_sparse_to_dense_bwd": (C.c_int, [p, p, i64, i32, C.POINTER(i64), p, p]),
 }

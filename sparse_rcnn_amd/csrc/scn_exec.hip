@@ -1,0 +1,219 @@
+// Step executor: one C call walks the launch plan of a whole network pass (include/scn_mi355x.h, "Step executor").
+//
+// Why: the reference drives the scn surface layer by layer from Python; this package's autograd functions did the same.  A
+// backbone step is ~330 launches, a detection + mask step ~760, and every launch cost ~13 us of host time of which only
+// 4-5 us are hipLaunchKernel -- the bf16-storage steps (BASELINE configs 3-5) were bound by the interpreter, not by the
+// GPU.  Here the per-layer calls are made from a flat op list: no interpreter, no allocator, no autograd
+// node per layer.  Every op IS one of the library's own entry points with the arguments the layer-by-layer path passes, so
+// the two paths produce the same bits (tests/test_gpu_exec.py).
+#include "scn_common.h"
+
+using scn::cdiv;
+
+namespace {
+
+struct Ctx {
+    const scn_exec_level* levels;
+    int n_levels;
+    void* const* bufs;
+    const void* const* params;
+    void* const* grads;
+    void* scratch;
+    int32_t* arrival;
+    scn_stream_t stream;
+};
+
+inline bool bf(const scn_exec_op& o) { return (o.flags & SCN_XF_BF16) != 0; }
+inline int call_flags(const scn_exec_op& o) { return o.flags & 0xffff; }
+inline int64_t rows_of(const scn_exec_op& o, const scn_exec_level& L) {
+    return (o.flags & SCN_XF_COARSE_ROWS) ? L.n_coarse : L.n;
+}
+
+template <typename T>
+inline T* B(const Ctx& c, int id) { return id < 0 ? nullptr : (T*)c.bufs[id]; }
+template <typename T>
+inline const T* P(const Ctx& c, int id) { return id < 0 ? nullptr : (const T*)c.params[id]; }
+template <typename T>
+inline T* G(const Ctx& c, int id) { return id < 0 ? nullptr : (T*)c.grads[id]; }
+
+int run_op(const Ctx& c, const scn_exec_op& o) {
+    SCN_REQUIRE(o.level >= 0 && o.level < c.n_levels);
+    const scn_exec_level& L = c.levels[o.level];
+    const int fl = call_flags(o);
+    const bool h = bf(o);
+    scn_stream_t st = c.stream;
+    typedef uint16_t u16;
+    switch (o.op) {
+    case SCN_OP_GEMM_IDENT: {
+        const int64_t n = rows_of(o, L);
+        if (h) return scn_gemm_table_bf16(B<u16>(c, o.x), n, o.cin, nullptr, 1, n, P<float>(c, o.w), P<float>(c, o.b),
+                                          B<u16>(c, o.r), B<u16>(c, o.m), B<u16>(c, o.y), o.cout, fl, st);
+        return scn_gemm_table(B<float>(c, o.x), n, o.cin, nullptr, 1, n, P<float>(c, o.w), P<float>(c, o.b), B<float>(c, o.r),
+                              B<float>(c, o.m), B<float>(c, o.y), o.cout, fl, st);
+    }
+    case SCN_OP_CONV_SUBM:
+    case SCN_OP_CONV_CHILD: {
+        const bool child = o.op == SCN_OP_CONV_CHILD;
+        const int64_t n_in = L.n, n_out = child ? L.n_coarse : L.n;
+        const int n_off = child ? 8 : 27;
+        const int32_t* tstab = child ? L.c_tstab : L.tstab;
+        const uint32_t* tmask = child ? L.c_tile_mask : L.tile_mask;
+        const int32_t* perm = child ? L.c_perm : L.perm;
+        const int32_t* order = child ? L.c_tile_order : L.tile_order;
+        if (h) {
+            int32_t* arr = scn_conv_tiles_bf16_arrival_counters(o.cin, n_out, o.cout) ? c.arrival : nullptr;
+            return scn_conv_tiles_bf16(B<u16>(c, o.x), n_in, o.cin, tstab, tmask, perm, order, n_off, n_out, P<u16>(c, o.w),
+                                       P<float>(c, o.b), B<u16>(c, o.r), B<u16>(c, o.m), B<u16>(c, o.y), o.cout, fl, c.scratch,
+                                       arr, st);
+        }
+        int32_t* arr = o.cin > 32 ? c.arrival : nullptr;
+        return scn_conv_tiles(B<float>(c, o.x), n_in, o.cin, tstab, tmask, perm, order, n_off, n_out, P<float>(c, o.w),
+                              P<float>(c, o.b), B<float>(c, o.r), B<float>(c, o.m), B<float>(c, o.y), o.cout, fl, c.scratch, arr,
+                              st);
+    }
+    case SCN_OP_RULES_CHILD: {       // coarse rows -> fine rows: the strided rules with their roles swapped
+        if (h) return scn_gemm_rules_bf16(B<u16>(c, o.x), o.cin, L.c_out_rows, L.c_in_rows, L.c_prefix_host, 8, P<float>(c, o.w),
+                                          P<float>(c, o.b), B<u16>(c, o.m), B<u16>(c, o.y), o.cout, fl, st);
+        return scn_gemm_rules(B<float>(c, o.x), o.cin, L.c_out_rows, L.c_in_rows, L.c_prefix_host, 8, P<float>(c, o.w),
+                              P<float>(c, o.b), B<float>(c, o.m), B<float>(c, o.y), o.cout, fl, st);
+    }
+    case SCN_OP_ROWS2: {
+        const int64_t n = rows_of(o, L);
+        if (o.y1 >= 0)               // two destinations: backward-data of the NiN over a JoinTable
+            return scn_gemm_rows2(B<void>(c, o.x), o.cin, nullptr, 0, n, P<float>(c, o.w), nullptr, nullptr, nullptr,
+                                  B<void>(c, o.y), o.cout, B<void>(c, o.y1), o.c1, fl, h ? 1 : 0, st);
+        return scn_gemm_rows2(B<void>(c, o.x), o.cin, B<void>(c, o.x1), o.c1, n, P<float>(c, o.w), P<float>(c, o.b), nullptr,
+                              nullptr, B<void>(c, o.y), o.cout, nullptr, 0, fl, h ? 1 : 0, st);
+    }
+    case SCN_OP_WGRAD_SUBM: {
+        const uint32_t dbm = o.b >= 0 ? (1u << 13) : 0u;
+        if (h) return scn_wgrad_bias_rules_bf16(B<u16>(c, o.x), o.cin, B<u16>(c, o.y), o.cout, L.in_rows, L.out_rows, L.prefix_host,
+                                                27, G<float>(c, o.w), G<float>(c, o.b), dbm, c.scratch, fl, st);
+        return scn_wgrad_bias_rules(B<float>(c, o.x), o.cin, B<float>(c, o.y), o.cout, L.in_rows, L.out_rows, L.prefix_host, 27,
+                                    G<float>(c, o.w), G<float>(c, o.b), dbm, c.scratch, fl, st);
+    }
+    case SCN_OP_WGRAD2_SUBM: {
+        const uint32_t dbm = o.b >= 0 ? (1u << 13) : 0u;
+        if (h) return scn_wgrad_bias_rules2_bf16(B<u16>(c, o.x), B<u16>(c, o.y), B<u16>(c, o.x1), B<u16>(c, o.y1), o.cin, o.cout,
+                                                 L.in_rows, L.out_rows, L.prefix_host, 27, G<float>(c, o.w), G<float>(c, o.b), dbm,
+                                                 c.scratch, fl, st);
+        return scn_wgrad_bias_rules2(B<float>(c, o.x), B<float>(c, o.y), B<float>(c, o.x1), B<float>(c, o.y1), o.cin, o.cout,
+                                     L.in_rows, L.out_rows, L.prefix_host, 27, G<float>(c, o.w), G<float>(c, o.b), dbm, c.scratch,
+                                     fl, st);
+    }
+    case SCN_OP_WGRAD_DOWN: {        // Convolution: X fine rows, dY coarse rows
+        if (h) return scn_wgrad_rules_bf16(B<u16>(c, o.x), o.cin, B<u16>(c, o.y), o.cout, L.c_in_rows, L.c_out_rows,
+                                           L.c_prefix_host, 8, G<float>(c, o.w), c.scratch, fl, st);
+        return scn_wgrad_rules(B<float>(c, o.x), o.cin, B<float>(c, o.y), o.cout, L.c_in_rows, L.c_out_rows, L.c_prefix_host, 8,
+                               G<float>(c, o.w), c.scratch, fl, st);
+    }
+    case SCN_OP_WGRAD_UP: {          // Deconvolution: X coarse rows, dY fine rows; every fine row occurs in exactly one list
+        if (o.b < 0) {
+            if (h) return scn_wgrad_rules_bf16(B<u16>(c, o.x), o.cin, B<u16>(c, o.y), o.cout, L.c_out_rows, L.c_in_rows,
+                                               L.c_prefix_host, 8, G<float>(c, o.w), c.scratch, fl, st);
+            return scn_wgrad_rules(B<float>(c, o.x), o.cin, B<float>(c, o.y), o.cout, L.c_out_rows, L.c_in_rows, L.c_prefix_host,
+                                   8, G<float>(c, o.w), c.scratch, fl, st);
+        }
+        if (h) return scn_wgrad_bias_rules_bf16(B<u16>(c, o.x), o.cin, B<u16>(c, o.y), o.cout, L.c_out_rows, L.c_in_rows,
+                                                L.c_prefix_host, 8, G<float>(c, o.w), G<float>(c, o.b), 0xFFu, c.scratch, fl, st);
+        return scn_wgrad_bias_rules(B<float>(c, o.x), o.cin, B<float>(c, o.y), o.cout, L.c_out_rows, L.c_in_rows, L.c_prefix_host,
+                                    8, G<float>(c, o.w), G<float>(c, o.b), 0xFFu, c.scratch, fl, st);
+    }
+    case SCN_OP_WGRAD_IDENT: {
+        const int64_t ident[2] = {0, rows_of(o, L)};
+        float* dW = G<float>(c, o.w);
+        SCN_REQUIRE(dW != nullptr);
+        dW += o.aux;
+        if (o.b < 0) {
+            if (h) return scn_wgrad_rules_bf16(B<u16>(c, o.x), o.cin, B<u16>(c, o.y), o.cout, nullptr, nullptr, ident, 1, dW,
+                                               c.scratch, fl, st);
+            return scn_wgrad_rules(B<float>(c, o.x), o.cin, B<float>(c, o.y), o.cout, nullptr, nullptr, ident, 1, dW, c.scratch, fl,
+                                   st);
+        }
+        if (h) return scn_wgrad_bias_rules_bf16(B<u16>(c, o.x), o.cin, B<u16>(c, o.y), o.cout, nullptr, nullptr, ident, 1, dW,
+                                                G<float>(c, o.b), 1u, c.scratch, fl, st);
+        return scn_wgrad_bias_rules(B<float>(c, o.x), o.cin, B<float>(c, o.y), o.cout, nullptr, nullptr, ident, 1, dW,
+                                    G<float>(c, o.b), 1u, c.scratch, fl, st);
+    }
+    case SCN_OP_COLSUM: {
+        const int64_t n = rows_of(o, L);
+        if (h) return scn_colsum_bf16(B<u16>(c, o.x), n, o.cin, G<float>(c, o.b), c.scratch, st);
+        return scn_colsum(B<float>(c, o.x), n, o.cin, G<float>(c, o.b), c.scratch, st);
+    }
+    case SCN_OP_ADD: {
+        const int64_t count = rows_of(o, L) * o.cin;
+        if (h) return scn_add_bf16(B<u16>(c, o.x), B<u16>(c, o.x1), count, B<u16>(c, o.y), st);
+        return scn_add(B<float>(c, o.x), B<float>(c, o.x1), count, B<float>(c, o.y), st);
+    }
+    case SCN_OP_CAST: {
+        const int64_t count = rows_of(o, L) * o.cin;
+        if (h) return scn_cast_f32_to_bf16(B<float>(c, o.x), count, B<u16>(c, o.y), st);
+        return scn_cast_bf16_to_f32(B<u16>(c, o.x), count, B<float>(c, o.y), st);
+    }
+    default:
+        return scn::fail(SCN_EINVAL, "scn_exec_run: unknown op %s%lld", "", o.op);
+    }
+}
+
+}  // namespace
+
+extern "C" int scn_exec_requirements(const scn_exec_op* ops, int n_ops, const scn_exec_level* levels, int n_levels,
+                                     int64_t* scratch_bytes, int64_t* arrival_counters) {
+    SCN_REQUIRE(n_ops >= 0 && (n_ops == 0 || ops) && levels && n_levels >= 1 && scratch_bytes && arrival_counters);
+    int64_t sb = 256, ac = 0;
+    for (int i = 0; i < n_ops; ++i) {
+        const scn_exec_op& o = ops[i];
+        SCN_REQUIRE(o.level >= 0 && o.level < n_levels);
+        const scn_exec_level& L = levels[o.level];
+        int64_t s = 0, a = 0;
+        switch (o.op) {
+        case SCN_OP_CONV_SUBM:
+        case SCN_OP_CONV_CHILD: {
+            const int64_t n_out = o.op == SCN_OP_CONV_CHILD ? L.n_coarse : L.n;
+            if (bf(o)) {
+                s = scn_conv_tiles_bf16_scratch_bytes(o.cin, n_out, o.cout);
+                a = scn_conv_tiles_bf16_arrival_counters(o.cin, n_out, o.cout);
+            } else {
+                s = scn_conv_tiles_scratch_bytes(o.cin, n_out, o.cout);
+                a = scn_conv_tiles_arrival_counters(o.cin, n_out, o.cout);
+            }
+            break;
+        }
+        case SCN_OP_WGRAD_SUBM: s = scn_wgrad_scratch_bytes(o.cin, o.cout, L.prefix_host, 27); break;
+        case SCN_OP_WGRAD2_SUBM: s = scn_wgrad_scratch_bytes2(o.cin, o.cout, L.prefix_host, 27); break;
+        case SCN_OP_WGRAD_DOWN:
+        case SCN_OP_WGRAD_UP: s = scn_wgrad_scratch_bytes(o.cin, o.cout, L.c_prefix_host, 8); break;
+        case SCN_OP_WGRAD_IDENT: {
+            const int64_t ident[2] = {0, rows_of(o, L)};
+            s = scn_wgrad_scratch_bytes(o.cin, o.cout, ident, 1);
+            break;
+        }
+        case SCN_OP_COLSUM: s = (int64_t)SCN_COLSUM_BLOCKS * o.cin * (int64_t)sizeof(float); break;
+        default: break;
+        }
+        if (s < 0) return scn::fail(SCN_EINVAL, "scn_exec_requirements: op %s%lld has bad arguments", "", i);
+        if (s > sb) sb = s;
+        if (a > ac) ac = a;
+    }
+    *scratch_bytes = sb;
+    *arrival_counters = ac;
+    return SCN_OK;
+}
+
+extern "C" int scn_exec_run(const scn_exec_op* ops, int n_ops, const scn_exec_level* levels, int n_levels, void* const* bufs,
+                            const void* const* params, void* const* grads, void* scratch, int64_t scratch_bytes,
+                            int32_t* arrival, scn_stream_t stream) {
+    SCN_REQUIRE(n_ops >= 0 && (n_ops == 0 || ops) && levels && n_levels >= 1 && bufs && scratch && scratch_bytes >= 256);
+    Ctx c{levels, n_levels, bufs, params, grads, scratch, arrival, stream};
+    for (int i = 0; i < n_ops; ++i) {
+        const int rc = run_op(c, ops[i]);
+        if (rc != SCN_OK) {
+            char inner[400];
+            snprintf(inner, sizeof(inner), "%s", scn::g_err);
+            snprintf(scn::g_err, sizeof(scn::g_err), "scn_exec_run: op %d (kind %d, level %d): %s", i, ops[i].op, ops[i].level,
+                     inner);
+            return rc;
+        }
+    }
+    return SCN_OK;
+}

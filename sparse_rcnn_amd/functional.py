@@ -42,6 +42,18 @@ def _is_bf16(t):
     return t.dtype == torch.bfloat16
 
 
+# Debug hook for the parity tests: when a list, every FORWARD that applies a ReLU to a stored slab
+# (the fused input ReLU of a convolution, scn.ReLU) appends that slab's sign mask (x > 0, bool, on the host) in call order.
+# An oracle that takes these masks instead of its own `relu` decisions differentiates the same piecewise-linear function,
+# so ReLU inputs within rounding of zero no longer separate the two gradients.  None (default): nothing is recorded.
+RELU_RECORD = None
+
+
+def _rec_relu(X):
+    if RELU_RECORD is not None:
+        RELU_RECORD.append((X.detach() > 0).cpu())
+
+
 # ------------------------------------------------------------------------------------------------------
 # raw kernels (no autograd)
 # ------------------------------------------------------------------------------------------------------
@@ -406,6 +418,8 @@ class SubmanifoldConvolutionFunction(torch.autograd.Function):
         cout = W.shape[-1]
         b = _f32(bias) if bias is not None else None
         R = _feat(residual) if residual is not None else None
+        if relu_in:
+            _rec_relu(X)
         if USE_TILES and rb.rules is not None:
             Y = conv_rules(X, rb.tiles, rb.n, W, b, cout, L.F_RELU_IN if relu_in else 0, residual=R,
                            n_rules=rb.rules.count)
@@ -471,6 +485,7 @@ class ResidualBlockFunction(torch.autograd.Function):
         B2 = _f32(b2) if b2 is not None else None
         Y1 = conv_rules(X, rb.tiles, rb.n, W1, B1, W1.shape[-1], L.F_RELU_IN, n_rules=rb.rules.count)
         Y = conv_rules(Y1, rb.tiles, rb.n, W2, B2, W2.shape[-1], L.F_RELU_IN, residual=X, n_rules=rb.rules.count)
+        _rec_relu(X); _rec_relu(Y1)
         ctx.save_for_backward(X, Y1, W1, W2)
         ctx.rb, ctx.has_b1, ctx.has_b2 = rb, b1 is not None, b2 is not None
         return Y
@@ -532,6 +547,7 @@ class ResidualBlockFunctionBF16(torch.autograd.Function):
         B2 = _f32(b2) if b2 is not None else None
         Y1 = conv_rules_bf16(X, rb.tiles, rb.n, W1, B1, W1.shape[-1], L.F_RELU_IN, n_rules=rb.rules.count)
         Y = conv_rules_bf16(Y1, rb.tiles, rb.n, W2, B2, W2.shape[-1], L.F_RELU_IN, residual=X, n_rules=rb.rules.count)
+        _rec_relu(X); _rec_relu(Y1)
         ctx.save_for_backward(X, Y1, W1, W2)
         ctx.rb, ctx.has_b1, ctx.has_b2 = rb, b1 is not None, b2 is not None
         ctx.bwd_images = (packed_image(W1, W1.shape[-1], W1.shape[1], 27, _BACK),
@@ -583,6 +599,8 @@ class ConvolutionFunction(torch.autograd.Function):
         X, W = _feat(features), _f32(weight)
         rb = metadata.strided_rulebook(in_size)
         b = _f32(bias) if bias is not None else None
+        if relu_in:
+            _rec_relu(X)
         if USE_TILES:
             Y = conv_rules(X, rb.tiles, rb.n_coarse, W, b, W.shape[-1], L.F_RELU_IN if relu_in else 0,
                            n_rules=rb.n_fine)
@@ -628,6 +646,8 @@ class DeconvolutionFunction(torch.autograd.Function):
                              "reference only deconvolves back to an encoder level (custom_container.py:70-83)")
         r = rb.rules
         b = _f32(bias) if bias is not None else None
+        if relu_in:
+            _rec_relu(X)
         Y = gemm_rules(X, r.out_rows, r.in_rows, r.prefix_host, 8, rb.n_fine, W, b, W.shape[-1],
                        L.F_RELU_IN if relu_in else 0)
         ctx.save_for_backward(X, W)
@@ -791,6 +811,7 @@ class ReLUFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features):
         X = _f32(features)
+        _rec_relu(X)
         Y = torch.empty_like(X)
         L.check(L.lib().scn_relu_fwd(L.ptr(X), X.numel(), L.ptr(Y), L.stream()))
         ctx.save_for_backward(X)

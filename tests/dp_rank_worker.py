@@ -31,8 +31,11 @@ def main():
     assert job.flat.buckets, "the bucketed, overlapped all-reduce must be active with 2 ranks"
     if rank == empty_rank:
         job.boxes = [b + 10_000.0 for b in job.boxes]
+    from sparse_rcnn_amd import functional as F
+    F.RELU_RECORD = []                      # the sign masks of this rank's forward, for the oracle's FrozenReLU
     job.step()
     torch.cuda.synchronize()
+    masks, F.RELU_RECORD = F.RELU_RECORD, None
     named = {k: p for k, p in job.model.backbone.unet.named_oracle_params().items()}
     if job.model.mask is not None:
         named.update({"m:" + k: p for k, p in job.model.mask.named_oracle_params().items()})
@@ -40,7 +43,9 @@ def main():
     views = dict(zip([id(p) for p in job.flat.params], job.flat.mean_grad_views()))
     assert len(views) == len(named), (len(views), len(named))       # every parameter of the step is named
     grads = {"g:" + k: views[id(p)].detach().cpu().numpy() for k, p in named.items()}
-    np.savez(out_path, n_active=job.n_active, n_roi_rows=job.n_roi_rows, **params, **grads)
+    mk = {f"mask{i}": np.packbits(m.numpy().reshape(-1)) for i, m in enumerate(masks)}
+    mk["mask_shapes"] = np.array([tuple(m.shape) for m in masks], np.int64).reshape(-1, 2)
+    np.savez(out_path, n_active=job.n_active, n_roi_rows=job.n_roi_rows, **params, **grads, **mk)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -1,0 +1,433 @@
+"""Host side of the step executor (csrc/scn_exec.hip, include/scn_mi355x.h "Step executor").
+
+The reference drives the scn surface one layer at a time from Python (module_factory.py builds nested scn.Sequential trees,
+model.py:414-431 / 758-782 run them), and so did this package's autograd functions: ~330 launches per backbone step, ~760
+with the mask branch, ~13 us of host time each.  Here a U-Net LEVEL runs as one autograd node whose forward and backward are
+one C call each: the node's launch plan (a flat list of `scn_exec_op`) is compiled ONCE per network from the module tree,
+and a step only fills three pointer tables (feature slabs carved out of one workspace tensor, parameters / bf16 weight
+images, parameter gradients).  Every op is one of the library's own entry points with the arguments the layer-by-layer
+path passes, so both paths produce the same bits (tests/test_gpu_exec.py).
+
+One node per LEVEL rather than per network: the parameter gradients of a level leave its node when that level's backward
+ends, so the bucketed gradient all-reduce of dp.py still overlaps with the rest of backward, skip connections stay ordinary
+autograd edges, and the encoder outputs (`SparseUNet.interims`, the RPN's inputs in the reference) stay differentiable.
+
+Not covered (the layer-by-layer path runs instead): batch norm, `bf16_blocks=True` (casts around every run of units),
+channel plans the two-source NetworkInNetwork kernel does not take, empty levels, and any step in which
+`profiling.TIMER` brackets single launches with events.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib as L
+from . import functional as F
+from . import modules as M
+
+ENABLED = os.environ.get("SCN_EXEC", "1") != "0"
+
+i32, i64, vp = C.c_int32, C.c_int64, C.c_void_p
+
+OP_GEMM_IDENT, OP_CONV_SUBM, OP_CONV_CHILD, OP_RULES_CHILD, OP_ROWS2 = 1, 2, 3, 4, 5
+OP_WGRAD_SUBM, OP_WGRAD2_SUBM, OP_WGRAD_DOWN, OP_WGRAD_UP, OP_WGRAD_IDENT, OP_COLSUM, OP_ADD, OP_CAST = 6, 7, 8, 9, 10, 11, 12, 13
+XF_BF16, XF_COARSE_ROWS = 1 << 16, 1 << 17
+BACK = L.F_W_TRANSPOSED | L.F_OFF_REVERSE
+
+
+class ExecOp(C.Structure):
+    _fields_ = [(n, i32) for n in ("op", "flags", "level", "cin", "cout", "x", "y", "r", "m", "x1", "y1", "c1", "w", "b", "aux",
+                                   "reserved")]
+
+
+class ExecLevel(C.Structure):
+    _fields_ = [("n", i64), ("tstab", vp), ("tile_mask", vp), ("perm", vp), ("tile_order", vp), ("in_rows", vp),
+                ("out_rows", vp), ("prefix_host", vp), ("n_coarse", i64), ("c_tstab", vp), ("c_tile_mask", vp),
+                ("c_perm", vp), ("c_tile_order", vp), ("c_in_rows", vp), ("c_out_rows", vp), ("c_prefix_host", vp)]
+
+
+def _addr(prefix_host):
+    return C.cast(prefix_host, vp).value
+
+
+def build_levels(md, size, n_levels):
+    """The index structures of `n_levels` U-Net levels below spatial size `size`, as the executor's level table.
+    -> (ctypes array, objects kept alive, rows per level), cached on the Metadata; None when a level is empty."""
+    size = tuple(int(s) for s in size)
+    cache = md.__dict__.setdefault("_exec_levels", {})
+    hit = cache.get((size, n_levels))
+    if hit is not None:
+        return hit or None
+    arr = (ExecLevel * n_levels)()
+    keep, ns = [], []
+    sz = size
+    for l in range(n_levels):
+        rb = md.subm_rulebook(sz, 3)
+        if rb.n == 0 or rb.rules is None or rb.tiles is None:
+            cache[(size, n_levels)] = False
+            return None
+        e, t, r = arr[l], rb.tiles, rb.rules
+        e.n = rb.n
+        e.tstab, e.tile_mask, e.perm, e.tile_order = t.tstab.data_ptr(), t.tile_mask.data_ptr(), t.perm.data_ptr(), t.tile_order.data_ptr()
+        ph = r.prefix_host
+        e.in_rows, e.out_rows, e.prefix_host = r.in_rows.data_ptr(), r.out_rows.data_ptr(), _addr(ph)
+        keep += [rb, ph]
+        ns.append(rb.n)
+        if l + 1 < n_levels:
+            sb = md.strided_rulebook(sz)
+            if sb.n_coarse == 0:
+                cache[(size, n_levels)] = False
+                return None
+            ct, cr = sb.tiles, sb.rules
+            cph = cr.prefix_host
+            e.n_coarse = sb.n_coarse
+            e.c_tstab, e.c_tile_mask, e.c_perm, e.c_tile_order = ct.tstab.data_ptr(), ct.tile_mask.data_ptr(), ct.perm.data_ptr(), ct.tile_order.data_ptr()
+            e.c_in_rows, e.c_out_rows, e.c_prefix_host = cr.in_rows.data_ptr(), cr.out_rows.data_ptr(), _addr(cph)
+            keep += [sb, cph]
+            sz = sb.coarse_size
+    out = cache[(size, n_levels)] = (arr, keep, ns)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# plan compiler
+# ----------------------------------------------------------------------------------------------------------------------
+class Stage:
+    """The launch plan of one autograd node: forward and backward op lists over symbolic buffer / parameter / gradient ids."""
+
+    def __init__(self, bf16, n_inputs):
+        self.bf16 = bool(bf16)
+        self.hb = XF_BF16 if bf16 else 0
+        self.es = 2 if bf16 else 4
+        self.n_inputs = n_inputs
+        self.fwd, self.bwd = [], []
+        self.bufs = []                  # id -> (level, channels, elem bytes, kind)   kind: "f" fwd ws | "b" bwd ws | "x" external
+        self.mods = []                  # modules whose (W, b) the node takes: (module, cin_phys)
+        self.params = []                # params-table descriptors: ("w", mod idx) | ("b", mod idx) | ("img", mod idx, cin, cout, n_off, flags)
+        self.gregions = []              # gradient regions: list of [(mod idx, "w"|"b"), ...] laid out back to back
+        self.in_ids, self.din_ids = [], []
+        self.out_id = self.dout_id = None
+
+    # ---- symbols ----------------------------------------------------------------------------------------------------
+    def buf(self, level, ch, es=None, kind="f"):
+        self.bufs.append((level, int(ch), self.es if es is None else es, kind))
+        return len(self.bufs) - 1
+
+    def mod(self, module, cin_phys):
+        for i, (m, c) in enumerate(self.mods):
+            if m is module:
+                return i
+        self.mods.append((module, int(cin_phys)))
+        return len(self.mods) - 1
+
+    def param(self, *desc):
+        if desc not in self.params:
+            self.params.append(desc)
+        return self.params.index(desc)
+
+    def weight(self, mi, cin, cout, n_off, flags, tile_kernel):
+        """params id of the weight operand of a data op: the fp32 weight, or (bf16 storage, tile kernel) its packed image."""
+        if self.bf16 and tile_kernel:
+            return self.param("img", mi, cin, cout, n_off, flags & BACK)
+        return self.param("w", mi)
+
+    def gregion(self, *members):
+        self.gregions.append(list(members))
+        return len(self.gregions) - 1
+
+    def op(self, lst, op, level, cin, cout, x=-1, y=-1, r=-1, m=-1, x1=-1, y1=-1, c1=0, w=-1, b=-1, aux=0, flags=0):
+        lst.append(ExecOp(op, flags, level, cin, cout, x, y, r, m, x1, y1, c1, w, b, aux, 0))
+
+    # ---- residual units ----------------------------------------------------------------------------------------------
+    def units_fwd(self, level, c, x, blocks, out_id=None):
+        """blocks: [(conv1, conv2)] of x + SubM3(ReLU(SubM3(ReLU(x)))) at `c` physical channels.  -> (output id, saved)"""
+        saved = []
+        for k, (c1, c2) in enumerate(blocks):
+            m1, m2 = self.mod(c1, c), self.mod(c2, c)
+            y1 = self.buf(level, c)
+            y = out_id if (out_id is not None and k == len(blocks) - 1) else self.buf(level, c)
+            fl = L.F_RELU_IN | self.hb
+            self.op(self.fwd, OP_CONV_SUBM, level, c, c, x=x, y=y1, w=self.weight(m1, c, c, 27, 0, True), b=self.param("b", m1), flags=fl)
+            self.op(self.fwd, OP_CONV_SUBM, level, c, c, x=y1, y=y, r=x, w=self.weight(m2, c, c, 27, 0, True), b=self.param("b", m2), flags=fl)
+            saved.append((x, y1, m1, m2))
+            x = y
+        return x, saved
+
+    def units_bwd(self, level, c, g, saved, din_id=None):
+        """Backward of units_fwd: g = gradient of the last block's output -> id of the gradient of the first block's input."""
+        for k, (x, y1, m1, m2) in enumerate(reversed(saved)):
+            dy1 = self.buf(level, c, kind="b")
+            dx = din_id if (din_id is not None and k == len(saved) - 1) else self.buf(level, c, kind="b")
+            self.op(self.bwd, OP_CONV_SUBM, level, c, c, x=g, y=dy1, m=y1, w=self.weight(m2, c, c, 27, BACK, True), flags=BACK | self.hb)
+            self.op(self.bwd, OP_CONV_SUBM, level, c, c, x=dy1, y=dx, m=x, r=g, w=self.weight(m1, c, c, 27, BACK, True),
+                    flags=BACK | L.F_RESIDUAL_LAST | self.hb)
+            gw, gb = self.gregion((m1, "w"), (m2, "w")), self.gregion((m1, "b"), (m2, "b"))
+            self.op(self.bwd, OP_WGRAD2_SUBM, level, c, c, x=x, y=dy1, x1=y1, y1=g, w=gw, b=gb, flags=L.F_RELU_IN | self.hb)
+            g = dx
+        return g
+
+    # ---- finish -----------------------------------------------------------------------------------------------------
+    def freeze(self):
+        self.fwd_arr = (ExecOp * len(self.fwd))(*self.fwd)
+        self.bwd_arr = (ExecOp * len(self.bwd))(*self.bwd)
+        self.fwd_ws = [i for i, b in enumerate(self.bufs) if b[3] == "f"]
+        self.bwd_ws = [i for i, b in enumerate(self.bufs) if b[3] == "b"]
+        covered = sorted(m for reg in self.gregions for m in reg)
+        want = sorted((i, k) for i in range(len(self.mods)) for k in ("w", "b"))
+        if covered != want:
+            raise RuntimeError("executor plan: every parameter must sit in exactly one gradient region")
+        return self
+
+
+def _plain_blocks(unit_seq):
+    """[(conv1, conv2)] of a `units(...)` Sequential, or None when a block is not the plain pre-activation unit."""
+    out = []
+    for block in unit_seq:
+        if not (type(block) is M.Sequential and len(block) == 2 and type(block[0]) is M.ConcatTable and type(block[1]) is M.AddTable):
+            return None
+        a, inner = list(block[0]._modules.values()) if len(block[0]._modules) == 2 else (None, None)
+        if type(a) is not M.Identity or type(inner) is not M.Sequential or len(inner) != 4:
+            return None
+        r0, c1, r1, c2 = list(inner._modules.values())
+        if not (type(r0) is M.ReLU and type(r1) is M.ReLU and type(c1) is M.SubmanifoldConvolution
+                and type(c2) is M.SubmanifoldConvolution and c1.filter_size == 3 and c2.filter_size == 3
+                and c1.bias is not None and c2.bias is not None and c1.nIn == c2.nOut and c1.nOut == c2.nIn == c1.nIn):
+            return None
+        out.append((c1, c2))
+    return out
+
+
+def _phys(m):
+    return int(getattr(m, "pad_out_to", None) or m.nOut)
+
+
+def compile_encoder_stage(level, head, blocks, cin_phys, bf16, cast_first=False, cast_last=False):
+    """Encoder level: head (SubM 1^3 at level 0 | Convolution 2^3/2 from level-1) + residual units.
+    level 0 in bf16 storage: the head runs in fp32 on the fp32 input and its result is cast (SparseUNet), or -- cast_first,
+    the mask branch's input stage -- the input is cast first and the head runs on bf16 rows; cast_last: fp32 output."""
+    st = Stage(bf16, 1)
+    es_in = 4 if (level == 0) else st.es
+    c = _phys(head)
+    IN = st.buf(level if level == 0 else level - 1, cin_phys, es_in, "x")
+    st.in_ids = [IN]
+    mh = st.mod(head, cin_phys)
+    out_es = 4 if (cast_last or not bf16) else 2
+    OUT = st.buf(level, c, out_es, "x")
+    st.out_id = OUT
+    if level == 0:
+        if bf16 and cast_first:
+            xin = st.buf(0, cin_phys)
+            st.op(st.fwd, OP_CAST, 0, cin_phys, 0, x=IN, y=xin, flags=XF_BF16)
+            h = st.buf(0, c)
+            st.op(st.fwd, OP_GEMM_IDENT, 0, cin_phys, c, x=xin, y=h, w=st.param("w", mh), b=st.param("b", mh), flags=XF_BF16)
+            x, head_in, head_hb = h, xin, XF_BF16
+        else:
+            h = st.buf(0, c, 4)
+            st.op(st.fwd, OP_GEMM_IDENT, 0, cin_phys, c, x=IN, y=h, w=st.param("w", mh), b=st.param("b", mh), flags=0)
+            x, head_in, head_hb = h, IN, 0
+            if bf16:
+                x = st.buf(0, c)
+                st.op(st.fwd, OP_CAST, 0, c, 0, x=h, y=x, flags=XF_BF16)
+    else:
+        x = st.buf(level, c)
+        st.op(st.fwd, OP_CONV_CHILD, level - 1, cin_phys, c, x=IN, y=x, w=st.weight(mh, cin_phys, c, 8, 0, True),
+              b=st.param("b", mh), flags=st.hb)
+    head_out = x
+    if bf16 and cast_last:
+        last, saved = st.units_fwd(level, c, x, blocks)
+        st.op(st.fwd, OP_CAST, level, c, 0, x=last, y=OUT, flags=0)
+    else:
+        last, saved = st.units_fwd(level, c, x, blocks, out_id=OUT)
+    # ---- backward
+    DOUT = st.buf(level, c, out_es, "x")
+    st.dout_id = DOUT
+    g = DOUT
+    if bf16 and cast_last:
+        g = st.buf(level, c, kind="b")
+        st.op(st.bwd, OP_CAST, level, c, 0, x=DOUT, y=g, flags=XF_BF16)
+    g = st.units_bwd(level, c, g, saved)
+    DIN = st.buf(level if level == 0 else level - 1, cin_phys, es_in, "x")
+    st.din_ids = [DIN]
+    gw, gb = st.gregion((mh, "w")), st.gregion((mh, "b"))
+    if level == 0:
+        if head_hb:                                           # head ran on bf16 rows: its input gradient is cast back at the end
+            dinb = st.buf(0, cin_phys, kind="b")
+            st.op(st.bwd, OP_GEMM_IDENT, 0, c, cin_phys, x=g, y=dinb, w=st.param("w", mh), flags=BACK | XF_BF16)
+            st.op(st.bwd, OP_WGRAD_IDENT, 0, cin_phys, c, x=head_in, y=g, w=gw, b=gb, flags=XF_BF16)
+            st.op(st.bwd, OP_CAST, 0, cin_phys, 0, x=dinb, y=DIN, flags=0)
+        else:
+            gf = g
+            if bf16:
+                gf = st.buf(0, c, 4, "b")
+                st.op(st.bwd, OP_CAST, 0, c, 0, x=g, y=gf, flags=0)
+            st.op(st.bwd, OP_GEMM_IDENT, 0, c, cin_phys, x=gf, y=DIN, w=st.param("w", mh), flags=BACK)
+            st.op(st.bwd, OP_WGRAD_IDENT, 0, cin_phys, c, x=IN, y=gf, w=gw, b=gb, flags=0)
+    else:
+        st.op(st.bwd, OP_RULES_CHILD, level - 1, c, cin_phys, x=g, y=DIN, w=st.param("w", mh), flags=L.F_W_TRANSPOSED | st.hb)
+        st.op(st.bwd, OP_WGRAD_DOWN, level - 1, cin_phys, c, x=IN, y=g, w=gw, flags=st.hb)
+        st.op(st.bwd, OP_COLSUM, level, c, 0, x=g, b=gb, flags=st.hb)
+    del head_out
+    return st.freeze()
+
+
+def compile_decoder_stage(level, up, nin, blocks, c_coarse, bf16):
+    """Decoder level: ReLU -> Deconvolution 2^3/2 (coarse level+1 -> level) -> JoinTable([up, skip]) -> NetworkInNetwork ->
+    residual units.  Inputs: (coarse slab, skip slab)."""
+    st = Stage(bf16, 2)
+    c = _phys(up)
+    IN0 = st.buf(level + 1, c_coarse, None, "x")
+    IN1 = st.buf(level, c, None, "x")
+    st.in_ids = [IN0, IN1]
+    OUT = st.buf(level, c, None, "x")
+    st.out_id = OUT
+    mu, mn = st.mod(up, c_coarse), st.mod(nin, 2 * c)
+    upb = st.buf(level, c)
+    st.op(st.fwd, OP_RULES_CHILD, level, c_coarse, c, x=IN0, y=upb, w=st.param("w", mu), b=st.param("b", mu),
+          flags=L.F_RELU_IN | st.hb)
+    h = st.buf(level, c)
+    st.op(st.fwd, OP_ROWS2, level, c, c, x=upb, x1=IN1, c1=c, y=h, w=st.param("w", mn), b=st.param("b", mn), flags=st.hb)
+    last, saved = st.units_fwd(level, c, h, blocks, out_id=OUT)
+    # ---- backward
+    DOUT = st.buf(level, c, None, "x")
+    st.dout_id = DOUT
+    g = st.units_bwd(level, c, DOUT, saved)
+    DIN0 = st.buf(level + 1, c_coarse, None, "x")
+    DIN1 = st.buf(level, c, None, "x")
+    st.din_ids = [DIN0, DIN1]
+    dup = st.buf(level, c, kind="b")
+    st.op(st.bwd, OP_ROWS2, level, c, c, x=g, y=dup, y1=DIN1, c1=c, w=st.param("w", mn), flags=L.F_W_TRANSPOSED | st.hb)
+    gwn, gbn = st.gregion((mn, "w")), st.gregion((mn, "b"))
+    st.op(st.bwd, OP_WGRAD_IDENT, level, c, c, x=upb, y=g, w=gwn, b=gbn, aux=0, flags=st.hb)
+    st.op(st.bwd, OP_WGRAD_IDENT, level, c, c, x=IN1, y=g, w=gwn, b=-1, aux=c * c, flags=st.hb)
+    st.op(st.bwd, OP_CONV_CHILD, level, c, c_coarse, x=dup, y=DIN0, m=IN0,
+          w=st.weight(mu, c, c_coarse, 8, L.F_W_TRANSPOSED, True), flags=L.F_W_TRANSPOSED | st.hb)
+    gwu, gbu = st.gregion((mu, "w")), st.gregion((mu, "b"))
+    st.op(st.bwd, OP_WGRAD_UP, level, c_coarse, c, x=IN0, y=dup, w=gwu, b=gbu, flags=L.F_RELU_IN | st.hb)
+    return st.freeze()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# run time
+# ----------------------------------------------------------------------------------------------------------------------
+def _layout(stage, ids, ns):
+    offs, tot = [], 0
+    for i in ids:
+        lv, ch, es, _ = stage.bufs[i]
+        offs.append(tot)
+        tot += (ns[lv] * ch * es + 255) & ~255
+    return offs, tot
+
+
+def _run(stage, ops, levels, table, ptab, gtab, dev):
+    lib = L.lib()
+    arr, _, ns = levels
+    sb, ac = i64(0), i64(0)
+    L.check(lib.scn_exec_requirements(ops, len(ops), arr, len(ns), C.byref(sb), C.byref(ac)))
+    scratch = L.scratch(sb.value, dev)
+    arrival = L.arrival(max(ac.value, 1), dev)
+    L.check(lib.scn_exec_run(ops, len(ops), arr, len(ns), table, ptab, gtab, scratch.data_ptr(), scratch.numel(),
+                             arrival.data_ptr(), L.stream()))
+
+
+class StageFunction(torch.autograd.Function):
+    """forward(stage, levels, *inputs, *(W, b per module of the stage)) -> the stage's output slab."""
+
+    @staticmethod
+    def forward(ctx, stage, levels, *ts):
+        n_in = stage.n_inputs
+        inputs = [F._feat(t) for t in ts[:n_in]]
+        phys = ts[n_in:]
+        dev = inputs[0].device
+        ns = levels[2]
+        offs, total = _layout(stage, stage.fwd_ws, ns)
+        ws = torch.empty(max(total, 256), dtype=torch.uint8, device=dev)
+        lv, ch, es, _ = stage.bufs[stage.out_id]
+        out = torch.empty((ns[lv], ch), dtype=torch.float32 if es == 4 else torch.bfloat16, device=dev)
+        table = (vp * len(stage.bufs))()
+        base = ws.data_ptr()
+        for i, o in zip(stage.fwd_ws, offs):
+            table[i] = base + o
+        for i, t in zip(stage.in_ids, inputs):
+            blv, bch, bes, _ = stage.bufs[i]
+            if t.shape != (ns[blv], bch) or t.element_size() != bes:
+                raise L.ScnError(f"executor: input slab {tuple(t.shape)} {t.dtype} where the plan expects {(ns[blv], bch)} x {bes} B")
+            table[i] = t.data_ptr()
+        table[stage.out_id] = out.data_ptr()
+        ptab = (vp * max(len(stage.params), 1))()
+        images = []
+        for k, d in enumerate(stage.params):
+            if d[0] == "w":
+                ptab[k] = F._f32(phys[2 * d[1]]).data_ptr()
+            elif d[0] == "b":
+                b = phys[2 * d[1] + 1]
+                ptab[k] = 0 if b is None else F._f32(b).data_ptr()
+            else:
+                _, mi, cin, cout, n_off, fl = d
+                W = phys[2 * mi]
+                img = F.packed_image(W, cin, cout, n_off, fl)
+                if img is None:
+                    img = F.pack_weights_bf16(W.detach(), cin, cout, n_off, fl)
+                images.append(img)
+                ptab[k] = img.data_ptr()
+        _run(stage, stage.fwd_arr, levels, table, ptab, None, dev)
+        ctx.stage, ctx.levels, ctx.table, ctx.ptab, ctx.keep = stage, levels, table, ptab, (ws, images, inputs)
+        ctx.phys_shapes = [None if t is None else tuple(t.shape) for t in phys]
+        ctx.save_for_backward(*[t for t in phys if t is not None])          # (keeps the parameter tensors the pointers name alive)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        stage, levels, table, ptab = ctx.stage, ctx.levels, ctx.table, ctx.ptab
+        ns = levels[2]
+        dev = dout.device
+        lv, ch, es, _ = stage.bufs[stage.dout_id]
+        dout = dout.contiguous()
+        if dout.element_size() != es:
+            dout = dout.to(torch.float32 if es == 4 else torch.bfloat16)
+        offs, total = _layout(stage, stage.bwd_ws, ns)
+        ws = torch.empty(max(total, 256), dtype=torch.uint8, device=dev)
+        base = ws.data_ptr()
+        for i, o in zip(stage.bwd_ws, offs):
+            table[i] = base + o
+        table[stage.dout_id] = dout.data_ptr()
+        dins = []
+        for i in stage.din_ids:
+            blv, bch, bes, _ = stage.bufs[i]
+            t = torch.empty((ns[blv], bch), dtype=torch.float32 if bes == 4 else torch.bfloat16, device=dev)
+            dins.append(t)
+            table[i] = t.data_ptr()
+        # gradient regions back to back in one fp32 buffer; the returned gradients are views of it
+        shapes = ctx.phys_shapes
+        goffs, gtot, views = [], 0, [None] * len(shapes)
+        for reg in stage.gregions:
+            goffs.append(gtot)
+            for mi, kind in reg:
+                sh = shapes[2 * mi + (kind == "b")]
+                if sh is not None:
+                    n = 1
+                    for s in sh:
+                        n *= s
+                    views[2 * mi + (kind == "b")] = (gtot, n, sh)
+                    gtot += n
+            gtot = (gtot + 63) & ~63
+        flat = torch.empty(max(gtot, 1), dtype=torch.float32, device=dev)
+        gtab = (vp * max(len(stage.gregions), 1))()
+        gb = flat.data_ptr()
+        for k, o in enumerate(goffs):
+            gtab[k] = gb + 4 * o
+        _run(stage, stage.bwd_arr, levels, table, ptab, gtab, dev)
+        grads = [None if v is None else flat[v[0]:v[0] + v[1]].view(v[2]) for v in views]
+        ctx.keep = None
+        return (None, None, *dins, *grads)
+
+
+def run_stage(stage, levels, inputs, module_list=None):
+    """Apply a compiled stage: the physical (W, b) of its modules are fetched through `_wb` (zero-padded views of the logical
+    parameters where a layer is channel-padded -- autograd carries their gradients back through the pad)."""
+    phys = []
+    for m, cin_phys in stage.mods:
+        W, b = m._wb(cin_phys)
+        phys += [W, b]
+    return StageFunction.apply(stage, levels, *inputs, *phys)

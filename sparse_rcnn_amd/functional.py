@@ -934,6 +934,8 @@ class InputLayerFunction(torch.autograd.Function):
         mode = int(mode)
         dev = torch.device("cuda", torch.cuda.current_device())
         F = input_features.to(dev)
+        if F.dtype == torch.bfloat16:           # bf16-stored point features (the ROI crop of a bf16 slab): widened exactly;
+            F = F.float()                       # the mean over a voxel's points accumulates in fp32 / fp64
         F = _f32(F)
         if coords.shape[0] != F.shape[0]:
             raise ValueError("coords / features row mismatch")
@@ -954,7 +956,8 @@ class InputLayerFunction(torch.autograd.Function):
         L.check(lib.scn_input_fwd(L.ptr(F), L.ptr(metadata.item_row), L.ptr(metadata.row_count),
                                   L.ptr(metadata.row_first), n_items, grid.n, c, mode, L.ptr(Y), L.ptr(acc),
                                   L.ptr(metadata.row_last), L.stream()))
-        ctx.md, ctx.mode, ctx.shape, ctx.in_device = metadata, mode, (n_items, c), input_features.device
+        ctx.md, ctx.mode, ctx.shape, ctx.in_device, ctx.in_dtype = metadata, mode, (n_items, c), input_features.device, \
+            input_features.dtype
         return Y
 
     @staticmethod
@@ -965,7 +968,7 @@ class InputLayerFunction(torch.autograd.Function):
         dF = _new((n_items, c), dY)
         L.check(L.lib().scn_input_bwd(L.ptr(dY), L.ptr(md.item_row), L.ptr(md.row_count), L.ptr(md.row_first),
                                       L.ptr(md.row_last), n_items, c, ctx.mode, L.ptr(dF), L.stream()))
-        return None, None, None, None, dF.to(ctx.in_device), None, None
+        return None, None, None, None, dF.to(device=ctx.in_device, dtype=ctx.in_dtype), None, None
 
 
 class OutputLayerFunction(torch.autograd.Function):
@@ -973,24 +976,25 @@ class OutputLayerFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dimension, metadata, input_features):
-        X = _f32(input_features)
+        X = _feat(input_features)               # fp32, or bf16 storage (a row copy either way)
         if metadata.item_row is None:
             raise L.ScnError("OutputLayer: this Metadata has no InputLayer rules")
         c = X.shape[1]
-        Y = _new((metadata.n_items, c), X)
-        L.check(L.lib().scn_gather_rows(L.ptr(X), L.ptr(metadata.item_row), metadata.n_items, c, L.ptr(Y), L.stream()))
-        ctx.md, ctx.n_rows = metadata, X.shape[0]
+        Y = _new((metadata.n_items, c), X, X.dtype)
+        gather = L.lib().scn_gather_rows_bf16 if _is_bf16(X) else L.lib().scn_gather_rows
+        L.check(gather(L.ptr(X), L.ptr(metadata.item_row), metadata.n_items, c, L.ptr(Y), L.stream()))
+        ctx.md, ctx.n_rows, ctx.hb = metadata, X.shape[0], _is_bf16(X)
         return Y
 
     @staticmethod
     def backward(ctx, dY):
         md = ctx.md
-        dY = _f32(dY)
+        dY = dY.to(torch.bfloat16).contiguous() if ctx.hb else _f32(dY)
         c = dY.shape[1]
-        dX = _new((ctx.n_rows, c), dY)
+        dX = _new((ctx.n_rows, c), dY, dY.dtype)
         acc = torch.empty((ctx.n_rows, c), dtype=torch.float64, device=dY.device)
-        L.check(L.lib().scn_segment_sum(L.ptr(dY), L.ptr(md.item_row), md.n_items, ctx.n_rows, c, L.ptr(dX),
-                                        L.ptr(acc), L.stream()))
+        seg = L.lib().scn_segment_sum_bf16 if ctx.hb else L.lib().scn_segment_sum
+        L.check(seg(L.ptr(dY), L.ptr(md.item_row), md.n_items, ctx.n_rows, c, L.ptr(dX), L.ptr(acc), L.stream()))
         return None, None, dX
 
 
@@ -1000,25 +1004,27 @@ class OutputLayerFunction(torch.autograd.Function):
 class SparseToDenseFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features, metadata, spatial_size):
-        X = _f32(features)
+        X = _feat(features)                     # fp32, or bf16 storage (the dense volume then is bf16 too)
         size = tuple(int(s) for s in spatial_size)
         g = metadata.grid(size)
         n, c = X.shape
-        out = torch.zeros((metadata.n_samples, c) + size, dtype=torch.float32, device=X.device)
+        out = torch.zeros((metadata.n_samples, c) + size, dtype=X.dtype, device=X.device)
         hs = L.host_i64(3)
         hs[0], hs[1], hs[2] = size
-        L.check(L.lib().scn_sparse_to_dense_fwd(L.ptr(X), L.ptr(g.coords), n, c, hs, L.ptr(out), L.stream()))
-        ctx.g, ctx.size, ctx.shape = g, size, (n, c)
+        fwd = L.lib().scn_sparse_to_dense_fwd_bf16 if _is_bf16(X) else L.lib().scn_sparse_to_dense_fwd
+        L.check(fwd(L.ptr(X), L.ptr(g.coords), n, c, hs, L.ptr(out), L.stream()))
+        ctx.g, ctx.size, ctx.shape, ctx.hb = g, size, (n, c), _is_bf16(X)
         return out
 
     @staticmethod
     def backward(ctx, dOut):
-        dOut = _f32(dOut)
+        dOut = dOut.to(torch.bfloat16).contiguous() if ctx.hb else _f32(dOut)
         n, c = ctx.shape
-        dX = _new((n, c), dOut)
+        dX = _new((n, c), dOut, dOut.dtype)
         hs = L.host_i64(3)
         hs[0], hs[1], hs[2] = ctx.size
-        L.check(L.lib().scn_sparse_to_dense_bwd(L.ptr(dOut), L.ptr(ctx.g.coords), n, c, hs, L.ptr(dX), L.stream()))
+        bwd = L.lib().scn_sparse_to_dense_bwd_bf16 if ctx.hb else L.lib().scn_sparse_to_dense_bwd
+        L.check(bwd(L.ptr(dOut), L.ptr(ctx.g.coords), n, c, hs, L.ptr(dX), L.stream()))
         return dX, None, None
 
 
@@ -1028,11 +1034,12 @@ class SparseToDenseFunction(torch.autograd.Function):
 class PoolingFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features, metadata: Metadata, in_size, average):
-        X = _f32(features)
+        X = _feat(features)                     # fp32, or bf16 storage
         rb = metadata.strided_rulebook(in_size)
         c = X.shape[1]
-        Y = _new((rb.n_coarse, c), X)
-        L.check(L.lib().scn_pool_fwd(L.ptr(X), L.ptr(rb.child), rb.n_coarse, c, int(average), L.ptr(Y), L.stream()))
+        Y = _new((rb.n_coarse, c), X, X.dtype)
+        fwd = L.lib().scn_pool_fwd_bf16 if _is_bf16(X) else L.lib().scn_pool_fwd
+        L.check(fwd(L.ptr(X), L.ptr(rb.child), rb.n_coarse, c, int(average), L.ptr(Y), L.stream()))
         ctx.save_for_backward(X, Y)
         ctx.rb, ctx.average = rb, int(average)
         return Y
@@ -1040,8 +1047,10 @@ class PoolingFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dY):
         X, Y = ctx.saved_tensors
-        dY = _f32(dY)
+        hb = _is_bf16(X)
+        dY = dY.to(torch.bfloat16).contiguous() if hb else _f32(dY)
         dX = torch.empty_like(X)
-        L.check(L.lib().scn_pool_bwd(L.ptr(X), L.ptr(Y), L.ptr(dY), L.ptr(ctx.rb.parent), X.shape[0], X.shape[1],
-                                     ctx.average, L.ptr(dX), L.stream()))
+        bwd = L.lib().scn_pool_bwd_bf16 if hb else L.lib().scn_pool_bwd
+        L.check(bwd(L.ptr(X), L.ptr(Y), L.ptr(dY), L.ptr(ctx.rb.parent), X.shape[0], X.shape[1], ctx.average, L.ptr(dX),
+                    L.stream()))
         return dX, None, None, None

@@ -77,15 +77,20 @@ class MaskBranch(nn.Module):
         how = {True: "thread", False: "0", "1": "thread"}.get(how, how)
         pending = None if how == "0" else self.output_roi_cut.prepare_cut_in_thread(coords, size, selected_bbox,
                                                                                   in_thread=how == "thread")
-        if self.bf16:       # the scene-level units on bf16-stored features; the per-point gather (OutputLayer) takes fp32
-            converted = M.CastFeatures(torch.float32)(self.input_conv_layer(M.CastFeatures(torch.bfloat16)(backbone_features)))
-        else:
+        # bf16 storage: the scene-level units, the per-point gather (OutputLayer), the per-point slab and the crop's feature
+        # gather all run on bf16 rows (round 3: no fp32 island between backbone and internal U-Net); only the InputLayer's
+        # mean over the cropped points accumulates in fp32 / fp64
+        converted = self._input_stage_exec(backbone_features)            # one C call each way (executor.py) where it applies
+        if converted is None and self.bf16:
+            converted = self.input_conv_layer(M.CastFeatures(torch.bfloat16)(backbone_features))
+        elif converted is None:
             converted = self.input_conv_layer(backbone_features)
         per_point = self.output_layer(converted)
-        parts = (per_point, features)
+        raw = features.to(per_point.dtype)
+        parts = (per_point, raw)
         unet = self.output_conv_layer
         if unet.phys0 != unet.channels[0]:      # 23 -> 24 columns: zero column appended where the slab is assembled anyway
-            parts += (features.new_zeros((features.shape[0], unet.phys0 - unet.channels[0])),)
+            parts += (raw.new_zeros((raw.shape[0], unet.phys0 - unet.channels[0])),)
         combined = torch.cat(parts, dim=-1)
         roi_tensor, selection = self.output_roi_cut((coords, combined, size, *other, batch_splits), selected_bbox,
                                                     prepared=pending)
@@ -94,6 +99,30 @@ class MaskBranch(nn.Module):
             return skip_features.new_zeros((0, self.classes)), selection
         out = self.roi_output_layer(unet(roi_tensor))            # [cropped points, phys0]; the pad column is zero
         return self._linear(out), selection
+
+    def _input_stage_exec(self, fmap):
+        """input_conv_layer (SubM 1^3 + residual units on the scene's level 0; bf16 storage: cast in, cast out) through the
+        step executor, or None when it does not apply."""
+        from . import executor as EX, functional as F, profiling
+        from .tensor import SparseConvNetTensor
+        f = fmap.features
+        if (not (EX.ENABLED and SparseUNet.EXEC) or profiling.TIMER is not None or F.RELU_RECORD is not None
+                or not (f.is_cuda and f.dtype == torch.float32 and f.shape[0] > 0)):
+            return None
+        st = self.__dict__.get("_input_stage")
+        if st is None:
+            blocks = EX._plain_blocks(self.input_conv_layer[1])
+            head = self.input_conv_layer[0]
+            st = False
+            if blocks is not None and head.nOut % 8 == 0 and head.nIn % 8 == 0:
+                st = EX.compile_encoder_stage(0, head, blocks, head.nIn, self.bf16, cast_first=True, cast_last=False)
+            object.__setattr__(self, "_input_stage", st)
+        if not st:
+            return None
+        lv = EX.build_levels(fmap.metadata, fmap.spatial_size, 1)
+        if lv is None:
+            return None
+        return SparseConvNetTensor(features=EX.run_stage(st, lv, [f]), metadata=fmap.metadata, spatial_size=fmap.spatial_size)
 
     # parameter naming shared with the checker (tests map the oracle's mask-branch parameters by these names)
     def named_oracle_params(self):

@@ -32,21 +32,23 @@ class _GatherRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, features, rows, n_src):
-        X = _f32(features)
+        hb = features.dtype == torch.bfloat16          # bf16 storage: the same row copy on half the bytes
+        X = features.contiguous() if hb else _f32(features)
         m, c = rows.shape[0], X.shape[1]
-        Y = torch.empty((m, c), dtype=torch.float32, device=X.device)
-        L.check(L.lib().scn_gather_rows(L.ptr(X), L.ptr(rows), m, c, L.ptr(Y), L.stream()))
-        ctx.rows, ctx.n_src = rows, n_src
+        Y = torch.empty((m, c), dtype=X.dtype, device=X.device)
+        gather = L.lib().scn_gather_rows_bf16 if hb else L.lib().scn_gather_rows
+        L.check(gather(L.ptr(X), L.ptr(rows), m, c, L.ptr(Y), L.stream()))
+        ctx.rows, ctx.n_src, ctx.hb = rows, n_src, hb
         return Y
 
     @staticmethod
     def backward(ctx, dY):
-        dY = _f32(dY)
+        dY = dY.to(torch.bfloat16).contiguous() if ctx.hb else _f32(dY)
         c = dY.shape[1]
-        dX = torch.empty((ctx.n_src, c), dtype=torch.float32, device=dY.device)
+        dX = torch.empty((ctx.n_src, c), dtype=dY.dtype, device=dY.device)
         acc = torch.empty((ctx.n_src, c), dtype=torch.float64, device=dY.device)
-        L.check(L.lib().scn_segment_sum(L.ptr(dY), L.ptr(ctx.rows), ctx.rows.shape[0], ctx.n_src, c, L.ptr(dX),
-                                        L.ptr(acc), L.stream()))
+        seg = L.lib().scn_segment_sum_bf16 if ctx.hb else L.lib().scn_segment_sum
+        L.check(seg(L.ptr(dY), L.ptr(ctx.rows), ctx.rows.shape[0], ctx.n_src, c, L.ptr(dX), L.ptr(acc), L.stream()))
         return dX, None, None
 
 

@@ -143,9 +143,80 @@ class SparseUNet(nn.Module):
                 return self._forward(x, prebuild)
         return self._forward(x, prebuild)
 
+    # ---- step executor (executor.py): one autograd node and two C calls per LEVEL instead of one per layer -------------
+    EXEC = True                 # class-wide switch (tests compare the two ways of driving the same kernels)
+
+    def _exec_plan(self):
+        """Launch plans of the levels, compiled once from the module tree; False when this network is not covered (batch
+        norm, bf16_blocks=True, a block that is not the plain pre-activation unit, channel counts the two-source
+        NetworkInNetwork kernel does not take)."""
+        plan = self.__dict__.get("_exec_plan_cache")
+        if plan is not None:
+            return plan
+        from . import executor as EX
+        plan = False
+        ch, L = self.channels, len(self.channels)
+        ok = not self.bf16_blocks and all(c % 8 == 0 for c in ch[1:]) and (self.phys0 % 8 == 0)
+        enc_blocks = [EX._plain_blocks(lvl[1]) if not (l == 0 and self.identity_first) else [] for l, lvl in enumerate(self.encoder)]
+        dec_blocks = [EX._plain_blocks(d["units"]) for d in self.decoder]
+        if ok and all(b is not None for b in enc_blocks + dec_blocks):
+            bf16 = self.bf16_all
+            phys = [self.phys0] + list(ch[1:])
+            enc = []
+            for l in range(L):
+                if l == 0 and self.identity_first:
+                    enc.append(None)
+                    continue
+                head = self.encoder[l][0]
+                cin_phys = head.nIn if l == 0 else phys[l - 1]
+                enc.append(EX.compile_encoder_stage(l, head, enc_blocks[l], cin_phys, bf16))
+            dec = []
+            for i, d in enumerate(self.decoder):
+                l = L - 2 - i
+                dec.append(EX.compile_decoder_stage(l, d["up"][1], d["nin"], dec_blocks[i], phys[l + 1], bf16))
+            plan = dict(enc=enc, dec=dec)
+        object.__setattr__(self, "_exec_plan_cache", plan)
+        return plan
+
+    def _forward_exec(self, x):
+        """The forward through the step executor, or None when it does not apply to this call."""
+        from . import executor as EX, functional as F, profiling
+        from .tensor import SparseConvNetTensor
+        if not (EX.ENABLED and SparseUNet.EXEC) or profiling.TIMER is not None or F.RELU_RECORD is not None:
+            return None
+        f = x.features
+        if not (f.is_cuda and f.dtype == torch.float32 and f.dim() == 2 and f.shape[0] > 0):
+            return None
+        plan = self._exec_plan()
+        if not plan:
+            return None
+        L = len(self.channels)
+        lv = EX.build_levels(x.metadata, x.spatial_size, L)
+        if lv is None:                                        # an empty level: the layer-by-layer path handles it
+            return None
+        size = [int(s) for s in x.spatial_size]
+        sizes = [torch.as_tensor([s >> l for s in size], dtype=torch.long) for l in range(L)]
+        interims = []
+        for l in range(L):
+            if plan["enc"][l] is None:                       # identity_first: the level's slab is the input (stored: cast)
+                f = f.to(torch.bfloat16) if self.bf16_all else f
+            else:
+                f = EX.run_stage(plan["enc"][l], lv, [f])
+            interims.append(SparseConvNetTensor(features=f, metadata=x.metadata, spatial_size=sizes[l]))
+        object.__setattr__(self, "interims", interims)
+        for i, st in enumerate(plan["dec"]):
+            l = L - 2 - i
+            f = EX.run_stage(st, lv, [f, interims[l].features])
+        if self.bf16_all:
+            f = f.to(torch.float32)
+        return SparseConvNetTensor(features=f, metadata=x.metadata, spatial_size=sizes[0])
+
     def _forward(self, x, prebuild):
         if prebuild:
             x.metadata.build_pyramid(x.spatial_size, len(self.channels), 3)
+            y = self._forward_exec(x)
+            if y is not None:
+                return y
         interims = []
         for l, level in enumerate(self.encoder):
             x = level[0](x)

@@ -244,8 +244,8 @@ def test_dropin_path_equals_backbone_path_at_150k(gpu, scene150k):
 # ------------------------------------------------------------------------------------------------ cfg 3
 def _oracle_mask_branch(coords_np, raw, bb_feats, mp, boxes_np, assoc, scene, bf16=False, relu=None):
     """SparseMaskNetwork forward (model.py:758-782) on the oracle ops, reference configuration (run.py:741-810).
-    bf16: with the storage roundings of the HIP path's bf16 mode (stored slabs and the tile-kernel layers' weights rounded;
-    OutputLayer / crop / InputLayer mean / Linear stay fp32)."""
+    bf16: with the storage roundings of the HIP path's bf16 mode (stored slabs -- incl. the per-point slab the crop reads --
+    and the tile-kernel layers' weights rounded; InputLayer mean and the Linear stack stay fp32)."""
     relu = torch.relu if relu is None else relu                 # O.FrozenReLU: the masks the HIP forward recorded
     q = O.bf16_storage if bf16 else (lambda t: t)               # stored slabs (gradient passes straight through)
     wq = q                                                      # tile-kernel weights
@@ -259,7 +259,7 @@ def _oracle_mask_branch(coords_np, raw, bb_feats, mp, boxes_np, assoc, scene, bf
         y = O.conv(relu(y), wq(mp[f"in.res{u}.conv1.weight"]), mp[f"in.res{u}.conv1.bias"], rules, n0)
         x = q(x + y)
     per_point = x[torch.from_numpy(scene.prow)]                              # OutputLayer
-    cat = torch.cat([per_point, raw], 1)
+    cat = torch.cat([per_point, q(raw)], 1)                                  # (bf16 storage: the per-point slab is bf16)
     src, box_of, inside = O.roi_crop(coords_np, boxes_np, assoc)
     if len(src) == 0:                                    # no box caught a point: the branch ends here (model.py:768-770)
         return None, src, box_of, None

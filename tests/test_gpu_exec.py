@@ -1,0 +1,145 @@
+"""-m gpu: the step executor (sparse_rcnn_amd/executor.py + csrc/scn_exec.hip: one autograd node and two C calls per U-Net
+level) against the layer-by-layer module path.  Both drive the same entry points with the same arguments, so EVERYTHING must
+be bit-identical: output features, encoder outputs, the input-feature gradient and every parameter gradient -- fp32 and bf16
+storage, the benchmark plan, the reference's own plan 32-48-64-80-96-112, the mask branch (channel-padded internal U-Net,
+cast-in / cast-out input stage), gradients arriving at the encoder outputs (the RPN's inputs in the reference)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(target, grid, seed):
+    from sparse_rcnn_amd.synthetic import make_batch
+    return make_batch(1, grid, target, dup=1.15, seed=seed)
+
+
+def _run_backbone(net, coords, feats, size, gy_seed, gpu, use_exec, with_interims=False):
+    from sparse_rcnn_amd.unet import SparseUNet
+    SparseUNet.EXEC = use_exec
+    try:
+        for p in net.parameters():
+            p.grad = None
+        fin = feats.to(gpu).requires_grad_()
+        out = net(coords, fin, size, 1)
+        g = torch.Generator().manual_seed(gy_seed)
+        gy = torch.randn(out.features.shape, generator=g).to(gpu)
+        outs, grads = [out.features], [gy]
+        if with_interims:                       # gradients arriving at encoder outputs too (SparseToDense -> RPN in the reference)
+            for t in net.unet.interims[1:]:
+                outs.append(t.features)
+                grads.append(torch.randn(t.features.shape, generator=g).to(gpu).to(t.features.dtype))
+        torch.autograd.backward(outs, grads)
+        torch.cuda.synchronize()
+        return (out.features.detach().clone(), [t.features.detach().clone() for t in net.unet.interims], fin.grad.clone(),
+                [p.grad.clone() for p in net.parameters()])
+    finally:
+        SparseUNet.EXEC = True
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("plan", ["bench", "reference", "two-level"])
+def test_executor_backbone_is_bit_identical_to_the_module_path(gpu, dtype, plan):
+    from sparse_rcnn_amd.unet import Backbone
+    ch, grid, target = {"bench": ((32, 64, 128, 256), (256, 256, 128), 30_000),
+                        "reference": ((32, 48, 64, 80, 96, 112), (256, 256, 128), 20_000),
+                        "two-level": ((16, 40), (64, 64, 32), 3_000)}[plan]
+    coords, feats, size, bs, _ = _scene(target, grid, seed=7)
+    torch.manual_seed(3)
+    net = Backbone(7, ch, bf16_blocks="all" if dtype == "bf16" else False).to(gpu)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.05)
+    assert net.unet._exec_plan(), "this network must be covered by the executor"
+    for with_interims in (False, True):
+        a = _run_backbone(net, coords, feats, size, 11, gpu, True, with_interims)
+        b = _run_backbone(net, coords, feats, size, 11, gpu, False, with_interims)
+        assert torch.equal(a[0], b[0]), "output features"
+        for l, (x, y) in enumerate(zip(a[1], b[1])):
+            assert x.dtype == y.dtype and torch.equal(x, y), f"encoder output {l}"
+        assert torch.equal(a[2], b[2]), "input-feature gradient"
+        names = [n for n, _ in net.named_parameters()]
+        for n, x, y in zip(names, a[3], b[3]):
+            assert torch.equal(x, y), f"gradient of {n} (interims={with_interims})"
+
+
+def test_executor_is_actually_used_and_cuts_the_autograd_graph_to_one_node_per_level(gpu):
+    from sparse_rcnn_amd.unet import Backbone
+    from sparse_rcnn_amd import executor as EX
+    coords, feats, size, bs, _ = _scene(3000, (64, 64, 32), seed=2)
+    net = Backbone(7, (16, 32, 64)).to(gpu)
+    out = net(coords, feats.to(gpu).requires_grad_(), size, 1)
+    seen, todo, n_stage = set(), [out.features.grad_fn], 0
+    while todo:
+        f = todo.pop()
+        if f is None or f in seen:
+            continue
+        seen.add(f)
+        n_stage += type(f).__name__.startswith("StageFunction")
+        todo += [g for g, _ in f.next_functions]
+    assert n_stage == 3 + 2, n_stage                          # 3 encoder levels + 2 decoder levels
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_executor_mask_branch_is_bit_identical_to_the_module_path(gpu, dtype):
+    """trainstep's cfg3 step (backbone -> input stage -> OutputLayer -> crop -> channel-padded internal U-Net -> Linear) with
+    the executor on and off: logits, backbone output and every gradient bit for bit."""
+    from sparse_rcnn_amd.trainstep import SceneStep
+    from sparse_rcnn_amd.unet import SparseUNet
+    res = []
+    for use in (True, False):
+        SparseUNet.EXEC = use
+        try:
+            job = SceneStep("cfg3", gpu, dtype=dtype, prefetch=False, seed=5, grad_seed=9, target=20_000, grid=(256, 256, 128),
+                            n_boxes=12, lr=0.0)
+            with torch.no_grad():
+                g = torch.Generator().manual_seed(1)
+                for p in job.model.parameters():
+                    if p.dim() == 1:
+                        p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+            job.forward_backward()
+            torch.cuda.synchronize()
+            res.append((job.out.features.detach().clone(), job.logits.detach().clone(), job.fin.grad.clone(),
+                        [(n, p.grad.clone()) for n, p in job.model.named_parameters()]))
+        finally:
+            SparseUNet.EXEC = True
+    a, b = res
+    assert a[1].shape[0] > 1000
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for (n, x), (_, y) in zip(a[3], b[3]):
+        assert torch.equal(x, y), n
+
+
+def test_bf16_elementwise_forms_match_torch(gpu):
+    """scn_cast_* / scn_add_bf16 / scn_gather_rows_bf16 / scn_segment_sum_bf16 / pooling / SparseToDense in bf16 storage against
+    torch on the same bits (casts and gathers bit-exact; sums within one bf16 rounding of the fp64 sum)."""
+    from sparse_rcnn_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(5000, 24, generator=g) * 3).to(gpu)
+    xb = torch.empty(x.shape, dtype=torch.bfloat16, device=gpu)
+    L.check(lib.scn_cast_f32_to_bf16(x.data_ptr(), x.numel(), xb.data_ptr(), L.stream()))
+    assert torch.equal(xb, x.to(torch.bfloat16))
+    xf = torch.empty_like(x)
+    L.check(lib.scn_cast_bf16_to_f32(xb.data_ptr(), xb.numel(), xf.data_ptr(), L.stream()))
+    assert torch.equal(xf, xb.float())
+    odd = x[:777, :7].contiguous()                                            # unaligned tail path
+    ob = torch.empty(odd.shape, dtype=torch.bfloat16, device=gpu)
+    L.check(lib.scn_cast_f32_to_bf16(odd.data_ptr(), odd.numel(), ob.data_ptr(), L.stream()))
+    assert torch.equal(ob, odd.to(torch.bfloat16))
+    yb = (torch.randn(5000, 24, generator=g)).to(gpu).to(torch.bfloat16)
+    zb = torch.empty_like(xb)
+    L.check(lib.scn_add_bf16(xb.data_ptr(), yb.data_ptr(), xb.numel(), zb.data_ptr(), L.stream()))
+    assert torch.equal(zb, xb + yb)
+    rows = torch.randint(0, 5000, (12345,), generator=g).to(torch.int32).to(gpu)
+    out = torch.empty((len(rows), 24), dtype=torch.bfloat16, device=gpu)
+    L.check(lib.scn_gather_rows_bf16(xb.data_ptr(), rows.data_ptr(), len(rows), 24, out.data_ptr(), L.stream()))
+    assert torch.equal(out, xb[rows.long()])
+    dy = torch.randn(len(rows), 24, generator=g).to(gpu).to(torch.bfloat16)
+    dx = torch.empty((5000, 24), dtype=torch.bfloat16, device=gpu)
+    acc = torch.empty((5000, 24), dtype=torch.float64, device=gpu)
+    L.check(lib.scn_segment_sum_bf16(dy.data_ptr(), rows.data_ptr(), len(rows), 5000, 24, dx.data_ptr(), acc.data_ptr(), L.stream()))
+    exp = torch.zeros(5000, 24, dtype=torch.float64, device=gpu).index_add_(0, rows.long(), dy.double())
+    assert torch.equal(dx, exp.float().to(torch.bfloat16))

@@ -45,9 +45,11 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--target", type=int, default=None, help="active voxels per scene (default: the workload's)")
-    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg5"), default="cfg2",
+    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg5", "ref", "ref-crop"), default="cfg2",
                     help="cfg2 = the configuration the metric is quoted on (default); cfg3 = backbone + OutputLayer + "
-                         "sparse ROI crop (64 boxes) + mask-branch U-Net, fwd+bwd; cfg5 = 600k voxels, 5 levels to 512")
+                         "sparse ROI crop (64 boxes) + mask-branch U-Net, fwd+bwd; cfg5 = 600k voxels, 5 levels to 512; "
+                         "ref = the reference's own 6-level plan 32-48-64-80-96-112 on the 150k scene; ref-crop = the same "
+                         "plan on the reference's training batch (12 crops of 128x128x64)")
     ap.add_argument("--dtype", choices=("f32", "bf16", "bf16-blocks"), default="f32",
                     help="feature STORAGE type: f32 (the headline, the reference's arithmetic) or bf16 (BASELINE configs "
                          "3-5: bf16-stored features, fp32 accumulation, fp32 parameters)")
@@ -389,7 +391,7 @@ def side_measurements(job, args, world, dist, torch):
         if i == 2:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        md = Metadata(3).build_native(job.size, job.coords, 1, 4, n_levels, 3)
+        md = Metadata(3).build_native(job.size, job.coords, job.batch_size, 4, n_levels, 3)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / reps * 1e3
     # algorithmic bytes of the build: per level 16 N (coords) + 8 P (pairs) + 16 N (hash insert + init);

@@ -18,6 +18,7 @@
 //     permutation of the summation order shared by A and B so each lane fetches 4 channels per 16-byte access.
 //     C/D: acc[j] = D[4*kq + j][lane & 15].
 #include <atomic>
+#include <stdlib.h>
 
 #include "scn_common.h"
 
@@ -64,7 +65,16 @@ __device__ __forceinline__ int ts_ws_off(int o, int k, int n) { return (o * TS_K
 // wave drains its stores (s_waitcnt vmcnt(0)) before its agent-scope ticket add, the combiner learns it is last from the
 // value its own add returned and reads the payload with sc1 loads only; no fence.  The counters are zero on entry and the
 // last arriver puts its counter back to zero, so the caller zeroes the array once, not per launch.
-template <bool WT, bool VEC, bool VECN, bool FULLK, bool PART, bool FUSED>
+// TAIL (round 3; the reference's own channel plan 32-48-64-80-96-112, scannet_config/run.py:539-549): a K-chunk with at most
+// 16 valid channels skips the eight MFMAs of its dead half, a column chunk with at most 16 valid columns the eight MFMAs of
+// its dead column block -- a 48-channel layer executes 48 x 48, not 64 x 64 (the skipped MFMAs multiplied zeros: same bits).
+// The (column chunk, K-chunk) slices then differ in cost, so the host hands every slice a share of the workgroups in
+// proportion to its work instead of the uniform modulo mapping.  There are four classes of slices -- full, dead column block
+// (last column chunk), dead K half (last K-chunk), both -- and a slice of a class gets g[class] workgroups; workgroups are
+// numbered class by class: [full slices][column-tail slices][K-tail slices][the corner slice].
+struct TsSlices { int g_full, g_ntail, g_ktail, g_both; };
+
+template <bool WT, bool VEC, bool VECN, bool FULLK, bool PART, bool FUSED, bool TAIL = false>
 __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     const float* __restrict__ X, long long n_in, int cin, const int* __restrict__ tstab,
     const unsigned* __restrict__ tile_mask,
@@ -72,13 +82,37 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     const float* __restrict__ W, const float* __restrict__ bias,
     const float* __restrict__ residual, const float* __restrict__ relu_mask, float* __restrict__ Y,
     float* __restrict__ slabs, long long n_out, int cout, int flags, int n_chunks, int n_kc,
-    int* __restrict__ counters) {
+    int* __restrict__ counters, TsSlices slices) {
     extern __shared__ __attribute__((aligned(16))) float Ws[];           // [n_off][32 k][32 n] swizzled
     constexpr int THREADS = TS_NW * 64;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int chunk = blockIdx.x % n_chunks;
-    const int kci = (blockIdx.x / n_chunks) % n_kc;
+    int chunk, kci, tg, n_tg;
+    if constexpr (TAIL) {
+        const int ncf = n_chunks - (slices.g_ntail ? 1 : 0), nkf = n_kc - (slices.g_ktail ? 1 : 0);   // full column / K chunks
+        int b = (int)blockIdx.x;
+        const int end_full = nkf * ncf * slices.g_full, end_n = end_full + nkf * slices.g_ntail;
+        const int end_k = end_n + ncf * slices.g_ktail;
+        if (b < end_full) {
+            n_tg = slices.g_full;
+            const int sl = b / n_tg;
+            tg = b - sl * n_tg; kci = sl / ncf; chunk = sl - kci * ncf;
+        } else if (b < end_n) {
+            b -= end_full; n_tg = slices.g_ntail;
+            kci = b / n_tg; tg = b - kci * n_tg; chunk = n_chunks - 1;
+        } else if (b < end_k) {
+            b -= end_n; n_tg = slices.g_ktail;
+            chunk = b / n_tg; tg = b - chunk * n_tg; kci = n_kc - 1;
+        } else {
+            tg = b - end_k; n_tg = slices.g_both; chunk = n_chunks - 1; kci = n_kc - 1;
+        }
+    } else {
+        chunk = blockIdx.x % n_chunks;
+        kci = (blockIdx.x / n_chunks) % n_kc;
+        tg = blockIdx.x / (n_chunks * n_kc);
+        n_tg = gridDim.x / (n_chunks * n_kc);
+    }
     const int n0 = chunk * TS_CT, kc = kci * TS_KC;
+    const bool kh = TAIL && cin - kc <= 16, nh = TAIL && cout - n0 <= 16;     // wave-uniform: dead K half / dead column block
     const bool relu_in = flags & SCN_F_RELU_IN;
     const bool rev = flags & SCN_F_OFF_REVERSE;
     const bool res_last = flags & SCN_F_RESIDUAL_LAST;
@@ -89,7 +123,6 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     // the imbalance they remove -- DESIGN.md.)
     long long tl_t0 = 0, tl_t1 = 0, tl_c1 = 0, tl_steps = 0, tl_tiles = 0;
     if (TS_TIMELINE) tl_t0 = wall_clock64();
-    const int tg = blockIdx.x / (n_chunks * n_kc), n_tg = gridDim.x / (n_chunks * n_kc);
     const int n_tiles = (int)((nt - tg + n_tg - 1) / n_tg);
     int* counter = (int*)(Ws + n_off * TS_KC * TS_CT);
     if (tid == 0) *counter = 0;
@@ -274,19 +307,23 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         const float* wb_ = Ws + (oq0 * (TS_KC * TS_CT) + bofs);                                      \
         const float* wc_ = Ws + (oq0 * (TS_KC * TS_CT) + (bofs ^ 16));                               \
         float bl_[8], bh_[8];                                                                        \
+        /* TS_KH / TS_NH (compile-time per copy of the tile loop): dead K half / dead column block skipped; the order of   \
+           the MFMAs that remain is unchanged per accumulator */                                                          \
         _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                           \
             bl_[e_] = wb_[e_ * TS_CT];                                                               \
-            bh_[e_] = wc_[e_ * TS_CT];                                                               \
-            bl_[4 + e_] = wb_[(16 + e_) * TS_CT];                                                    \
-            bh_[4 + e_] = wc_[(16 + e_) * TS_CT];                                                    \
+            if (!TS_NH) bh_[e_] = wc_[e_ * TS_CT];                                                   \
+            if (!TS_KH) bl_[4 + e_] = wb_[(16 + e_) * TS_CT];                                        \
+            if (!TS_KH && !TS_NH) bh_[4 + e_] = wc_[(16 + e_) * TS_CT];                              \
         }                                                                                            \
         _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                           \
             c0 = MFMA16(a0_[e_], bl_[e_], c0);                                                       \
-            c1 = MFMA16(a0_[e_], bh_[e_], c1);                                                       \
+            if (!TS_NH) c1 = MFMA16(a0_[e_], bh_[e_], c1);                                           \
         }                                                                                            \
-        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                           \
-            c0 = MFMA16(a1_[e_], bl_[4 + e_], c0);                                                   \
-            c1 = MFMA16(a1_[e_], bh_[4 + e_], c1);                                                   \
+        if (!TS_KH) {                                                                                \
+            _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                       \
+                c0 = MFMA16(a1_[e_], bl_[4 + e_], c0);                                               \
+                if (!TS_NH) c1 = MFMA16(a1_[e_], bh_[4 + e_], c1);                                   \
+            }                                                                                        \
         }                                                                                            \
         oq0 = oq1; oq1 = oq2; oq2 = oq3; oq3 = oq4; oq4 = o4_;                                       \
     } while (0)
@@ -411,81 +448,38 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     };
 
     // ---- tile loop: the id, mask and output rows of the NEXT tile are fetched while the current one computes --------
-    while (tile_next >= 0) {
-        const long long tile = tile_next;
-        unsigned m = m_next;
-        int orow[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) orow[j] = orow_next[j];
-        const int* tb_s = tstab + tile * n_off * TS_T;              // wave-uniform base; the lane adds i
-        const int n_steps = __popc(m);
-        float rs_t[4][2], mk_t[4][2];
-        if constexpr (FULLK) {
-            if (!(FUSED && !single)) TS_LOAD_OPS(orow, rs_t, mk_t);    // oldest loads of the tile: back before its epilogue
+    if constexpr (TAIL) {
+        if (kh && nh) {
+#define TS_KH 1
+#define TS_NH 1
+#include "scn_conv_ts_loop.inc"
+#undef TS_KH
+#undef TS_NH
+        } else if (kh) {
+#define TS_KH 1
+#define TS_NH 0
+#include "scn_conv_ts_loop.inc"
+#undef TS_KH
+#undef TS_NH
+        } else if (nh) {
+#define TS_KH 0
+#define TS_NH 1
+#include "scn_conv_ts_loop.inc"
+#undef TS_KH
+#undef TS_NH
+        } else {
+#define TS_KH 0
+#define TS_NH 0
+#include "scn_conv_ts_loop.inc"
+#undef TS_KH
+#undef TS_NH
         }
-        if (TS_TIMELINE) { tl_tiles += 1; tl_steps += n_steps; }
-        tile_next = grab();
-        if (tile_next >= 0) {
-            m_next = tile_mask[tile_next];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) orow_next[j] = perm[tile_next * TS_T + 4 * kq + j];
-        }
-
-        // queue of the next four offsets of this tile (-1 = none) and their row indices; loads are unconditional
-        // (a finished list re-reads its last offset)
-        int oq0 = -1, oq1 = -1, oq2 = -1, oq3 = -1, oq4 = -1, iq0, iq1, iq2, iqa, iqb, iqc, iqd;
-        int olast = 0;
-        if (m) { oq0 = __builtin_ctz(m); m &= m - 1; olast = oq0; }
-        iq0 = tb_s[olast * TS_T + i];
-        if (m) { oq1 = __builtin_ctz(m); m &= m - 1; olast = oq1; }
-        iq1 = tb_s[olast * TS_T + i];
-        if (m) { oq2 = __builtin_ctz(m); m &= m - 1; olast = oq2; }
-        iq2 = tb_s[olast * TS_T + i];
-        if (m) { oq3 = __builtin_ctz(m); m &= m - 1; olast = oq3; }
-        iqa = tb_s[olast * TS_T + i];
-        if (m) { oq4 = __builtin_ctz(m); m &= m - 1; olast = oq4; }
-        iqb = tb_s[olast * TS_T + i];
-        // (issue order pinned: if the compiler sinks the last two index loads below the gathers they become the newest
-        // loads and the first step of the loop waits for everything)
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 s00, s01, s10, s11, s20, s21, s30, s31;
-        TS_GATHER(iq0, s00, s01);
-        TS_GATHER(iq1, s10, s11);
-        TS_GATHER(iq2, s20, s21);
-        __builtin_amdgcn_sched_barrier(0);
-
-        const float iA = single ? bA : 0.f, iB = single ? bB : 0.f;
-        f32x4 c0 = {iA, iA, iA, iA}, c1 = {iB, iB, iB, iB};
-        // n_steps offsets: whole rounds of four steps without a per-step exit test, then the 0-3 left over
-        int n_left = n_steps;
-        for (; n_left >= 4; n_left -= 4) {
-            TS_STEP(s00, s01, s30, s31, iqa, iqc);
-            TS_STEP(s10, s11, s00, s01, iqb, iqd);
-            TS_STEP(s20, s21, s10, s11, iqc, iqa);
-            TS_STEP(s30, s31, s20, s21, iqd, iqb);
-        }
-        if (n_left >= 1) { TS_STEP(s00, s01, s30, s31, iqa, iqc); }
-        if (n_left >= 2) { TS_STEP(s10, s11, s00, s01, iqb, iqd); }
-        if (n_left >= 3) { TS_STEP(s20, s21, s10, s11, iqc, iqa); }
-
-        // ---- tile epilogue -----------------------------------------------------------------------------------------
-        if (FUSED && !single) {
-            // The hand-off is PIPELINED over the wave's tiles so that no wave waits for a store acknowledgement or a
-            // ticket round trip (a stall of 2-4 us per tile where a tile is 10-40 us of work):
-            //   end of tile t   : publish t's partial (two write-through stores)
-            //   end of tile t+1 : everything this wave issued before its t+1 loop has long completed -- the wait below is
-            //                     (nearly) free -- so t's stores are drained: take t's ticket (returning atomic, not awaited)
-            //   end of tile t+2 : t's ticket is back; if it is the last one, combine t
-            // and two flush rounds after the tile loop.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            ts_retire();
-            ts_publish(tile, c0, c1);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) orow_q1[j] = orow[j];
-            continue;
-        }
-        if constexpr (FULLK) ts_store(orow, c0, c1, rs_t, mk_t);
-        else ts_write(orow, c0, c1);
+    } else {
+#define TS_KH 0
+#define TS_NH 0
+#include "scn_conv_ts_loop.inc"
+#undef TS_KH
+#undef TS_NH
     }
     if (FUSED && !single) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -588,27 +582,59 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     const bool fullk = vec && n_in < (1ll << 23) && n_in * cin * 4 < (1ll << 32) - (1ll << 24) &&
                        n_out < (1ll << 23) && n_out * cout * 4 < (1ll << 32) - (1ll << 24);
     const bool part = cin % TS_KC != 0;
+    // TAIL: a dead K half or a dead column block exists (the reference's 48 / 80 / 112-channel layers): those MFMAs are
+    // skipped and the slices get workgroups in proportion to their cost.  Estimated cost of a tile step relative to a
+    // full 16-MFMA step: one dead half 0.62, both 0.42 (the per-step fixed work -- index load, gathers, ~15 VALU -- does
+    // not shrink with the MFMAs; calibrated with tools/ablate_conv.py on the 48 / 80 / 112-channel layers).
+    const bool k_tail = cin % TS_KC != 0 && cin % TS_KC <= 16, n_tail = cout % TS_CT != 0 && cout % TS_CT <= 16;
+    const bool tail = fullk && (k_tail || n_tail) && !getenv("SCN_TS_NO_TAIL");
+    TsSlices slices = {0, 0, 0, 0};
+    int64_t grid_x = n_tg * n_chunks * n_kc;
+    if (tail) {
+        static const double w_half = getenv("SCN_TS_W_HALF") ? atof(getenv("SCN_TS_W_HALF")) : 0.62;
+        static const double w_both = getenv("SCN_TS_W_BOTH") ? atof(getenv("SCN_TS_W_BOTH")) : 0.42;
+        const int ncf = n_chunks - (n_tail ? 1 : 0), nkf = n_kc - (k_tail ? 1 : 0);
+        const double wsum = (double)nkf * ncf + (n_tail ? nkf * w_half : 0.0) + (k_tail ? ncf * w_half : 0.0) +
+                            (n_tail && k_tail ? w_both : 0.0);
+        const int64_t total_wg = 256 * wg_per_cu, cap = cdiv(nt, TS_NW);   // a workgroup should see at least ~16 tiles
+        auto share = [&](double w) { int64_t g = (int64_t)(total_wg * w / wsum); return (int)(g > cap ? cap : (g < 1 ? 1 : g)); };
+        slices.g_full = share(1.0);
+        slices.g_ntail = n_tail ? share(w_half) : 0;
+        slices.g_ktail = k_tail ? share(w_half) : 0;
+        slices.g_both = n_tail && k_tail ? share(w_both) : 0;
+        grid_x = (int64_t)nkf * ncf * slices.g_full + (int64_t)nkf * slices.g_ntail + (int64_t)ncf * slices.g_ktail + slices.g_both;
+    }
     g_ts_paths[fullk ? 0 : 1].fetch_add(1, std::memory_order_relaxed);
     if (n_kc > 1) g_ts_paths[fused ? 2 : 3].fetch_add(1, std::memory_order_relaxed);
-    dim3 grid((unsigned)(n_tg * n_chunks * n_kc));
+    dim3 grid((unsigned)grid_x);
     hipStream_t st = S(stream);
-#define LAUNCH_TS_F(T, V, VN, FK, PT, FU)                                                                           \
+#define LAUNCH_TS_F(T, V, VN, FK, PT, FU, TL)                                                                       \
     do {                                                                                                            \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
-            SCN_HIP(hipFuncSetAttribute((const void*)k_conv_ts<T, V, VN, FK, PT, FU>,                                   \
+            SCN_HIP(hipFuncSetAttribute((const void*)k_conv_ts<T, V, VN, FK, PT, FU, TL>,                           \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((k_conv_ts<T, V, VN, FK, PT, FU>), grid, dim3(TS_NW * 64), lds, st, X, (long long)n_in, cin, tstab, tile_mask, \
+        hipLaunchKernelGGL((k_conv_ts<T, V, VN, FK, PT, FU, TL>), grid, dim3(TS_NW * 64), lds, st, X, (long long)n_in, cin, tstab, tile_mask, \
                            perm, tile_order, n_off, (long long)nt, W, bias, residual, relu_mask, Y, slabs,                      \
-                           (long long)n_out, cout, flags, n_chunks, n_kc, counters);                                \
+                           (long long)n_out, cout, flags, n_chunks, n_kc, counters, slices);                        \
     } while (0)
 #define LAUNCH_TS(T, V, VN, FK, PT)                                                                                 \
     do {                                                                                                            \
-        if (fused) LAUNCH_TS_F(T, V, VN, FK, PT, true); else LAUNCH_TS_F(T, V, VN, FK, PT, false);                  \
+        if (fused) LAUNCH_TS_F(T, V, VN, FK, PT, true, false); else LAUNCH_TS_F(T, V, VN, FK, PT, false, false);    \
     } while (0)
-    if (fullk && wt && part) LAUNCH_TS(true, true, true, true, true);
+#define LAUNCH_TS_TAIL(T, VN, PT)                                                                                   \
+    do {                                                                                                            \
+        if (fused) LAUNCH_TS_F(T, true, VN, true, PT, true, true); else LAUNCH_TS_F(T, true, VN, true, PT, false, true); \
+    } while (0)
+    if (tail && wt && part) LAUNCH_TS_TAIL(true, true, true);
+    else if (tail && wt) LAUNCH_TS_TAIL(true, true, false);
+    else if (tail && vecn && part) LAUNCH_TS_TAIL(false, true, true);
+    else if (tail && vecn) LAUNCH_TS_TAIL(false, true, false);
+    else if (tail && part) LAUNCH_TS_TAIL(false, false, true);
+    else if (tail) LAUNCH_TS_TAIL(false, false, false);
+    else if (fullk && wt && part) LAUNCH_TS(true, true, true, true, true);
     else if (fullk && wt) LAUNCH_TS(true, true, true, true, false);
     else if (fullk && vecn && part) LAUNCH_TS(false, true, true, true, true);
     else if (fullk && vecn) LAUNCH_TS(false, true, true, true, false);
@@ -618,6 +644,7 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     else if (vecn) LAUNCH_TS(false, false, true, false, false);
     else LAUNCH_TS(false, false, false, false, false);
 #undef LAUNCH_TS
+#undef LAUNCH_TS_TAIL
 #undef LAUNCH_TS_F
     SCN_LAUNCH_CHECK();
     if (fused || (flags & SCN_F_SPLIT_SUM)) return SCN_OK;

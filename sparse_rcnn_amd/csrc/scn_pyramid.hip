@@ -10,14 +10,36 @@
 // prefetch fought the main thread for the GIL and gained nothing); tools/bound_no_index.py: 7.18 -> 6.08 ms/step if the
 // index build were free.
 //
-// The call waits for the device five times (row counts of the levels, then the rule-list sizes, after which the
-// compacted rule lists are queued too); all of them on the caller's stream only.
+// The call waits for the device once per level size (events behind the count copies, which are queued AHEAD of the SubM work
+// of the level above: the GPU keeps working while the host learns a size) and once for the rule-list sizes, after which the
+// compacted rule lists are queued too; all of them on the caller's stream only.
 #include "scn_common.h"
 
 using scn::S;
 using scn::cdiv;
 
 namespace {
+// Pinned host words for the row counts that travel back during a build, and events that mark their arrival: the D2H copy of
+// a level's coarse-row count is queued right after the numbering kernels, BEFORE the SubM table / scan / tile kernels of the
+// level above are queued, and the host waits for the copy's event only -- it learns the count while that work still runs
+// and queues the next level behind it, so the GPU no longer idles through a host round trip per level (round 2: the copy
+// sat behind the SubM work and the host waited for the whole stream, five times per build).
+struct HostSlots {
+    int64_t* words = nullptr;                       // [SCN_PYRAMID_MAX_LEVELS + 2]
+    hipEvent_t ev[SCN_PYRAMID_MAX_LEVELS + 2] = {};
+    bool ok = false;
+    bool init() {
+        if (ok) return true;
+        if (hipHostMalloc((void**)&words, sizeof(int64_t) * (SCN_PYRAMID_MAX_LEVELS + 2), hipHostMallocDefault) != hipSuccess)
+            return false;
+        for (auto& e : ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+        ok = true;
+        return true;
+    }
+};
+thread_local HostSlots g_slots;                     // one per calling thread (main thread, index helper thread)
+
 struct Bump {
     char* base;
     int64_t used, cap;
@@ -95,11 +117,15 @@ extern "C" int scn_pyramid_build(const int64_t* coords, int64_t n_points, int n_
     if ((rc = scn_dedup_launch(c32, n_points, 0, keys, hrows, cap0, item_row, row_count, row_first, row_coords, dscr,
                                cnt_dev, stream)))
         return rc;
-    int64_t n_rows = 0;
-    int32_t bad = 0;
-    SCN_HIP(hipMemcpyAsync(&n_rows, cnt_dev, 8, hipMemcpyDeviceToHost, st));
-    SCN_HIP(hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, st));
-    SCN_HIP(hipStreamSynchronize(st));
+    if (!g_slots.init()) return scn::fail(SCN_EHIP, "%spinned host words / events for the level sizes could not be created", "");
+    HostSlots& hs = g_slots;
+    hs.words[0] = 0; hs.words[1] = 0;
+    SCN_HIP(hipMemcpyAsync(&hs.words[0], cnt_dev, 8, hipMemcpyDeviceToHost, st));
+    SCN_HIP(hipMemcpyAsync(&hs.words[1], flag, 4, hipMemcpyDeviceToHost, st));
+    SCN_HIP(hipEventRecord(hs.ev[0], st));
+    SCN_HIP(hipEventSynchronize(hs.ev[0]));
+    const int64_t n_rows = hs.words[0];
+    const int32_t bad = (int32_t)hs.words[1];
     desc[3] = bad;
     if (bad) return scn::fail(SCN_EHASH, "%scoordinates outside [0,65535] in %lld wave(s)", "", (long long)bad);
 
@@ -130,6 +156,9 @@ extern "C" int scn_pyramid_build(const int64_t* coords, int64_t n_points, int n_
             if ((rc = scn_dedup_launch(lv_coords, n, 1, nkeys, nhrows, ncap, parent, nullptr, nullptr, ncoords, s2, ncnt,
                                        stream)))
                 return rc;
+            // the count starts its way back now; the SubM work of this level is queued behind it
+            SCN_HIP(hipMemcpyAsync(&hs.words[2 + l], ncnt, 8, hipMemcpyDeviceToHost, st));
+            SCN_HIP(hipEventRecord(hs.ev[1 + l], st));
         }
         if (n > 0 && k > 1) {
             const int64_t nt = nt_of(n);
@@ -153,9 +182,8 @@ extern "C" int scn_pyramid_build(const int64_t* coords, int64_t n_points, int n_
                 for (int m = l + 1; m < n_levels; ++m) desc[8 + m * SCN_PYRAMID_LEVEL_STRIDE] = 0;
             break;
         }
-        int64_t nc = 0;
-        SCN_HIP(hipMemcpyAsync(&nc, ncnt, 8, hipMemcpyDeviceToHost, st));
-        SCN_HIP(hipStreamSynchronize(st));
+        SCN_HIP(hipEventSynchronize(hs.ev[1 + l]));
+        const int64_t nc = hs.words[2 + l];
         {
             const int64_t ntc = nt_of(nc);
             int32_t* fine_off = (int32_t*)ws.take(n * 4, &off);                          L[15] = off;

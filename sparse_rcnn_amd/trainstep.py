@@ -18,10 +18,17 @@ from .maskhead import MaskBranch
 from .synthetic import make_batch, make_boxes
 from .unet import Backbone
 
-WORKLOADS = {      # name -> (channels, grid, active voxels, boxes per scene, BASELINE.json entry)
-    "cfg2": ((32, 64, 128, 256), (512, 512, 256), 150_000, 0, "configs[1]"),
-    "cfg3": ((32, 64, 128, 256), (512, 512, 256), 150_000, 64, "configs[2]"),
-    "cfg5": ((32, 64, 128, 256, 512), (1024, 1024, 512), 600_000, 0, "configs[4] shape (one scene per GPU)"),
+REF_PLAN = (32, 48, 64, 80, 96, 112)      # the reference's own sparse U-Net plan, `arange * 16 + 32` (scannet_config/run.py:539-549,587-591)
+
+WORKLOADS = {      # name -> (channels, grid, active voxels per sample, boxes per scene, BASELINE.json entry, samples per rank)
+    "cfg2": ((32, 64, 128, 256), (512, 512, 256), 150_000, 0, "configs[1]", 1),
+    "cfg3": ((32, 64, 128, 256), (512, 512, 256), 150_000, 64, "configs[2]", 1),
+    "cfg5": ((32, 64, 128, 256, 512), (1024, 1024, 512), 600_000, 0, "configs[4] shape (one scene per GPU)", 1),
+    # the network the reference actually trains: 6 levels 32-48-64-80-96-112 ...
+    "ref": (REF_PLAN, (512, 512, 256), 150_000, 0, "configs[1] scene, the REFERENCE's own channel plan 32-48-64-80-96-112", 1),
+    # ... on its own training input: 12 random crops of 128 x 128 x 64 voxels per batch (run.py:364,485-488)
+    "ref-crop": (REF_PLAN, (128, 128, 64), 12_500, 0, "the reference's training batch: 12 crops of 128x128x64 voxels, "
+                 "plan 32-48-64-80-96-112", 12),
 }
 
 
@@ -37,7 +44,7 @@ class SparseStepModel(torch.nn.Module):
 class SceneStep:
     def __init__(self, workload="cfg2", device=None, dtype="f32", prefetch=True, seed=1, grad_seed=100, n_buckets=4,
                  target=None, channels=None, grid=None, n_boxes=None, lr=1e-6):
-        ch, gr, tg, nb, self.baseline_entry = WORKLOADS[workload]
+        ch, gr, tg, nb, self.baseline_entry, n_samples = WORKLOADS[workload]
         self.workload, self.dtype, self.prefetch, self.lr = workload, dtype, prefetch, lr
         self.channels = tuple(channels or ch)
         self.grid = tuple(grid or gr)
@@ -46,7 +53,7 @@ class SceneStep:
         if dtype not in ("f32", "bf16", "bf16-blocks"):
             raise ValueError("dtype: f32 | bf16 | bf16-blocks")
         storage = {"f32": False, "bf16": "all", "bf16-blocks": True}[dtype]
-        coords, feats, size, bs, splits = make_batch(1, self.grid, target or tg, dup=1.15, seed=seed)
+        coords, feats, size, bs, splits = make_batch(n_samples, self.grid, target or tg, dup=1.15, seed=seed)
         self.coords_cpu, self.feats_cpu, self.size, self.batch_size, self.splits = coords, feats, size, bs, splits
         self.coords, self.feats = coords.to(self.device), feats.to(self.device)      # resident in HBM
         self.boxes = make_boxes(coords, self.n_boxes, seed=seed + 2) if self.n_boxes else None
@@ -72,8 +79,8 @@ class SceneStep:
         # the index structures of the NEXT batch depend on its coordinates only (a data loader's output): a helper thread
         # builds them on the high-priority index stream while this batch runs; every step contains one complete build
         if self.prefetch:
-            self._md_next = m.backbone.prefetch_in_thread(self.coords, self.size, 1)
-        out = m.backbone(self.coords, fin, self.size, 1, metadata=md)
+            self._md_next = m.backbone.prefetch_in_thread(self.coords, self.size, self.batch_size)
+        out = m.backbone(self.coords, fin, self.size, self.batch_size, metadata=md)
         if self._gy is None or self._gy.shape != out.features.shape:
             self._gy = torch.randn(out.features.shape, generator=self._gen).to(self.device)   # upstream grad dY ~ N(0,1)
             self.n_active = out.features.shape[0]
@@ -103,8 +110,8 @@ class SceneStep:
             self._md_next = None
 
     def describe(self):
-        s = (f"BASELINE {self.baseline_entry}: one synthetic ScanNet-shaped scene per GPU, {self.n_active} active voxels "
-             f"(grid {self.grid[0]}x{self.grid[1]}x{self.grid[2]}, 1.15 points/voxel), U-Net "
+        s = (f"BASELINE {self.baseline_entry}: {self.batch_size} synthetic ScanNet-shaped sample(s) per GPU, {self.n_active} "
+             f"active voxels (grid {self.grid[0]}x{self.grid[1]}x{self.grid[2]}, 1.15 points/voxel), U-Net "
              + "-".join(map(str, self.channels)) + ", 2 pre-act residual blocks/level, 2^3/2 conv+deconv")
         if self.n_boxes:
             s += (f"; + {self.n_boxes} fp32 boxes/scene (edges 8-96 voxels) -> sparse ROI crop ({self.n_roi_rows} cropped "

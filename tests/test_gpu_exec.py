@@ -143,3 +143,44 @@ def test_bf16_elementwise_forms_match_torch(gpu):
     L.check(lib.scn_segment_sum_bf16(dy.data_ptr(), rows.data_ptr(), len(rows), 5000, 24, dx.data_ptr(), acc.data_ptr(), L.stream()))
     exp = torch.zeros(5000, 24, dtype=torch.float64, device=gpu).index_add_(0, rows.long(), dy.double())
     assert torch.equal(dx, exp.float().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("cin,cout", [(48, 48), (80, 80), (112, 112), (16, 16), (48, 32), (32, 48), (96, 80), (24, 40), (144, 48)])
+def test_conv_tiles_tail_slices_reproduce_the_padded_kernel_bit_for_bit(gpu, cin, cout):
+    """k_conv_ts TAIL variants (round 3: the reference's own plan 32-48-64-80-96-112, scannet_config/run.py:539-549): a
+    K-chunk with <= 16 valid channels / a column chunk with <= 16 valid columns skips the MFMAs of its dead half, and the
+    slices get workgroups in proportion to their cost.  The skipped MFMAs multiplied zeros: forward, backward-data (with
+    ReLU mask and residual) and the in-launch K reduction give the bits of the padded kernel (SCN_TS_NO_TAIL=1)."""
+    import os
+    import sparse_rcnn_amd as scn
+    from sparse_rcnn_amd import functional as F, _lib as L
+    coords, feats, size, bs, _ = _scene(20_000, (256, 256, 128), seed=4)
+    x = scn.InputLayer(3, size, mode=4)((coords, feats.to(gpu), 1))
+    rb = x.metadata.subm_rulebook(size, 3)
+    sb = x.metadata.strided_rulebook(size)
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    X = torch.randn(rb.n, cin, generator=g).to(gpu)
+    W = (torch.randn(27, cin, cout, generator=g) * 0.1).to(gpu)
+    b = torch.randn(cout, generator=g).to(gpu)
+    R = torch.randn(rb.n, cout, generator=g).to(gpu)
+    Mk = torch.randn(rb.n, cout, generator=g).to(gpu)
+    W8 = (torch.randn(8, cin, cout, generator=g) * 0.1).to(gpu)
+
+    def run():
+        out = [F.conv_rules(X, rb.tiles, rb.n, W, b, cout, L.F_RELU_IN, residual=R),
+               F.conv_rules(X, rb.tiles, rb.n, W.transpose(1, 2).contiguous(), None, cout, L.F_W_TRANSPOSED | L.F_OFF_REVERSE | L.F_RESIDUAL_LAST,
+                            residual=R, relu_mask=Mk),
+               F.conv_rules(X, sb.tiles, sb.n_coarse, W8, b, cout, 0)]
+        torch.cuda.synchronize()
+        return out
+    import ctypes
+    paths = (ctypes.c_int64 * 4)()
+    a = run()
+    os.environ["SCN_TS_NO_TAIL"] = "1"
+    try:
+        ref = run()
+    finally:
+        del os.environ["SCN_TS_NO_TAIL"]
+    for u, v in zip(a, ref):
+        assert torch.equal(u, v)
+    assert float(a[0].abs().max()) > 0

@@ -571,6 +571,13 @@ int scn_exec_requirements(const scn_exec_op* ops, int n_ops, const scn_exec_leve
 int scn_exec_run(const scn_exec_op* ops, int n_ops, const scn_exec_level* levels, int n_levels, void* const* bufs,
                  const void* const* params, void* const* grads, void* scratch, int64_t scratch_bytes, int32_t* arrival,
                  scn_stream_t stream);
+/* The same with the parameter-gradient ops (SCN_OP_WGRAD_* / SCN_OP_COLSUM: leaves of a backward pass) on `side_stream`, each
+ * behind an event of `stream`; `stream` is ordered behind the last of them before the call returns.  side_scratch: a
+ * second scratch buffer of at least scratch_bytes.  side_stream == NULL: scn_exec_run. */
+int scn_exec_run_streams(const scn_exec_op* ops, int n_ops, const scn_exec_level* levels, int n_levels, void* const* bufs,
+                         const void* const* params, void* const* grads, void* scratch, int64_t scratch_bytes,
+                         int32_t* arrival, scn_stream_t stream, scn_stream_t side_stream, void* side_scratch,
+                         int64_t side_scratch_bytes);
 
 #ifdef __cplusplus
 }

@@ -584,15 +584,16 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     const bool part = cin % TS_KC != 0;
     // TAIL: a dead K half or a dead column block exists (the reference's 48 / 80 / 112-channel layers): those MFMAs are
     // skipped and the slices get workgroups in proportion to their cost.  Estimated cost of a tile step relative to a
-    // full 16-MFMA step: one dead half 0.62, both 0.42 (the per-step fixed work -- index load, gathers, ~15 VALU -- does
-    // not shrink with the MFMAs; calibrated with tools/ablate_conv.py on the 48 / 80 / 112-channel layers).
+    // full 16-MFMA step: one dead half 0.70, both 0.50 (the per-step fixed work -- index load, gathers, ~15 VALU -- does
+    // not shrink with the MFMAs; calibrated with tools/ablate_conv_tail.py on the 48 / 80 / 112-channel layers:
+    // profiles/r3_ablate_conv_tail.txt).
     const bool k_tail = cin % TS_KC != 0 && cin % TS_KC <= 16, n_tail = cout % TS_CT != 0 && cout % TS_CT <= 16;
     const bool tail = fullk && (k_tail || n_tail) && !getenv("SCN_TS_NO_TAIL");
     TsSlices slices = {0, 0, 0, 0};
     int64_t grid_x = n_tg * n_chunks * n_kc;
     if (tail) {
-        static const double w_half = getenv("SCN_TS_W_HALF") ? atof(getenv("SCN_TS_W_HALF")) : 0.62;
-        static const double w_both = getenv("SCN_TS_W_BOTH") ? atof(getenv("SCN_TS_W_BOTH")) : 0.42;
+        static const double w_half = getenv("SCN_TS_W_HALF") ? atof(getenv("SCN_TS_W_HALF")) : 0.70;
+        static const double w_both = getenv("SCN_TS_W_BOTH") ? atof(getenv("SCN_TS_W_BOTH")) : 0.50;
         const int ncf = n_chunks - (n_tail ? 1 : 0), nkf = n_kc - (k_tail ? 1 : 0);
         const double wsum = (double)nkf * ncf + (n_tail ? nkf * w_half : 0.0) + (k_tail ? ncf * w_half : 0.0) +
                             (n_tail && k_tail ? w_both : 0.0);

@@ -200,13 +200,52 @@ extern "C" int scn_exec_requirements(const scn_exec_op* ops, int n_ops, const sc
     return SCN_OK;
 }
 
-extern "C" int scn_exec_run(const scn_exec_op* ops, int n_ops, const scn_exec_level* levels, int n_levels, void* const* bufs,
-                            const void* const* params, void* const* grads, void* scratch, int64_t scratch_bytes,
-                            int32_t* arrival, scn_stream_t stream) {
+namespace {
+// Events for the fork / join of the side stream: created once per calling thread, reused by every call.
+struct EventPool {
+    static constexpr int N = 32;
+    hipEvent_t ev[N] = {};
+    int next = 0;
+    bool ok = false;
+    bool init() {
+        if (ok) return true;
+        for (auto& e : ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+        return ok = true;
+    }
+    hipEvent_t take() { hipEvent_t e = ev[next]; next = (next + 1) % N; return e; }
+};
+thread_local EventPool g_events;
+
+inline bool is_leaf(int op) {
+    return op == SCN_OP_WGRAD_SUBM || op == SCN_OP_WGRAD2_SUBM || op == SCN_OP_WGRAD_DOWN || op == SCN_OP_WGRAD_UP ||
+           op == SCN_OP_WGRAD_IDENT || op == SCN_OP_COLSUM;
+}
+}  // namespace
+
+extern "C" int scn_exec_run_streams(const scn_exec_op* ops, int n_ops, const scn_exec_level* levels, int n_levels,
+                                    void* const* bufs, const void* const* params, void* const* grads, void* scratch,
+                                    int64_t scratch_bytes, int32_t* arrival, scn_stream_t stream, scn_stream_t side_stream,
+                                    void* side_scratch, int64_t side_scratch_bytes) {
     SCN_REQUIRE(n_ops >= 0 && (n_ops == 0 || ops) && levels && n_levels >= 1 && bufs && scratch && scratch_bytes >= 256);
+    const bool fork = side_stream != nullptr && side_stream != stream && side_scratch != nullptr && side_scratch_bytes >= scratch_bytes;
+    if (fork && !g_events.init()) return scn::fail(SCN_EHIP, "%sevents for the side stream could not be created", "");
     Ctx c{levels, n_levels, bufs, params, grads, scratch, arrival, stream};
+    Ctx cs{levels, n_levels, bufs, params, grads, side_scratch, arrival, side_stream};
+    bool side_used = false;
     for (int i = 0; i < n_ops; ++i) {
-        const int rc = run_op(c, ops[i]);
+        int rc;
+        if (fork && is_leaf(ops[i].op)) {
+            // a parameter-gradient op is a leaf of the pass: it reads slabs the main stream has produced and nothing reads
+            // its result before the pass ends -- it runs beside the backward-data chain, behind an event of the main stream
+            hipEvent_t e = g_events.take();
+            SCN_HIP(hipEventRecord(e, scn::S(stream)));
+            SCN_HIP(hipStreamWaitEvent(scn::S(side_stream), e, 0));
+            rc = run_op(cs, ops[i]);
+            side_used = true;
+        } else {
+            rc = run_op(c, ops[i]);
+        }
         if (rc != SCN_OK) {
             char inner[400];
             snprintf(inner, sizeof(inner), "%s", scn::g_err);
@@ -215,5 +254,17 @@ extern "C" int scn_exec_run(const scn_exec_op* ops, int n_ops, const scn_exec_le
             return rc;
         }
     }
+    if (side_used) {                  // join: whatever follows on the main stream sees the gradients (and may reuse the slabs)
+        hipEvent_t e = g_events.take();
+        SCN_HIP(hipEventRecord(e, scn::S(side_stream)));
+        SCN_HIP(hipStreamWaitEvent(scn::S(stream), e, 0));
+    }
     return SCN_OK;
+}
+
+extern "C" int scn_exec_run(const scn_exec_op* ops, int n_ops, const scn_exec_level* levels, int n_levels, void* const* bufs,
+                            const void* const* params, void* const* grads, void* scratch, int64_t scratch_bytes,
+                            int32_t* arrival, scn_stream_t stream) {
+    return scn_exec_run_streams(ops, n_ops, levels, n_levels, bufs, params, grads, scratch, scratch_bytes, arrival, stream,
+                                nullptr, nullptr, 0);
 }

@@ -28,6 +28,9 @@ from . import functional as F
 from . import modules as M
 
 ENABLED = os.environ.get("SCN_EXEC", "1") != "0"
+# parameter-gradient ops of a backward pass on a second stream beside the backward-data chain (scn_exec_run_streams)
+SIDE_LEAVES = os.environ.get("SCN_EXEC_SIDE", "0") != "0"
+_side_streams, _side_scratch = {}, {}
 
 i32, i64, vp = C.c_int32, C.c_int64, C.c_void_p
 
@@ -320,13 +323,24 @@ def _layout(stage, ids, ns):
     return offs, tot
 
 
-def _run(stage, ops, levels, table, ptab, gtab, dev):
+def _run(stage, ops, levels, table, ptab, gtab, dev, side=False):
     lib = L.lib()
     arr, _, ns = levels
     sb, ac = i64(0), i64(0)
     L.check(lib.scn_exec_requirements(ops, len(ops), arr, len(ns), C.byref(sb), C.byref(ac)))
     scratch = L.scratch(sb.value, dev)
     arrival = L.arrival(max(ac.value, 1), dev)
+    if side and SIDE_LEAVES:
+        key = (dev.index, L.stream())
+        st = _side_streams.get(key)
+        if st is None:
+            st = _side_streams[key] = torch.cuda.Stream(device=dev)
+        ss = _side_scratch.get(key)
+        if ss is None or ss.numel() < scratch.numel():
+            ss = _side_scratch[key] = torch.empty(scratch.numel(), dtype=torch.uint8, device=dev)
+        L.check(lib.scn_exec_run_streams(ops, len(ops), arr, len(ns), table, ptab, gtab, scratch.data_ptr(), scratch.numel(),
+                                         arrival.data_ptr(), L.stream(), st.cuda_stream, ss.data_ptr(), ss.numel()))
+        return
     L.check(lib.scn_exec_run(ops, len(ops), arr, len(ns), table, ptab, gtab, scratch.data_ptr(), scratch.numel(),
                              arrival.data_ptr(), L.stream()))
 
@@ -417,7 +431,7 @@ class StageFunction(torch.autograd.Function):
         gb = flat.data_ptr()
         for k, o in enumerate(goffs):
             gtab[k] = gb + 4 * o
-        _run(stage, stage.bwd_arr, levels, table, ptab, gtab, dev)
+        _run(stage, stage.bwd_arr, levels, table, ptab, gtab, dev, side=True)
         grads = [None if v is None else flat[v[0]:v[0] + v[1]].view(v[2]) for v in views]
         ctx.keep = None
         return (None, None, *dins, *grads)

@@ -224,6 +224,12 @@ def test_reference_plan_32_112_full_unet_vs_oracle_at_150k(gpu, scene150k):
     gy = torch.randn(out.features.shape, generator=torch.Generator().manual_seed(6))
     out.features.backward(gy.to(gpu))
     torch.cuda.synchronize()
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    fo = feats.clone().requires_grad_()
+    fr = O.FrozenReLU(masks)
+    exp = O.unet_forward(scene, fo, po, list(ch), relu=fr)
+    assert fr.k == len(masks)
+    exp.backward(gy)
     md = out.metadata
     sz = tuple(int(s) // 16 for s in size)
     for level in (4, 5):                                        # the levels the 4-level benchmark plan never builds
@@ -234,12 +240,6 @@ def test_reference_plan_32_112_full_unet_vs_oracle_at_150k(gpu, scene150k):
         assert np.array_equal(rb.rules.in_rows.cpu().numpy(), pairs[:, 0]) and \
             np.array_equal(rb.rules.out_rows.cpu().numpy(), pairs[:, 1]), level
         sz = tuple(v // 2 for v in sz)
-    po = {k: v.clone().requires_grad_() for k, v in params.items()}
-    fo = feats.clone().requires_grad_()
-    fr = O.FrozenReLU(masks)
-    exp = O.unet_forward(scene, fo, po, list(ch), relu=fr)
-    assert fr.k == len(masks)
-    exp.backward(gy)
     name = "ref_plan_32_112_150k"
     e = _err(out.features, exp)
     _record(name, "forward features", e, FEAT_TOL)
@@ -308,95 +308,6 @@ def _oracle_mask_branch(coords_np, raw, bb_feats, mp, boxes_np, assoc, scene, bf
     return h @ mp["lin1.weight"].t() + mp["lin1.bias"], src, box_of, rscene
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_cfg3_roi_crop_and_mask_branch_vs_oracle_at_size(gpu, scene150k, dtype):
-    """BASELINE configs[2] at size: 150k voxels x 64 make_boxes boxes.  ROI selection bit-exact vs O.roi_crop; the mask
-    branch with the reference's plan (SubM1 32->16 + 2 units; 23 -> 32 -> 48 -> 64 internal U-Net; Linear 23-32-18,
-    scannet_config/run.py:749-810) against the oracle in fp32: logits and the gradients of the backbone features, the
-    raw point features and every parameter (the oracle takes the ReLU masks the HIP forward recorded: 2e-5 relative L2).
-    dtype = "bf16": the branch in bf16 STORAGE against the oracle evaluated with the same roundings AND the ReLU sign masks
-    the HIP forward recorded (O.FrozenReLU): every gradient within 1e-2 relative L2 (round 2 held them to 2.5e-1, the
-    distance mask flips open between two realisations of such a network)."""
-    import sparse_rcnn_amd as scn
-    from sparse_rcnn_amd import roi
-    from sparse_rcnn_amd.maskhead import MaskBranch
-    bf16 = dtype == "bf16"
-    from sparse_rcnn_amd.synthetic import make_boxes
-    coords, feats, size, bs, splits, scene = scene150k
-    bbox_batch = make_boxes(coords, 64, seed=3)
-    g = torch.Generator().manual_seed(11)
-    n0 = scene.n(0)
-    bb = torch.randn(n0, 32, generator=g)
-    torch.manual_seed(3)
-    branch = MaskBranch(32, 7, bf16_blocks="all" if bf16 else False).to(gpu)
-    with torch.no_grad():
-        for p in branch.parameters():
-            if p.dim() == 1:
-                p.normal_(0, 0.05)
-    # HIP path
-    raw_g = feats.to(gpu).requires_grad_()
-    bb_g = bb.to(gpu).requires_grad_()
-    x0 = scn.InputLayer(3, size, mode=4)((coords, raw_g.detach(), 1))
-    fmap = scn.SparseConvNetTensor(features=bb_g, metadata=x0.metadata, spatial_size=x0.spatial_size)
-    with _record_relu_masks() as masks:
-        logits, selection = branch((coords, raw_g, size, 1, splits), fmap, bbox_batch)
-    assert len(masks) == 4 + 12 + 15 + 1           # input units, internal U-Net (3 encoder levels, 3 decoder levels), Linear
-    sel = selection[0]
-    assert isinstance(sel, roi.RoiSelection) and sel._inside is None          # no [boxes, points] object was built
-    # oracle
-    boxes_np, cnt, assoc = O.transform_boxes([b.numpy() for b in bbox_batch])
-    mp = {}
-    ic = branch.input_conv_layer
-    mp["in.weight"], mp["in.bias"] = ic[0].weight, ic[0].bias
-    for u, block in enumerate(ic[1]):
-        convs = [m for m in block[0][1] if isinstance(m, scn.SubmanifoldConvolution)]
-        for v, cv in enumerate(convs):
-            mp[f"in.res{u}.conv{v}.weight"], mp[f"in.res{u}.conv{v}.bias"] = cv.weight, cv.bias
-    for k, p in branch.output_conv_layer.named_oracle_params().items():
-        mp["unet." + k] = p
-    mp["lin0.weight"], mp["lin0.bias"] = branch.linear_layer[0].weight, branch.linear_layer[0].bias
-    mp["lin1.weight"], mp["lin1.bias"] = branch.linear_layer[2].weight, branch.linear_layer[2].bias
-    shapes = dict(O.unet_param_shapes(23, [23, 32, 48, 64], identity_first=True))
-    mo = {}
-    for k, p in mp.items():
-        t = p.detach().cpu().clone()
-        if k.startswith("unet."):
-            t = t.view(shapes[k[5:]])
-        elif k.endswith("conv0.weight") or k.endswith("conv1.weight"):
-            t = t.view(27, 16, 16)
-        elif k == "in.weight":
-            t = t.view(1, 32, 16)
-        mo[k] = t.requires_grad_()
-    raw_o = feats.clone().requires_grad_()
-    bb_o = bb.clone().requires_grad_()
-    exp, src, box_of, rscene = _oracle_mask_branch(coords.numpy(), raw_o, bb_o, mo, boxes_np, assoc, scene, bf16=bf16,
-                                                   relu=O.FrozenReLU(masks))
-    name = "cfg3_mask_branch_64boxes_150k" + ("_bf16_storage" if bf16 else "")
-    assert np.array_equal(sel.src_row.cpu().numpy(), src) and np.array_equal(sel.box_of.cpu().numpy(), box_of)
-    assert selection[1] == cnt and sel.prefix[-1] == len(src)
-    assert np.array_equal(sel.new_coords.cpu().numpy(), np.concatenate([coords.numpy()[src][:, :3], box_of[:, None]], 1))
-    print(f"[parity] {name}: {len(src)} cropped points in 64 boxes, {rscene.n(0)} ROI voxels")
-    e = _err(logits, exp)
-    gl = torch.randn(exp.shape, generator=g)
-    if bf16:
-        _record(name, "mask logits vs oracle with the same roundings", e, "rel_to_scale <= 2^-5, rel_l2 <= 2e-2")
-        assert e["rel_to_scale"] <= 2.0 ** -5 and e["rel_l2"] <= 2e-2, e
-        logits.backward(gl.to(gpu))
-        exp.backward(gl)
-        for what, a, b in [("grad backbone features", bb_g.grad, bb_o.grad), ("grad raw point features", raw_g.grad, raw_o.grad)] + \
-                [("grad " + k, p.grad, mo[k].grad.view_as(p)) for k, p in mp.items()]:
-            _check_grad_frozen(name, what, a, b, FROZEN_L2_BF16)
-        return
-    _record(name, "mask logits", e, FEAT_TOL)
-    assert e["rel_to_scale"] <= FEAT_TOL, e
-    logits.backward(gl.to(gpu))
-    exp.backward(gl)
-    _check_grad_frozen(name, "grad backbone features", bb_g.grad, bb_o.grad, FROZEN_L2_F32)
-    _check_grad_frozen(name, "grad raw point features", raw_g.grad, raw_o.grad, FROZEN_L2_F32)
-    for k, p in mp.items():
-        _check_grad_frozen(name, "grad " + k, p.grad, mo[k].grad.view_as(p), FROZEN_L2_F32)
-
-
 def _mask_oracle_params(named, dt=torch.float32):
     """MaskBranch.named_oracle_params() tensors (torch or numpy) -> oracle-shaped leaf tensors of dtype dt."""
     shapes = dict(O.unet_param_shapes(23, [23, 32, 48, 64], identity_first=True))
@@ -452,9 +363,13 @@ def test_cfg3_end_to_end_backbone_crop_mask_vs_oracle_at_150k(gpu, dtype):
     parameter gradients and the input-feature gradient against the oracle, which takes the ReLU sign masks the HIP forward
     recorded (O.FrozenReLU: 63 masks) -- fp32 within 2e-4 relative L2 per tensor, bf16 storage (oracle with the same
     roundings) within 1e-2."""
+    from sparse_rcnn_amd import roi
     from sparse_rcnn_amd.trainstep import SceneStep
     bf16 = dtype == "bf16"
-    job = SceneStep("cfg3", gpu, dtype=dtype, prefetch=False, seed=1, grad_seed=100, lr=0.0)
+    # (the bf16 leg runs the same chain on a 60k-voxel scene: the CPU oracle is the long pole of the GPU suite)
+    job = SceneStep("cfg3", gpu, dtype=dtype, prefetch=False, seed=1, grad_seed=100, lr=0.0, target=60_000 if bf16 else None)
+    grabbed = []
+    hook = job.model.mask.output_roi_cut.register_forward_hook(lambda m, a, out: grabbed.append(out[1]))
     with torch.no_grad():                    # biases away from zero (they are initialised to zero)
         g = torch.Generator().manual_seed(21)
         for p in job.model.parameters():
@@ -469,8 +384,16 @@ def test_cfg3_end_to_end_backbone_crop_mask_vs_oracle_at_150k(gpu, dtype):
     ch = job.channels
     out, logits, grads, n_sel = _oracle_cfg3_step(job.coords_cpu, job.feats_cpu, job.boxes, pb, pm, ch, 100, bf16=bf16,
                                                   masks=masks)
-    name = "cfg3_end_to_end_150k" + ("_bf16_storage" if bf16 else "")
-    assert job.out.features.shape[0] == 150_000 and job.logits.shape == logits.shape and n_sel == job.n_roi_rows
+    hook.remove()
+    name = "cfg3_end_to_end_" + ("60k_bf16_storage" if bf16 else "150k")
+    assert job.out.features.shape[0] == (60_000 if bf16 else 150_000) and job.logits.shape == logits.shape and n_sel == job.n_roi_rows
+    # the sparse ROI crop at size: 64 boxes x ~172k points, the selection bit for bit against the oracle, no [boxes, points] object
+    sel, counts = grabbed[0][0], grabbed[0][1]
+    boxes_np, cnt, assoc = O.transform_boxes([b.numpy() for b in job.boxes])
+    src, box_of, _ = O.roi_crop(job.coords_cpu.numpy(), boxes_np, assoc)
+    assert isinstance(sel, roi.RoiSelection) and sel._inside is None and counts == cnt
+    assert np.array_equal(sel.src_row.cpu().numpy(), src) and np.array_equal(sel.box_of.cpu().numpy(), box_of)
+    assert np.array_equal(sel.new_coords.cpu().numpy(), np.concatenate([job.coords_cpu.numpy()[src][:, :3], box_of[:, None]], 1))
     print(f"[parity] {name}: {n_sel} cropped points")
     e_out, e_log = _err(job.out.features, out), _err(job.logits, logits)
     got = {k: p.grad for k, p in pb.items()}
@@ -531,7 +454,7 @@ def test_two_rank_dp_step_matches_oracle(gpu, tmp_path):
     """BASELINE configs[3]'s mechanism on one GPU: two fresh processes (gloo, both on cuda:0), one scene each, one step of
     the real Backbone 32-64-128-256 through trainstep.SceneStep with the bucketed all-reduce overlapped with backward.
     The averaged gradient every rank ends up with == the mean of the two scenes' ORACLE gradients."""
-    target, grid = 30_000, (256, 256, 128)
+    target, grid = 12_000, (128, 128, 64)
     port = _free_port()
     procs, outs = [], []
     for r in range(2):
@@ -567,7 +490,7 @@ def test_two_rank_dp_step_matches_oracle(gpu, tmp_path):
                            mean[k].reshape(-1), FROZEN_L2_F32)
 
 
-@pytest.mark.parametrize("case", ["f32", "bf16", "f32-empty-rank"])
+@pytest.mark.parametrize("case", ["bf16", "f32-empty-rank"])
 def test_two_rank_dp_cfg3_step_matches_oracle(gpu, tmp_path, case):
     """BASELINE configs[3] (data-parallel detection + mask step) on what one GPU can run: two fresh
     gloo ranks on cuda:0, one scene and its 16 boxes each, ONE flat buffer over backbone + mask branch, bucketed all-reduce
@@ -578,7 +501,7 @@ def test_two_rank_dp_cfg3_step_matches_oracle(gpu, tmp_path, case):
     (zero-filled) in the same order as rank 0's."""
     dtype = "bf16" if case == "bf16" else "f32"
     empty = 1 if case.endswith("empty-rank") else -1
-    target, grid, n_boxes = 30_000, (256, 256, 128), 16
+    target, grid, n_boxes = 12_000, (128, 128, 64), 8
     port = _free_port()
     procs, outs = [], []
     for r in range(2):

@@ -350,337 +350,6 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
 #undef TB_STEP
 #undef TB_GATHER
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// k_conv_tbf (round 3): the same convolution with the wave's tiles walked as ONE item stream.
-//
-// k_conv_tb restarts its three-deep (index -> rows -> MFMA) pipeline at every tile: a tile's row indices are requested only
-// when the previous tile has finished, its first rows one round trip later -- two dependent round trips (2-3 us) for ~10
-// offsets x NB MFMAs (0.1-0.3 us of matrix work).  That chain, not bandwidth, was the kernel (5-6 % of the
-// HBM roofline).  Here the items (tile, offset) of all tiles of a wave form one stream: the generator that feeds the
-// index stage simply moves on to the wave's next tile when a tile's mask is exhausted, so indices and rows of tile t + 1 are
-// in flight while tile t is multiplied, and a tile boundary costs the epilogue only.  On fp32 (k_conv_ts) the same idea
-// lost to its own bookkeeping (the matrix pipe is the bound there and every VALU op costs MFMA time); on bf16 the pipe is
-// idle most of the time and the bookkeeping is free.
-//   * an item descriptor q = offset | last-of-its-tile << 5 | slot << 6 travels through the stages in scalar registers;
-//   * the output rows and the id of a tile in flight sit in a per-wave LDS ring of 8 slots (at most 6 tiles can be between
-//     the index stage and the MFMA stage: the stream is 5 items deep and a tile has at least one item);
-//   * per-tile arithmetic is untouched: offsets ascending into the same accumulators, same epilogue, same K-split
-//     hand-off -- the bits of k_conv_tb (tests: scn_conv_tiles_bf16 with SCN_TB_FLAT=0 / 1).
-// ---------------------------------------------------------------------------------------------------------------------------
-#define TBF_SLOTS 8
-#define TBF_SLOT_INTS 32            // [0..15] output rows of the tile, [16] tile id
-
-template <int NB, bool FUSED>
-__global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB == 2 && !FUSED ? 8 : 4))) void k_conv_tbf(
-    const unsigned short* __restrict__ X, long long n_in, int cin, const int* __restrict__ tstab,
-    const unsigned* __restrict__ tile_mask, const int* __restrict__ perm, const int* __restrict__ tile_order, int n_off,
-    long long nt, const unsigned short* __restrict__ image, const float* __restrict__ bias,
-    const unsigned short* __restrict__ residual, const unsigned short* __restrict__ relu_mask,
-    unsigned short* __restrict__ Y, float* __restrict__ slabs, long long n_out, int cout, int flags, int n_chunks,
-    int n_kc, int* __restrict__ counters) {
-    constexpr int CT = 16 * NB;
-    constexpr int KC = TB_KC;
-    constexpr int THREADS = TB_NW * 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned short Wb[];     // [n_off][CT][32] bf16, counter, tile ring
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int chunk = blockIdx.x % n_chunks;
-    const int kci = (blockIdx.x / n_chunks) % n_kc;
-    const int n0 = chunk * CT, kc = kci * KC;
-    const bool relu_in = flags & SCN_F_RELU_IN;
-    const bool res_last = flags & SCN_F_RESIDUAL_LAST;
-
-    const int tg = blockIdx.x / (n_chunks * n_kc), n_tg = gridDim.x / (n_chunks * n_kc);
-    const int n_tiles = (int)((nt - tg + n_tg - 1) / n_tg);
-    int* counter = (int*)(Wb + (size_t)n_off * CT * KC);
-    int* ring = counter + 4 + wave * (TBF_SLOTS * TBF_SLOT_INTS);           // this wave's tile ring
-    if (tid == 0) *counter = 0;
-    __syncthreads();
-    auto grab = [&]() -> long long {
-        int tl = 0;
-        if (lane == 0) tl = atomicAdd(counter, 1);
-        tl = __builtin_amdgcn_readfirstlane(tl);
-        return tl < n_tiles ? tile_order[tg + (long long)tl * n_tg] : -1;
-    };
-    const int i = lane & 15, kq = lane >> 4;
-    // the wave's first tile: id, mask and output rows are requested before the weight slice is staged
-    long long n_tile = grab();
-    unsigned n_m = 0;
-    int n_perm = -1;
-    if (n_tile >= 0) {
-        n_m = tile_mask[n_tile];
-        n_perm = perm[n_tile * TB_T + i];
-    }
-
-    {
-        const int total16 = n_off * KC * CT / 8;
-        const uint4* src = (const uint4*)image + (size_t)(chunk * n_kc + kci) * total16;
-        constexpr int SB = 4;
-        for (int base = 0; base < total16; base += THREADS * SB) {
-            uint4 v[SB];
-#pragma unroll
-            for (int u = 0; u < SB; ++u) {
-                const int e = base + u * THREADS + tid;
-                v[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (e < total16) v[u] = src[e];
-            }
-#pragma unroll
-            for (int u = 0; u < SB; ++u) {
-                const int e = base + u * THREADS + tid;
-                if (e < total16) ((uint4*)Wb)[e] = v[u];
-            }
-        }
-    }
-    __syncthreads();
-
-    const bool k_ok = kc + 8 * kq + 7 < cin;
-    const bool single = n_kc == 1;
-    const bool direct = single || FUSED;
-    const int ncol = n0 + NB * i;
-    const bool n_ok = ncol < cout;
-    float bcol[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) bcol[nb] = (direct && bias && ncol + nb < cout) ? bias[ncol + nb] : 0.f;
-    float* out_slab = slabs + (long long)kci * n_out * cout;
-    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)slabs, 0, FUSED && !single ? (int)(unsigned)(nt * n_chunks * n_kc * (TB_T * CT * 4)) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t xrsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(unsigned)(n_in * cin * 2), 0x00020000);
-    const int row_bytes = cin * 2;
-    const int lane_boff = (kc + 8 * kq) * 2;
-    const unsigned short* wlane = Wb + (size_t)i * TB_KC + 8 * kq;
-
-    constexpr int NWD = NB / 2;
-    const bool vec_ok = (cout % NB == 0) && ((((uintptr_t)Y | (uintptr_t)residual | (uintptr_t)relu_mask) & (2 * NB - 1)) == 0);
-    auto tb_write = [&](const int (&orow)[4], const f32x4 (&acc)[NB]) {
-        unsigned rw[4][NWD], mw[4][NWD];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const long long e = (long long)(orow[j] < 0 ? 0 : orow[j]) * cout + ncol;
-#pragma unroll
-            for (int w = 0; w < NWD; ++w) { rw[j][w] = 0u; mw[j][w] = 0x3f803f80u; }
-            if (vec_ok && n_ok) {
-                if (residual) {
-                    if (NB == 2) rw[j][0] = *(const unsigned*)(residual + e);
-                    else { const uint2 t = *(const uint2*)(residual + e); rw[j][0] = t.x; rw[j][NWD - 1] = t.y; }
-                }
-                if (relu_mask) {
-                    if (NB == 2) mw[j][0] = *(const unsigned*)(relu_mask + e);
-                    else { const uint2 t = *(const uint2*)(relu_mask + e); mw[j][0] = t.x; mw[j][NWD - 1] = t.y; }
-                }
-            } else if (!vec_ok) {
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    if (ncol + nb >= cout) continue;
-                    if (residual) rw[j][nb >> 1] = (nb & 1) ? (rw[j][nb >> 1] & 0xffffu) | ((unsigned)residual[e + nb] << 16)
-                                                            : (rw[j][nb >> 1] & 0xffff0000u) | residual[e + nb];
-                    if (relu_mask) mw[j][nb >> 1] = (nb & 1) ? (mw[j][nb >> 1] & 0xffffu) | ((unsigned)relu_mask[e + nb] << 16)
-                                                             : (mw[j][nb >> 1] & 0xffff0000u) | relu_mask[e + nb];
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (orow[j] < 0) continue;
-            unsigned ow[NWD];
-#pragma unroll
-            for (int w = 0; w < NWD; ++w) ow[w] = 0u;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const unsigned rbits = (nb & 1) ? (rw[j][nb >> 1] & 0xffff0000u) : (rw[j][nb >> 1] << 16);
-                const unsigned mbits = (nb & 1) ? (mw[j][nb >> 1] & 0xffff0000u) : (mw[j][nb >> 1] << 16);
-                const float r = __uint_as_float(rbits);
-                float y = acc[nb][j] + (res_last ? 0.f : r);
-                if (!(__uint_as_float(mbits) > 0.f)) y = 0.f;
-                if (res_last) y += r;
-                ow[nb >> 1] |= (unsigned)f32_to_bf16(y) << (16 * (nb & 1));
-            }
-            unsigned short* yp = Y + (long long)orow[j] * cout + ncol;
-            if (vec_ok) {
-                if (n_ok) {
-                    if (NB == 2) *(unsigned*)yp = ow[0];
-                    else *(uint2*)yp = make_uint2(ow[0], ow[NWD - 1]);
-                }
-            } else {
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    if (ncol + nb < cout) yp[nb] = (unsigned short)(ow[nb >> 1] >> (16 * (nb & 1)));
-            }
-        }
-    };
-    long long q1 = -1, q2 = -1;
-    int tk_v = 0;
-    auto tb_publish = [&](long long t, const f32x4 (&acc)[NB]) {
-        const int sb = (int)((t * n_chunks + chunk) * n_kc + kci) * (TB_T * CT * 4) + lane * 16;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, acc[nb]),
-                                                   srsrc, sb + nb * 1024, 0, 16);
-        q1 = t;
-    };
-    auto tb_retire = [&]() {
-        if (q2 >= 0) {
-            const int ticket = __builtin_amdgcn_readfirstlane(tk_v);
-            if (ticket == n_kc - 1) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int unit = (int)(q2 * n_chunks + chunk);
-                if (lane == 0) __hip_atomic_store(counters + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                int orow2[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) orow2[j] = perm[q2 * TB_T + 4 * kq + j];
-                const int sb = (unit * n_kc) * (TB_T * CT * 4) + lane * 16;
-                f32x4 y[NB];
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) y[nb] = (f32x4){bcol[nb], bcol[nb], bcol[nb], bcol[nb]};
-                for (int k0 = 0; k0 < n_kc; k0 += 2) {
-                    f32x4 p[2][NB];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int k = k0 + u < n_kc ? k0 + u : n_kc - 1;
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            p[u][nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                srsrc, sb + k * (TB_T * CT * 4) + nb * 1024, 0, 16));
-                    }
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        if (k0 + u < n_kc) {
-#pragma unroll
-                            for (int nb = 0; nb < NB; ++nb) y[nb] += p[u][nb];
-                        }
-                    }
-                }
-                tb_write(orow2, y);
-            }
-        }
-        if (q1 >= 0 && lane == 0)
-            tk_v = __hip_atomic_fetch_add(counters + (int)(q1 * n_chunks + chunk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        q2 = q1;
-        q1 = -1;
-    };
-
-    // ---- the item stream ---------------------------------------------------------------------------------------------
-    // generator (feeds the index stage): the tile it enumerates, what is left of its mask, its slot in the ring
-    unsigned g_m = 0;
-    const int* g_tb = tstab;
-    int g_slot = 0, g_seq = 0;
-    // GEN: descriptor of the next item into Q (-1: the wave has no more items) and its row index into INEW
-#define TBF_GEN(Q, INEW)                                                                             \
-    do {                                                                                             \
-        if (g_m == 0 && n_tile >= 0) {          /* tile exhausted: move on to the prefetched one */   \
-            g_m = (unsigned)__builtin_amdgcn_readfirstlane((int)n_m);          /* wave-uniform by construction */ \
-            g_tb = tstab + n_tile * n_off * TB_T;                                                    \
-            g_slot = g_seq & (TBF_SLOTS - 1);                                                        \
-            ++g_seq;                                                                                 \
-            if (lane < 16) ring[g_slot * TBF_SLOT_INTS + lane] = n_perm;                             \
-            if (lane == 16) ring[g_slot * TBF_SLOT_INTS + 16] = (int)n_tile;                         \
-            n_tile = grab();                                                                         \
-            if (n_tile >= 0) {                                                                       \
-                n_m = tile_mask[n_tile];                                                             \
-                n_perm = perm[n_tile * TB_T + i];                                                    \
-            }                                                                                        \
-        }                                                                                            \
-        if (g_m) {                                                                                   \
-            const int o_ = __builtin_ctz(g_m);                                                       \
-            g_m &= g_m - 1;                                                                          \
-            Q = o_ | (g_m == 0 ? 32 : 0) | (g_slot << 6);                                            \
-            INEW = g_tb[o_ * TB_T + i];                                                              \
-        } else {                                                                                     \
-            Q = -1;                                                                                  \
-            INEW = -1;                                                                               \
-        }                                                                                            \
-    } while (0)
-#define TBF_GATHER(IDX, A)                                                                           \
-    do {                                                                                             \
-        /* row -1 or a channel group past Cin -> out-of-range byte offset -> the hardware returns zeros */ \
-        const int off_ = k_ok ? __mul24((IDX), row_bytes) + lane_boff : (int)0xFFFFFFF0;             \
-        A = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off_, 0, 0);                                \
-    } while (0)
-
-    f32x4 acc[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const float b0 = single ? bcol[nb] : 0.f;
-        acc[nb] = (f32x4){b0, b0, b0, b0};
-    }
-    // one step: descriptor + index of the item five ahead, rows of the item three ahead (index loaded two steps ago),
-    // MFMAs (and, at a tile's last item, its epilogue) on the oldest item
-#define TBF_STEP(CUR, GSET, IOLD, INEW)                                                              \
-    do {                                                                                             \
-        int qn_;                                                                                     \
-        TBF_GEN(qn_, INEW);                                                                          \
-        TBF_GATHER(IOLD, GSET);                                                                      \
-        {                                                                                            \
-            s16x8 a_ = __builtin_bit_cast(s16x8, CUR);                                               \
-            if (relu_in) a_ = __builtin_elementwise_max(a_, (s16x8){0, 0, 0, 0, 0, 0, 0, 0});        \
-            const bf16x8 af_ = __builtin_bit_cast(bf16x8, a_);                                       \
-            const unsigned short* wo_ = wlane + (size_t)(q0 & 31) * (CT * TB_KC);                    \
-            _Pragma("unroll") for (int nb_ = 0; nb_ < NB; ++nb_) {                                   \
-                const bf16x8 bf_ = *(const bf16x8*)(wo_ + nb_ * 16 * TB_KC);                         \
-                acc[nb_] = MFMAB(af_, bf_, acc[nb_]);                                                \
-            }                                                                                        \
-        }                                                                                            \
-        if (q0 & 32) {                           /* last item of its tile: epilogue, fresh accumulators */ \
-            const int* sl_ = ring + (q0 >> 6) * TBF_SLOT_INTS;                                       \
-            int orow_[4];                                                                            \
-            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) orow_[j_] = sl_[4 * kq + j_];           \
-            const long long tile_ = sl_[16];                                                         \
-            if (FUSED && !single) {                                                                  \
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
-                tb_retire();                                                                         \
-                tb_publish(tile_, acc);                                                              \
-            } else if (direct) {                                                                     \
-                tb_write(orow_, acc);                                                                \
-            } else {                                                                                 \
-                _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                   \
-                    if (orow_[j_] < 0) continue;                                                     \
-                    _Pragma("unroll") for (int nb_ = 0; nb_ < NB; ++nb_)                             \
-                        if (ncol + nb_ < cout) out_slab[(long long)orow_[j_] * cout + ncol + nb_] = acc[nb_][j_]; \
-                }                                                                                    \
-            }                                                                                        \
-            _Pragma("unroll") for (int nb_ = 0; nb_ < NB; ++nb_) {                                   \
-                const float b0_ = single ? bcol[nb_] : 0.f;                                          \
-                acc[nb_] = (f32x4){b0_, b0_, b0_, b0_};                                              \
-            }                                                                                        \
-        }                                                                                            \
-        q0 = q1d; q1d = q2d; q2d = q3d; q3d = q4d; q4d = qn_;                                        \
-    } while (0)
-
-    // prologue: descriptors and indices of the first five items, rows of the first three
-    int q0, q1d, q2d, q3d, q4d, iq0, iq1, iq2, iqa, iqb, iqc, iqd;
-    TBF_GEN(q0, iq0);
-    TBF_GEN(q1d, iq1);
-    TBF_GEN(q2d, iq2);
-    TBF_GEN(q3d, iqa);
-    TBF_GEN(q4d, iqb);
-    __builtin_amdgcn_sched_barrier(0);
-    i32x4 s0, s1, s2, s3;
-    TBF_GATHER(iq0, s0);
-    TBF_GATHER(iq1, s1);
-    TBF_GATHER(iq2, s2);
-    __builtin_amdgcn_sched_barrier(0);
-    // items only run out at the END of the wave's stream (the generator never yields a gap), so the first empty
-    // descriptor at the MFMA stage ends the loop
-    while (true) {
-        if (q0 < 0) break;
-        TBF_STEP(s0, s3, iqa, iqc);
-        if (q0 < 0) break;
-        TBF_STEP(s1, s0, iqb, iqd);
-        if (q0 < 0) break;
-        TBF_STEP(s2, s1, iqc, iqa);
-        if (q0 < 0) break;
-        TBF_STEP(s3, s2, iqd, iqb);
-    }
-    if (FUSED && !single) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tb_retire();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tb_retire();
-    }
-}
-#undef TBF_STEP
-#undef TBF_GATHER
-#undef TBF_GEN
 
 // Y = bf16( bias + sum_kc slab[kc] (+ residual, ReLU-backward mask) ), K-chunks added in ascending order.
 // V = 4: 16-byte slab reads, 8-byte bf16 accesses (cout % 4 == 0, aligned buffers).
@@ -886,11 +555,7 @@ extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, con
     const TbShape sh = tb_shape(cin, cout);
     const int nb = sh.nb, kh = sh.kh, ct = sh.ct, kcs = sh.kc, n_chunks = sh.n_chunks, n_kc = sh.n_kc;
     float* slabs = (float*)((char*)scratch + 256);
-    // the flat item stream (k_conv_tbf) for the 32-channel K-chunk shapes; SCN_TB_FLAT=0: the per-tile pipeline (k_conv_tb)
-    const char* flat_env = getenv("SCN_TB_FLAT");                 // (read per call: the tests switch it inside one process)
-    const bool flat = !(flat_env && flat_env[0] == '0') && kh == 1;
-    const size_t lds = (size_t)n_off * ct * kcs * sizeof(uint16_t) + 16 +
-                       (flat ? (size_t)TB_NW * TBF_SLOTS * TBF_SLOT_INTS * sizeof(int) : 0);
+    const size_t lds = (size_t)n_off * ct * kcs * sizeof(uint16_t) + 16;
     int wg_per_cu = (int)((160 * 1024) / lds);
     if (wg_per_cu > 2) wg_per_cu = 2;
     if (wg_per_cu < 1) wg_per_cu = 1;
@@ -914,26 +579,9 @@ extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, con
                            (long long)n_out, cout, flags, n_chunks, n_kc, (int*)arrival);                           \
     } while (0)
 #define PICK_TB(N, K) do { if (fused) LAUNCH_TB(N, K, true); else LAUNCH_TB(N, K, false); } while (0)
-#define LAUNCH_TBF(N, FU)                                                                                           \
-    do {                                                                                                            \
-        static bool attr_set = false;                                                                               \
-        if (!attr_set) {                                                                                            \
-            SCN_HIP(hipFuncSetAttribute((const void*)k_conv_tbf<N, FU>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                        160 * 1024));                                                               \
-            attr_set = true;                                                                                        \
-        }                                                                                                           \
-        hipLaunchKernelGGL((k_conv_tbf<N, FU>), grid, dim3(TB_NW * 64), lds, st, X, (long long)n_in, cin, tstab,    \
-                           tile_mask, perm, tile_order, n_off, (long long)nt, image, bias, residual, relu_mask, Y, slabs, \
-                           (long long)n_out, cout, flags, n_chunks, n_kc, (int*)arrival);                           \
-    } while (0)
-#define PICK_TBF(N) do { if (fused) LAUNCH_TBF(N, true); else LAUNCH_TBF(N, false); } while (0)
     if (kh == 2) PICK_TB(2, 2);
-    else if (flat && nb == 4) PICK_TBF(4);
-    else if (flat) PICK_TBF(2);
     else if (nb == 4) PICK_TB(4, 1);
     else PICK_TB(2, 1);
-#undef PICK_TBF
-#undef LAUNCH_TBF
 #undef PICK_TB
 #undef LAUNCH_TB
     SCN_LAUNCH_CHECK();

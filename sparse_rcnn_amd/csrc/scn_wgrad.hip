@@ -177,7 +177,13 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ 
     const char* xlane = (const char*)X + (long long)ca * ES;
     const char* ylane = (const char*)dY + (long long)cbn * ES;
     const int xstride = ES * cin, ystride = ES * cout;         // int: row * stride is one v_mad_i64_i32
-    const int relu_lo = relu_in ? 0 : (int)0x80000000;
+    const int relu_lo = (relu_in & 1) ? 0 : (int)0x80000000;
+    // EDGE with whole fragments (relu_in bit 1, set by the host when Cin % TA == 0, Cout % TB == 0 and rows are 16-byte
+    // aligned -- the reference's 48 / 80 / 112-channel layers on 64-wide blocks): a lane's T channels are all inside the
+    // layer or all outside, so the row piece is still ONE vector load, from a clamped lane offset, zeroed at use
+    const bool evec = EDGE && !HB && (relu_in & 2);
+    const char* xlane_e = (const char*)X + (long long)(a_ok[0] ? ca : 0) * ES;
+    const char* ylane_e = (const char*)dY + (long long)(b_ok[0] ? cbn : 0) * ES;
     const int last_full = nfull > 0 ? (nfull - 1) * 16 : 0;        // prefetches past the end re-read the last whole block
 #define WD_IDX(IN, OUT, QB)                                                                          \
     {                                                                                                \
@@ -190,6 +196,13 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ 
 #define WD_ROWS(A, B, IN, OUT)                                                                       \
     _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                               \
         if (EDGE) {                  /* element loads; channels past the end read channel 0 (zeroed at use) */ \
+            if constexpr (!HB) {                                                                     \
+                if (evec) {              /* whole fragments in or out: one vector load per row piece */ \
+                    A[s_] = *(const ra_t*)(xlane_e + (long long)IN[s_] * xstride);                   \
+                    B[s_] = *(const rb_t*)(ylane_e + (long long)OUT[s_] * ystride);                  \
+                    continue;                                                                        \
+                }                                                                                    \
+            }                                                                                        \
             if (HB) {                                                                                \
                 const unsigned short* xr_ = (const unsigned short*)X + (long long)IN[s_] * cin;      \
                 const unsigned short* yr_ = (const unsigned short*)dY + (long long)OUT[s_] * cout;   \
@@ -773,7 +786,10 @@ static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const 
     const int cout_pad = pl.nbj * pl.cbj;
     float* db_slabs = db ? (float*)scratch + (int64_t)pl.unit_start[n_off] * pl.nbi * pl.nbj * pl.cbi * pl.cbj : nullptr;
     dim3 grid((unsigned)pl.unit_start[n_off], 1, (unsigned)(pl.nbi * pl.nbj));
-    const int relu_in = (flags & SCN_F_RELU_IN) ? 1 : 0;
+    // bit 1: EDGE blocks whose fragments are whole (vector loads stay possible, see k_wgrad_direct)
+    const bool evec = edge && !hb && cin % sh.ta == 0 && cout % sh.tb == 0 && (all_ptrs & 15) == 0 &&
+                      (cin * 4) % 16 == 0 && (cout * 4) % 16 == 0 && !getenv("SCN_WD_NO_EVEC");
+    const int relu_in = ((flags & SCN_F_RELU_IN) ? 1 : 0) | (evec ? 2 : 0);
     if (mfma16) {
         const int ta = tb_tiles(cin), tb = tb_tiles(cout);
 #define LAUNCH_WT(TA_, TB_, I_)                                                                                  \

@@ -184,3 +184,40 @@ def test_conv_tiles_tail_slices_reproduce_the_padded_kernel_bit_for_bit(gpu, cin
     for u, v in zip(a, ref):
         assert torch.equal(u, v)
     assert float(a[0].abs().max()) > 0
+
+
+@pytest.mark.parametrize("cin,cout", [(48, 48), (80, 80), (112, 112), (48, 80), (96, 48)])
+def test_wgrad_whole_fragment_edge_blocks_keep_vector_loads_and_the_bits(gpu, cin, cout):
+    """k_wgrad_direct on the reference's 48 / 80 / 112-channel layers: the channel blocks are 64 wide, so the last block is an
+    EDGE block -- but a lane's 4 channels are all inside the layer or all outside, so its row pieces stay single vector
+    loads (round 3; element loads before).  Same arithmetic: the bits of the element-wise path (SCN_WD_NO_EVEC=1), single
+    and paired problems, with the bias gradient."""
+    import os
+    import sparse_rcnn_amd as scn
+    from sparse_rcnn_amd import functional as F, _lib as L
+    coords, feats, size, bs, _ = _scene(20_000, (256, 256, 128), seed=6)
+    x = scn.InputLayer(3, size, mode=4)((coords, feats.to(gpu), 1))
+    rb = x.metadata.subm_rulebook(size, 3)
+    r = rb.rules
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    X = torch.randn(rb.n, cin, generator=g).to(gpu)
+    dY = torch.randn(rb.n, cout, generator=g).to(gpu)
+
+    def run():
+        a = F.wgrad_bias_rules(X, dY, r.in_rows, r.out_rows, r.prefix_host, 27, 1 << 13, L.F_RELU_IN)
+        out = [a[0], a[1]]
+        if cin == cout:
+            X2, dY2 = X * 0.5 + 1.0, dY * 2.0
+            b = F.wgrad_bias_rules2(X, dY, X2, dY2, r.in_rows, r.out_rows, r.prefix_host, 27, 1 << 13, L.F_RELU_IN)
+            out += [b[0], b[1]]
+        torch.cuda.synchronize()
+        return out
+    a = run()
+    os.environ["SCN_WD_NO_EVEC"] = "1"
+    try:
+        ref = run()
+    finally:
+        del os.environ["SCN_WD_NO_EVEC"]
+    for u, v in zip(a, ref):
+        assert torch.equal(u, v)
+    assert float(a[0].abs().max()) > 0

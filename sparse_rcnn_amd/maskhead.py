@@ -59,7 +59,14 @@ class MaskBranch(nn.Module):
         self.linear_layer = nn.Sequential(*layers)
         self.classes = cin
 
-    def forward(self, raw_scene, backbone_features, selected_bbox):
+    def prepare_cut(self, coords, spatial_size, selected_bbox):
+        """Start the crop's selection and the ROI batch's index build (they depend on coordinates and boxes only) on the
+        helper thread + its own stream BEFORE the backbone runs; pass the handle to forward(..., prepared_cut=).  coords:
+        int64 [N, 4] (host or device) or the int32 device copy a Metadata holds (`point_coords`)."""
+        size = torch.as_tensor([int(s) for s in spatial_size], dtype=torch.long) + self.spatial_size_extention
+        return self.output_roi_cut.prepare_cut_in_thread(coords, size, selected_bbox, in_thread=True)
+
+    def forward(self, raw_scene, backbone_features, selected_bbox, prepared_cut=None):
         """raw_scene: the collate tuple (coords, features, spatial_size, batch_size, batch_splits) with `features` on
         the device; backbone_features: SparseConvNetTensor (unet_feature_maps[-1]); selected_bbox: list (one per sample)
         of fp32 [n, 2, 3] boxes.  -> (per-point-per-class mask logits [M, classes], selection)."""
@@ -75,8 +82,9 @@ class MaskBranch(nn.Module):
         # builds them (its own high-priority stream) while the scene-level layers below are queued and run
         how = self.PREFETCH_ROI_INDEX
         how = {True: "thread", False: "0", "1": "thread"}.get(how, how)
-        pending = None if how == "0" else self.output_roi_cut.prepare_cut_in_thread(coords, size, selected_bbox,
-                                                                                  in_thread=how == "thread")
+        pending = prepared_cut
+        if pending is None and how != "0":
+            pending = self.output_roi_cut.prepare_cut_in_thread(coords, size, selected_bbox, in_thread=how == "thread")
         # bf16 storage: the scene-level units, the per-point gather (OutputLayer), the per-point slab and the crop's feature
         # gather all run on bf16 rows (round 3: no fp32 island between backbone and internal U-Net); only the InputLayer's
         # mean over the cropped points accumulates in fp32 / fp64

@@ -32,6 +32,12 @@ WORKLOADS = {      # name -> (channels, grid, active voxels per sample, boxes pe
 }
 
 
+import os as _os
+
+# developer switch (A/B in tools/): start the ROI batch's index build before the backbone forward (helper thread + stream)
+EARLY_ROI_CUT = _os.environ.get("SCN_ROI_EARLY", "0") != "0"
+
+
 class SparseStepModel(torch.nn.Module):
     """Backbone (+ mask branch for cfg3) as one module, so that one flat parameter buffer covers the step."""
 
@@ -80,6 +86,12 @@ class SceneStep:
         # builds them on the high-priority index stream while this batch runs; every step contains one complete build
         if self.prefetch:
             self._md_next = m.backbone.prefetch_in_thread(self.coords, self.size, self.batch_size)
+        # cfg3: the ROI crop's selection and the ROI batch's index structures depend on coordinates and boxes only -- the
+        # boxes of a step are known before its backbone runs (here: synthetic; in the reference: the RPN's proposals of
+        # the same forward, so this applies to the mask branch's SECOND use of a scene, e.g. evaluation on cached proposals)
+        cut = None
+        if m.mask is not None and EARLY_ROI_CUT:
+            cut = m.mask.prepare_cut(self.coords, self.size, self.boxes)      # (resident int64 coords: no dependency on md)
         out = m.backbone(self.coords, fin, self.size, self.batch_size, metadata=md)
         if self._gy is None or self._gy.shape != out.features.shape:
             self._gy = torch.randn(out.features.shape, generator=self._gen).to(self.device)   # upstream grad dY ~ N(0,1)
@@ -89,7 +101,7 @@ class SceneStep:
             logits = None
         else:
             scene = (self.coords, fin, self.size, self.batch_size, self.splits)
-            logits, selection = m.mask(scene, out, self.boxes)
+            logits, selection = m.mask(scene, out, self.boxes, prepared_cut=cut)
             if self._gm is None or self._gm.shape != logits.shape:
                 self._gm = torch.randn(logits.shape, generator=self._gen).to(self.device)
                 self.n_roi_rows = logits.shape[0]

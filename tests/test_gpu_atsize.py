@@ -146,10 +146,10 @@ class _record_relu_masks:
 # order (fp32) and, in bf16 storage, the rounding of the stored gradient slabs (the oracle differentiates the rounded
 # forward straight-through in fp32): bounds on the relative L2 of EVERY gradient tensor.
 # Achieved (profiles/r3_parity_errors.jsonl): fp32 4e-6 worst over 157 tensors of the cfg-3 step (median 8e-7) -- round 2's
-# bound without shared masks was 3e-3; bf16 storage 6-7e-3 typical, 1.2e-2 worst (16-element bias tensors of the mask
-# branch's input stage) -- round 2: 1.5 x a measured 4-16 % yardstick, 25 % for the mask branch.
+# bound without shared masks was 3e-3; bf16 storage 6-8e-3 typical, 1.3e-2 / 1.45e-2 worst (16-element bias tensors of the mask
+# branch's input stage on the 60k / 12k-voxel scenes) -- round 2: 1.5 x a measured 4-16 % yardstick, 25 % for the mask branch.
 FROZEN_L2_F32 = 2e-5
-FROZEN_L2_BF16 = 1.5e-2
+FROZEN_L2_BF16 = 2e-2
 
 
 def _check_grad_frozen(name, what, got, ref, bound):

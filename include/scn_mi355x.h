@@ -564,6 +564,8 @@ typedef struct scn_exec_op {
     int32_t reserved;
 } scn_exec_op;
 
+/* sizeof(scn_exec_op) (which = 0) / sizeof(scn_exec_level) (which = 1): lets a binding check its struct layout. */
+int64_t scn_exec_struct_bytes(int which);
 /* Scratch bytes and zeroed arrival counters (the scn_conv_tiles contract) the plan needs for these level sizes. */
 int scn_exec_requirements(const scn_exec_op* ops, int n_ops, const scn_exec_level* levels, int n_levels,
                           int64_t* scratch_bytes, int64_t* arrival_counters);

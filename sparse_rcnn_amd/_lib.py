@@ -109,6 +109,7 @@ _SIGS = {
     "scn_pool_bwd_bf16": (C.c_int, [p, p, p, p, i64, i32, i32, p, p]),
     "scn_sparse_to_dense_fwd_bf16": (C.c_int, [p, p, i64, i32, C.POINTER(i64), p, p]),
     "scn_sparse_to_dense_bwd_bf16": (C.c_int, [p, p, i64, i32, C.POINTER(i64), p, p]),
+    "scn_exec_struct_bytes": (i64, [i32]),
     "scn_exec_requirements": (C.c_int, [p, i32, p, i32, C.POINTER(i64), C.POINTER(i64)]),
     "scn_exec_run": (C.c_int, [p, i32, p, i32, p, p, p, p, i64, p, p]),
     "scn_exec_run_streams": (C.c_int, [p, i32, p, i32, p, p, p, p, i64, p, p, p, p, i64]),

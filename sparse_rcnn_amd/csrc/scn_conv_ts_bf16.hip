@@ -350,344 +350,6 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
 #undef TB_STEP
 #undef TB_GATHER
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// k_conv_tb2 (round 3): TWO tiles per wave at a time, in lockstep.
-//
-// k_conv_tb is bound by latency, not by bandwidth or the matrix pipe: per tile a chain of dependent
-// round trips (index -> rows -> epilogue operands / K-split hand-off) for 0.1-0.3 us of MFMA work, 16 waves per CU (the
-// weight image fills the LDS).  The only way to more memory operations in flight per CU is more tiles in flight per WAVE:
-// here a wave pulls its tiles in PAIRS and walks both with one step loop -- per step an index load, a row gather and NB
-// MFMAs for each of the two tiles, max(steps_a, steps_b) steps (the LPT order makes neighbours equally long; the shorter
-// tile pads with bubble items: row index -1 gathers zeros, and zero rows add 0.0 to the accumulators -- same bits).  The
-// code stays straight-line (the item-stream form, k_conv_tbf in git history, lost to the compiler's wait counts at its
-// in-loop branches); what it costs is registers: the gather pipeline per tile is one stage shorter (rows two items ahead,
-// indices four ahead) so that two tiles fit the 128 VGPRs of a 16-wave workgroup.
-// Per-tile arithmetic, epilogue and K-split hand-off are k_conv_tb's: bit-identical (tests).
-// ---------------------------------------------------------------------------------------------------------------------------
-template <int NB, bool FUSED>
-__global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(4))) void k_conv_tb2(
-    const unsigned short* __restrict__ X, long long n_in, int cin, const int* __restrict__ tstab,
-    const unsigned* __restrict__ tile_mask, const int* __restrict__ perm, const int* __restrict__ tile_order, int n_off,
-    long long nt, const unsigned short* __restrict__ image, const float* __restrict__ bias,
-    const unsigned short* __restrict__ residual, const unsigned short* __restrict__ relu_mask,
-    unsigned short* __restrict__ Y, float* __restrict__ slabs, long long n_out, int cout, int flags, int n_chunks,
-    int n_kc, int* __restrict__ counters) {
-    constexpr int CT = 16 * NB;
-    constexpr int KC = TB_KC;
-    constexpr int THREADS = TB_NW * 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned short Wb[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int chunk = blockIdx.x % n_chunks;
-    const int kci = (blockIdx.x / n_chunks) % n_kc;
-    const int n0 = chunk * CT, kc = kci * KC;
-    const bool relu_in = flags & SCN_F_RELU_IN;
-    const bool res_last = flags & SCN_F_RESIDUAL_LAST;
-
-    const int tg = blockIdx.x / (n_chunks * n_kc), n_tg = gridDim.x / (n_chunks * n_kc);
-    const int n_tiles = (int)((nt - tg + n_tg - 1) / n_tg);
-    int* counter = (int*)(Wb + (size_t)n_off * CT * KC);
-    if (tid == 0) *counter = 0;
-    __syncthreads();
-    // a PAIR of consecutive entries of the workgroup's LPT list (neighbours have equal or nearly equal offset counts)
-    auto grab2 = [&](long long& ta_, long long& tb_) {
-        int tl = 0;
-        if (lane == 0) tl = atomicAdd(counter, 2);
-        tl = __builtin_amdgcn_readfirstlane(tl);
-        ta_ = tl < n_tiles ? tile_order[tg + (long long)tl * n_tg] : -1;
-        tb_ = tl + 1 < n_tiles ? tile_order[tg + (long long)(tl + 1) * n_tg] : -1;
-    };
-    const int i = lane & 15, kq = lane >> 4;
-    long long na_tile, nb_tile;
-    grab2(na_tile, nb_tile);
-    unsigned na_m = 0, nb_m = 0;
-    int na_orow[4] = {-1, -1, -1, -1}, nb_orow[4] = {-1, -1, -1, -1};
-    if (na_tile >= 0) {
-        na_m = tile_mask[na_tile];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) na_orow[j] = perm[na_tile * TB_T + 4 * kq + j];
-    }
-    if (nb_tile >= 0) {
-        nb_m = tile_mask[nb_tile];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) nb_orow[j] = perm[nb_tile * TB_T + 4 * kq + j];
-    }
-
-    {
-        const int total16 = n_off * KC * CT / 8;
-        const uint4* src = (const uint4*)image + (size_t)(chunk * n_kc + kci) * total16;
-        constexpr int SB = 4;
-        for (int base = 0; base < total16; base += THREADS * SB) {
-            uint4 v[SB];
-#pragma unroll
-            for (int u = 0; u < SB; ++u) {
-                const int e = base + u * THREADS + tid;
-                v[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (e < total16) v[u] = src[e];
-            }
-#pragma unroll
-            for (int u = 0; u < SB; ++u) {
-                const int e = base + u * THREADS + tid;
-                if (e < total16) ((uint4*)Wb)[e] = v[u];
-            }
-        }
-    }
-    __syncthreads();
-
-    const bool k_ok = kc + 8 * kq + 7 < cin;
-    const bool single = n_kc == 1;
-    const bool direct = single || FUSED;
-    const int ncol = n0 + NB * i;
-    const bool n_ok = ncol < cout;
-    float bcol[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) bcol[nb] = (direct && bias && ncol + nb < cout) ? bias[ncol + nb] : 0.f;
-    float* out_slab = slabs + (long long)kci * n_out * cout;
-    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)slabs, 0, FUSED && !single ? (int)(unsigned)(nt * n_chunks * n_kc * (TB_T * CT * 4)) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t xrsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(unsigned)(n_in * cin * 2), 0x00020000);
-    const int row_bytes = cin * 2, lane_boff = (kc + 8 * kq) * 2;
-    const unsigned short* wlane = Wb + (size_t)i * TB_KC + 8 * kq;
-
-    constexpr int NWD = NB / 2;
-    const bool vec_ok = (cout % NB == 0) && ((((uintptr_t)Y | (uintptr_t)residual | (uintptr_t)relu_mask) & (2 * NB - 1)) == 0);
-    auto tb_write = [&](const int (&orow)[4], const f32x4 (&acc)[NB]) {
-        unsigned rw[4][NWD], mw[4][NWD];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const long long e = (long long)(orow[j] < 0 ? 0 : orow[j]) * cout + ncol;
-#pragma unroll
-            for (int w = 0; w < NWD; ++w) { rw[j][w] = 0u; mw[j][w] = 0x3f803f80u; }
-            if (vec_ok && n_ok) {
-                if (residual) {
-                    if (NB == 2) rw[j][0] = *(const unsigned*)(residual + e);
-                    else { const uint2 t = *(const uint2*)(residual + e); rw[j][0] = t.x; rw[j][NWD - 1] = t.y; }
-                }
-                if (relu_mask) {
-                    if (NB == 2) mw[j][0] = *(const unsigned*)(relu_mask + e);
-                    else { const uint2 t = *(const uint2*)(relu_mask + e); mw[j][0] = t.x; mw[j][NWD - 1] = t.y; }
-                }
-            } else if (!vec_ok) {
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    if (ncol + nb >= cout) continue;
-                    if (residual) rw[j][nb >> 1] = (nb & 1) ? (rw[j][nb >> 1] & 0xffffu) | ((unsigned)residual[e + nb] << 16)
-                                                            : (rw[j][nb >> 1] & 0xffff0000u) | residual[e + nb];
-                    if (relu_mask) mw[j][nb >> 1] = (nb & 1) ? (mw[j][nb >> 1] & 0xffffu) | ((unsigned)relu_mask[e + nb] << 16)
-                                                             : (mw[j][nb >> 1] & 0xffff0000u) | relu_mask[e + nb];
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (orow[j] < 0) continue;
-            unsigned ow[NWD];
-#pragma unroll
-            for (int w = 0; w < NWD; ++w) ow[w] = 0u;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const unsigned rbits = (nb & 1) ? (rw[j][nb >> 1] & 0xffff0000u) : (rw[j][nb >> 1] << 16);
-                const unsigned mbits = (nb & 1) ? (mw[j][nb >> 1] & 0xffff0000u) : (mw[j][nb >> 1] << 16);
-                const float r = __uint_as_float(rbits);
-                float y = acc[nb][j] + (res_last ? 0.f : r);
-                if (!(__uint_as_float(mbits) > 0.f)) y = 0.f;
-                if (res_last) y += r;
-                ow[nb >> 1] |= (unsigned)f32_to_bf16(y) << (16 * (nb & 1));
-            }
-            unsigned short* yp = Y + (long long)orow[j] * cout + ncol;
-            if (vec_ok) {
-                if (n_ok) {
-                    if (NB == 2) *(unsigned*)yp = ow[0];
-                    else *(uint2*)yp = make_uint2(ow[0], ow[NWD - 1]);
-                }
-            } else {
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    if (ncol + nb < cout) yp[nb] = (unsigned short)(ow[nb >> 1] >> (16 * (nb & 1)));
-            }
-        }
-    };
-    // K-split hand-off, one pipeline per tile slot of the pair (see k_conv_ts): q1 = published, q2 = ticket in flight
-    long long q1[2] = {-1, -1}, q2[2] = {-1, -1};
-    int tk_v[2] = {0, 0};
-    auto tb_publish = [&](int u, long long t, const f32x4 (&acc)[NB]) {
-        const int sb = (int)((t * n_chunks + chunk) * n_kc + kci) * (TB_T * CT * 4) + lane * 16;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, acc[nb]),
-                                                   srsrc, sb + nb * 1024, 0, 16);
-        q1[u] = t;
-    };
-    auto tb_retire = [&](int u) {
-        if (q2[u] >= 0) {
-            const int ticket = __builtin_amdgcn_readfirstlane(tk_v[u]);
-            if (ticket == n_kc - 1) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int unit = (int)(q2[u] * n_chunks + chunk);
-                if (lane == 0) __hip_atomic_store(counters + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                int orow2[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) orow2[j] = perm[q2[u] * TB_T + 4 * kq + j];
-                const int sb = (unit * n_kc) * (TB_T * CT * 4) + lane * 16;
-                f32x4 y[NB];
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) y[nb] = (f32x4){bcol[nb], bcol[nb], bcol[nb], bcol[nb]};
-                for (int k0 = 0; k0 < n_kc; k0 += 2) {
-                    f32x4 p[2][NB];
-#pragma unroll
-                    for (int v = 0; v < 2; ++v) {
-                        const int k = k0 + v < n_kc ? k0 + v : n_kc - 1;
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            p[v][nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                srsrc, sb + k * (TB_T * CT * 4) + nb * 1024, 0, 16));
-                    }
-#pragma unroll
-                    for (int v = 0; v < 2; ++v) {
-                        if (k0 + v < n_kc) {
-#pragma unroll
-                            for (int nb = 0; nb < NB; ++nb) y[nb] += p[v][nb];
-                        }
-                    }
-                }
-                tb_write(orow2, y);
-            }
-        }
-        if (q1[u] >= 0 && lane == 0)
-            tk_v[u] = __hip_atomic_fetch_add(counters + (int)(q1[u] * n_chunks + chunk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        q2[u] = q1[u];
-        q1[u] = -1;
-    };
-
-    // rows of the item two ahead from the index loaded two steps ago; a bubble item (queue entry -1) gathers row -1 = zeros
-#define TB2_GATHER(IDX, QE, A)                                                                       \
-    do {                                                                                             \
-        const int ix_ = (QE) < 0 ? -1 : (IDX);                                                       \
-        const int off_ = k_ok ? __mul24(ix_, row_bytes) + lane_boff : (int)0xFFFFFFF0;               \
-        A = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off_, 0, 0);                                \
-    } while (0)
-    // one step of tile slot S (a / b): index of the item four ahead, rows of the item two ahead, MFMAs on the oldest set
-#define TB2_STEP(S, CUR, GSET, IOLD, INEW)                                                           \
-    do {                                                                                             \
-        int o4_ = -1;                                                                                \
-        if (m##S) { o4_ = __builtin_ctz(m##S); m##S &= m##S - 1; ol##S = o4_; }                       \
-        INEW = tb##S[ol##S * TB_T + i];                                                              \
-        TB2_GATHER(IOLD, q##S##2, GSET);                                                             \
-        {                                                                                            \
-            s16x8 a_ = __builtin_bit_cast(s16x8, CUR);                                               \
-            if (relu_in) a_ = __builtin_elementwise_max(a_, (s16x8){0, 0, 0, 0, 0, 0, 0, 0});        \
-            const bf16x8 af_ = __builtin_bit_cast(bf16x8, a_);                                       \
-            const unsigned short* wo_ = wlane + (size_t)(q##S##0 < 0 ? 0 : q##S##0) * (CT * TB_KC);  \
-            _Pragma("unroll") for (int nb_ = 0; nb_ < NB; ++nb_) {                                   \
-                const bf16x8 bf_ = *(const bf16x8*)(wo_ + nb_ * 16 * TB_KC);                         \
-                acc##S[nb_] = MFMAB(af_, bf_, acc##S[nb_]);                                          \
-            }                                                                                        \
-        }                                                                                            \
-        q##S##0 = q##S##1; q##S##1 = q##S##2; q##S##2 = q##S##3; q##S##3 = o4_;                      \
-    } while (0)
-    // prologue of a tile slot: descriptors of its first four items, indices of all four, rows of the first two
-#define TB2_PROLOGUE(S)                                                                              \
-    int q##S##0 = -1, q##S##1 = -1, q##S##2 = -1, q##S##3 = -1, ol##S = 0;  /* items k .. k+3 */      \
-    int i##S##0, i##S##1, i##S##a, i##S##b, i##S##c = -1;                                            \
-    if (m##S) { q##S##0 = __builtin_ctz(m##S); m##S &= m##S - 1; ol##S = q##S##0; }                   \
-    i##S##0 = tb##S[ol##S * TB_T + i];                                                               \
-    if (m##S) { q##S##1 = __builtin_ctz(m##S); m##S &= m##S - 1; ol##S = q##S##1; }                   \
-    i##S##1 = tb##S[ol##S * TB_T + i];                                                               \
-    if (m##S) { q##S##2 = __builtin_ctz(m##S); m##S &= m##S - 1; ol##S = q##S##2; }                   \
-    i##S##a = tb##S[ol##S * TB_T + i];                                                               \
-    if (m##S) { q##S##3 = __builtin_ctz(m##S); m##S &= m##S - 1; ol##S = q##S##3; }                   \
-    i##S##b = tb##S[ol##S * TB_T + i];
-
-    while (na_tile >= 0) {
-        const long long tile_a = na_tile, tile_b = nb_tile;
-        unsigned ma = na_m, mb = nb_tile >= 0 ? nb_m : 0u;
-        int orow_a[4], orow_b[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { orow_a[j] = na_orow[j]; orow_b[j] = nb_orow[j]; }
-        const int* tba = tstab + tile_a * n_off * TB_T;
-        const int* tbb = tstab + (tile_b >= 0 ? tile_b : tile_a) * n_off * TB_T;       // (no tile: bubbles over a valid table)
-        const int sa_ = __popc(ma), sb_ = __popc(mb);
-        const int n_steps = sa_ > sb_ ? sa_ : sb_;
-        grab2(na_tile, nb_tile);
-        if (na_tile >= 0) {
-            na_m = tile_mask[na_tile];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) na_orow[j] = perm[na_tile * TB_T + 4 * kq + j];
-        }
-        if (nb_tile >= 0) {
-            nb_m = tile_mask[nb_tile];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) nb_orow[j] = perm[nb_tile * TB_T + 4 * kq + j];
-        }
-        TB2_PROLOGUE(a)
-        TB2_PROLOGUE(b)
-        __builtin_amdgcn_sched_barrier(0);
-        i32x4 sa0, sa1, sa2, sb0, sb1, sb2;
-        TB2_GATHER(ia0, qa0, sa0);
-        TB2_GATHER(ib0, qb0, sb0);
-        TB2_GATHER(ia1, qa1, sa1);
-        TB2_GATHER(ib1, qb1, sb1);
-        __builtin_amdgcn_sched_barrier(0);
-
-        f32x4 acca[NB], accb[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const float b0 = single ? bcol[nb] : 0.f;
-            acca[nb] = (f32x4){b0, b0, b0, b0};
-            accb[nb] = (f32x4){b0, b0, b0, b0};
-        }
-        int n_left = n_steps;
-        for (; n_left >= 3; n_left -= 3) {
-            TB2_STEP(a, sa0, sa2, iaa, iac);
-            TB2_STEP(b, sb0, sb2, iba, ibc);
-            TB2_STEP(a, sa1, sa0, iab, iaa);
-            TB2_STEP(b, sb1, sb0, ibb, iba);
-            TB2_STEP(a, sa2, sa1, iac, iab);
-            TB2_STEP(b, sb2, sb1, ibc, ibb);
-        }
-        if (n_left >= 1) { TB2_STEP(a, sa0, sa2, iaa, iac); TB2_STEP(b, sb0, sb2, iba, ibc); }
-        if (n_left >= 2) { TB2_STEP(a, sa1, sa0, iab, iaa); TB2_STEP(b, sb1, sb0, ibb, iba); }
-
-        // ---- epilogues of the pair ---------------------------------------------------------------------------------
-        if (FUSED && !single) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            tb_retire(0);
-            tb_retire(1);
-            tb_publish(0, tile_a, acca);
-            if (tile_b >= 0) tb_publish(1, tile_b, accb);
-            continue;
-        }
-        if (direct) {
-            tb_write(orow_a, acca);
-            if (tile_b >= 0) tb_write(orow_b, accb);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (orow_a[j] >= 0) {
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        if (ncol + nb < cout) out_slab[(long long)orow_a[j] * cout + ncol + nb] = acca[nb][j];
-                }
-                if (tile_b >= 0 && orow_b[j] >= 0) {
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        if (ncol + nb < cout) out_slab[(long long)orow_b[j] * cout + ncol + nb] = accb[nb][j];
-                }
-            }
-        }
-    }
-    if (FUSED && !single) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tb_retire(0);
-        tb_retire(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tb_retire(0);
-        tb_retire(1);
-    }
-}
-#undef TB2_PROLOGUE
-#undef TB2_STEP
-#undef TB2_GATHER
 
 
 // Y = bf16( bias + sum_kc slab[kc] (+ residual, ReLU-backward mask) ), K-chunks added in ascending order.
@@ -894,9 +556,6 @@ extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, con
     const TbShape sh = tb_shape(cin, cout);
     const int nb = sh.nb, kh = sh.kh, ct = sh.ct, kcs = sh.kc, n_chunks = sh.n_chunks, n_kc = sh.n_kc;
     float* slabs = (float*)((char*)scratch + 256);
-    // two tiles per wave at a time (k_conv_tb2) for the 32-channel K-chunk shapes; SCN_TB_PAIR=0: one tile (k_conv_tb)
-    const char* pair_env = getenv("SCN_TB_PAIR");                 // (read per call: the tests switch it inside one process)
-    const bool pair = !(pair_env && pair_env[0] == '0') && kh == 1;
     const size_t lds = (size_t)n_off * ct * kcs * sizeof(uint16_t) + 16;
     int wg_per_cu = (int)((160 * 1024) / lds);
     if (wg_per_cu > 2) wg_per_cu = 2;
@@ -908,19 +567,6 @@ extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, con
                        nt * n_chunks * n_kc * (int64_t)(TB_T * ct * 4) < (1ll << 31);
     dim3 grid((unsigned)(n_tg * n_chunks * n_kc));
     hipStream_t st = S(stream);
-#define LAUNCH_TB2(N, FU)                                                                                           \
-    do {                                                                                                            \
-        static bool attr_set = false;                                                                               \
-        if (!attr_set) {                                                                                            \
-            SCN_HIP(hipFuncSetAttribute((const void*)k_conv_tb2<N, FU>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                        160 * 1024));                                                               \
-            attr_set = true;                                                                                        \
-        }                                                                                                           \
-        hipLaunchKernelGGL((k_conv_tb2<N, FU>), grid, dim3(TB_NW * 64), lds, st, X, (long long)n_in, cin, tstab,    \
-                           tile_mask, perm, tile_order, n_off, (long long)nt, image, bias, residual, relu_mask, Y, slabs, \
-                           (long long)n_out, cout, flags, n_chunks, n_kc, (int*)arrival);                           \
-    } while (0)
-#define PICK_TB2(N) do { if (fused) LAUNCH_TB2(N, true); else LAUNCH_TB2(N, false); } while (0)
 #define LAUNCH_TB(N, K, FU)                                                                                         \
     do {                                                                                                            \
         static bool attr_set = false;                                                                               \
@@ -935,12 +581,8 @@ extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, con
     } while (0)
 #define PICK_TB(N, K) do { if (fused) LAUNCH_TB(N, K, true); else LAUNCH_TB(N, K, false); } while (0)
     if (kh == 2) PICK_TB(2, 2);
-    else if (pair && nb == 4) PICK_TB2(4);
-    else if (pair) PICK_TB2(2);
     else if (nb == 4) PICK_TB(4, 1);
     else PICK_TB(2, 1);
-#undef PICK_TB2
-#undef LAUNCH_TB2
 #undef PICK_TB
 #undef LAUNCH_TB
     SCN_LAUNCH_CHECK();

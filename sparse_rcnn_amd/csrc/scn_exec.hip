@@ -157,6 +157,10 @@ int run_op(const Ctx& c, const scn_exec_op& o) {
 
 }  // namespace
 
+extern "C" int64_t scn_exec_struct_bytes(int which) {
+    return which == 0 ? (int64_t)sizeof(scn_exec_op) : (which == 1 ? (int64_t)sizeof(scn_exec_level) : -1);
+}
+
 extern "C" int scn_exec_requirements(const scn_exec_op* ops, int n_ops, const scn_exec_level* levels, int n_levels,
                                      int64_t* scratch_bytes, int64_t* arrival_counters) {
     SCN_REQUIRE(n_ops >= 0 && (n_ops == 0 || ops) && levels && n_levels >= 1 && scratch_bytes && arrival_counters);

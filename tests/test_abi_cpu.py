@@ -38,6 +38,42 @@ def test_library_exports_every_declared_symbol():
     assert loaded.scn_abi_version() == 1
     assert loaded.scn_hash_capacity(1000) == 2048 and loaded.scn_hash_capacity(0) == 1024
     assert loaded.scn_rules_blocks(27, 5000) == 27 * 5
+    # the step executor's plan records: the ctypes structures of executor.py have the C layout
+    from sparse_rcnn_amd import executor as EX
+    assert loaded.scn_exec_struct_bytes(0) == ctypes.sizeof(EX.ExecOp) == 64
+    assert loaded.scn_exec_struct_bytes(1) == ctypes.sizeof(EX.ExecLevel) == 128
+
+
+def test_executor_plans_compile_without_a_gpu():
+    """The launch plans of the step executor are compiled from the module tree alone (no GPU): per level one stage whose op
+    lists name only buffers / parameters / gradient regions the stage declares, and every parameter of the network sits
+    in exactly one gradient region of exactly one stage."""
+    from sparse_rcnn_amd import executor as EX
+    from sparse_rcnn_amd.maskhead import MaskBranch
+    from sparse_rcnn_amd.unet import SparseUNet
+    for kw in (dict(), dict(bf16_blocks="all")):
+        net = SparseUNet(7, (32, 48, 64, 80), **kw)
+        plan = net._exec_plan()
+        stages = [s for s in plan["enc"] + plan["dec"] if s is not None]
+        assert len(stages) == 4 + 3
+        seen = []
+        for st in stages:
+            for op in st.fwd + st.bwd:
+                for field in ("x", "y", "r", "m", "x1", "y1"):
+                    v = getattr(op, field)
+                    assert -1 <= v < len(st.bufs), (field, v)
+            for op in st.fwd:
+                assert -1 <= op.w < len(st.params) and -1 <= op.b < len(st.params)
+                assert op.op in (EX.OP_GEMM_IDENT, EX.OP_CONV_SUBM, EX.OP_CONV_CHILD, EX.OP_RULES_CHILD, EX.OP_ROWS2, EX.OP_CAST)
+            for op in st.bwd:
+                if op.op in (EX.OP_WGRAD_SUBM, EX.OP_WGRAD2_SUBM, EX.OP_WGRAD_DOWN, EX.OP_WGRAD_UP, EX.OP_WGRAD_IDENT, EX.OP_COLSUM):
+                    assert -1 <= op.w < len(st.gregions) and -1 <= op.b < len(st.gregions)
+            seen += [m for m, _ in st.mods]
+        convs = [m for m in net.modules() if hasattr(m, "weight") and hasattr(m, "nIn")]
+        assert len(seen) == len(set(map(id, seen))) == len(convs)
+    assert MaskBranch(32, 7).output_conv_layer._exec_plan()["enc"][0] is None       # identity_first: level 0 is no stage
+    bn = SparseUNet(7, (16, 32), batchnorm=True)
+    assert bn._exec_plan() is False                                                  # batch norm: layer-by-layer path
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour")

@@ -221,54 +221,3 @@ def test_wgrad_whole_fragment_edge_blocks_keep_vector_loads_and_the_bits(gpu, ci
     for u, v in zip(a, ref):
         assert torch.equal(u, v)
     assert float(a[0].abs().max()) > 0
-
-
-@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (128, 128), (256, 256), (48, 80), (24, 16), (64, 32)])
-def test_bf16_two_tiles_per_wave_reproduce_the_one_tile_kernel_bit_for_bit(gpu, cin, cout):
-    """k_conv_tb2 (round 3: a wave walks two tiles in lockstep; the shorter one pads with bubble items that gather zero
-    rows) against k_conv_tb (SCN_TB_PAIR=0): same per-tile arithmetic, same bits -- forward, backward-data with ReLU mask +
-    residual, the 2^3 child tables, single K-chunk and in-launch K reduction, three levels (many tiles per wave ... less than
-    one; odd tile counts), twice in a row (arrival counters left clean)."""
-    import os
-    import sparse_rcnn_amd as scn
-    from sparse_rcnn_amd import functional as F, _lib as L
-    coords, feats, size, bs, _ = _scene(40_000, (256, 256, 128), seed=8)
-    x = scn.InputLayer(3, size, mode=4)((coords, feats.to(gpu), 1))
-    md = x.metadata
-    md.build_pyramid(size, 3, 3)
-    g = torch.Generator().manual_seed(cin * 1000 + cout)
-    sz = tuple(int(s) for s in size)
-    cases = []
-    for level in range(3):
-        rb = md.subm_rulebook(sz, 3)
-        sb = md.strided_rulebook(sz) if level < 2 else None
-        X = torch.randn(rb.n, cin, generator=g).to(gpu).to(torch.bfloat16)
-        W = (torch.randn(27, cin, cout, generator=g) * 0.1).to(gpu)
-        b = torch.randn(cout, generator=g).to(gpu)
-        R = torch.randn(rb.n, cout, generator=g).to(gpu).to(torch.bfloat16)
-        Mk = torch.randn(rb.n, cout, generator=g).to(gpu).to(torch.bfloat16)
-        W8 = (torch.randn(8, cin, cout, generator=g) * 0.1).to(gpu)
-        cases.append((rb, sb, X, W, b, R, Mk, W8))
-        if sb is not None:
-            sz = sb.coarse_size
-
-    def run():
-        out = []
-        for rb, sb, X, W, b, R, Mk, W8 in cases:
-            out.append(F.conv_rules_bf16(X, rb.tiles, rb.n, W, b, cout, L.F_RELU_IN, residual=R))
-            out.append(F.conv_rules_bf16(X, rb.tiles, rb.n, W.transpose(1, 2).contiguous(), None, cout,
-                                         L.F_W_TRANSPOSED | L.F_OFF_REVERSE | L.F_RESIDUAL_LAST, residual=R, relu_mask=Mk))
-            if sb is not None:
-                out.append(F.conv_rules_bf16(X, sb.tiles, sb.n_coarse, W8, b, cout, 0))
-        torch.cuda.synchronize()
-        return out
-    a = run()
-    a2 = run()
-    os.environ["SCN_TB_PAIR"] = "0"
-    try:
-        ref = run()
-    finally:
-        del os.environ["SCN_TB_PAIR"]
-    for u, v, w in zip(a, ref, a2):
-        assert torch.equal(u, v) and torch.equal(u, w)
-    assert float(a[0].float().abs().max()) > 0

@@ -27,6 +27,7 @@ def _empty(n, dtype, dev):
 
 
 _index_streams = {}
+_INDEX_PRIORITY = int(__import__("os").environ.get("SCN_INDEX_PRIORITY", "-1"))      # developer switch (A/B): -1 high, 0 normal
 
 
 def index_stream(device) -> "torch.cuda.Stream":
@@ -34,7 +35,7 @@ def index_stream(device) -> "torch.cuda.Stream":
     if st is None:
         # high priority: the index kernels are tiny and latency-bound; next to the matrix kernels of another batch they
         # should be dispatched as soon as a slot frees up
-        st = _index_streams[device] = torch.cuda.Stream(device=device, priority=-1)
+        st = _index_streams[device] = torch.cuda.Stream(device=device, priority=_INDEX_PRIORITY)
     return st
 
 

@@ -46,7 +46,7 @@ class FlatParams:
         self.grad_views = []
         # this rank's share of a count-weighted mean (the reference normalises its losses by batch-level counts,
         # loss.py:401-431: a scene contributes in proportion to its rows).  The bucketed path applies it when a slice is
-        # packed, i.e. DURING backward: set it before backward starts (SceneStep does).
+        # packed, i.e. DURING backward: set it before backward starts.
         self.rank_weight = 1.0
         self.grad_scale = 1.0         # mean gradient = flat_grad * grad_scale (valid after all_reduce_mean)
         self.flat_grad_valid = False  # False after a step that never packed the flat buffer (step_single_rank fast path)

@@ -237,7 +237,6 @@ def compile_encoder_stage(level, head, blocks, cin_phys, bf16, cast_first=False,
         x = st.buf(level, c)
         st.op(st.fwd, OP_CONV_CHILD, level - 1, cin_phys, c, x=IN, y=x, w=st.weight(mh, cin_phys, c, 8, 0, True),
               b=st.param("b", mh), flags=st.hb)
-    head_out = x
     if bf16 and cast_last:
         last, saved = st.units_fwd(level, c, x, blocks)
         st.op(st.fwd, OP_CAST, level, c, 0, x=last, y=OUT, flags=0)
@@ -271,7 +270,6 @@ def compile_encoder_stage(level, head, blocks, cin_phys, bf16, cast_first=False,
         st.op(st.bwd, OP_RULES_CHILD, level - 1, c, cin_phys, x=g, y=DIN, w=st.param("w", mh), flags=L.F_W_TRANSPOSED | st.hb)
         st.op(st.bwd, OP_WGRAD_DOWN, level - 1, cin_phys, c, x=IN, y=g, w=gw, flags=st.hb)
         st.op(st.bwd, OP_COLSUM, level, c, 0, x=g, b=gb, flags=st.hb)
-    del head_out
     return st.freeze()
 
 
@@ -437,7 +435,7 @@ class StageFunction(torch.autograd.Function):
         return (None, None, *dins, *grads)
 
 
-def run_stage(stage, levels, inputs, module_list=None):
+def run_stage(stage, levels, inputs):
     """Apply a compiled stage: the physical (W, b) of its modules are fetched through `_wb` (zero-padded views of the logical
     parameters where a layer is channel-padded -- autograd carries their gradients back through the pad)."""
     phys = []

@@ -49,9 +49,16 @@ class SparseStepModel(torch.nn.Module):
 
 class SceneStep:
     def __init__(self, workload="cfg2", device=None, dtype="f32", prefetch=True, seed=1, grad_seed=100, n_buckets=4,
-                 target=None, channels=None, grid=None, n_boxes=None, lr=1e-6):
+                 target=None, channels=None, grid=None, n_boxes=None, lr=1e-6, weighting="equal"):
+        """weighting: how the ranks' gradients are averaged -- "equal" (1 / world: balanced scenes, the benchmark) or "count"
+        (each rank in proportion to its active voxels: what a loss normalised by batch-level counts gives when the
+        batch is sharded one scene per rank, loss.py:401-431; the counts are summed over ranks once per step)."""
         ch, gr, tg, nb, self.baseline_entry, n_samples = WORKLOADS[workload]
         self.workload, self.dtype, self.prefetch, self.lr = workload, dtype, prefetch, lr
+        if weighting not in ("equal", "count"):
+            raise ValueError("weighting: equal | count")
+        self.weighting = weighting
+        self._total_weight = None
         self.channels = tuple(channels or ch)
         self.grid = tuple(grid or gr)
         self.n_boxes = nb if n_boxes is None else n_boxes
@@ -96,6 +103,14 @@ class SceneStep:
         if self._gy is None or self._gy.shape != out.features.shape:
             self._gy = torch.randn(out.features.shape, generator=self._gen).to(self.device)   # upstream grad dY ~ N(0,1)
             self.n_active = out.features.shape[0]
+        if self.weighting == "count":             # before backward: the bucketed path scales slices as it packs them
+            import torch.distributed as dist
+            self.flat.rank_weight = float(out.features.shape[0])
+            tot = torch.tensor([self.flat.rank_weight], dtype=torch.float64)
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                tot = tot.to(self.device if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(tot)
+            self._total_weight = float(tot.item())
         if m.mask is None:
             out.features.backward(self._gy)
             logits = None
@@ -113,6 +128,10 @@ class SceneStep:
 
     def step(self):
         self.forward_backward()
+        if self.weighting == "count":
+            self.flat.all_reduce_mean(total_weight=self._total_weight)
+            self.flat.sgd_step(self.lr)
+            return
         self.flat.step_single_rank(self.lr)      # = all_reduce_mean + sgd_step; one rank: no packing into the flat bucket
 
     def finish(self):

@@ -3,7 +3,7 @@ real Backbone (cfg2) or of Backbone + sparse ROI crop + mask branch (cfg3), run 
 MASTER_* in the environment, gloo collective so that two ranks may share one GPU).  Writes the parameters and the
 all-reduced mean gradient as seen by this rank.
 
-argv: out.npz target grid_x,grid_y,grid_z [workload [dtype [n_boxes [empty_rank]]]]
+argv: out.npz target[/target_rank1] grid_x,grid_y,grid_z [workload [dtype [n_boxes [empty_rank [weighting]]]]]
 empty_rank: that rank's boxes are moved outside the scene (its ROI crop is empty: no mask-branch gradients there)."""
 import os
 import sys
@@ -17,17 +17,20 @@ import torch.distributed as dist
 
 
 def main():
-    out_path, target, grid = sys.argv[1], int(sys.argv[2]), tuple(int(v) for v in sys.argv[3].split(","))
+    out_path, grid = sys.argv[1], tuple(int(v) for v in sys.argv[3].split(","))
+    targets = [int(t) for t in sys.argv[2].split("/")]             # one target per rank ("12000/8000") or one for all
     workload = sys.argv[4] if len(sys.argv) > 4 else "cfg2"
     dtype = sys.argv[5] if len(sys.argv) > 5 else "f32"
     n_boxes = int(sys.argv[6]) if len(sys.argv) > 6 else None
     empty_rank = int(sys.argv[7]) if len(sys.argv) > 7 else -1
+    weighting = sys.argv[8] if len(sys.argv) > 8 else "equal"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    target = targets[rank % len(targets)]
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
     from sparse_rcnn_amd.trainstep import SceneStep
     job = SceneStep(workload, torch.device("cuda", 0), dtype=dtype, prefetch=False, seed=10 + rank, grad_seed=100 + rank,
-                    n_buckets=4, target=target, grid=grid, lr=0.0, n_boxes=n_boxes)
+                    n_buckets=4, target=target, grid=grid, lr=0.0, n_boxes=n_boxes, weighting=weighting)
     assert job.flat.buckets, "the bucketed, overlapped all-reduce must be active with 2 ranks"
     if rank == empty_rank:
         job.boxes = [b + 10_000.0 for b in job.boxes]

@@ -450,11 +450,14 @@ def _load_masks(z):
     return out
 
 
-def test_two_rank_dp_step_matches_oracle(gpu, tmp_path):
+@pytest.mark.parametrize("weighting", ["equal", "count"])
+def test_two_rank_dp_step_matches_oracle(gpu, tmp_path, weighting):
     """BASELINE configs[3]'s mechanism on one GPU: two fresh processes (gloo, both on cuda:0), one scene each, one step of
     the real Backbone 32-64-128-256 through trainstep.SceneStep with the bucketed all-reduce overlapped with backward.
-    The averaged gradient every rank ends up with == the mean of the two scenes' ORACLE gradients."""
-    target, grid = 12_000, (128, 128, 64)
+    The averaged gradient every rank ends up with == the mean of the two scenes' ORACLE gradients (each oracle run with the
+    ReLU masks its rank recorded).  "count": scenes of 12k and 8k voxels, every rank weighted by its active voxels -- what a
+    loss normalised by batch-level counts gives when the batch is sharded one scene per rank (loss.py:401-431)."""
+    targets, grid = ((12_000, 12_000) if weighting == "equal" else (12_000, 8_000)), (128, 128, 64)
     port = _free_port()
     procs, outs = [], []
     for r in range(2):
@@ -462,8 +465,9 @@ def test_two_rank_dp_step_matches_oracle(gpu, tmp_path):
         outs.append(out)
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_rank_worker.py"), out, str(target),
-                                       ",".join(map(str, grid))], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_rank_worker.py"), out,
+                                       "/".join(map(str, targets)), ",".join(map(str, grid)), "cfg2", "f32", "0", "-1", weighting],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), logs
     z = [np.load(o) for o in outs]
@@ -474,19 +478,22 @@ def test_two_rank_dp_step_matches_oracle(gpu, tmp_path):
     for k in names:
         assert np.array_equal(z[0][k], z[1][k]), k                            # broadcast: ranks hold the same parameters
         assert np.array_equal(z[0]["g:" + k], z[1]["g:" + k]), k               # ... and the same reduced gradient
+    n_act = [int(z[r]["n_active"]) for r in range(2)]
+    w = [0.5, 0.5] if weighting == "equal" else [n / sum(n_act) for n in n_act]
+    assert weighting == "equal" or n_act[0] != n_act[1]
     mean = None
     for r in range(2):
-        coords, feats, size, bs, _ = make_batch(1, grid, target, dup=1.15, seed=10 + r)
+        coords, feats, size, bs, _ = make_batch(1, grid, targets[r], dup=1.15, seed=10 + r)
         scene = O.OracleScene(coords.numpy())
-        assert scene.n(0) == int(z[r]["n_active"])
+        assert scene.n(0) == n_act[r]
         po = {k: torch.from_numpy(z[0][k]).view(shapes[k]).requires_grad_() for k in names}
         out = O.unet_forward(scene, feats, po, ch, relu=O.FrozenReLU(_load_masks(z[r])))     # this rank's recorded masks
         gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(100 + r))
         out.backward(gy)
-        gr = {k: po[k].grad / 2 for k in names}
+        gr = {k: po[k].grad * w[r] for k in names}
         mean = gr if mean is None else {k: mean[k] + gr[k] for k in names}
     for k in names:
-        _check_grad_frozen("cfg4_two_rank_dp_step", "mean grad " + k, torch.from_numpy(z[0]["g:" + k]).reshape(-1),
+        _check_grad_frozen("cfg4_two_rank_dp_step_" + weighting, "mean grad " + k, torch.from_numpy(z[0]["g:" + k]).reshape(-1),
                            mean[k].reshape(-1), FROZEN_L2_F32)
 
 
@@ -510,7 +517,7 @@ def test_two_rank_dp_cfg3_step_matches_oracle(gpu, tmp_path, case):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_rank_worker.py"), out, str(target),
-                                       ",".join(map(str, grid)), "cfg3", dtype, str(n_boxes), str(empty)], env=env,
+                                       ",".join(map(str, grid)), "cfg3", dtype, str(n_boxes), str(empty), "equal"], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=900)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), logs

@@ -56,6 +56,11 @@ struct DPlan {
 
 template <int T>
 struct Frag { typedef float type __attribute__((ext_vector_type(T))); };
+// T = 3 (48-channel wave blocks: the reference's 48- and 96-channel layers are whole multiples): a row piece is three
+// dwords at a 12-byte lane pitch, so the type must not promise the 16-byte alignment a 3-vector has by default
+typedef float f32x3_u __attribute__((ext_vector_type(3), aligned(4)));
+template <>
+struct Frag<3> { typedef f32x3_u type; };
 
 // operand pairs of the problems of a launch (by value in the kernel arguments)
 struct WdOps { const void* X[WD_MAX_PROB]; const void* dY[WD_MAX_PROB]; };
@@ -72,7 +77,7 @@ __device__ __forceinline__ int wd_offset_of(const DPlan& plan, int unit, int lan
 // bf16 values as loaded (half the registers, half the gather bytes), widened to fp32 when the block is multiplied:
 // element 2j is the low half of word j (<< 16), element 2j+1 the high half (& 0xffff0000) -- exact, one VALU op each.
 template <int T, bool PACKED>
-struct RawFrag { typedef float type __attribute__((ext_vector_type(T))); };
+struct RawFrag { typedef typename Frag<T>::type type; };
 template <>
 struct RawFrag<2, true> { typedef unsigned type __attribute__((ext_vector_type(1))); };
 template <>
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ 
     // ([wave][element][lane], conflict-free) and then OWNS a quarter of the elements: it adds the four copies of its
     // quarter in wave order and writes those rows of the slab -- the epilogue is spread over the 4 waves and never holds
     // more than one quarter in registers (a first version had wave 0 add everything: 200+ VGPRs, one wave per SIMD).
-    // acc[a][b][j] is row TA*(4kq+j)+a, column TB*i+b of the wave block; owner of (a, j): a (TA = 4), 2a + j/2 (TA = 2).
+    // acc[a][b][j] is row TA*(4kq+j)+a, column TB*i+b of the wave block.
     if (!QUAD) {
         float* mine = red + wave * (NACC * 4 * 64);
 #pragma unroll
@@ -343,12 +348,12 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mine[((a * TB + b) * 4 + j) * 64 + lane] = acc[a][b][j];
         __syncthreads();
-        constexpr int NJ = TA == 4 ? 4 : 2;                              // (a, j) pairs per owner
-        const int a_own = TA == 4 ? wave : (wave >> 1);
-        const int j_own = TA == 4 ? 0 : 2 * (wave & 1);
+        // the 4 TA (a, j) pairs in order p = 4 a + j, TA consecutive ones per wave (TA = 4: a = wave; TA = 2: a = wave / 2,
+        // j = 2 (wave & 1) + jj -- the owners of rounds 1-2; TA = 3: three pairs that may straddle two a)
 #pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) {
-            const int jx = j_own + jj;
+        for (int jj = 0; jj < TA; ++jj) {
+            const int p_own = wave * TA + jj;
+            const int a_own = p_own >> 2, jx = p_own & 3;
             fb_t v;
 #pragma unroll
             for (int b = 0; b < TB; ++b) {
@@ -664,11 +669,15 @@ __global__ __launch_bounds__(256) void k_wgradd_sum(const float* __restrict__ sl
 namespace {
 struct Shape { int ta, tb; bool quad; };
 
-Shape pick_shape(int cin, int cout) {
+Shape pick_shape(int cin, int cout, bool hb = false) {
     Shape s;
     s.ta = cin > 32 ? 4 : 2;
     s.tb = cout > 32 ? 4 : 2;
     s.quad = cin > 64 && cout > 64;
+    // the reference's 48- and 96-channel layers (scannet_config/run.py:539-549): whole multiples of a 48-wide wave block
+    // (TA = TB = 3) -- 64- / 128-wide blocks execute 1.78x their MFMAs (fp32 rows only: no packed-bf16 ring for T = 3)
+    const bool no_t3 = getenv("SCN_WD_NO_T3") != nullptr;         // (read per call: the tests switch it inside one process)
+    if (!hb && !no_t3 && cin % 48 == 0 && cout % 48 == 0 && cin <= 96 && cout <= 96) { s.ta = s.tb = 3; s.quad = false; }
     return s;
 }
 
@@ -679,8 +688,8 @@ bool tb_usable(int cin, int cout) {
     return !off && cin % 8 == 0 && cout % 8 == 0;
 }
 
-int make_dplan(int cin, int cout, const int64_t* prefix_host, int n_off, DPlan& pl, bool hb_mfma = false) {
-    const Shape sh = pick_shape(cin, cout);
+int make_dplan(int cin, int cout, const int64_t* prefix_host, int n_off, DPlan& pl, bool hb_mfma = false, bool hb = false) {
+    const Shape sh = pick_shape(cin, cout, hb || hb_mfma);
     pl.n_off = n_off;
     pl.n_real = n_off;
     pl.p_rules = 0;
@@ -700,7 +709,7 @@ int make_dplan(int cin, int cout, const int64_t* prefix_host, int n_off, DPlan& 
     // 1.05 rounds costs as much as 2.  Slots = 256 CUs x workgroups per CU (registers / LDS of the instantiation).
     // Every offset rounds its unit count up, hence the n_off margin.  R and the slot counts: tools/sweep_wgrad_splits.py.
     int occ = sh.quad ? 2 : (sh.ta == 4 && sh.tb == 4 ? 2 : (sh.ta == 2 && sh.tb == 2 ? 4 : 3));
-    int rounds = (sh.quad ? nblk > 1 : (sh.ta == 4 && sh.tb == 4)) ? 2 : 1;
+    int rounds = (sh.quad ? nblk > 1 : (sh.ta == 4 && sh.tb == 4) || (sh.ta == 3 && nblk > 1)) ? 2 : 1;
     if (hb_mfma) { occ = 4; rounds = 1; }                                   // 32 KB of LDS, <= 128 registers: 4 per CU
     int64_t target = (256 * occ * rounds) / nblk - n_off;
     if (const char* e = getenv("SCN_WGRAD_SPLITS")) target = atoi(e);       // developer override
@@ -719,12 +728,13 @@ int make_dplan(int cin, int cout, const int64_t* prefix_host, int n_off, DPlan& 
 
 extern "C" int64_t scn_wgrad_scratch_bytes(int cin, int cout, const int64_t* prefix_host, int n_off) {
     if (!prefix_host || n_off < 1 || n_off > 32 || cin < 1 || cout < 1) return -1;
-    // the larger of the two plans a call may use (fp32-MFMA kernel; bf16-MFMA kernel for bf16-stored operands)
+    // the largest of the plans a call may use: fp32 rows (v = 0), bf16-stored rows on the fp32-MFMA kernel (v = 1: other
+    // block shapes than v = 0 where 48-wide blocks apply), bf16-MFMA kernel (v = 2)
     int64_t best = -1;
-    for (int hb = 0; hb < 2; ++hb) {
-        if (hb && !tb_usable(cin, cout)) continue;
+    for (int v = 0; v < 3; ++v) {
+        if (v == 2 && !tb_usable(cin, cout)) continue;
         DPlan pl;
-        if (make_dplan(cin, cout, prefix_host, n_off, pl, hb != 0) != SCN_OK) return -1;
+        if (make_dplan(cin, cout, prefix_host, n_off, pl, v == 2, v == 1) != SCN_OK) return -1;
         const int64_t b = (int64_t)pl.unit_start[n_off] *
                               ((int64_t)pl.nbi * pl.nbj * pl.cbi * pl.cbj + (int64_t)pl.nbj * pl.cbj) * (int64_t)sizeof(float) + 512;
         if (b > best) best = b;
@@ -735,13 +745,13 @@ extern "C" int64_t scn_wgrad_scratch_bytes(int cin, int cout, const int64_t* pre
 // n_prob problems on one rule list: n_prob x n_off virtual offsets, problem p's rules behind those of problem p - 1 in the
 // virtual rule space; dW = [n_prob][n_off][cin][cout], db = [n_prob][cout].
 static int multi_problem_plan(int cin, int cout, const int64_t* prefix_host, int n_off, int n_prob, DPlan& pl,
-                              bool hb_mfma = false) {
+                              bool hb_mfma = false, bool hb = false) {
     if (n_off > 32 || n_prob < 2 || n_prob > WD_MAX_PROB || prefix_host[0] != 0) return SCN_EINVAL;
     int64_t vprefix[129];
     const int64_t P = prefix_host[n_off];
     for (int v = 0; v <= n_prob * n_off; ++v) vprefix[v] = (v / n_off) * P + prefix_host[v % n_off];
     vprefix[n_prob * n_off] = n_prob * P;
-    const int rc = make_dplan(cin, cout, vprefix, n_prob * n_off, pl, hb_mfma);
+    const int rc = make_dplan(cin, cout, vprefix, n_prob * n_off, pl, hb_mfma, hb);
     pl.n_real = n_off;
     pl.p_rules = P;
     return rc;
@@ -769,8 +779,8 @@ static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const 
     const int n_off = n_prob * n_off_real;                                   // (virtual) offsets of the launch
     const bool mfma16 = hb && tb_usable(cin, cout) && ((all_ptrs & 15) == 0);
     DPlan pl;
-    if (multi) SCN_REQUIRE(multi_problem_plan(cin, cout, prefix_host, n_off_real, n_prob, pl, mfma16) == SCN_OK);
-    else SCN_REQUIRE(make_dplan(cin, cout, prefix_host, n_off, pl, mfma16) == SCN_OK);
+    if (multi) SCN_REQUIRE(multi_problem_plan(cin, cout, prefix_host, n_off_real, n_prob, pl, mfma16, hb) == SCN_OK);
+    else SCN_REQUIRE(make_dplan(cin, cout, prefix_host, n_off, pl, mfma16, hb) == SCN_OK);
     SCN_REQUIRE(prefix_host[n_off_real] == prefix_host[0] || (X && dY));
     SCN_REQUIRE((all_ptrs & (hb ? 1 : 3)) == 0);
     if (pl.unit_start[n_off] == 0) {
@@ -778,10 +788,10 @@ static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const 
         if (db) SCN_HIP(hipMemsetAsync(db, 0, sizeof(float) * (size_t)n_prob * cout, S(stream)));
         return SCN_OK;
     }
-    const Shape sh = pick_shape(cin, cout);
+    const Shape sh = pick_shape(cin, cout, hb);
     // vector row pieces need aligned rows and whole blocks; anything else takes the element-wise (EDGE) instantiation
     const bool edge = (cin % (16 * sh.ta) != 0) || (cout % (16 * sh.tb) != 0) ||
-                      ((all_ptrs & 15) != 0);
+                      ((all_ptrs & (sh.ta == 3 ? 3 : 15)) != 0);
     const bool ident = in_rows == nullptr;
     const int cout_pad = pl.nbj * pl.cbj;
     float* db_slabs = db ? (float*)scratch + (int64_t)pl.unit_start[n_off] * pl.nbi * pl.nbj * pl.cbi * pl.cbj : nullptr;
@@ -830,6 +840,7 @@ static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const 
         else { if (edge) PICK_I(TA_, TB_, Q_, true, false); else PICK_I(TA_, TB_, Q_, false, false); }           \
     } while (0)
     if (sh.quad) PICK_EI(4, 4, true);
+    else if (sh.ta == 3) { if (ident) LAUNCH_WD(3, 3, false, false, true, false); else LAUNCH_WD(3, 3, false, false, false, false); }
     else if (sh.ta == 4 && sh.tb == 4) PICK_EI(4, 4, false);
     else if (sh.ta == 4) PICK_EI(4, 2, false);
     else if (sh.tb == 4) PICK_EI(2, 4, false);
@@ -888,10 +899,10 @@ extern "C" int scn_wgrad_bias_rules(const float* X, int cin, const float* dY, in
 extern "C" int64_t scn_wgrad_scratch_bytes_n(int cin, int cout, const int64_t* prefix_host, int n_off, int n_prob) {
     if (!prefix_host || n_off < 1 || n_off > 32 || cin < 1 || cout < 1 || n_prob < 2 || n_prob > WD_MAX_PROB) return -1;
     int64_t best = -1;
-    for (int hb = 0; hb < 2; ++hb) {                 // fp32-MFMA plan; bf16-MFMA plan for bf16-stored operands
-        if (hb && !tb_usable(cin, cout)) continue;
+    for (int v = 0; v < 3; ++v) {                    // fp32 rows; bf16-stored rows on the fp32-MFMA kernel; bf16-MFMA plan
+        if (v == 2 && !tb_usable(cin, cout)) continue;
         DPlan pl;
-        if (multi_problem_plan(cin, cout, prefix_host, n_off, n_prob, pl, hb != 0) != SCN_OK) return -1;
+        if (multi_problem_plan(cin, cout, prefix_host, n_off, n_prob, pl, v == 2, v == 1) != SCN_OK) return -1;
         const int64_t b = (int64_t)pl.unit_start[n_prob * n_off] *
                               ((int64_t)pl.nbi * pl.nbj * pl.cbi * pl.cbj + (int64_t)pl.nbj * pl.cbj) * (int64_t)sizeof(float) + 512;
         if (b > best) best = b;

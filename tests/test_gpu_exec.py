@@ -221,3 +221,40 @@ def test_wgrad_whole_fragment_edge_blocks_keep_vector_loads_and_the_bits(gpu, ci
     for u, v in zip(a, ref):
         assert torch.equal(u, v)
     assert float(a[0].abs().max()) > 0
+
+
+@pytest.mark.parametrize("c", [48, 96])
+def test_wgrad_48_wide_blocks_match_the_padded_blocks(gpu, c):
+    """k_wgrad_direct<3,3> (round 3): the reference's 48- and 96-channel layers are whole multiples of a 48-wide wave block
+    (three-dword row pieces) instead of padded 64- / 128-wide ones (1.78x the MFMAs).  Same rules, same per-rule products;
+    the unit plan differs, so the fp32 unit sums associate differently: <= 2e-6 of the scale against the padded blocks
+    (SCN_WD_NO_T3=1), single and paired problems, weight and bias gradients, the identity list (NetworkInNetwork)."""
+    import os
+    import sparse_rcnn_amd as scn
+    from sparse_rcnn_amd import functional as F, _lib as L
+    coords, feats, size, bs, _ = _scene(20_000, (256, 256, 128), seed=6)
+    x = scn.InputLayer(3, size, mode=4)((coords, feats.to(gpu), 1))
+    rb = x.metadata.subm_rulebook(size, 3)
+    r = rb.rules
+    g = torch.Generator().manual_seed(c)
+    X = torch.randn(rb.n, c, generator=g).to(gpu)
+    dY = torch.randn(rb.n, c, generator=g).to(gpu)
+    X2, dY2 = (X * 0.5 + 1.0).contiguous(), (dY * 2.0).contiguous()
+
+    def run():
+        a = F.wgrad_bias_rules(X, dY, r.in_rows, r.out_rows, r.prefix_host, 27, 1 << 13, L.F_RELU_IN)
+        b = F.wgrad_bias_rules2(X, dY, X2, dY2, r.in_rows, r.out_rows, r.prefix_host, 27, 1 << 13, L.F_RELU_IN)
+        n = F.wgrad_bias_rules(X, dY, None, None, F._identity_prefix(rb.n), 1, 1)
+        torch.cuda.synchronize()
+        return [a[0], a[1], b[0], b[1], n[0], n[1]]
+    a = run()
+    a2 = run()
+    os.environ["SCN_WD_NO_T3"] = "1"
+    try:
+        ref = run()
+    finally:
+        del os.environ["SCN_WD_NO_T3"]
+    for u, v, w in zip(a, ref, a2):
+        assert torch.equal(u, w)                                              # reproducible
+        scale = float(v.abs().max())
+        assert float((u - v).abs().max()) <= 2e-6 * scale, (float((u - v).abs().max()), scale)

@@ -33,6 +33,7 @@ _SIGS = {
     "scn_rules_fill": (C.c_int, [p, i32, i64, p, p, p, p, p]),
     "scn_pyramid_workspace_bytes": (i64, [i64, i32, i32]),
     "scn_pyramid_build": (C.c_int, [p, i64, i32, i32, p, i64, C.POINTER(i64), p]),
+    "scn_pyramid_build_ex": (C.c_int, [p, i64, i32, i32, p, i64, C.POINTER(i64), i32, p]),
     "scn_roi_units": (i64, [i64]),
     "scn_roi_count": (C.c_int, [p, i64, p, i32, p, p, p, p]),
     "scn_roi_fill": (C.c_int, [p, i64, p, i32, p, p, p, p, p, p]),
@@ -122,6 +123,7 @@ EXPORTS = tuple(_SIGS)
 F_RELU_IN, F_W_TRANSPOSED, F_OFF_REVERSE, F_RESIDUAL_LAST, F_SPLIT_SUM, F_GEMM_V1 = 1, 2, 4, 8, 16, 32
 OK, EINVAL, ESIZE, EHASH, EHIP = 0, 1, 2, 3, 4
 PYRAMID_MAX_LEVELS, PYRAMID_LEVEL_STRIDE = 8, 72
+PYRAMID_TWO_QUEUES = 1
 PYRAMID_DESC_LEN = 8 + PYRAMID_MAX_LEVELS * PYRAMID_LEVEL_STRIDE
 COLSUM_BLOCKS = 512
 

@@ -13,6 +13,8 @@
 // The call waits for the device once per level size (events behind the count copies, which are queued AHEAD of the SubM work
 // of the level above: the GPU keeps working while the host learns a size) and once for the rule-list sizes, after which the
 // compacted rule lists are queued too; all of them on the caller's stream only.
+#include <stdlib.h>
+
 #include "scn_common.h"
 
 using scn::S;
@@ -24,9 +26,25 @@ namespace {
 // level above are queued, and the host waits for the copy's event only -- it learns the count while that work still runs
 // and queues the next level behind it, so the GPU no longer idles through a host round trip per level (round 2: the copy
 // sat behind the SubM work and the host waited for the whole stream, five times per build).
+// Round 3 also splits the build over TWO queues: the caller's stream carries the chain every level depends on (number the
+// coarse sites of level l + 1 -> child table / rule scan / tiles of the strided rulebook l -> number level l + 2 ...), a
+// library-owned side stream the SubM work of every level (neighbour table, rule scan, mask sort, tiles: ~30 launches per
+// level that nothing on the main chain waits for).  ~130 launches of a few microseconds each used to run back to back; now
+// the two chains (~55 and ~75 launches) run side by side: 1.06 -> 0.90 ms per build alone on an idle GPU, 1.50 -> 1.18 for
+// six levels (tools/index_ab.py).  The side stream is ordered behind the event that marks a level's grid complete, and the
+// caller's stream is ordered behind the side stream before the call returns (the caller still sees ONE stream-ordered
+// build).  It is an OPTION (scn_pyramid_build_ex, SCN_PYRAMID_TWO_QUEUES): next to another batch's matrix kernels -- the
+// pipelined prefetch of bench.py -- the second queue of tiny high-priority kernels costs the step ~0.1 ms (5.83 vs 5.71 ms,
+// three alternating runs), so only the inline builds ask for it.  One side stream PER LEVEL and rulebook kind (up to 16
+// queues) was measured too: no faster alone (1.27 vs 1.25 ms) and the pipelined step lost 0.4 ms.
+// SCN_PYRAMID_ONE_STREAM=1: everything on the caller's stream whatever the flag (same bits either way).
 struct HostSlots {
     int64_t* words = nullptr;                       // [SCN_PYRAMID_MAX_LEVELS + 2]
-    hipEvent_t ev[SCN_PYRAMID_MAX_LEVELS + 2] = {};
+    hipEvent_t ev[SCN_PYRAMID_MAX_LEVELS + 2] = {};  // count copies
+    hipEvent_t grid_ev[SCN_PYRAMID_MAX_LEVELS + 1] = {};   // grid of level l complete on the caller's stream
+    static constexpr int NSIDE = 1;
+    hipEvent_t join_ev[NSIDE] = {};
+    hipStream_t side[NSIDE] = {};                           // the SubM work of every level
     bool ok = false;
     bool init() {
         if (ok) return true;
@@ -34,6 +52,14 @@ struct HostSlots {
             return false;
         for (auto& e : ev)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+        for (auto& e : grid_ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+        for (auto& e : join_ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return false;
+        for (auto& q : side)
+            if (hipStreamCreateWithPriority(&q, hipStreamNonBlocking, hi) != hipSuccess) return false;
         ok = true;
         return true;
     }
@@ -88,6 +114,11 @@ extern "C" int64_t scn_pyramid_workspace_bytes(int64_t n_points, int n_levels, i
 
 extern "C" int scn_pyramid_build(const int64_t* coords, int64_t n_points, int n_levels, int k, void* workspace,
                                  int64_t workspace_bytes, int64_t* desc, scn_stream_t stream) {
+    return scn_pyramid_build_ex(coords, n_points, n_levels, k, workspace, workspace_bytes, desc, 0, stream);
+}
+
+extern "C" int scn_pyramid_build_ex(const int64_t* coords, int64_t n_points, int n_levels, int k, void* workspace,
+                                    int64_t workspace_bytes, int64_t* desc, int flags, scn_stream_t stream) {
     SCN_REQUIRE(coords && workspace && desc && n_points >= 1 && n_levels >= 1 && n_levels <= SCN_PYRAMID_MAX_LEVELS);
     SCN_REQUIRE(k == 1 || k == 3);
     SCN_REQUIRE(((uintptr_t)workspace & 255) == 0);
@@ -127,6 +158,18 @@ extern "C" int scn_pyramid_build(const int64_t* coords, int64_t n_points, int n_
     const int64_t n_rows = hs.words[0];
     const int32_t bad = (int32_t)hs.words[1];
     desc[3] = bad;
+    const bool two = (flags & SCN_PYRAMID_TWO_QUEUES) && getenv("SCN_PYRAMID_ONE_STREAM") == nullptr;
+    bool side_used[HostSlots::NSIDE] = {};
+    // an error return while side streams still work on the caller's workspace must not hand that workspace back
+    struct SideGuard {
+        hipStream_t* s; const bool* used; bool armed = true;
+        ~SideGuard() {
+            if (armed)
+                for (int q = 0; q < HostSlots::NSIDE; ++q)
+                    if (used[q]) (void)hipStreamSynchronize(s[q]);
+        }
+    } side_guard{hs.side, side_used};
+    if (two) SCN_HIP(hipEventRecord(hs.grid_ev[0], st));            // level 0's grid (row coordinates, hash) is complete
     if (bad) return scn::fail(SCN_EHASH, "%scoordinates outside [0,65535] in %lld wave(s)", "", (long long)bad);
 
     // ---- levels --------------------------------------------------------------------------------------------------
@@ -159,6 +202,7 @@ extern "C" int scn_pyramid_build(const int64_t* coords, int64_t n_points, int n_
             // the count starts its way back now; the SubM work of this level is queued behind it
             SCN_HIP(hipMemcpyAsync(&hs.words[2 + l], ncnt, 8, hipMemcpyDeviceToHost, st));
             SCN_HIP(hipEventRecord(hs.ev[1 + l], st));
+            if (two) SCN_HIP(hipEventRecord(hs.grid_ev[l + 1], st));    // level l + 1's grid is complete behind this point
         }
         if (n > 0 && k > 1) {
             const int64_t nt = nt_of(n);
@@ -172,9 +216,15 @@ extern "C" int scn_pyramid_build(const int64_t* coords, int64_t n_points, int n_
             int32_t* torder = (int32_t*)ws.take(nt * 4, &off);                           L[12] = off; L[13] = nt;
             void* tscr = ws.take(scn_tiles_scratch_bytes(n_off, n), &off);
             SCN_REQUIRE(ws.ok);
-            if ((rc = scn_subm_table(lv_coords, n, lv_keys, lv_hrows, lv_cap, k, table, stream))) return rc;
-            if ((rc = scn_rules_scan(table, n_off, n, bsums, prefix, nullptr, stream))) return rc;
-            if ((rc = scn_tiles_build(table, n_off, n, perm, tstab, tmask, torder, tscr, stream))) return rc;
+            scn_stream_t sub = stream;
+            if (two) {
+                SCN_HIP(hipStreamWaitEvent(hs.side[0], hs.grid_ev[l], 0));
+                side_used[0] = true;
+                sub = (scn_stream_t)hs.side[0];
+            }
+            if ((rc = scn_subm_table(lv_coords, n, lv_keys, lv_hrows, lv_cap, k, table, sub))) return rc;
+            if ((rc = scn_rules_scan(table, n_off, n, bsums, prefix, nullptr, sub))) return rc;
+            if ((rc = scn_tiles_build(table, n_off, n, perm, tstab, tmask, torder, tscr, sub))) return rc;
             prefix_dev[l][0] = prefix;
         }
         if (!has_next) {
@@ -197,15 +247,22 @@ extern "C" int scn_pyramid_build(const int64_t* coords, int64_t n_points, int n_
             int32_t* torder = (int32_t*)ws.take(ntc * 4, &off);                          L[23] = off; L[24] = ntc;
             void* tscr = ws.take(scn_tiles_scratch_bytes(8, nc), &off);
             SCN_REQUIRE(ws.ok);
-            if ((rc = scn_child_table(lv_coords, parent, n, nc, child, fine_off, stream))) return rc;
-            if ((rc = scn_rules_scan(child, 8, nc, bsums, prefix, nullptr, stream))) return rc;
-            if ((rc = scn_tiles_build(child, 8, nc, perm, tstab, tmask, torder, tscr, stream))) return rc;
+            scn_stream_t cs = stream;          // (the strided rulebook stays on the main chain)
+            if ((rc = scn_child_table(lv_coords, parent, n, nc, child, fine_off, cs))) return rc;
+            if ((rc = scn_rules_scan(child, 8, nc, bsums, prefix, nullptr, cs))) return rc;
+            if ((rc = scn_tiles_build(child, 8, nc, perm, tstab, tmask, torder, tscr, cs))) return rc;
             prefix_dev[l][1] = prefix;
         }
         lv_coords = ncoords; lv_keys = nkeys; lv_hrows = nhrows; lv_cap = ncap;
         lv_off_coords = off_ncoords; lv_off_keys = off_nkeys; lv_off_hrows = off_nhrows;
         n = nc;
     }
+    for (int q = 0; q < HostSlots::NSIDE; ++q)                // from here on the caller's stream sees the side work too
+        if (side_used[q]) {
+            SCN_HIP(hipEventRecord(hs.join_ev[q], hs.side[q]));
+            SCN_HIP(hipStreamWaitEvent(st, hs.join_ev[q], 0));
+        }
+    side_guard.armed = false;
     // ---- rule-list sizes (consumed by the weight-gradient / rule-list GEMMs) -----------------------------------------
     for (int l = 0; l < n_levels; ++l) {
         int64_t* L = desc + 8 + l * SCN_PYRAMID_LEVEL_STRIDE;

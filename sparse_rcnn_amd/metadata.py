@@ -445,10 +445,12 @@ class Metadata:
             self.n_samples = int(c64[:, 3].max().item()) + 1 if n else 0
         return grid
 
-    def build_native(self, spatial_size, coords: torch.Tensor, batch_size: int, mode: int, n_levels: int, k: int = 3):
-        """set_input + build_pyramid through ONE C call (scn_pyramid_build): same structures, bit-identical, carved out of
+    def build_native(self, spatial_size, coords: torch.Tensor, batch_size: int, mode: int, n_levels: int, k: int = 3,
+                     two_queues: bool = True):
+        """set_input + build_pyramid through ONE C call (scn_pyramid_build_ex): same structures, bit-identical, carved out of
         one workspace tensor; the call holds no interpreter state, so a helper thread can run it next to the main
-        thread's kernel queueing (prepare_in_thread)."""
+        thread's kernel queueing (prepare_in_thread).  two_queues: the SubM work of the levels on the library's side stream
+        (shorter when the build has the GPU to itself: the inline builds; the pipelined prefetch passes False)."""
         lib = L.lib()
         size = tuple(int(s) for s in spatial_size)
         if len(size) != 3:
@@ -472,7 +474,8 @@ class Metadata:
             return self
         ws = torch.empty(lib.scn_pyramid_workspace_bytes(n, n_levels, k), dtype=torch.uint8, device=dev)
         desc = (C.c_int64 * L.PYRAMID_DESC_LEN)()
-        L.check(lib.scn_pyramid_build(L.ptr(c64), n, n_levels, k, L.ptr(ws), ws.numel(), desc, L.stream()))
+        L.check(lib.scn_pyramid_build_ex(L.ptr(c64), n, n_levels, k, L.ptr(ws), ws.numel(), desc,
+                                         L.PYRAMID_TWO_QUEUES if two_queues else 0, L.stream()))
         self._workspace = ws
 
         def view(off, count, dtype, shape=None):
@@ -610,8 +613,8 @@ class Metadata:
         side.wait_stream(caller_stream if caller_stream is not None else torch.cuda.current_stream())
         self._prepared_for = (coords, coords._version)         # strong reference: the identity cannot be recycled
         with torch.cuda.stream(side):
-            if native and n_levels:
-                self.build_native(spatial_size, coords, batch_size, mode, n_levels, k)
+            if native and n_levels:        # beside another batch's matrix kernels: one queue (include/scn_mi355x.h)
+                self.build_native(spatial_size, coords, batch_size, mode, n_levels, k, two_queues=False)
             else:
                 self.set_input(spatial_size, coords, batch_size, mode, auto_native=False)
                 if n_levels:

@@ -401,9 +401,13 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         q1 = t;
     };
     auto ts_retire = [&]() {
-        // (a) the ticket of q2 has returned: combine if this wave arrived last
+        // (a) the ticket of q2 has returned; (b) the stores of q1 are drained: its ticket goes out FIRST, so that its round
+        // trip runs beside the combine of q2 instead of behind it (the two flush rounds behind a wave's last tile are a
+        // serial chain at the end of the launch); (c) combine q2 if this wave arrived last
+        const int ticket = __builtin_amdgcn_readfirstlane(tk_v);
+        if (q1 >= 0 && lane == 0)
+            tk_v = __hip_atomic_fetch_add(counters + (int)(q1 * n_chunks + chunk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (q2 >= 0) {
-            const int ticket = __builtin_amdgcn_readfirstlane(tk_v);
             if (ticket == n_kc - 1) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                    // compiler ordering only
                 const int unit = (int)(q2 * n_chunks + chunk);
@@ -438,9 +442,6 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
                 else ts_write(orow2, y0, y1);
             }
         }
-        // (b) the stores of q1 are drained: take its ticket
-        if (q1 >= 0 && lane == 0)
-            tk_v = __hip_atomic_fetch_add(counters + (int)(q1 * n_chunks + chunk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         q2 = q1;
         q1 = -1;
 #pragma unroll

@@ -26,6 +26,7 @@
 // K split over workgroups (Cin > 32 or 64): the partial tiles are added inside the launch by the wave that arrives last
 // at a (tile, column chunk) -- the pipelined hand-off of k_conv_ts (scn_conv_ts.hip), fp32 partials, fixed K-chunk order.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "scn_common.h"
 
@@ -38,6 +39,9 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define MFMAB(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
+#ifndef TB_EXP
+#define TB_EXP 0            // developer timing experiments (results invalid): 1 no K-split hand-off at all, 2 publish only,
+#endif                      // 3 publish + ticket without the combine
 static constexpr int TB_KC = 32;        // channels per K-chunk
 static constexpr int TB_T = 16;         // rows per tile
 static constexpr int TB_NW = 16;        // waves per workgroup
@@ -45,7 +49,7 @@ static constexpr int TB_NW = 16;        // waves per workgroup
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 
-template <int NB, int KH, bool FUSED>
+template <int NB, int KH, bool FUSED, bool PART>
 __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB == 2 && KH == 1 && !FUSED ? 8 : 4))) void k_conv_tb(
     const unsigned short* __restrict__ X, long long n_in, int cin, const int* __restrict__ tstab,
     const unsigned* __restrict__ tile_mask, const int* __restrict__ perm, const int* __restrict__ tile_order, int n_off,
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
     unsigned m_next = 0;
     int orow_next[4] = {-1, -1, -1, -1};
     if (tile_next >= 0) {
-        m_next = tile_mask[tile_next];
+        m_next = __builtin_amdgcn_readfirstlane(tile_mask[tile_next]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) orow_next[j] = perm[tile_next * TB_T + 4 * kq + j];
     }
@@ -129,26 +133,49 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
         __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(unsigned)(n_in * cin * 2), 0x00020000);
     const int row_bytes = cin * 2, lane_boff = (kc + 8 * kq) * 2;
     const unsigned short* wlane = Wb + (size_t)i * TB_KC + 8 * kq;   // + ((o KH + plane) CT + 16 nb) 32
+    // Round 3d: the step below is ISSUE-bound (four 16-cycle MFMAs against ~16 vector and ~12 scalar instructions of
+    // bookkeeping in the first version; SQ counters in profiles/r3_pmc_conv_tb.txt), so every piece of bookkeeping is
+    // written for its instruction count:
+    //   * row-index loads through a raw buffer descriptor of the tile table with a SCALAR offset (tile base + 64 offset):
+    //     no vector address arithmetic (was a 64-bit shift-add pair per load);
+    //   * the offset list is popped on the scalar unit (s_ff1_i32_b32 returns -1 for an empty mask, which is the queue's
+    //     "none" marker; a finished list re-reads its last offset: olast = max(olast, popped));
+    //   * the input ReLU is ONE v_pk_max_i16 per register against a scalar floor (0, or -32768 = identity), not a max
+    //     plus a select on the run-time flag;
+    //   * the channel-group guard of the gather address exists only in the PART instantiation (Cin % 32 != 0).
+    const __amdgpu_buffer_rsrc_t trsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)tstab, 0, (int)(unsigned)(nt * n_off * (TB_T * 4)), 0x00020000);
+    const int lane_i4 = i * 4;
+    const short relu_floor = relu_in ? (short)0 : (short)-32768;
+    const s16x8 floor8 = {relu_floor, relu_floor, relu_floor, relu_floor, relu_floor, relu_floor, relu_floor, relu_floor};
 
 #define TB_GATHER(IDX, A)                                                                             \
     do {                                                                                             \
         const int off_ = __mul24((IDX), row_bytes) + lane_boff;                                      \
         _Pragma("unroll") for (int hh_ = 0; hh_ < KH; ++hh_) {                                       \
-            const int oh_ = k_ok[hh_] ? off_ + 64 * hh_ : (int)0xFFFFFFF0;                           \
+            int oh_ = off_ + 64 * hh_;                                                               \
+            if constexpr (PART) oh_ = k_ok[hh_] ? oh_ : (int)0xFFFFFFF0;                             \
             A[hh_] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, oh_, 0, 0);                        \
         }                                                                                            \
     } while (0)
+    // pop the lowest offset of the (wave-uniform) mask m: O = its number or -1; olast = the last offset popped
+#define TB_POP(O)                                                                                    \
+    do {                                                                                             \
+        asm volatile("s_ff1_i32_b32 %0, %1" : "=s"(O) : "s"(m));                                     \
+        m &= m - 1;                                                                                  \
+        olast = max(olast, (O));                                                                     \
+    } while (0)
+#define TB_INDEX(DST) DST = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane_i4, tile_boff + olast * (TB_T * 4), 0)
 
     // one pipeline step: index of the offset five ahead, rows of the offset three ahead, MFMAs on the oldest set
 #define TB_STEP(CUR, GSET, IOLD, INEW)                                                               \
     do {                                                                                             \
-        int o4_ = -1;                                                                                \
-        if (m) { o4_ = __builtin_ctz(m); m &= m - 1; olast = o4_; }                                  \
-        INEW = tb_s[olast * TB_T + i];                                                               \
+        int o4_;                                                                                     \
+        TB_POP(o4_);                                                                                 \
+        TB_INDEX(INEW);                                                                              \
         TB_GATHER(IOLD, GSET);                                                                       \
         _Pragma("unroll") for (int hh_ = 0; hh_ < KH; ++hh_) {                                       \
-            s16x8 a_ = __builtin_bit_cast(s16x8, CUR[hh_]);                                          \
-            if (relu_in) a_ = __builtin_elementwise_max(a_, (s16x8){0, 0, 0, 0, 0, 0, 0, 0});        \
+            const s16x8 a_ = __builtin_elementwise_max(__builtin_bit_cast(s16x8, CUR[hh_]), floor8); \
             const bf16x8 af_ = __builtin_bit_cast(bf16x8, a_);                                       \
             const unsigned short* wo_ = wlane + ((size_t)oq0 * KH + hh_) * (CT * TB_KC);             \
             _Pragma("unroll") for (int nb_ = 0; nb_ < NB; ++nb_) {                                   \
@@ -165,8 +192,7 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
     // operands; otherwise every column is its own 2-byte access.
     constexpr int NWD = NB / 2;
     const bool vec_ok = (cout % NB == 0) && ((((uintptr_t)Y | (uintptr_t)residual | (uintptr_t)relu_mask) & (2 * NB - 1)) == 0);
-    auto tb_write = [&](const int (&orow)[4], const f32x4 (&acc)[NB]) {
-        unsigned rw[4][NWD], mw[4][NWD];
+    auto tb_load_ops = [&](const int (&orow)[4], unsigned (&rw)[4][NWD], unsigned (&mw)[4][NWD]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                                // all operand loads first, one wait
             const long long e = (long long)(orow[j] < 0 ? 0 : orow[j]) * cout + ncol;
@@ -192,6 +218,8 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
                 }
             }
         }
+    };
+    auto tb_store = [&](const int (&orow)[4], const f32x4 (&acc)[NB], const unsigned (&rw)[4][NWD], const unsigned (&mw)[4][NWD]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (orow[j] < 0) continue;
@@ -221,8 +249,20 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
             }
         }
     };
+    auto tb_write = [&](const int (&orow)[4], const f32x4 (&acc)[NB]) {
+        unsigned rw[4][NWD], mw[4][NWD];
+        tb_load_ops(orow, rw, mw);
+        tb_store(orow, acc, rw, mw);
+    };
+    // In-launch K reduction, pipelined over the wave's tiles (see k_conv_ts).  The combiner's loads are ONE round trip where
+    // it can be: the output rows are kept from the tile's own pass (not re-read through `perm`), the residual / ReLU-mask
+    // operands are requested together with the partial tiles, and R K-chunks of partials are in flight per round -- R = 2
+    // between tiles (the gather pipeline holds its registers), R = 4 in the two flush rounds behind the last tile, where the
+    // combine is a serial chain at the END of the launch (tools/ablate_tb_locality.py with -DTB_EXP: the combines cost
+    // 7-10 us of a 28-30 us launch at levels 1-3 of the cfg-2 scene before this).
     long long q1 = -1, q2 = -1;
     int tk_v = 0;
+    int orow_q1[4] = {-1, -1, -1, -1}, orow_q2[4] = {-1, -1, -1, -1};
     auto tb_publish = [&](long long t, const f32x4 (&acc)[NB]) {
         const int sb = (int)((t * n_chunks + chunk) * n_kc + kci) * (TB_T * CT * 4) + lane * 16;
 #pragma unroll
@@ -231,24 +271,32 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
                                                    srsrc, sb + nb * 1024, 0, 16);         // aux 16 = sc1: write-through
         q1 = t;
     };
-    auto tb_retire = [&]() {
+    auto tb_retire = [&](auto round_c) {
+        constexpr int R = decltype(round_c)::value;
+        // the ticket of q2 has returned (callers drained the wave); q1's ticket goes out FIRST, so that its round trip runs
+        // beside the combine of q2 instead of behind it
+        const int ticket = __builtin_amdgcn_readfirstlane(tk_v);
+        if (q1 >= 0 && lane == 0)
+            tk_v = __hip_atomic_fetch_add(counters + (int)(q1 * n_chunks + chunk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (q2 >= 0) {
-            const int ticket = __builtin_amdgcn_readfirstlane(tk_v);
             if (ticket == n_kc - 1) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                    // compiler ordering only
                 const int unit = (int)(q2 * n_chunks + chunk);
                 if (lane == 0) __hip_atomic_store(counters + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (TB_EXP == 3) goto tb_no_combine;
                 int orow2[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) orow2[j] = perm[q2 * TB_T + 4 * kq + j];
+                for (int j = 0; j < 4; ++j) orow2[j] = orow_q2[j];
+                unsigned rw[4][NWD], mw[4][NWD];
+                tb_load_ops(orow2, rw, mw);
                 const int sb = (unit * n_kc) * (TB_T * CT * 4) + lane * 16;
                 f32x4 y[NB];
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) y[nb] = (f32x4){bcol[nb], bcol[nb], bcol[nb], bcol[nb]};
-                for (int k0 = 0; k0 < n_kc; k0 += 2) {            // bias + slab[0] + slab[1] + ...: ascending K-chunks
-                    f32x4 p[2][NB];
+                for (int k0 = 0; k0 < n_kc; k0 += R) {            // bias + slab[0] + slab[1] + ...: ascending K-chunks
+                    f32x4 p[R][NB];
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
+                    for (int u = 0; u < R; ++u) {
                         const int k = k0 + u < n_kc ? k0 + u : n_kc - 1;
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb)
@@ -256,21 +304,24 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
                                 srsrc, sb + k * (TB_T * CT * 4) + nb * 1024, 0, 16));
                     }
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
+                    for (int u = 0; u < R; ++u) {
                         if (k0 + u < n_kc) {
 #pragma unroll
                             for (int nb = 0; nb < NB; ++nb) y[nb] += p[u][nb];
                         }
                     }
                 }
-                tb_write(orow2, y);
+                tb_store(orow2, y, rw, mw);
             }
         }
-        if (q1 >= 0 && lane == 0)
-            tk_v = __hip_atomic_fetch_add(counters + (int)(q1 * n_chunks + chunk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tb_no_combine:
         q2 = q1;
         q1 = -1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) orow_q2[j] = orow_q1[j];
     };
+    using R2 = std::integral_constant<int, 2>;
+    using R4 = std::integral_constant<int, 4>;
 
     while (tile_next >= 0) {
         const long long tile = tile_next;
@@ -278,26 +329,21 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
         int orow[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) orow[j] = orow_next[j];
-        const int* tb_s = tstab + tile * n_off * TB_T;
+        const int tile_boff = (int)tile * n_off * (TB_T * 4);       // byte offset of the tile's table block (< 2^31: host)
         const int n_steps = __popc(m);
         tile_next = grab();
         if (tile_next >= 0) {
-            m_next = tile_mask[tile_next];
+            m_next = __builtin_amdgcn_readfirstlane(tile_mask[tile_next]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) orow_next[j] = perm[tile_next * TB_T + 4 * kq + j];
         }
-        int oq0 = -1, oq1 = -1, oq2 = -1, oq3 = -1, oq4 = -1, iq0, iq1, iq2, iqa, iqb, iqc, iqd;
+        int oq0, oq1, oq2, oq3, oq4, iq0, iq1, iq2, iqa, iqb, iqc, iqd;
         int olast = 0;
-        if (m) { oq0 = __builtin_ctz(m); m &= m - 1; olast = oq0; }
-        iq0 = tb_s[olast * TB_T + i];
-        if (m) { oq1 = __builtin_ctz(m); m &= m - 1; olast = oq1; }
-        iq1 = tb_s[olast * TB_T + i];
-        if (m) { oq2 = __builtin_ctz(m); m &= m - 1; olast = oq2; }
-        iq2 = tb_s[olast * TB_T + i];
-        if (m) { oq3 = __builtin_ctz(m); m &= m - 1; olast = oq3; }
-        iqa = tb_s[olast * TB_T + i];
-        if (m) { oq4 = __builtin_ctz(m); m &= m - 1; olast = oq4; }
-        iqb = tb_s[olast * TB_T + i];
+        TB_POP(oq0); TB_INDEX(iq0);
+        TB_POP(oq1); TB_INDEX(iq1);
+        TB_POP(oq2); TB_INDEX(iq2);
+        TB_POP(oq3); TB_INDEX(iqa);
+        TB_POP(oq4); TB_INDEX(iqb);
         __builtin_amdgcn_sched_barrier(0);
         i32x4 s0[KH], s1[KH], s2[KH], s3[KH];
         TB_GATHER(iq0, s0);
@@ -324,9 +370,13 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
 
         // ---- tile epilogue -------------------------------------------------------------------------------------
         if (FUSED && !single) {             // pipelined hand-off, see k_conv_ts
+            if (TB_EXP == 1) { if (acc[0][0] == 123.456f) tb_publish(tile, acc); continue; }
+            if (TB_EXP == 2) { tb_publish(tile, acc); continue; }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            tb_retire();
+            tb_retire(R2{});
             tb_publish(tile, acc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) orow_q1[j] = orow[j];
             continue;
         }
         if (direct) tb_write(orow, acc);
@@ -342,12 +392,14 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
     }
     if (FUSED && !single) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tb_retire();
+        tb_retire(R4{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tb_retire();
+        tb_retire(R4{});
     }
 }
 #undef TB_STEP
+#undef TB_INDEX
+#undef TB_POP
 #undef TB_GATHER
 
 
@@ -552,6 +604,7 @@ extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, con
     SCN_REQUIRE(X && tstab && tile_mask && perm && tile_order && image && Y && scratch);
     SCN_REQUIRE((((uintptr_t)X | (uintptr_t)image) & 15) == 0);
     SCN_REQUIRE(n_in < (1ll << 23) && n_in * cin * 2 < (1ll << 32) - (1ll << 24));    // 24-bit rows, 32-bit offsets
+    SCN_REQUIRE(n_out < (1ll << 23));                             // the tile table is addressed with 31-bit byte offsets
     const int64_t nt = cdiv(n_out, TB_T);
     const TbShape sh = tb_shape(cin, cout);
     const int nb = sh.nb, kh = sh.kh, ct = sh.ct, kcs = sh.kc, n_chunks = sh.n_chunks, n_kc = sh.n_kc;
@@ -567,19 +620,26 @@ extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, con
                        nt * n_chunks * n_kc * (int64_t)(TB_T * ct * 4) < (1ll << 31);
     dim3 grid((unsigned)(n_tg * n_chunks * n_kc));
     hipStream_t st = S(stream);
-#define LAUNCH_TB(N, K, FU)                                                                                         \
+    const bool part = cin % kcs != 0;                              // the last K-chunk has channel groups past Cin
+#define LAUNCH_TB(N, K, FU, PT)                                                                                     \
     do {                                                                                                            \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
-            SCN_HIP(hipFuncSetAttribute((const void*)k_conv_tb<N, K, FU>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            SCN_HIP(hipFuncSetAttribute((const void*)k_conv_tb<N, K, FU, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                         160 * 1024));                                                               \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((k_conv_tb<N, K, FU>), grid, dim3(TB_NW * 64), lds, st, X, (long long)n_in, cin, tstab,  \
+        hipLaunchKernelGGL((k_conv_tb<N, K, FU, PT>), grid, dim3(TB_NW * 64), lds, st, X, (long long)n_in, cin, tstab, \
                            tile_mask, perm, tile_order, n_off, (long long)nt, image, bias, residual, relu_mask, Y, slabs, \
                            (long long)n_out, cout, flags, n_chunks, n_kc, (int*)arrival);                           \
     } while (0)
-#define PICK_TB(N, K) do { if (fused) LAUNCH_TB(N, K, true); else LAUNCH_TB(N, K, false); } while (0)
+#define PICK_TB(N, K)                                                                                               \
+    do {                                                                                                            \
+        if (fused && part) LAUNCH_TB(N, K, true, true);                                                             \
+        else if (fused) LAUNCH_TB(N, K, true, false);                                                               \
+        else if (part) LAUNCH_TB(N, K, false, true);                                                                \
+        else LAUNCH_TB(N, K, false, false);                                                                         \
+    } while (0)
     if (kh == 2) PICK_TB(2, 2);
     else if (nb == 4) PICK_TB(4, 1);
     else PICK_TB(2, 1);

@@ -1,3 +1,4 @@
+# Developer tool (GPU box): PMC passes (HBM-side bytes, L2 hit rate, SQ stall split, instruction mix) of the bf16 tile kernels over bench.py; summary per workload in gpurun_out/pmc_tb_<workload>/summary.txt
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 for wl in cfg5 cfg2; do
 O=$R/gpurun_out/pmc_tb_$wl; mkdir -p $O

@@ -141,7 +141,7 @@ def timed_baseline(coords, feats, channels, threads, budget_s=12.0):
     n, t_all = run(threads, reps)
     reps1 = max(1, min(2, int(budget_s * 0.5 / max(t_all * threads * 0.6, 1e-3))))
     _, t_one = run(1, reps1)
-    return dict(value=n / t_all, unit="active-voxels/s", cores=int(threads), kind="port-c++",
+    return dict(value=n / t_all, unit="active-voxels/s", cores=int(threads), kind="port", language="c++",
                 single_thread_value=n / t_one, cpu_model=_cpu_model(), isa=lib.scn_cpu_isa().decode(),
                 sample=f"{reps} full steps (rulebooks + fwd + bwd) of the same {n}-voxel scene on {threads} threads "
                        f"({t_all:.2f} s/step) and {reps1} on 1 thread ({t_one:.2f} s/step); C++17/OpenMP restatement of "

@@ -7,15 +7,15 @@ mkdir -p $O
 cd $R
 b() { name=$1; shift; python bench.py "$@" > $O/bench_$name.json 2> $O/bench_$name.err; echo "bench $name rc=$?"; }
 b default
-b cfg2_bf16 --dtype bf16 --steps 40 --warmup 10 --no-cpu-baseline
-b cfg3 --workload cfg3 --steps 30 --warmup 8 --no-cpu-baseline
-b cfg3_bf16 --workload cfg3 --dtype bf16 --steps 30 --warmup 8 --no-cpu-baseline
-b cfg5_fp32 --workload cfg5 --steps 10 --warmup 3 --no-cpu-baseline
-b cfg5_bf16 --workload cfg5 --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline
-b ref --workload ref --steps 30 --warmup 8 --no-cpu-baseline
-b ref_crop --workload ref-crop --steps 30 --warmup 8 --no-cpu-baseline
-SCN_EXEC=0 python bench.py --dtype bf16 --steps 40 --warmup 10 --no-cpu-baseline --no-extras > $O/bench_cfg2_bf16_no_executor.json 2>/dev/null; echo "bench bf16 noexec rc=$?"
-SCN_EXEC=0 python bench.py --workload cfg3 --dtype bf16 --steps 30 --warmup 8 --no-cpu-baseline --no-extras > $O/bench_cfg3_bf16_no_executor.json 2>/dev/null; echo "bench cfg3 bf16 noexec rc=$?"
+b cfg2_bf16 --dtype bf16 --steps 100 --warmup 20 --no-cpu-baseline
+b cfg3 --workload cfg3 --steps 100 --warmup 20 --no-cpu-baseline
+b cfg3_bf16 --workload cfg3 --dtype bf16 --steps 100 --warmup 20 --no-cpu-baseline
+b cfg5_fp32 --workload cfg5 --steps 30 --warmup 8 --no-cpu-baseline
+b cfg5_bf16 --workload cfg5 --dtype bf16 --steps 30 --warmup 8 --no-cpu-baseline
+b ref --workload ref --steps 100 --warmup 20 --no-cpu-baseline
+b ref_crop --workload ref-crop --steps 100 --warmup 20 --no-cpu-baseline
+SCN_EXEC=0 python bench.py --dtype bf16 --steps 100 --warmup 20 --no-cpu-baseline --no-extras > $O/bench_cfg2_bf16_no_executor.json 2>/dev/null; echo "bench bf16 noexec rc=$?"
+SCN_EXEC=0 python bench.py --workload cfg3 --dtype bf16 --steps 100 --warmup 20 --no-cpu-baseline --no-extras > $O/bench_cfg3_bf16_no_executor.json 2>/dev/null; echo "bench cfg3 bf16 noexec rc=$?"
 SCN_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_n2_gloo_one_gpu.json 2> $O/bench_n2.err; echo "bench n2 rc=$?"
 SCN_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload cfg3 --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_n2_gloo_cfg3_bf16.json 2> $O/bench_n2b.err; echo "bench n2 cfg3 rc=$?"
 SCN_BENCH_FORCE_DIST=1 SCN_DP_FORCE_BUCKETS=1 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-extras > $O/bench_rccl_one_rank.json 2> $O/bench_rccl.err; echo "bench rccl-1 rc=$?"

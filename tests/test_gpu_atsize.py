@@ -450,6 +450,15 @@ def _load_masks(z):
     return out
 
 
+def _both_ranks(fn):
+    """fn(0), fn(1) on two host threads (the oracle is torch-on-CPU: its kernels release the GIL); a failure in either
+    thread re-raises here."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(2) as ex:
+        futs = [ex.submit(fn, r) for r in range(2)]
+        return [f.result() for f in futs]
+
+
 @pytest.mark.parametrize("weighting", ["equal", "count"])
 def test_two_rank_dp_step_matches_oracle(gpu, tmp_path, weighting):
     """BASELINE configs[3]'s mechanism on one GPU: two fresh processes (gloo, both on cuda:0), one scene each, one step of
@@ -481,8 +490,7 @@ def test_two_rank_dp_step_matches_oracle(gpu, tmp_path, weighting):
     n_act = [int(z[r]["n_active"]) for r in range(2)]
     w = [0.5, 0.5] if weighting == "equal" else [n / sum(n_act) for n in n_act]
     assert weighting == "equal" or n_act[0] != n_act[1]
-    mean = None
-    for r in range(2):
+    def oracle_rank(r):
         coords, feats, size, bs, _ = make_batch(1, grid, targets[r], dup=1.15, seed=10 + r)
         scene = O.OracleScene(coords.numpy())
         assert scene.n(0) == n_act[r]
@@ -490,8 +498,9 @@ def test_two_rank_dp_step_matches_oracle(gpu, tmp_path, weighting):
         out = O.unet_forward(scene, feats, po, ch, relu=O.FrozenReLU(_load_masks(z[r])))     # this rank's recorded masks
         gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(100 + r))
         out.backward(gy)
-        gr = {k: po[k].grad * w[r] for k in names}
-        mean = gr if mean is None else {k: mean[k] + gr[k] for k in names}
+        return {k: po[k].grad * w[r] for k in names}
+    grs = _both_ranks(oracle_rank)                       # the two scenes' oracle passes side by side (host threads)
+    mean = {k: grs[0][k] + grs[1][k] for k in names}
     for k in names:
         _check_grad_frozen("cfg4_two_rank_dp_step_" + weighting, "mean grad " + k, torch.from_numpy(z[0]["g:" + k]).reshape(-1),
                            mean[k].reshape(-1), FROZEN_L2_F32)
@@ -532,8 +541,7 @@ def test_two_rank_dp_cfg3_step_matches_oracle(gpu, tmp_path, case):
         assert np.array_equal(z[0][k], z[1][k]), k                            # broadcast: ranks hold the same parameters
         assert np.array_equal(z[0]["g:" + k], z[1]["g:" + k]), k               # ... and the same reduced gradient
     bf16 = dtype == "bf16"
-    mean = None
-    for r in range(2):
+    def oracle_rank(r):
         coords, feats, size, bs, _ = make_batch(1, grid, target, dup=1.15, seed=10 + r)
         boxes = make_boxes(coords, n_boxes, seed=10 + r + 2)
         if r == empty:
@@ -545,8 +553,9 @@ def test_two_rank_dp_cfg3_step_matches_oracle(gpu, tmp_path, case):
         out, logits, gr, n_sel = _oracle_cfg3_step(coords, feats, boxes, pb, pm, ch, 100 + r, bf16=bf16, masks=masks)
         assert out.shape[0] == int(z[r]["n_active"]) and n_sel == int(z[r]["n_roi_rows"]), (r, n_sel)
         assert (n_sel == 0) == (r == empty)
-        gr = {k: gr[k] / 2 for k in keys}
-        mean = gr if mean is None else {k: mean[k] + gr[k] for k in keys}
+        return {k: gr[k] / 2 for k in keys}
+    grs = _both_ranks(oracle_rank)                       # the two scenes' oracle passes side by side (host threads)
+    mean = {k: grs[0][k] + grs[1][k] for k in keys}
     name = "cfg3_two_rank_dp_step_" + case
     for k in keys:
         _check_grad_frozen(name, "mean grad " + k, torch.from_numpy(z[0]["g:" + k]).reshape(-1), mean[k].reshape(-1),

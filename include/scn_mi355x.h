@@ -334,6 +334,13 @@ int scn_wgrad_bias_rules(const float* X, int cin, const float* dY, int cout, con
  * db_offsets == 0.  Per problem the units, the per-unit arithmetic and the fixed-order sum are those of
  * scn_wgrad_bias_rules under this call's plan; the launch pays its tail and its fixed costs once for twice the work.
  * Scratch: scn_wgrad_scratch_bytes2.  prefix_host[0] must be 0; n_off <= 32. */
+/* Deferred unit sums (round 3d).  Between scn_wgrad_defer_begin() and scn_wgrad_defer_flush(stream) ON THE CALLING THREAD the
+ * scn_wgrad_* calls launch their unit kernels only and record their sum; the flush adds the recorded sums in batched launches
+ * (up to six launches' sums per launch; per layer the arithmetic and its order are unchanged -- same bits).  Every call made
+ * in between needs a scratch region of its own that stays untouched until the flush.  Used by scn_exec_run for the weight
+ * gradients of a network level (27 sum launches of ~7 us per backbone step become 8). */
+int scn_wgrad_defer_begin(void);
+int scn_wgrad_defer_flush(scn_stream_t stream);
 int64_t scn_wgrad_scratch_bytes2(int cin, int cout, const int64_t* prefix_host, int n_off);
 int scn_wgrad_bias_rules2(const float* X0, const float* dY0, const float* X1, const float* dY1, int cin, int cout,
                           const int32_t* in_rows, const int32_t* out_rows, const int64_t* prefix_host, int n_off,

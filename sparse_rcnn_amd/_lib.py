@@ -66,6 +66,8 @@ _SIGS = {
     "scn_wgrad_bias_rules": (C.c_int, [p, i32, p, i32, p, p, C.POINTER(i64), i32, p, p, C.c_uint32, p, i32, p]),
     "scn_wgrad_bias_rules_bf16": (C.c_int, [p, i32, p, i32, p, p, C.POINTER(i64), i32, p, p, C.c_uint32, p, i32, p]),
     "scn_wgrad_scratch_bytes2": (i64, [i32, i32, C.POINTER(i64), i32]),
+    "scn_wgrad_defer_begin": (C.c_int, []),
+    "scn_wgrad_defer_flush": (C.c_int, [p]),
     "scn_wgrad_bias_rules2": (C.c_int, [p, p, p, p, i32, i32, p, p, C.POINTER(i64), i32, p, p, C.c_uint32, p, i32, p]),
     "scn_wgrad_bias_rules2_bf16": (C.c_int, [p, p, p, p, i32, i32, p, p, C.POINTER(i64), i32, p, p, C.c_uint32, p, i32, p]),
     "scn_wgrad_scratch_bytes_n": (i64, [i32, i32, C.POINTER(i64), i32, i32]),

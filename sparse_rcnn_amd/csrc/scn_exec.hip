@@ -6,12 +6,18 @@
 // GPU.  Here the per-layer calls are made from a flat op list: no interpreter, no allocator, no autograd
 // node per layer.  Every op IS one of the library's own entry points with the arguments the layer-by-layer path passes, so
 // the two paths produce the same bits (tests/test_gpu_exec.py).
+#include <stdlib.h>
+#include <vector>
+
 #include "scn_common.h"
 
 using scn::cdiv;
 
 namespace {
 
+// Scratch of a pass: [shared region: the largest need of any op that is not a deferred weight gradient][one region per
+// weight-gradient op of the pass].  With deferred sums (below) a weight-gradient launch keeps its unit slabs until the
+// batched sum at the end of the pass, so it cannot share them with the next launch.
 struct Ctx {
     const scn_exec_level* levels;
     int n_levels;
@@ -22,6 +28,23 @@ struct Ctx {
     int32_t* arrival;
     scn_stream_t stream;
 };
+
+inline int64_t align256(int64_t b) { return (b + 255) & ~(int64_t)255; }
+
+// scratch bytes of a weight-gradient op (0: not one)
+int64_t wgrad_scratch_of(const scn_exec_op& o, const scn_exec_level& L) {
+    switch (o.op) {
+    case SCN_OP_WGRAD_SUBM: return scn_wgrad_scratch_bytes(o.cin, o.cout, L.prefix_host, 27);
+    case SCN_OP_WGRAD2_SUBM: return scn_wgrad_scratch_bytes2(o.cin, o.cout, L.prefix_host, 27);
+    case SCN_OP_WGRAD_DOWN:
+    case SCN_OP_WGRAD_UP: return scn_wgrad_scratch_bytes(o.cin, o.cout, L.c_prefix_host, 8);
+    case SCN_OP_WGRAD_IDENT: {
+        const int64_t ident[2] = {0, (o.flags & SCN_XF_COARSE_ROWS) ? L.n_coarse : L.n};
+        return scn_wgrad_scratch_bytes(o.cin, o.cout, ident, 1);
+    }
+    default: return 0;
+    }
+}
 
 inline bool bf(const scn_exec_op& o) { return (o.flags & SCN_XF_BF16) != 0; }
 inline int call_flags(const scn_exec_op& o) { return o.flags & 0xffff; }
@@ -36,9 +59,12 @@ inline const T* P(const Ctx& c, int id) { return id < 0 ? nullptr : (const T*)c.
 template <typename T>
 inline T* G(const Ctx& c, int id) { return id < 0 ? nullptr : (T*)c.grads[id]; }
 
-int run_op(const Ctx& c, const scn_exec_op& o) {
-    SCN_REQUIRE(o.level >= 0 && o.level < c.n_levels);
-    const scn_exec_level& L = c.levels[o.level];
+// own_scratch: the op's own scratch region (a weight gradient whose sum is deferred), NULL: the pass's shared region
+int run_op(const Ctx& c0, const scn_exec_op& o, void* own_scratch = nullptr) {
+    SCN_REQUIRE(o.level >= 0 && o.level < c0.n_levels);
+    const scn_exec_level& L = c0.levels[o.level];
+    Ctx c = c0;
+    if (own_scratch) c.scratch = own_scratch;
     const int fl = call_flags(o);
     const bool h = bf(o);
     scn_stream_t st = c.stream;
@@ -161,10 +187,13 @@ extern "C" int64_t scn_exec_struct_bytes(int which) {
     return which == 0 ? (int64_t)sizeof(scn_exec_op) : (which == 1 ? (int64_t)sizeof(scn_exec_level) : -1);
 }
 
-extern "C" int scn_exec_requirements(const scn_exec_op* ops, int n_ops, const scn_exec_level* levels, int n_levels,
-                                     int64_t* scratch_bytes, int64_t* arrival_counters) {
-    SCN_REQUIRE(n_ops >= 0 && (n_ops == 0 || ops) && levels && n_levels >= 1 && scratch_bytes && arrival_counters);
-    int64_t sb = 256, ac = 0;
+namespace {
+// Needs of a pass: the largest scratch of an op that is NOT a weight gradient (shared region), the sum of the
+// weight-gradient regions, the largest weight-gradient region, the arrival counters.
+int pass_needs(const scn_exec_op* ops, int n_ops, const scn_exec_level* levels, int n_levels, int64_t* shared, int64_t* wg_sum,
+               int64_t* wg_max, int* n_wg, int64_t* arrival) {
+    int64_t sb = 256, ac = 0, ws = 0, wm = 0;
+    int nw = 0;
     for (int i = 0; i < n_ops; ++i) {
         const scn_exec_op& o = ops[i];
         SCN_REQUIRE(o.level >= 0 && o.level < n_levels);
@@ -183,22 +212,33 @@ extern "C" int scn_exec_requirements(const scn_exec_op* ops, int n_ops, const sc
             }
             break;
         }
-        case SCN_OP_WGRAD_SUBM: s = scn_wgrad_scratch_bytes(o.cin, o.cout, L.prefix_host, 27); break;
-        case SCN_OP_WGRAD2_SUBM: s = scn_wgrad_scratch_bytes2(o.cin, o.cout, L.prefix_host, 27); break;
-        case SCN_OP_WGRAD_DOWN:
-        case SCN_OP_WGRAD_UP: s = scn_wgrad_scratch_bytes(o.cin, o.cout, L.c_prefix_host, 8); break;
-        case SCN_OP_WGRAD_IDENT: {
-            const int64_t ident[2] = {0, rows_of(o, L)};
-            s = scn_wgrad_scratch_bytes(o.cin, o.cout, ident, 1);
+        case SCN_OP_COLSUM: s = (int64_t)SCN_COLSUM_BLOCKS * o.cin * (int64_t)sizeof(float); break;
+        default: {
+            const int64_t w = wgrad_scratch_of(o, L);
+            if (w < 0) return scn::fail(SCN_EINVAL, "scn_exec: op %s%lld has bad arguments", "", i);
+            if (w > 0) { ws += align256(w); ++nw; if (w > wm) wm = w; }
             break;
         }
-        case SCN_OP_COLSUM: s = (int64_t)SCN_COLSUM_BLOCKS * o.cin * (int64_t)sizeof(float); break;
-        default: break;
         }
-        if (s < 0) return scn::fail(SCN_EINVAL, "scn_exec_requirements: op %s%lld has bad arguments", "", i);
+        if (s < 0) return scn::fail(SCN_EINVAL, "scn_exec: op %s%lld has bad arguments", "", i);
         if (s > sb) sb = s;
         if (a > ac) ac = a;
     }
+    *shared = sb; *wg_sum = ws; *wg_max = wm; *n_wg = nw; *arrival = ac;
+    return SCN_OK;
+}
+}  // namespace
+
+extern "C" int scn_exec_requirements(const scn_exec_op* ops, int n_ops, const scn_exec_level* levels, int n_levels,
+                                     int64_t* scratch_bytes, int64_t* arrival_counters) {
+    SCN_REQUIRE(n_ops >= 0 && (n_ops == 0 || ops) && levels && n_levels >= 1 && scratch_bytes && arrival_counters);
+    int64_t shared, wg_sum, wg_max, ac;
+    int n_wg;
+    const int rc = pass_needs(ops, n_ops, levels, n_levels, &shared, &wg_sum, &wg_max, &n_wg, &ac);
+    if (rc != SCN_OK) return rc;
+    // shared region + one region per weight-gradient op (deferred sums); never less than the largest single op
+    int64_t sb = align256(shared) + wg_sum;
+    if (wg_max > sb) sb = wg_max;
     *scratch_bytes = sb;
     *arrival_counters = ac;
     return SCN_OK;
@@ -221,6 +261,10 @@ struct EventPool {
 };
 thread_local EventPool g_events;
 
+inline bool is_wgrad(int op) {
+    return op == SCN_OP_WGRAD_SUBM || op == SCN_OP_WGRAD2_SUBM || op == SCN_OP_WGRAD_DOWN || op == SCN_OP_WGRAD_UP ||
+           op == SCN_OP_WGRAD_IDENT;
+}
 inline bool is_leaf(int op) {
     return op == SCN_OP_WGRAD_SUBM || op == SCN_OP_WGRAD2_SUBM || op == SCN_OP_WGRAD_DOWN || op == SCN_OP_WGRAD_UP ||
            op == SCN_OP_WGRAD_IDENT || op == SCN_OP_COLSUM;
@@ -234,8 +278,32 @@ extern "C" int scn_exec_run_streams(const scn_exec_op* ops, int n_ops, const scn
     SCN_REQUIRE(n_ops >= 0 && (n_ops == 0 || ops) && levels && n_levels >= 1 && bufs && scratch && scratch_bytes >= 256);
     const bool fork = side_stream != nullptr && side_stream != stream && side_scratch != nullptr && side_scratch_bytes >= scratch_bytes;
     if (fork && !g_events.init()) return scn::fail(SCN_EHIP, "%sevents for the side stream could not be created", "");
+    // Deferred sums: the unit sums of the pass's weight-gradient launches run as ONE batched launch at its end (7 us
+    // launches of a few hundred workgroups each, 27 per backbone step; SCN_EXEC_DEFER_SUMS=0: one sum per launch).  Needs
+    // the per-op scratch regions scn_exec_requirements counts; a caller that sized the scratch otherwise keeps the old form.
+    static const bool defer_env = !(getenv("SCN_EXEC_DEFER_SUMS") && atoi(getenv("SCN_EXEC_DEFER_SUMS")) == 0);
+    // (the weight-gradient needs are computed once per pass and only for passes that have such ops: backward passes)
+    int n_wg = 0;
+    for (int i = 0; i < n_ops; ++i) n_wg += is_wgrad(ops[i].op) ? 1 : 0;
+    std::vector<int64_t> own(defer_env && !fork && n_wg >= 2 ? n_ops : 0, 0);      // offset of an op's own region, 0: none
+    bool defer = false;
+    if (!own.empty()) {
+        int64_t shared, wg_sum, wg_max, ac;
+        int nw;
+        const int rc_needs = pass_needs(ops, n_ops, levels, n_levels, &shared, &wg_sum, &wg_max, &nw, &ac);
+        if (rc_needs != SCN_OK) return rc_needs;
+        if (align256(shared) + wg_sum <= scratch_bytes) {
+            int64_t cursor = align256(shared);
+            for (int i = 0; i < n_ops; ++i) {
+                const int64_t w = is_wgrad(ops[i].op) ? wgrad_scratch_of(ops[i], levels[ops[i].level]) : 0;
+                if (w > 0) { own[i] = cursor; cursor += align256(w); }
+            }
+            defer = true;
+        }
+    }
     Ctx c{levels, n_levels, bufs, params, grads, scratch, arrival, stream};
     Ctx cs{levels, n_levels, bufs, params, grads, side_scratch, arrival, side_stream};
+    if (defer) SCN_REQUIRE(scn_wgrad_defer_begin() == SCN_OK);
     bool side_used = false;
     for (int i = 0; i < n_ops; ++i) {
         int rc;
@@ -248,15 +316,20 @@ extern "C" int scn_exec_run_streams(const scn_exec_op* ops, int n_ops, const scn
             rc = run_op(cs, ops[i]);
             side_used = true;
         } else {
-            rc = run_op(c, ops[i]);
+            rc = run_op(c, ops[i], defer && own[i] ? (char*)scratch + own[i] : nullptr);
         }
         if (rc != SCN_OK) {
             char inner[400];
             snprintf(inner, sizeof(inner), "%s", scn::g_err);
             snprintf(scn::g_err, sizeof(scn::g_err), "scn_exec_run: op %d (kind %d, level %d): %s", i, ops[i].op, ops[i].level,
                      inner);
+            if (defer) (void)scn_wgrad_defer_flush(stream);
             return rc;
         }
+    }
+    if (defer) {
+        const int rc = scn_wgrad_defer_flush(stream);
+        if (rc != SCN_OK) return rc;
     }
     if (side_used) {                  // join: whatever follows on the main stream sees the gradients (and may reuse the slabs)
         hipEvent_t e = g_events.take();

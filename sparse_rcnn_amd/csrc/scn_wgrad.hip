@@ -19,6 +19,9 @@
 // reproducible, no float atomics).  Bias gradient: column sums of the dY fragments of the offsets in db_mask, same route.
 #include <stdlib.h>
 
+#include <string.h>
+#include <vector>
+
 #include "scn_common.h"
 
 #ifndef WD_DEEP_ALL
@@ -603,36 +606,43 @@ __global__ __launch_bounds__(256) void k_wgrad_tb(const unsigned short* __restri
 // per unit at V = 4) and every G-th unit; the G partial sums of an element meet in LDS and are added in ascending g --
 // a fixed association for a given plan (bitwise reproducible).  G is chosen on the host so that small dW (many units,
 // few elements) still fill the chip.  Trailing blocks: bias gradient, one column each.
-template <int V>
-__global__ __launch_bounds__(256) void k_wgradd_sum(const float* __restrict__ slabs, DPlan plan, int cin, int cout,
-                                                    float* __restrict__ dW, const float* __restrict__ db_slabs,
-                                                    unsigned db_mask, int cout_pad, float* __restrict__ db,
-                                                    int main_blocks, int G) {
+// What the sum of one weight-gradient launch needs (the unit prefix of its plan and its block shape), by value.
+struct SumArgs {
+    const float* slabs; float* dW; const float* db_slabs; float* db;
+    int unit_start[129];
+    int n_off, n_real, cbi, cbj, nbi, nbj, cin, cout, cout_pad, main_blocks, G;
+    unsigned db_mask;
+};
+
+template <int V, typename A>
+__device__ __forceinline__ void wgradd_sum_body(const A& a, int block) {
     typedef typename Frag<V>::type vec_t;
-    if ((int)blockIdx.x >= main_blocks) {
-        const int cidx = blockIdx.x - main_blocks;                   // (problem, column)
+    const float* __restrict__ slabs = a.slabs;
+    const int cin = a.cin, cout = a.cout, G = a.G;
+    if (block >= a.main_blocks) {
+        const int cidx = block - a.main_blocks;                      // (problem, column)
         const int prob = cidx / cout, co = cidx - prob * cout;
         float s = 0.f;
-        for (int o = 0; o < plan.n_real; ++o) {
-            if (!((db_mask >> o) & 1u)) continue;
-            const int ov = prob * plan.n_real + o;
-            for (int u = plan.unit_start[ov] + threadIdx.x; u < plan.unit_start[ov + 1]; u += 256)
-                s += db_slabs[(long long)u * cout_pad + co];
+        for (int o = 0; o < a.n_real; ++o) {
+            if (!((a.db_mask >> o) & 1u)) continue;
+            const int ov = prob * a.n_real + o;
+            for (int u = a.unit_start[ov] + threadIdx.x; u < a.unit_start[ov + 1]; u += 256)
+                s += a.db_slabs[(long long)u * a.cout_pad + co];
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d);
         __shared__ float w[4];
         if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
         __syncthreads();
-        if (threadIdx.x == 0) db[cidx] = (w[0] + w[1]) + (w[2] + w[3]);
+        if (threadIdx.x == 0) a.db[cidx] = (w[0] + w[1]) + (w[2] + w[3]);
         return;
     }
     __shared__ __attribute__((aligned(16))) float part[256 * V];
     const int per_block = 256 / G;                                   // element groups per block
     const int el = threadIdx.x % per_block, g = threadIdx.x / per_block;
-    const long long total = (long long)plan.n_off * cin * (cout / V);    // element groups (cout % V == 0)
-    const int cbi = plan.cbi, cbj = plan.cbj, nblk = plan.nbi * plan.nbj;
-    const long long eg = (long long)blockIdx.x * per_block + el;
+    const long long total = (long long)a.n_off * cin * (cout / V);       // element groups (cout % V == 0)
+    const int cbi = a.cbi, cbj = a.cbj, nblk = a.nbi * a.nbj;
+    const long long eg = (long long)block * per_block + el;
     vec_t sum;
 #pragma unroll
     for (int v = 0; v < V; ++v) sum[v] = 0.f;
@@ -642,8 +652,8 @@ __global__ __launch_bounds__(256) void k_wgradd_sum(const float* __restrict__ sl
         const int co = (int)(e % cout);
         const int ci = (int)((e / cout) % cin);
         const int o = (int)(e / ((long long)cin * cout));
-        const int blk = (ci / cbi) * plan.nbj + co / cbj;
-        const int u0 = plan.unit_start[o], nu = plan.unit_start[o + 1] - u0;
+        const int blk = (ci / cbi) * a.nbj + co / cbj;
+        const int u0 = a.unit_start[o], nu = a.unit_start[o + 1] - u0;
         const long long stride = (long long)nblk * cbi * cbj;
         const float* p = slabs + ((long long)u0 * nblk + blk) * (cbi * cbj) + (ci % cbi) * cbj + co % cbj;
         for (int s = g; s < nu; s += G) {
@@ -663,7 +673,21 @@ __global__ __launch_bounds__(256) void k_wgradd_sum(const float* __restrict__ sl
             }
         }
     }
-    if (g == 0 && eg < total) *(vec_t*)(dW + e) = sum;
+    if (g == 0 && eg < total) *(vec_t*)(a.dW + e) = sum;
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void k_wgradd_sum(SumArgs a) { wgradd_sum_body<V>(a, (int)blockIdx.x); }
+
+// The sums of several weight-gradient launches in ONE launch (deferred sums of a network level, scn_wgrad_defer_begin /
+// _flush): block -> (job, block of the job); per job the arithmetic and its order are k_wgradd_sum's.
+#define WD_SUM_MANY 6
+struct SumJobs { int n; int block_start[WD_SUM_MANY + 1]; SumArgs job[WD_SUM_MANY]; };
+
+__global__ __launch_bounds__(256) void k_wgradd_sum_many(SumJobs jobs) {
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.block_start[j + 1]) ++j;
+    wgradd_sum_body<4>(jobs.job[j], (int)blockIdx.x - jobs.block_start[j]);
 }
 
 namespace {
@@ -756,6 +780,12 @@ static int multi_problem_plan(int cin, int cout, const int64_t* prefix_host, int
     pl.p_rules = P;
     return rc;
 }
+
+// Deferred sums (scn_wgrad_defer_begin / _flush): per calling thread, the sums of the launches made in between.
+namespace {
+struct DeferState { bool on = false; std::vector<SumArgs> jobs; std::vector<int> blocks; };
+thread_local DeferState g_defer;
+}  // namespace
 
 static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const int32_t* in_rows,
                       const int32_t* out_rows, const int64_t* prefix_host, int n_off_real, float* dW, float* db,
@@ -855,16 +885,49 @@ static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const 
     const int64_t groups = (int64_t)n_off * cin * (cout / V);
     int G = 1;
     while (G < 16 && groups * G < 128 * 1024) G *= 2;
-    const int main_blocks = (int)cdiv(groups, 256 / G);
-    if (V == 4)
-        hipLaunchKernelGGL(k_wgradd_sum<4>, dim3(main_blocks + (db ? n_prob * cout : 0)), dim3(256), 0, S(stream),
-                           (const float*)scratch, pl, cin, cout, dW, (const float*)db_slabs, db_mask, cout_pad, db,
-                           main_blocks, G);
-    else
-        hipLaunchKernelGGL(k_wgradd_sum<1>, dim3(main_blocks + (db ? n_prob * cout : 0)), dim3(256), 0, S(stream),
-                           (const float*)scratch, pl, cin, cout, dW, (const float*)db_slabs, db_mask, cout_pad, db,
-                           main_blocks, G);
+    SumArgs sa;
+    sa.slabs = (const float*)scratch; sa.dW = dW; sa.db_slabs = db_slabs; sa.db = db;
+    memcpy(sa.unit_start, pl.unit_start, sizeof(sa.unit_start));
+    sa.n_off = pl.n_off; sa.n_real = pl.n_real; sa.cbi = pl.cbi; sa.cbj = pl.cbj; sa.nbi = pl.nbi; sa.nbj = pl.nbj;
+    sa.cin = cin; sa.cout = cout; sa.cout_pad = cout_pad; sa.main_blocks = (int)cdiv(groups, 256 / G); sa.G = G;
+    sa.db_mask = db_mask;
+    const int blocks = sa.main_blocks + (db ? n_prob * cout : 0);
+    if (g_defer.on && V == 4) {                  // the caller batches the sums of several launches (own scratch per launch)
+        g_defer.jobs.push_back(sa);
+        g_defer.blocks.push_back(blocks);
+        return SCN_OK;
+    }
+    if (V == 4) hipLaunchKernelGGL(k_wgradd_sum<4>, dim3(blocks), dim3(256), 0, S(stream), sa);
+    else hipLaunchKernelGGL(k_wgradd_sum<1>, dim3(blocks), dim3(256), 0, S(stream), sa);
     SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+extern "C" int scn_wgrad_defer_begin(void) {
+    g_defer.on = true;                           // (a recorder left open by a failed pass is simply restarted)
+    g_defer.jobs.clear();
+    g_defer.blocks.clear();
+    return SCN_OK;
+}
+
+extern "C" int scn_wgrad_defer_flush(scn_stream_t stream) {
+    SCN_REQUIRE(g_defer.on);
+    g_defer.on = false;
+    const size_t n = g_defer.jobs.size();
+    for (size_t base = 0; base < n; base += WD_SUM_MANY) {
+        SumJobs jobs;
+        jobs.n = (int)(n - base < WD_SUM_MANY ? n - base : WD_SUM_MANY);
+        jobs.block_start[0] = 0;
+        for (int j = 0; j < jobs.n; ++j) {
+            jobs.job[j] = g_defer.jobs[base + j];
+            jobs.block_start[j + 1] = jobs.block_start[j] + g_defer.blocks[base + j];
+        }
+        if (jobs.n == 1) hipLaunchKernelGGL(k_wgradd_sum<4>, dim3(jobs.block_start[1]), dim3(256), 0, S(stream), jobs.job[0]);
+        else hipLaunchKernelGGL(k_wgradd_sum_many, dim3(jobs.block_start[jobs.n]), dim3(256), 0, S(stream), jobs);
+        SCN_LAUNCH_CHECK();
+    }
+    g_defer.jobs.clear();
+    g_defer.blocks.clear();
     return SCN_OK;
 }
 

@@ -258,3 +258,46 @@ def test_wgrad_48_wide_blocks_match_the_padded_blocks(gpu, c):
         assert torch.equal(u, w)                                              # reproducible
         scale = float(v.abs().max())
         assert float((u - v).abs().max()) <= 2e-6 * scale, (float((u - v).abs().max()), scale)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_deferred_weight_gradient_sums_equal_the_immediate_ones_bit_for_bit(gpu, bf16):
+    """scn_wgrad_defer_begin / _flush (round 3d): eight weight-gradient launches of different channel shapes record their
+    unit sums, the flush adds them in two batched launches (six + two).  Per layer the sum's arithmetic and order are the
+    single launch's: same bits as eight immediate calls (dW and db), fp32 and bf16-stored operands."""
+    import sparse_rcnn_amd as scn
+    from sparse_rcnn_amd import functional as F, _lib as L
+    coords, feats, size, bs, _ = _scene(6_000, (128, 128, 64), seed=8)
+    x = scn.InputLayer(3, size, mode=4)((coords, feats.to(gpu), 1))
+    rb = x.metadata.subm_rulebook(size, 3)
+    r = rb.rules
+    lib = L.lib()
+    shapes = [(32, 32), (64, 64), (32, 64), (128, 128), (64, 32), (48, 48), (16, 32), (256, 64)]
+    g = torch.Generator().manual_seed(5)
+    ops = []
+    for cin, cout in shapes:
+        X = torch.randn(rb.n, cin, generator=g).to(gpu)
+        dY = torch.randn(rb.n, cout, generator=g).to(gpu)
+        if bf16:
+            X, dY = X.bfloat16(), dY.bfloat16()
+        ops.append((X, dY))
+    ref = [F.wgrad_bias_rules(X, dY, r.in_rows, r.out_rows, r.prefix_host, 27, 1 << 13, L.F_RELU_IN) for X, dY in ops]
+    torch.cuda.synchronize()
+    entry = lib.scn_wgrad_bias_rules_bf16 if bf16 else lib.scn_wgrad_bias_rules
+    outs, keep = [], []
+    L.check(lib.scn_wgrad_defer_begin())
+    for X, dY in ops:
+        cin, cout = X.shape[1], dY.shape[1]
+        scratch = torch.empty(lib.scn_wgrad_scratch_bytes(cin, cout, r.prefix_host, 27), dtype=torch.uint8, device=gpu)
+        dW = torch.full((27, cin, cout), float("nan"), device=gpu)
+        db = torch.full((cout,), float("nan"), device=gpu)
+        L.check(entry(L.ptr(X), cin, L.ptr(dY), cout, L.ptr(r.in_rows), L.ptr(r.out_rows), r.prefix_host, 27, L.ptr(dW),
+                      L.ptr(db), 1 << 13, L.ptr(scratch), L.F_RELU_IN, L.stream()))
+        outs.append((dW, db)); keep.append(scratch)
+    torch.cuda.synchronize()
+    assert all(bool(torch.isnan(dW).all()) for dW, _ in outs)            # nothing is summed before the flush
+    L.check(lib.scn_wgrad_defer_flush(L.stream()))
+    torch.cuda.synchronize()
+    for (dW, db), (rW, rb_) in zip(outs, ref):
+        assert torch.equal(dW, rW) and torch.equal(db, rb_)
+    assert float(outs[0][0].abs().max()) > 0

@@ -55,6 +55,8 @@ extern "C" {
                                 dX = mask(conv^T dY1) + dY), default is before */
 #define SCN_F_SPLIT_SUM 16    /* scn_conv_tiles: launch the tile kernel only; the caller runs scn_conv_tiles_finish next
                                * (lets a profiler bracket the two kernels separately; results are identical) */
+#define SCN_F_TILE_ORDER_X 64 /* scn_conv_tiles_bf16: `tile_order` was built by scn_tiles_build_x(with_x): hand the tiles out by
+                               * spatial bin, bin x to the workgroups of XCD x (same results, L2-local row gathers) */
 #define SCN_F_GEMM_V1 32      /* scn_gemm_table / scn_gemm_rules: run the register-only kernels (operands straight from
                                * global memory) where the LDS-tiled ones would be taken; same bits -- the tests' cross-check */
 
@@ -153,6 +155,7 @@ int scn_pyramid_build(const int64_t* coords, int64_t n_points, int n_levels, int
  * four levels), slightly in the way when it runs next to another batch's matrix kernels -- so the inline callers (a forward
  * that builds its own index structures, the ROI batch) ask for it and the pipelined prefetch does not.  Same structures. */
 #define SCN_PYRAMID_TWO_QUEUES 1
+#define SCN_PYRAMID_XCD_ORDER 2   /* the SubM tiles of every level also get the XCD-local hand-out order (scn_tiles_build_x) */
 int scn_pyramid_build_ex(const int64_t* coords, int64_t n_points, int n_levels, int k, void* workspace,
                          int64_t workspace_bytes, int64_t* desc, int flags, scn_stream_t stream);
 
@@ -211,6 +214,16 @@ int scn_gemm_table(const float* X, int64_t n_in, int cin, const int32_t* table, 
 int64_t scn_tiles_scratch_bytes(int n_off, int64_t n);
 int scn_tiles_build(const int32_t* table, int n_off, int64_t n, int32_t* perm, int32_t* tstab, uint32_t* tile_mask,
                     int32_t* tile_order, void* scratch, scn_stream_t stream);
+/* The same build with a second hand-out order behind the first (with_x != 0): tile_order then holds scn_tiles_order_ints(n, 1)
+ * = 2 NT + 16 ints -- [NT] tile ids by offset count descending (as above), [NT] tile ids by (spatial bin, offset count
+ * descending) where the bin of a tile is (its first row * 8 / n) (rows are numbered in the order the points arrive, so a row
+ * range is a region of the scene), [9] bin starts in that second list (bin_start[8] = NT).  scn_conv_tiles_bf16 with
+ * SCN_F_TILE_ORDER_X hands the tiles of bin x to the workgroups of XCD x: their row gathers then meet in one L2 (the bf16 tile
+ * kernel waits for L2 misses at the fine levels: 87 -> 71 us per launch at 600 k voxels, 24.5 -> 21.5 at 150 k; the fp32
+ * kernel is bound by its matrix pipe and loses to the shorter per-bin lists, so it keeps the first order). */
+int64_t scn_tiles_order_ints(int64_t n, int with_x);
+int scn_tiles_build_x(const int32_t* table, int n_off, int64_t n, int32_t* perm, int32_t* tstab, uint32_t* tile_mask,
+                      int32_t* tile_order, int with_x, void* scratch, scn_stream_t stream);
 
 /* Stable LSD radix sort of (uint32 key, int32 value) pairs on the low `bits` key bits -- the primitive behind
  * scn_tiles_build (rows by offset mask, tiles by offset count); exported so that it can be checked on its own.  It takes
@@ -563,7 +576,9 @@ typedef struct scn_exec_level {
     const int32_t* c_in_rows;        /* strided rules: in = fine rows, out = coarse rows */
     const int32_t* c_out_rows;
     const int64_t* c_prefix_host;    /* int64[9] on the host */
+    int64_t flags;                   /* SCN_XL_* */
 } scn_exec_level;
+#define SCN_XL_TILE_ORDER_X 1        /* tile_order continues with the XCD-local order (scn_tiles_build_x): bf16 SubM convolutions use it */
 
 typedef struct scn_exec_op {
     int32_t op;                      /* SCN_OP_* */

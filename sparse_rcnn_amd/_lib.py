@@ -43,6 +43,8 @@ _SIGS = {
     "scn_gemm_table": (C.c_int, [p, i64, i32, p, i32, i64, p, p, p, p, p, i32, i32, p]),
     "scn_tiles_scratch_bytes": (i64, [i32, i64]),
     "scn_tiles_build": (C.c_int, [p, i32, i64, p, p, p, p, p, p]),
+    "scn_tiles_build_x": (C.c_int, [p, i32, i64, p, p, p, p, i32, p, p]),
+    "scn_tiles_order_ints": (i64, [i64, i32]),
     "scn_sort_pairs_scratch_bytes": (i64, [i64]),
     "scn_sort_pairs": (C.c_int, [p, p, i64, i32, p, p, p, p]),
     "scn_conv_tiles_scratch_bytes": (i64, [i32, i64, i32]),
@@ -123,9 +125,11 @@ _SIGS = {
 EXPORTS = tuple(_SIGS)
 
 F_RELU_IN, F_W_TRANSPOSED, F_OFF_REVERSE, F_RESIDUAL_LAST, F_SPLIT_SUM, F_GEMM_V1 = 1, 2, 4, 8, 16, 32
+F_TILE_ORDER_X = 64
 OK, EINVAL, ESIZE, EHASH, EHIP = 0, 1, 2, 3, 4
 PYRAMID_MAX_LEVELS, PYRAMID_LEVEL_STRIDE = 8, 72
 PYRAMID_TWO_QUEUES = 1
+PYRAMID_XCD_ORDER = 2
 PYRAMID_DESC_LEN = 8 + PYRAMID_MAX_LEVELS * PYRAMID_LEVEL_STRIDE
 COLSUM_BLOCKS = 512
 

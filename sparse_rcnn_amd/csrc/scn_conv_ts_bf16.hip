@@ -56,7 +56,7 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
     long long nt, const unsigned short* __restrict__ image, const float* __restrict__ bias,
     const unsigned short* __restrict__ residual, const unsigned short* __restrict__ relu_mask,
     unsigned short* __restrict__ Y, float* __restrict__ slabs, long long n_out, int cout, int flags, int n_chunks,
-    int n_kc, int* __restrict__ counters) {
+    int n_kc, int* __restrict__ counters, int xbins) {
     constexpr int CT = 16 * NB;
     constexpr int KC = TB_KC * KH;              // channels per K-chunk: 32, or 64 as two 32-channel planes of the image
     constexpr int THREADS = TB_NW * 64;
@@ -69,8 +69,25 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
     const bool res_last = flags & SCN_F_RESIDUAL_LAST;
 
     // ---- tile queue (as in k_conv_ts): the workgroup owns every n_tg-th entry of the LPT order --------------------
+    // xbins > 1 (SCN_F_TILE_ORDER_X, round 3d): XCD-local hand-out.  Behind the LPT order sits a second list of the tiles
+    // by (spatial bin of their first row, cost descending) with its nine bin starts (scn_tiles_build_x).  Workgroups are
+    // dealt to XCDs round-robin by block index, so the slices of tile group tg run on the XCDs (tg n_slices + s) % 8: with
+    // xbins = 8 / n_slices groups of XCDs, group tg % xbins takes the tiles of ITS run of bins -- the rows its waves gather
+    // (neighbours of the tile's rows) then meet in that group's L2s instead of anywhere on the chip.  Placement only
+    // decides the speed; any hand-out gives the same results.
     const int tg = blockIdx.x / (n_chunks * n_kc), n_tg = gridDim.x / (n_chunks * n_kc);
-    const int n_tiles = (int)((nt - tg + n_tg - 1) / n_tg);
+    const int* list = tile_order + tg;
+    int lstride = n_tg;
+    int n_tiles = (int)((nt - tg + n_tg - 1) / n_tg);
+    if (xbins > 1) {
+        const int bin = tg % xbins, lw = tg / xbins, nw = (n_tg - bin + xbins - 1) / xbins;
+        const int* order_x = tile_order + nt;
+        const int* bs = order_x + nt;
+        const int s0 = bs[bin * (8 / xbins)], s1 = bs[(bin + 1) * (8 / xbins)];
+        list = order_x + s0 + lw;
+        lstride = nw;
+        n_tiles = s1 - s0 > lw ? (s1 - s0 - lw + nw - 1) / nw : 0;
+    }
     int* counter = (int*)(Wb + (size_t)n_off * CT * KC);
     if (tid == 0) *counter = 0;
     __syncthreads();
@@ -78,7 +95,7 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
         int tl = 0;
         if (lane == 0) tl = atomicAdd(counter, 1);
         tl = __builtin_amdgcn_readfirstlane(tl);
-        return tl < n_tiles ? tile_order[tg + (long long)tl * n_tg] : -1;
+        return tl < n_tiles ? list[(long long)tl * lstride] : -1;
     };
     const int i = lane & 15, kq = lane >> 4;
     long long tile_next = grab();
@@ -621,6 +638,12 @@ extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, con
     dim3 grid((unsigned)(n_tg * n_chunks * n_kc));
     hipStream_t st = S(stream);
     const bool part = cin % kcs != 0;                              // the last K-chunk has channel groups past Cin
+    // XCD-local hand-out (SCN_F_TILE_ORDER_X): possible when the slices of a tile group fall on 8 / n_slices whole groups of
+    // XCDs, i.e. 1, 2 or 4 slices; with 8 or more every XCD sees every tile group anyway
+    const int n_slices = n_chunks * n_kc;
+    const bool x_off = getenv("SCN_TB_NO_XORDER") != nullptr;        // (read per call: the tests switch it inside one process)
+    const int xbins = ((flags & SCN_F_TILE_ORDER_X) && !x_off && (n_slices == 1 || n_slices == 2 || n_slices == 4) &&
+                       n_tg >= 8) ? 8 / n_slices : 1;
 #define LAUNCH_TB(N, K, FU, PT)                                                                                     \
     do {                                                                                                            \
         static bool attr_set = false;                                                                               \
@@ -631,7 +654,7 @@ extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, con
         }                                                                                                           \
         hipLaunchKernelGGL((k_conv_tb<N, K, FU, PT>), grid, dim3(TB_NW * 64), lds, st, X, (long long)n_in, cin, tstab, \
                            tile_mask, perm, tile_order, n_off, (long long)nt, image, bias, residual, relu_mask, Y, slabs, \
-                           (long long)n_out, cout, flags, n_chunks, n_kc, (int*)arrival);                           \
+                           (long long)n_out, cout, flags, n_chunks, n_kc, (int*)arrival, xbins);                    \
     } while (0)
 #define PICK_TB(N, K)                                                                                               \
     do {                                                                                                            \

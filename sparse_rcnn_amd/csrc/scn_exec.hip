@@ -88,8 +88,9 @@ int run_op(const Ctx& c0, const scn_exec_op& o, void* own_scratch = nullptr) {
         const int32_t* order = child ? L.c_tile_order : L.tile_order;
         if (h) {
             int32_t* arr = scn_conv_tiles_bf16_arrival_counters(o.cin, n_out, o.cout) ? c.arrival : nullptr;
+            const int flx = fl | ((!child && (L.flags & SCN_XL_TILE_ORDER_X)) ? SCN_F_TILE_ORDER_X : 0);
             return scn_conv_tiles_bf16(B<u16>(c, o.x), n_in, o.cin, tstab, tmask, perm, order, n_off, n_out, P<u16>(c, o.w),
-                                       P<float>(c, o.b), B<u16>(c, o.r), B<u16>(c, o.m), B<u16>(c, o.y), o.cout, fl, c.scratch,
+                                       P<float>(c, o.b), B<u16>(c, o.r), B<u16>(c, o.m), B<u16>(c, o.y), o.cout, flx, c.scratch,
                                        arr, st);
         }
         int32_t* arr = o.cin > 32 ? c.arrival : nullptr;

@@ -89,7 +89,7 @@ int64_t level_bytes(int64_t n, int n_off, bool has_next) {
     b += (int64_t)n_off * n * 4 + pad;                                  // table
     b += scn_rules_blocks(n_off, n) * 4 + pad + (n_off + 1) * 8 + pad;  // scan
     b += 2 * ((int64_t)n_off * n * 4 + pad);                            // compacted rules (at most one per table entry)
-    b += nt * 16 * 4 + pad + nt * n_off * 16 * 4 + pad + nt * 4 + pad + nt * 4 + pad + scn_tiles_scratch_bytes(n_off, n) + pad;
+    b += nt * 16 * 4 + pad + nt * n_off * 16 * 4 + pad + nt * 4 + pad + (2 * nt + 16) * 4 + pad + scn_tiles_scratch_bytes(n_off, n) + pad;
     if (has_next) {                                                     // numbering of the coarse sites + strided rulebook
         const int64_t cap = scn_hash_capacity(n);
         b += cap * 8 + pad + cap * 4 + pad + n * 4 + pad + n * 16 + pad + scn_dedup_scratch_bytes(n) + pad + 8 + pad;
@@ -213,7 +213,9 @@ extern "C" int scn_pyramid_build_ex(const int64_t* coords, int64_t n_points, int
             int32_t* perm = (int32_t*)ws.take(nt * 16 * 4, &off);                        L[9] = off;
             int32_t* tstab = (int32_t*)ws.take(nt * n_off * 16 * 4, &off);               L[10] = off;
             uint32_t* tmask = (uint32_t*)ws.take(nt * 4, &off);                          L[11] = off;
-            int32_t* torder = (int32_t*)ws.take(nt * 4, &off);                           L[12] = off; L[13] = nt;
+            // (with SCN_PYRAMID_XCD_ORDER the XCD-local hand-out order and its bin starts sit behind the first order)
+            const bool with_x = (flags & SCN_PYRAMID_XCD_ORDER) != 0;
+            int32_t* torder = (int32_t*)ws.take(scn_tiles_order_ints(n, with_x ? 1 : 0) * 4, &off);   L[12] = off; L[13] = nt;
             void* tscr = ws.take(scn_tiles_scratch_bytes(n_off, n), &off);
             SCN_REQUIRE(ws.ok);
             scn_stream_t sub = stream;
@@ -224,7 +226,7 @@ extern "C" int scn_pyramid_build_ex(const int64_t* coords, int64_t n_points, int
             }
             if ((rc = scn_subm_table(lv_coords, n, lv_keys, lv_hrows, lv_cap, k, table, sub))) return rc;
             if ((rc = scn_rules_scan(table, n_off, n, bsums, prefix, nullptr, sub))) return rc;
-            if ((rc = scn_tiles_build(table, n_off, n, perm, tstab, tmask, torder, tscr, sub))) return rc;
+            if ((rc = scn_tiles_build_x(table, n_off, n, perm, tstab, tmask, torder, with_x ? 1 : 0, tscr, sub))) return rc;
             prefix_dev[l][0] = prefix;
         }
         if (!has_next) {

@@ -62,7 +62,8 @@ __global__ void k_row_masks(const int* __restrict__ table, int n_off, long long 
 
 __global__ void k_build_tiles(const int* __restrict__ table, int n_off, long long n, const int* __restrict__ sorted_rows,
                               const unsigned* __restrict__ sorted_key, KeyBits kb, long long nt, int* __restrict__ perm,
-                              int* __restrict__ tstab, unsigned* __restrict__ tile_mask, unsigned* __restrict__ tile_cost) {
+                              int* __restrict__ tstab, unsigned* __restrict__ tile_mask, unsigned* __restrict__ tile_cost,
+                              unsigned* __restrict__ tile_xkey) {
     // one thread per (tile, lane i); 16 threads of a tile are adjacent
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < nt * 16;
          e += (long long)gridDim.x * blockDim.x) {
@@ -87,6 +88,9 @@ __global__ void k_build_tiles(const int* __restrict__ table, int n_off, long lon
         if (i == 0) {
             tile_mask[t] = m;
             tile_cost[t] = 32u - (unsigned)__popc(m);       // sort key of the hand-out order: most offsets first
+            // key of the XCD-local hand-out order (scn_tiles_build_x): (spatial bin of the tile's first row, cost) -- rows
+            // are numbered in the order the points arrive (mesh order), so a row range is a region of the scene
+            if (tile_xkey) tile_xkey[t] = ((unsigned)(((long long)(row < 0 ? 0 : row) * 8) / n) << 6) | (32u - (unsigned)__popc(m));
         }
     }
 }
@@ -97,15 +101,26 @@ __global__ void k_build_tiles(const int* __restrict__ table, int n_off, long lon
 
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
+// bin_start[b] = first position of the (bin, cost)-sorted tile list whose bin is >= b (b = 0..8; bin_start[8] = nt)
+__global__ void k_xbin_start(const unsigned* __restrict__ xkey_sorted, long long nt, int* __restrict__ bin_start) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < nt; t += (long long)gridDim.x * blockDim.x) {
+        const int kb = (int)(xkey_sorted[t] >> 6);
+        const int kp = t ? (int)(xkey_sorted[t - 1] >> 6) : -1;
+        for (int b = kp + 1; b <= kb; ++b) bin_start[b] = (int)t;
+        if (t == nt - 1)
+            for (int b = kb + 1; b <= 8; ++b) bin_start[b] = (int)nt;
+    }
+}
+
 extern "C" int64_t scn_tiles_scratch_bytes(int n_off, int64_t n) {
     if (n_off < 1 || n_off > 32 || n < 0) return -1;
     const int64_t nt = cdiv(n, 16);
-    return align256(4 * n) * 3 + align256(scn::sort_pairs_scratch_bytes(n)) + align256(4 * nt) * 2 +
+    return align256(4 * n) * 3 + align256(scn::sort_pairs_scratch_bytes(n)) + align256(4 * nt) * 4 +
            align256(scn::sort_pairs_scratch_bytes(nt)) + 256;
 }
 
-extern "C" int scn_tiles_build(const int32_t* table, int n_off, int64_t n, int32_t* perm, int32_t* tstab,
-                               uint32_t* tile_mask, int32_t* tile_order, void* scratch, scn_stream_t stream) {
+extern "C" int scn_tiles_build_x(const int32_t* table, int n_off, int64_t n, int32_t* perm, int32_t* tstab,
+                                 uint32_t* tile_mask, int32_t* tile_order, int with_x, void* scratch, scn_stream_t stream) {
     SCN_REQUIRE(n_off >= 1 && n_off <= 32 && n >= 0);
     if (n == 0) return SCN_OK;
     SCN_REQUIRE(table && perm && tstab && tile_mask && tile_order && scratch);
@@ -118,6 +133,8 @@ extern "C" int scn_tiles_build(const int32_t* table, int n_off, int64_t n, int32
     void* sort_scr = p;                     p += align256(scn::sort_pairs_scratch_bytes(n));
     unsigned* cost = (unsigned*)p;          p += align256(4 * nt);
     unsigned* cost_sorted = (unsigned*)p;   p += align256(4 * nt);
+    unsigned* xkey = (unsigned*)p;          p += align256(4 * nt);
+    unsigned* xkey_sorted = (unsigned*)p;   p += align256(4 * nt);
     void* sort_scr2 = p;
     hipStream_t st = S(stream);
     const KeyBits kb = make_key_bits(n_off);
@@ -127,9 +144,29 @@ extern "C" int scn_tiles_build(const int32_t* table, int n_off, int64_t n, int32
     if (rc) return rc;
     hipLaunchKernelGGL(k_build_tiles, dim3(scn::ew_grid(nt * 16, 256)), dim3(256), 0, st, table, n_off, (long long)n,
                        (const int*)rows_sorted, (const unsigned*)mask_sorted, kb, (long long)nt, perm, tstab, tile_mask,
-                       cost);
+                       cost, with_x ? xkey : (unsigned*)nullptr);
     SCN_LAUNCH_CHECK();
     rc = scn::sort_pairs(cost, nullptr, nt, 6, cost_sorted, tile_order, sort_scr2, st);
     if (rc) return rc;
+    if (with_x) {
+        // the XCD-local hand-out order behind the first one: tile ids by (bin, cost) and the nine bin starts
+        int32_t* order_x = tile_order + nt;
+        rc = scn::sort_pairs(xkey, nullptr, nt, 9, xkey_sorted, order_x, sort_scr2, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_xbin_start, dim3(scn::ew_grid(nt, 256)), dim3(256), 0, st, (const unsigned*)xkey_sorted,
+                           (long long)nt, order_x + nt);
+        SCN_LAUNCH_CHECK();
+    }
     return SCN_OK;
+}
+
+extern "C" int64_t scn_tiles_order_ints(int64_t n, int with_x) {
+    if (n < 0) return -1;
+    const int64_t nt = cdiv(n, 16);
+    return with_x ? 2 * nt + 16 : nt;
+}
+
+extern "C" int scn_tiles_build(const int32_t* table, int n_off, int64_t n, int32_t* perm, int32_t* tstab,
+                               uint32_t* tile_mask, int32_t* tile_order, void* scratch, scn_stream_t stream) {
+    return scn_tiles_build_x(table, n_off, n, perm, tstab, tile_mask, tile_order, 0, scratch, stream);
 }

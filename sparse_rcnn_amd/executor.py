@@ -48,7 +48,8 @@ class ExecOp(C.Structure):
 class ExecLevel(C.Structure):
     _fields_ = [("n", i64), ("tstab", vp), ("tile_mask", vp), ("perm", vp), ("tile_order", vp), ("in_rows", vp),
                 ("out_rows", vp), ("prefix_host", vp), ("n_coarse", i64), ("c_tstab", vp), ("c_tile_mask", vp),
-                ("c_perm", vp), ("c_tile_order", vp), ("c_in_rows", vp), ("c_out_rows", vp), ("c_prefix_host", vp)]
+                ("c_perm", vp), ("c_tile_order", vp), ("c_in_rows", vp), ("c_out_rows", vp), ("c_prefix_host", vp),
+                ("flags", i64)]
 
 
 def _addr(prefix_host):
@@ -73,6 +74,7 @@ def build_levels(md, size, n_levels):
             return None
         e, t, r = arr[l], rb.tiles, rb.rules
         e.n = rb.n
+        e.flags = 1 if getattr(t, "has_x", False) else 0           # SCN_XL_TILE_ORDER_X
         e.tstab, e.tile_mask, e.perm, e.tile_order = t.tstab.data_ptr(), t.tile_mask.data_ptr(), t.perm.data_ptr(), t.tile_order.data_ptr()
         ph = r.prefix_host
         e.in_rows, e.out_rows, e.prefix_host = r.in_rows.data_ptr(), r.out_rows.data_ptr(), _addr(ph)

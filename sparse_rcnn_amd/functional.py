@@ -237,6 +237,8 @@ def conv_rules_bf16(X, tiles, n_out, W, bias, cout, flags=0, residual=None, relu
     if image is None:
         image = pack_weights_bf16(W, cin, cout, n_off, flags)
     Y = torch.empty((n_out, cout), dtype=torch.bfloat16, device=X.device)
+    if getattr(tiles, "has_x", False):
+        flags |= L.F_TILE_ORDER_X               # tile_order continues with the XCD-local hand-out order (scn_tiles_build_x)
     key = (cin, n_out, cout)
     sz = _tb_sizes.get(key)
     if sz is None:

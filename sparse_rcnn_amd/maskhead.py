@@ -105,6 +105,10 @@ class MaskBranch(nn.Module):
         skip_features = self.scene_roi_extra_cut(raw_scene, selection)
         if len(skip_features) == 0 or roi_tensor is None:
             return skip_features.new_zeros((0, self.classes)), selection
+        if self.bf16:           # the ROI batch's SubM tiles (built on first use below) with the XCD-local hand-out order
+            from . import metadata as MD
+            if MD.XCD_ORDER_BF16 and not roi_tensor.metadata.subm:
+                roi_tensor.metadata.xcd_order = True
         out = self.roi_output_layer(unet(roi_tensor))            # [cropped points, phys0]; the pad column is zero
         return self._linear(out), selection
 

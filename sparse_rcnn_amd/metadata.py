@@ -14,6 +14,7 @@ Buffers are torch tensors (caching allocator, stream ordered); the C library onl
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Dict, Optional, Tuple
 
@@ -273,6 +274,11 @@ class Rules:
                 if t is not None]
 
 
+# default of Metadata.xcd_order (SCN_XCD_ORDER=1: every Metadata builds the second order; 0: nobody does)
+XCD_ORDER_DEFAULT = os.environ.get("SCN_XCD_ORDER", "") == "1"
+XCD_ORDER_BF16 = os.environ.get("SCN_XCD_ORDER", "") != "0"     # bf16-storage networks ask for it
+
+
 @dataclass
 class Tiles:
     """Mask-sorted row tiles of a rule table (scn_tiles_build): what the hot kernel scn_conv_tiles walks."""
@@ -282,20 +288,22 @@ class Tiles:
     n_off: int
     n: int
     tile_order: Optional[torch.Tensor] = None    # int32 [nt], tiles by offset count descending
+    has_x: bool = False             # tile_order's buffer continues with the XCD-local order and its bin starts (scn_tiles_build_x)
 
 
-def build_tiles(table: torch.Tensor, n_off: int, n: int) -> Tiles:
+def build_tiles(table: torch.Tensor, n_off: int, n: int, with_x: bool = False) -> Tiles:
+    """with_x: also the XCD-local hand-out order of the bf16 tile kernel (behind the first order, in the same buffer)."""
     lib = L.lib()
     dev = table.device
     nt = (n + 15) // 16
     perm = _empty(nt * 16, torch.int32, dev)
     tstab = torch.empty((nt, n_off, 16), dtype=torch.int32, device=dev)
     tile_mask = _empty(nt, torch.int32, dev)
-    tile_order = _empty(nt, torch.int32, dev)
+    order_buf = _empty(lib.scn_tiles_order_ints(n, 1 if with_x else 0), torch.int32, dev)
     scratch = _empty(lib.scn_tiles_scratch_bytes(n_off, n), torch.uint8, dev)
-    L.check(lib.scn_tiles_build(L.ptr(table), n_off, n, L.ptr(perm), L.ptr(tstab), L.ptr(tile_mask),
-                                L.ptr(tile_order), L.ptr(scratch), L.stream()))
-    return Tiles(perm, tstab, tile_mask, n_off, n, tile_order)
+    L.check(lib.scn_tiles_build_x(L.ptr(table), n_off, n, L.ptr(perm), L.ptr(tstab), L.ptr(tile_mask),
+                                  L.ptr(order_buf), 1 if with_x else 0, L.ptr(scratch), L.stream()))
+    return Tiles(perm, tstab, tile_mask, n_off, n, order_buf[:nt] if with_x else order_buf, bool(with_x))
 
 
 @dataclass
@@ -391,6 +399,9 @@ class Metadata:
         self.point_coords: Optional[torch.Tensor] = None     # int32 [Npts,4] device copy of the InputLayer coordinates
         self._depth: Dict[Tuple[int, ...], int] = {}
         self._unrequested = set()       # strided rulebooks built ahead on a depth hint that no layer has asked for yet
+        # SubM tiles also get the XCD-local hand-out order of the bf16 tile kernel (scn_tiles_build_x): set by the owner of a
+        # bf16-storage network BEFORE the structures are built (unet.Backbone / maskhead.MaskBranch do)
+        self.xcd_order = XCD_ORDER_DEFAULT
         self._prepared_for = None       # identity of the coords tensor a prefetch was built for
 
     def _note_levels(self, size, extra):
@@ -446,12 +457,15 @@ class Metadata:
         return grid
 
     def build_native(self, spatial_size, coords: torch.Tensor, batch_size: int, mode: int, n_levels: int, k: int = 3,
-                     two_queues: bool = True):
+                     two_queues: bool = True, xcd_order: Optional[bool] = None):
         """set_input + build_pyramid through ONE C call (scn_pyramid_build_ex): same structures, bit-identical, carved out of
         one workspace tensor; the call holds no interpreter state, so a helper thread can run it next to the main
         thread's kernel queueing (prepare_in_thread).  two_queues: the SubM work of the levels on the library's side stream
-        (shorter when the build has the GPU to itself: the inline builds; the pipelined prefetch passes False)."""
+        (shorter when the build has the GPU to itself: the inline builds; the pipelined prefetch passes False).
+        xcd_order: the SubM tiles also get the XCD-local hand-out order of the bf16 tile kernel (None: `self.xcd_order`)."""
         lib = L.lib()
+        if xcd_order is not None:
+            self.xcd_order = bool(xcd_order)
         size = tuple(int(s) for s in spatial_size)
         if len(size) != 3:
             raise ValueError("spatial_size must have 3 entries")
@@ -475,7 +489,8 @@ class Metadata:
         ws = torch.empty(lib.scn_pyramid_workspace_bytes(n, n_levels, k), dtype=torch.uint8, device=dev)
         desc = (C.c_int64 * L.PYRAMID_DESC_LEN)()
         L.check(lib.scn_pyramid_build_ex(L.ptr(c64), n, n_levels, k, L.ptr(ws), ws.numel(), desc,
-                                         L.PYRAMID_TWO_QUEUES if two_queues else 0, L.stream()))
+                                         (L.PYRAMID_TWO_QUEUES if two_queues else 0) |
+                                         (L.PYRAMID_XCD_ORDER if self.xcd_order else 0), L.stream()))
         self._workspace = ws
 
         def view(off, count, dtype, shape=None):
@@ -512,7 +527,7 @@ class Metadata:
                 rules = Rules.from_scan(table, n_off, nl, view(D[6], D[7], torch.int32), view(D[8], n_off + 1, torch.int64),
                                         D[25:25 + n_off + 1], view(D[64], P, torch.int32), view(D[65], P, torch.int32))
                 tiles = Tiles(view(D[9], nt * 16, torch.int32), view(D[10], nt * n_off * 16, torch.int32, (nt, n_off, 16)),
-                              view(D[11], nt, torch.int32), n_off, nl, view(D[12], nt, torch.int32))
+                              view(D[11], nt, torch.int32), n_off, nl, view(D[12], nt, torch.int32), bool(self.xcd_order))
                 self.subm[(lv_size, k)] = SubmRulebook(table, rules, k, nl, tiles)
             if l + 1 < n_levels and nl > 0:
                 nc = int(desc[8 + (l + 1) * L.PYRAMID_LEVEL_STRIDE])
@@ -550,7 +565,8 @@ class Metadata:
                 table = torch.empty((k ** 3, g.n), dtype=torch.int32, device=g.coords.device)
                 L.check(lib.scn_subm_table(L.ptr(g.coords), g.n, L.ptr(g.table_keys), L.ptr(g.table_rows), g.cap, k,
                                            L.ptr(table), L.stream()))
-                rb = SubmRulebook(table, compact_rules(table, k ** 3, g.n), k, g.n, build_tiles(table, k ** 3, g.n))
+                rb = SubmRulebook(table, compact_rules(table, k ** 3, g.n), k, g.n,
+                                  build_tiles(table, k ** 3, g.n, with_x=self.xcd_order))
             self.subm[key] = rb
         if k == 3:
             self._note_levels(size, 1)
@@ -600,13 +616,15 @@ class Metadata:
 
     # ---- index prefetch on a side stream -----------------------------------------------------------
     def prepare_async(self, spatial_size, coords, batch_size: int = 0, mode: int = 4, n_levels: int = 0, k: int = 3,
-                      native: bool = False, caller_stream=None):
+                      native: bool = False, caller_stream=None, xcd_order: Optional[bool] = None):
         """Build the InputLayer rules (and optionally the rulebook pyramid of an n_levels U-Net) on the index stream.
 
         All index structures depend only on the coordinates, so a training loop can build those of batch i+1 while the
         matrix kernels of batch i still run: the index kernels are short and latency-bound and fit beside them, and
         the host syncs of the size queries then wait on the index stream only.  `InputLayerFunction` adopts a prepared
         Metadata (same coords) instead of rebuilding it; `handover()` orders the consumer stream behind the build."""
+        if xcd_order is not None:
+            self.xcd_order = bool(xcd_order)
         side = index_stream(torch.device("cuda", torch.cuda.current_device()))
         # coords may have been produced on the CALLER's stream (prepare_in_thread captures it: on the helper thread
         # torch.cuda.current_stream() is that thread's default stream, not the caller's)
@@ -624,7 +642,7 @@ class Metadata:
         return self
 
     def prepare_in_thread(self, spatial_size, coords, batch_size: int = 0, mode: int = 4, n_levels: int = 0,
-                          k: int = 3, native: bool = True) -> "PendingMetadata":
+                          k: int = 3, native: bool = True, xcd_order: Optional[bool] = None) -> "PendingMetadata":
         """prepare_async on a helper thread.  The build waits four times for a row count; on the caller's thread those
         waits would keep it from queueing the matrix kernels of the current batch (measured: slower than no prefetch).
         The helper spends its time inside C calls and event waits, which release the GIL."""
@@ -634,7 +652,7 @@ class Metadata:
         def fn():
             torch.cuda.set_device(dev)
             return self.prepare_async(spatial_size, coords, batch_size, mode, n_levels, k, native=native,
-                                      caller_stream=caller_stream)
+                                      caller_stream=caller_stream, xcd_order=xcd_order)
         return PendingMetadata(fn)
 
     def prepared_for(self, coords: torch.Tensor) -> bool:

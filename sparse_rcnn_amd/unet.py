@@ -313,9 +313,15 @@ class Backbone(nn.Module):
         """metadata: optional Metadata prepared for the same coords (`prefetch` / `prefetch_in_thread`)."""
         if metadata is None and self.NATIVE_INDEX and coords.shape[0] > 0:
             from .metadata import Metadata
-            metadata = Metadata(3).build_native(spatial_size, coords, batch_size, 4, len(self.unet.channels), 3)
+            metadata = Metadata(3).build_native(spatial_size, coords, batch_size, 4, len(self.unet.channels), 3,
+                                                xcd_order=self._xcd_order())
         x = InputLayer(3, spatial_size, mode=4)((coords, feats, batch_size), metadata)
         return self.unet(x)
+
+    def _xcd_order(self):
+        """bf16 storage: the SubM tiles of the pyramid also get the XCD-local hand-out order (scn_tiles_build_x)."""
+        from . import metadata as MD
+        return bool((self.unet.bf16_all or self.unet.bf16_blocks) and MD.XCD_ORDER_BF16) or MD.XCD_ORDER_DEFAULT
 
     def load_reference_state_dict(self, state_dict, prefix=None, strict=True):
         """A reference FeatureExtractor checkpoint -> this backbone (SparseUNet.load_reference_state_dict)."""
@@ -324,12 +330,14 @@ class Backbone(nn.Module):
     def prefetch_in_thread(self, coords, spatial_size, batch_size=0):
         """As `prefetch`, on a helper thread: returns a PendingMetadata whose `.result()` is passed as `metadata=`."""
         from .metadata import Metadata
-        return Metadata(3).prepare_in_thread(spatial_size, coords, batch_size, 4, len(self.unet.channels), 3)
+        return Metadata(3).prepare_in_thread(spatial_size, coords, batch_size, 4, len(self.unet.channels), 3,
+                                             xcd_order=self._xcd_order())
 
     def prefetch(self, coords, spatial_size, batch_size=0):
         """Build the index structures of a coming batch on the index stream (overlaps the current batch's kernels)."""
         from .metadata import Metadata
-        return Metadata(3).prepare_async(spatial_size, coords, batch_size, 4, len(self.unet.channels), 3, native=True)
+        return Metadata(3).prepare_async(spatial_size, coords, batch_size, 4, len(self.unet.channels), 3, native=True,
+                                         xcd_order=self._xcd_order())
 
 
 class DropinBackbone(nn.Module):

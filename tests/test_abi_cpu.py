@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol():
     # the step executor's plan records: the ctypes structures of executor.py have the C layout
     from sparse_rcnn_amd import executor as EX
     assert loaded.scn_exec_struct_bytes(0) == ctypes.sizeof(EX.ExecOp) == 64
-    assert loaded.scn_exec_struct_bytes(1) == ctypes.sizeof(EX.ExecLevel) == 128
+    assert loaded.scn_exec_struct_bytes(1) == ctypes.sizeof(EX.ExecLevel) == 136
 
 
 def test_executor_plans_compile_without_a_gpu():

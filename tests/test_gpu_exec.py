@@ -301,3 +301,52 @@ def test_deferred_weight_gradient_sums_equal_the_immediate_ones_bit_for_bit(gpu,
     for (dW, db), (rW, rb_) in zip(outs, ref):
         assert torch.equal(dW, rW) and torch.equal(db, rb_)
     assert float(outs[0][0].abs().max()) > 0
+
+
+def test_xcd_local_tile_order_is_a_valid_second_order_and_changes_no_bit(gpu):
+    """scn_tiles_build_x (round 3d): behind the LPT order sits the list of the tiles by (spatial bin of the first row, cost
+    descending) and its nine bin starts; scn_conv_tiles_bf16 with SCN_F_TILE_ORDER_X hands bin x to the workgroups of XCD x.
+    The list is a permutation of the tiles, bins are row ranges, costs descend inside a bin; the first order is unchanged;
+    the convolution gives the SAME bits with either hand-out (forward and backward-data, with and without the K split)."""
+    import os
+    import sparse_rcnn_amd as scn
+    from sparse_rcnn_amd import functional as F, _lib as L, metadata as MD
+    coords, feats, size, bs, _ = _scene(40_000, (256, 256, 128), seed=9)
+    x = scn.InputLayer(3, size, mode=4)((coords, feats.to(gpu), 1))
+    md = x.metadata
+    rb_plain = md.subm_rulebook(size, 3)
+    t0 = rb_plain.tiles
+    assert not t0.has_x
+    tx = MD.build_tiles(rb_plain.table, 27, rb_plain.n, with_x=True)
+    assert tx.has_x
+    nt = (rb_plain.n + 15) // 16
+    assert torch.equal(tx.tile_order, t0.tile_order) and torch.equal(tx.perm, t0.perm) and torch.equal(tx.tstab, t0.tstab)
+    full = torch.as_strided(tx.tile_order, (2 * nt + 9,), (1,)).cpu().numpy()          # the buffer behind the first order
+    order_x, bs9 = full[nt:2 * nt], full[2 * nt:2 * nt + 9]
+    assert sorted(order_x.tolist()) == list(range(nt))
+    assert bs9[0] == 0 and bs9[8] == nt and all(bs9[i] <= bs9[i + 1] for i in range(8))
+    first_row = tx.perm.cpu().numpy().reshape(nt, 16)[:, 0]
+    cost = np.array([bin(int(v)).count("1") for v in tx.tile_mask.cpu().numpy().view(np.uint32)])
+    for b in range(8):
+        ids = order_x[bs9[b]:bs9[b + 1]]
+        if len(ids) == 0:
+            continue
+        assert all((np.maximum(first_row[ids], 0).astype(np.int64) * 8) // rb_plain.n == b)
+        c = cost[ids]
+        assert all(c[i] >= c[i + 1] for i in range(len(c) - 1))
+    sizes = np.diff(bs9)
+    assert sizes.min() > 0.5 * nt / 8 and sizes.max() < 1.5 * nt / 8, sizes           # row ranges hold similar tile counts
+    for cin, cout in ((32, 32), (64, 64), (32, 64), (128, 128)):
+        X = torch.randn(rb_plain.n, cin, device=gpu).bfloat16()
+        W = torch.randn(27, cin, cout, device=gpu) * 0.1
+        for fl in (0, L.F_W_TRANSPOSED | L.F_OFF_REVERSE if cin == cout else 0):
+            Wc = W if not fl else W.transpose(1, 2).contiguous()
+            a = F.conv_rules_bf16(X, tx, rb_plain.n, Wc, None, cout, fl | L.F_RELU_IN)
+            b = F.conv_rules_bf16(X, t0, rb_plain.n, Wc, None, cout, fl | L.F_RELU_IN)
+            os.environ["SCN_TB_NO_XORDER"] = "1"
+            try:
+                c = F.conv_rules_bf16(X, tx, rb_plain.n, Wc, None, cout, fl | L.F_RELU_IN)
+            finally:
+                del os.environ["SCN_TB_NO_XORDER"]
+            assert torch.equal(a, b) and torch.equal(a, c)
+            assert float(a.float().abs().max()) > 0

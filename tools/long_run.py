@@ -12,7 +12,8 @@ for seed, target in ((1, 150000), (2, 120000), (3, 165000), (4, 90000)):
     c, f, size, bs, _ = make_batch(1, (512, 512, 256), target, dup=1.15, seed=seed)
     scenes.append((c.to(dev), f.to(dev), size))
 torch.manual_seed(0)
-model = Backbone(7, (32, 64, 128, 256)).to(dev)
+BF16 = len(sys.argv) > 2 and sys.argv[2] == "bf16"        # bf16 storage (XCD-local tile order, bf16 tile kernels)
+model = Backbone(7, (32, 64, 128, 256), bf16_blocks="all" if BF16 else False).to(dev)
 flat = FlatParams(model, n_buckets=4)
 n_steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 pending = model.prefetch_in_thread(scenes[0][0], scenes[0][2], 1)
@@ -25,7 +26,7 @@ for it in range(n_steps):
     flat.zero_grad()
     out = model(c, f.detach().requires_grad_(), size, 1, metadata=md)
     out.features.backward(torch.ones_like(out.features))
-    flat.sgd_step(1e-7)
+    flat.step_single_rank(1e-12)        # (upstream gradient = ones on every row: keep the weights where they are)
     vox += out.features.shape[0]
     if it == 4:
         gc.collect(); gc.freeze()

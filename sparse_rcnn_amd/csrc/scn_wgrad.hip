@@ -734,12 +734,30 @@ int make_dplan(int cin, int cout, const int64_t* prefix_host, int n_off, DPlan& 
     // Every offset rounds its unit count up, hence the n_off margin.  R and the slot counts: tools/sweep_wgrad_splits.py.
     int occ = sh.quad ? 2 : (sh.ta == 4 && sh.tb == 4 ? 2 : (sh.ta == 2 && sh.tb == 2 ? 4 : 3));
     int rounds = (sh.quad ? nblk > 1 : (sh.ta == 4 && sh.tb == 4) || (sh.ta == 3 && nblk > 1)) ? 2 : 1;
+    const bool tb_big = hb_mfma && tb_tiles(cin) == 4 && tb_tiles(cout) == 4;      // 128 x 128 workgroup blocks
     if (hb_mfma) { occ = 4; rounds = 1; }                                   // 32 KB of LDS, <= 128 registers: 4 per CU
     int64_t target = (256 * occ * rounds) / nblk - n_off;
     if (const char* e = getenv("SCN_WGRAD_SPLITS")) target = atoi(e);       // developer override
     if (target < 1) target = 1;
     const int64_t gran = hb_mfma ? 32 : (sh.quad ? 16 : 64);
     int64_t per = cdiv(cdiv(total, target), gran) * gran;
+    if (tb_big && !getenv("SCN_WGRAD_SPLITS") && n_off > 0 && total > 0 && per < 1024) {
+        // bf16-MFMA kernel, 128 x 128 blocks, SHORT units (a unit writes 64 KB of partial sums for `per` rules): half as many
+        // workgroups, and units of EQUAL length inside an offset -- k units per (average) offset.  A `per` just above half
+        // an offset's rules makes units of 1 : 0.35 and half again as many of them (tools/sweep_wgrad_tb_units.py: the
+        // paired launch at C = 256 jumps from 42.5 to 57.3 us between 110 and 120 target units: per 672 = two equal units
+        // of the ~1340 rules of an offset, per 608 = three).  Measured on the cfg-2 scene: 51.8 -> 40.6 us per paired
+        // launch at C = 128, 50.4 -> 42.6 at C = 256; long units (600 k voxels) keep all four workgroups per CU.
+        const int64_t avg = cdiv(total, n_off), slots = (256 * 2) / nblk;
+        int64_t k = (slots + n_off / 2) / n_off;
+        if (k < 1) k = 1;
+        for (;; --k) {                           // the largest k whose units still fit the slots in one round
+            per = cdiv(cdiv(avg, k), gran) * gran;
+            int64_t units = 0;
+            for (int o = 0; o < n_off; ++o) units += cdiv(prefix_host[o + 1] - prefix_host[o], per);
+            if (units <= slots || k == 1) break;
+        }
+    }
     const int64_t min_per = hb_mfma ? 256 : (sh.quad ? 128 : 512);         // >= 8 steps per workgroup
     if (per < min_per) per = min_per;
     pl.per = per;

@@ -1,4 +1,4 @@
-"""Developer tool (GPU box): unit count of the bf16-MFMA weight gradient (k_wgrad_tb), paired launch (two problems), per level:
+"""Developer tool (GPU box): unit count of the bf16-MFMA weight gradient (k_wgrad_tb; SWEEP_F32=1: k_wgrad_direct on fp32 rows), paired launch (two problems), per level:
 SCN_WGRAD_SPLITS sweeps the target number of units (each unit writes a cin x cout fp32 block to the slabs).
     python tools/sweep_wgrad_tb_units.py [voxels=150000] [grid=512]"""
 import os, sys, subprocess
@@ -16,7 +16,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "child":
     out = []
     for level, C in enumerate((32, 64, 128, 256)):
         rb = md.subm_rulebook(sz, 3); r = rb.rules
-        mk = lambda: torch.randn(rb.n, C, device="cuda").bfloat16()
+        mk = (lambda: torch.randn(rb.n, C, device="cuda")) if os.environ.get("SWEEP_F32") else (lambda: torch.randn(rb.n, C, device="cuda").bfloat16())
         Xs, dYs = [mk() for _ in range(2)], [mk() for _ in range(2)]
         fn = lambda: F.wgrad_bias_rules_n(Xs, dYs, r.in_rows, r.out_rows, r.prefix_host, 27, 1 << 13, L.F_RELU_IN)
         for _ in range(3): fn()

@@ -386,14 +386,22 @@ class StageFunction(torch.autograd.Function):
                 images.append(img)
                 ptab[k] = img.data_ptr()
         _run(stage, stage.fwd_arr, levels, table, ptab, None, dev)
-        ctx.stage, ctx.levels, ctx.table, ctx.ptab, ctx.keep = stage, levels, table, ptab, (ws, images, inputs)
+        if F.RELU_RECORD is not None:
+            _record_relu_masks(stage, ns, ws, offs, inputs, out)
+        ctx.stage, ctx.levels, ctx.table, ctx.ptab = stage, levels, table, ptab
         ctx.phys_shapes = [None if t is None else tuple(t.shape) for t in phys]
-        ctx.save_for_backward(*[t for t in phys if t is not None])          # (keeps the parameter tensors the pointers name alive)
+        # Everything the pointer tables name travels through save_for_backward: the parameter tensors, the forward workspace,
+        # the packed weight images and the input slabs.  They stay alive exactly as long as autograd keeps the graph
+        # (retain_graph=True: a second backward reads the same slabs; otherwise they are released when backward ends and a
+        # second backward raises autograd's own "backward through the graph a second time" error).
+        ctx.save_for_backward(*[t for t in phys if t is not None], ws, *images, *inputs)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        stage, levels, table, ptab = ctx.stage, ctx.levels, ctx.table, ctx.ptab
+        kept = ctx.saved_tensors                 # (raises when the graph's buffers have been freed)
+        stage, levels, ptab = ctx.stage, ctx.levels, ctx.ptab
+        table = type(ctx.table).from_buffer_copy(ctx.table)      # a fresh table per pass: the forward's entries stay as they were
         ns = levels[2]
         dev = dout.device
         lv, ch, es, _ = stage.bufs[stage.dout_id]
@@ -417,6 +425,7 @@ class StageFunction(torch.autograd.Function):
         goffs, gtot, views = [], 0, [None] * len(shapes)
         for reg in stage.gregions:
             goffs.append(gtot)
+            start = gtot
             for mi, kind in reg:
                 sh = shapes[2 * mi + (kind == "b")]
                 if sh is not None:
@@ -425,6 +434,8 @@ class StageFunction(torch.autograd.Function):
                         n *= s
                     views[2 * mi + (kind == "b")] = (gtot, n, sh)
                     gtot += n
+            if gtot == start:                    # (plans are only compiled for layers WITH bias: _require_bias)
+                raise L.ScnError("executor: a gradient region without a tensor (bias=None layer in a compiled stage)")
             gtot = (gtot + 63) & ~63
         flat = torch.empty(max(gtot, 1), dtype=torch.float32, device=dev)
         gtab = (vp * max(len(stage.gregions), 1))()
@@ -433,8 +444,34 @@ class StageFunction(torch.autograd.Function):
             gtab[k] = gb + 4 * o
         _run(stage, stage.bwd_arr, levels, table, ptab, gtab, dev, side=True)
         grads = [None if v is None else flat[v[0]:v[0] + v[1]].view(v[2]) for v in views]
-        ctx.keep = None
+        del kept
         return (None, None, *dins, *grads)
+
+
+def _record_relu_masks(stage, ns, ws, offs, inputs, out):
+    """functional.RELU_RECORD for a stage (the parity tests' frozen ReLU masks): the sign mask of every slab a forward op of
+    the plan applies its fused input ReLU to, in op order -- the order the layer-by-layer path records them in (a residual
+    unit: x, then y1; a decoder level: the coarse input of its deconvolution first).  Read from the slabs the executor
+    keeps for backward, after the forward launches have been queued."""
+    where = dict(zip(stage.fwd_ws, offs))
+    ext = dict(zip(stage.in_ids, inputs))
+    ext[stage.out_id] = out
+    for op in stage.fwd:
+        if not (op.flags & L.F_RELU_IN):
+            continue
+        lv, ch, es, kind = stage.bufs[op.x]
+        if op.x in ext:
+            t = ext[op.x]
+        else:
+            nb = ns[lv] * ch * es
+            t = ws[where[op.x]:where[op.x] + nb].view(torch.float32 if es == 4 else torch.bfloat16).view(ns[lv], ch)
+        F._rec_relu(t)
+
+
+def _require_bias(*mods):
+    """Plans write a bias gradient for every conv-type layer they cover (COLSUM / the b region of the WGRAD ops): a layer
+    built with bias=False keeps the layer-by-layer path."""
+    return all(getattr(m, "bias", None) is not None for m in mods)
 
 
 def run_stage(stage, levels, inputs):

@@ -118,7 +118,7 @@ class MaskBranch(nn.Module):
         from . import executor as EX, functional as F, profiling
         from .tensor import SparseConvNetTensor
         f = fmap.features
-        if (not (EX.ENABLED and SparseUNet.EXEC) or profiling.TIMER is not None or F.RELU_RECORD is not None
+        if (not (EX.ENABLED and SparseUNet.EXEC) or profiling.TIMER is not None
                 or not (f.is_cuda and f.dtype == torch.float32 and f.shape[0] > 0)):
             return None
         st = self.__dict__.get("_input_stage")
@@ -126,7 +126,7 @@ class MaskBranch(nn.Module):
             blocks = EX._plain_blocks(self.input_conv_layer[1])
             head = self.input_conv_layer[0]
             st = False
-            if blocks is not None and head.nOut % 8 == 0 and head.nIn % 8 == 0:
+            if blocks is not None and head.nOut % 8 == 0 and head.nIn % 8 == 0 and EX._require_bias(head):
                 st = EX.compile_encoder_stage(0, head, blocks, head.nIn, self.bf16, cast_first=True, cast_last=False)
             object.__setattr__(self, "_input_stage", st)
         if not st:

@@ -159,6 +159,8 @@ class SparseUNet(nn.Module):
         ok = not self.bf16_blocks and all(c % 8 == 0 for c in ch[1:]) and (self.phys0 % 8 == 0)
         enc_blocks = [EX._plain_blocks(lvl[1]) if not (l == 0 and self.identity_first) else [] for l, lvl in enumerate(self.encoder)]
         dec_blocks = [EX._plain_blocks(d["units"]) for d in self.decoder]
+        heads = [lvl[0] for l, lvl in enumerate(self.encoder) if not (l == 0 and self.identity_first)]
+        ok = ok and EX._require_bias(*heads, *[d["up"][1] for d in self.decoder], *[d["nin"] for d in self.decoder])
         if ok and all(b is not None for b in enc_blocks + dec_blocks):
             bf16 = self.bf16_all
             phys = [self.phys0] + list(ch[1:])
@@ -182,7 +184,7 @@ class SparseUNet(nn.Module):
         """The forward through the step executor, or None when it does not apply to this call."""
         from . import executor as EX, functional as F, profiling
         from .tensor import SparseConvNetTensor
-        if not (EX.ENABLED and SparseUNet.EXEC) or profiling.TIMER is not None or F.RELU_RECORD is not None:
+        if not (EX.ENABLED and SparseUNet.EXEC) or profiling.TIMER is not None:
             return None
         f = x.features
         if not (f.is_cuda and f.dtype == torch.float32 and f.dim() == 2 and f.shape[0] > 0):

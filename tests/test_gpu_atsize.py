@@ -1,7 +1,11 @@
 """-m gpu: ORACLE parity at BASELINE sizes.  The CPU oracle finishes a full 150k-voxel forward +
 backward in a few seconds, so it IS the checker here: index structures bit-exact, features and every gradient against
 oracle/scn_oracle.py on the same seeded inputs.  Every test records the errors it achieved (max abs, max abs relative
-to the oracle's max, relative L2) in gpurun_out/parity_r3.jsonl; the committed copy is profiles/r3_parity_errors.jsonl.
+to the oracle's max, relative L2) in gpurun_out/parity_r4.jsonl; the committed copy is profiles/r4_parity_errors.jsonl.
+
+Round 4: the sign masks are recorded by the step executor from the slabs it keeps for backward, so the cfg-2 / cfg-3 tests
+below run the path bench.py TIMES (one autograd node per level, scn_exec_run, deferred weight-gradient sums); the
+reference-plan test keeps the layer-by-layer module path (SparseUNet.EXEC = False) as the second variant.
 
 Bounds: the north star's "features within 1e-4 fp32" is read relative to the output scale (max |oracle|); gradients are
 bounded by relative L2 per tensor with the ReLU masks of the HIP forward prescribed to the oracle."""
@@ -19,7 +23,7 @@ from oracle import scn_oracle as O
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LOG = os.path.join(ROOT, "gpurun_out", "parity_r3.jsonl")
+LOG = os.path.join(ROOT, "gpurun_out", "parity_r4.jsonl")
 
 FEAT_TOL = 1e-4          # BASELINE.json north_star, relative to max |oracle|
 # Gradients of the 60-layer nets are ill-conditioned in fp32 when each side makes its OWN ReLU decisions: the fp32 oracle
@@ -108,6 +112,7 @@ def test_cfg2_full_unet_forward_and_every_gradient_vs_oracle_at_150k(gpu, scene1
     fin = feats.to(gpu).requires_grad_()
     with _record_relu_masks() as masks:
         out = net(coords, fin, size, 1)
+    assert _n_stage_nodes(out.features) == 7 and len(masks) == 31       # the step executor ran (the path bench.py times)
     gy = torch.randn(out.features.shape, generator=torch.Generator().manual_seed(5))
     out.features.backward(gy.to(gpu))
     torch.cuda.synchronize()
@@ -124,6 +129,19 @@ def test_cfg2_full_unet_forward_and_every_gradient_vs_oracle_at_150k(gpu, scene1
     assert out.features.shape[0] == 150_000 and e["rel_to_scale"] <= FEAT_TOL, e
     for k, p in list(net.unet.named_oracle_params().items()) + [("input features", fin)]:
         _check_grad_frozen(name, "grad " + k, p.grad, fo.grad if p is fin else po[k].grad.view_as(p), FROZEN_L2_F32)
+
+
+def _n_stage_nodes(t):
+    """Number of step-executor nodes (executor.StageFunction) in the autograd graph below tensor t."""
+    n, seen, todo = 0, set(), [t.grad_fn]
+    while todo:
+        f = todo.pop()
+        if f is None or f in seen:
+            continue
+        seen.add(f)
+        n += type(f).__name__.startswith("StageFunction")
+        todo += [g for g, _ in f.next_functions]
+    return n
 
 
 class _record_relu_masks:
@@ -145,9 +163,13 @@ class _record_relu_masks:
 # With the ReLU masks of the HIP forward prescribed to the oracle, what is left between the two gradients is summation
 # order (fp32) and, in bf16 storage, the rounding of the stored gradient slabs (the oracle differentiates the rounded
 # forward straight-through in fp32): bounds on the relative L2 of EVERY gradient tensor.
-# Achieved (profiles/r3_parity_errors.jsonl): fp32 4e-6 worst over 157 tensors of the cfg-3 step (median 8e-7) -- round 2's
-# bound without shared masks was 3e-3; bf16 storage 6-8e-3 typical, 1.3e-2 / 1.45e-2 worst (16-element bias tensors of the mask
-# branch's input stage on the 60k / 12k-voxel scenes) -- round 2: 1.5 x a measured 4-16 % yardstick, 25 % for the mask branch.
+# Achieved in round 3 (profiles/r3_parity_errors.jsonl; this round's values: profiles/r4_parity_errors.jsonl): fp32 4e-6 worst
+# over 157 tensors of the cfg-3 step (median 8e-7) -- round 2's bound without shared masks was 3e-3; bf16 storage 6-9e-3 for
+# the backbone (worst 8.9e-3, deepest encoder level), 1.2-1.45e-2 for the deepest levels of the mask branch's internal U-Net
+# (`m:unet.enc3.res1.conv1.weight` 1.32e-2 / 1.43e-2, `m:unet.dec2.res1.conv1.weight` 1.29e-2 / 1.45e-2 on the 60k chain / the
+# 12k two-rank scenes: the longest chain of bf16-rounded gradient slabs) -- round 2: 1.5 x a measured 4-16 % yardstick, 25 % for
+# the mask branch.  THE BF16 BOUND IS 2e-2: round 3 first tried 1e-2 and was red on the mask branch's tensors (first failures
+# `m:in.res0.conv0.bias` 1.19e-2 and `m:in.bias` 1.23e-2, gpurun_out/r3c_tests.log); the backbone alone stays below 1e-2.
 FROZEN_L2_F32 = 2e-5
 FROZEN_L2_BF16 = 2e-2
 
@@ -170,8 +192,8 @@ def test_cfg2_bf16_storage_vs_oracle_with_the_same_roundings_at_150k(gpu, scene1
     Gradients (round 3): the ORACLE takes the ReLU sign masks the HIP forward recorded (O.FrozenReLU) -- round 2 measured
     that mask flips, not gradient rounding, were what separated the two (two ulp-nudged realisations of the oracle itself
     sat 4-16 % apart), and bounded each tensor by 1.5 x that distance.  With the masks shared, every parameter gradient and
-    the input gradient is held to 1e-2 relative L2 (the HIP path stores its gradient slabs in bf16, the oracle
-    differentiates the rounded forward straight-through in fp32)."""
+    the input gradient is held to FROZEN_L2_BF16 = 2e-2 relative L2 (the HIP path stores its gradient slabs in bf16, the
+    oracle differentiates the rounded forward straight-through in fp32; achieved: worst 8.9e-3 here)."""
     from sparse_rcnn_amd.unet import Backbone
     coords, feats, size, bs, splits, scene = scene150k
     ch = (32, 64, 128, 256)
@@ -182,6 +204,7 @@ def test_cfg2_bf16_storage_vs_oracle_with_the_same_roundings_at_150k(gpu, scene1
     with _record_relu_masks() as masks:
         out = net(coords, fin, size, 1)
     assert out.features.dtype == torch.float32 and len(masks) == 31          # 2 per residual unit + 1 per deconvolution
+    assert _n_stage_nodes(out.features) == 7                                 # through the step executor
     gy = torch.randn(out.features.shape, generator=torch.Generator().manual_seed(5))
     out.features.backward(gy.to(gpu))
     torch.cuda.synchronize()
@@ -207,10 +230,12 @@ def test_cfg2_bf16_storage_vs_oracle_with_the_same_roundings_at_150k(gpu, scene1
 def test_reference_plan_32_112_full_unet_vs_oracle_at_150k(gpu, scene150k):
     """The network the reference actually trains (scannet_config/run.py:539-549,587-591: six levels 32-48-64-80-96-112) on
     the 150k-voxel scene: rulebooks of the two extra levels bit-exact, forward within 1e-4 of the scale, every one of the
-    120 parameter gradients and the input gradient within 2e-4 relative L2 of the oracle (ReLU masks of the HIP forward
-    prescribed to the oracle).  The 48 / 80 / 112-channel layers run the TAIL variants of k_conv_ts (dead K halves and
-    column blocks skipped)."""
-    from sparse_rcnn_amd.unet import Backbone
+    120 parameter gradients and the input gradient within FROZEN_L2_F32 = 2e-5 relative L2 of the oracle (ReLU masks of the
+    HIP forward prescribed to the oracle).  The 48 / 80 / 112-channel layers run the TAIL variants of k_conv_ts (dead K
+    halves and column blocks skipped).  This test keeps the LAYER-BY-LAYER module path (SparseUNet.EXEC = False: one autograd
+    node per residual unit / layer, immediate weight-gradient sums) -- the way the reference's own module tree drives the
+    surface; the cfg-2 / cfg-3 tests run the step executor."""
+    from sparse_rcnn_amd.unet import Backbone, SparseUNet
     from sparse_rcnn_amd.trainstep import REF_PLAN
     coords, feats, size, bs, splits, scene = scene150k
     ch = REF_PLAN
@@ -218,12 +243,16 @@ def test_reference_plan_32_112_full_unet_vs_oracle_at_150k(gpu, scene150k):
     net = Backbone(7, ch).to(gpu)
     net.unet.load_oracle_params(params)
     fin = feats.to(gpu).requires_grad_()
-    with _record_relu_masks() as masks:
-        out = net(coords, fin, size, 1)
-    assert len(masks) == 6 * 4 + 5 * 5
-    gy = torch.randn(out.features.shape, generator=torch.Generator().manual_seed(6))
-    out.features.backward(gy.to(gpu))
-    torch.cuda.synchronize()
+    SparseUNet.EXEC = False
+    try:
+        with _record_relu_masks() as masks:
+            out = net(coords, fin, size, 1)
+        assert len(masks) == 6 * 4 + 5 * 5 and _n_stage_nodes(out.features) == 0
+        gy = torch.randn(out.features.shape, generator=torch.Generator().manual_seed(6))
+        out.features.backward(gy.to(gpu))
+        torch.cuda.synchronize()
+    finally:
+        SparseUNet.EXEC = True
     po = {k: v.clone().requires_grad_() for k, v in params.items()}
     fo = feats.clone().requires_grad_()
     fr = O.FrozenReLU(masks)
@@ -361,13 +390,13 @@ def test_cfg3_end_to_end_backbone_crop_mask_vs_oracle_at_150k(gpu, dtype):
     ROI crop -> internal U-Net -> Linear stack, backward from BOTH heads (dY on the backbone output, dM on the logits).  The
     mask branch consumes the backbone's own output (not random features): forward of both heads, every one of the 76 + 80
     parameter gradients and the input-feature gradient against the oracle, which takes the ReLU sign masks the HIP forward
-    recorded (O.FrozenReLU: 63 masks) -- fp32 within 2e-4 relative L2 per tensor, bf16 storage (oracle with the same
-    roundings) within 1e-2."""
+    recorded (O.FrozenReLU: 63 masks) -- fp32 within FROZEN_L2_F32 = 2e-5 relative L2 per tensor, bf16 storage (oracle with
+    the same roundings) within FROZEN_L2_BF16 = 2e-2.  Round 4: both legs at 150k voxels (round 3 ran the bf16 leg at 60k),
+    both through the step executor (the masks come from the slabs its nodes keep for backward)."""
     from sparse_rcnn_amd import roi
     from sparse_rcnn_amd.trainstep import SceneStep
     bf16 = dtype == "bf16"
-    # (the bf16 leg runs the same chain on a 60k-voxel scene: the CPU oracle is the long pole of the GPU suite)
-    job = SceneStep("cfg3", gpu, dtype=dtype, prefetch=False, seed=1, grad_seed=100, lr=0.0, target=60_000 if bf16 else None)
+    job = SceneStep("cfg3", gpu, dtype=dtype, prefetch=False, seed=1, grad_seed=100, lr=0.0)
     grabbed = []
     hook = job.model.mask.output_roi_cut.register_forward_hook(lambda m, a, out: grabbed.append(out[1]))
     with torch.no_grad():                    # biases away from zero (they are initialised to zero)
@@ -379,14 +408,15 @@ def test_cfg3_end_to_end_backbone_crop_mask_vs_oracle_at_150k(gpu, dtype):
         job.forward_backward()
     torch.cuda.synchronize()
     assert len(masks) == 31 + 32
+    assert _n_stage_nodes(job.out.features) == 7 and _n_stage_nodes(job.logits) == 7 + 1 + 6     # backbone; + input stage + 3 + 3
     pb = dict(job.model.backbone.unet.named_oracle_params())
     pm = dict(job.model.mask.named_oracle_params())
     ch = job.channels
     out, logits, grads, n_sel = _oracle_cfg3_step(job.coords_cpu, job.feats_cpu, job.boxes, pb, pm, ch, 100, bf16=bf16,
                                                   masks=masks)
     hook.remove()
-    name = "cfg3_end_to_end_" + ("60k_bf16_storage" if bf16 else "150k")
-    assert job.out.features.shape[0] == (60_000 if bf16 else 150_000) and job.logits.shape == logits.shape and n_sel == job.n_roi_rows
+    name = "cfg3_end_to_end_" + ("150k_bf16_storage" if bf16 else "150k")
+    assert job.out.features.shape[0] == 150_000 and job.logits.shape == logits.shape and n_sel == job.n_roi_rows
     # the sparse ROI crop at size: 64 boxes x ~172k points, the selection bit for bit against the oracle, no [boxes, points] object
     sel, counts = grabbed[0][0], grabbed[0][1]
     boxes_np, cnt, assoc = O.transform_boxes([b.numpy() for b in job.boxes])
@@ -512,7 +542,9 @@ def test_two_rank_dp_cfg3_step_matches_oracle(gpu, tmp_path, case):
     gloo ranks on cuda:0, one scene and its 16 boxes each, ONE flat buffer over backbone + mask branch, bucketed all-reduce
     from the gradient hooks.  The averaged flat gradient every rank ends up with == the mean of the two scenes' ORACLE
     gradients (backbone and mask parameters), each oracle run taking the ReLU sign masks its rank's forward recorded
-    (fp32 <= 2e-4, bf16 storage against the oracle with the same roundings <= 1e-2 relative L2 per tensor).
+    (fp32 <= FROZEN_L2_F32 = 2e-5, bf16 storage against the oracle with the same roundings <= FROZEN_L2_BF16 = 2e-2 relative
+    L2 per tensor).  Round 4: the ranks run the step executor (stage nodes hand a level's gradients to the bucket hooks
+    together) -- the production path -- and record their masks from it.
     "f32-empty-rank": rank 1's boxes catch no point -- its mask branch produces no gradient and its buckets go out
     (zero-filled) in the same order as rank 0's."""
     dtype = "bf16" if case == "bf16" else "f32"

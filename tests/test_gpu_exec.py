@@ -112,6 +112,120 @@ def test_executor_mask_branch_is_bit_identical_to_the_module_path(gpu, dtype):
         assert torch.equal(x, y), n
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("workload", ["cfg2", "cfg3"])
+def test_executor_is_bit_identical_to_the_module_path_at_baseline_size(gpu, workload, dtype):
+    """the path bench.py TIMES (step executor: scn_exec_run, deferred weight-gradient sums, one autograd
+    node per level) against the layer-by-layer module path at BASELINE size -- the seed-1 150k-voxel scene of configs[1] and
+    the configs[2] step (150k voxels + 64 boxes -> crop -> mask branch), fp32 and bf16 storage.  Kernel plans depend on the
+    size (fast-path thresholds, the weight-gradient unit plan, XCD-local hand-out), so the small-scene identity tests above do
+    not cover this point.  Every output and every gradient: torch.equal."""
+    from sparse_rcnn_amd.trainstep import SceneStep
+    from sparse_rcnn_amd.unet import SparseUNet
+    res = []
+    for use in (True, False):
+        SparseUNet.EXEC = use
+        try:
+            job = SceneStep(workload, gpu, dtype=dtype, prefetch=False, seed=1, grad_seed=100, lr=0.0)
+            with torch.no_grad():
+                g = torch.Generator().manual_seed(21)
+                for p in job.model.parameters():
+                    if p.dim() == 1:
+                        p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+            job.forward_backward()
+            torch.cuda.synchronize()
+            assert job.out.features.shape[0] == 150_000
+            n_stage, seen, todo = 0, set(), [job.out.features.grad_fn]
+            while todo:
+                f = todo.pop()
+                if f is None or f in seen:
+                    continue
+                seen.add(f)
+                n_stage += type(f).__name__.startswith("StageFunction")
+                todo += [h for h, _ in f.next_functions]
+            assert (n_stage == 7) if use else (n_stage == 0), (use, n_stage)      # the executor really ran / really did not
+            res.append((job.out.features.detach().clone(), None if job.logits is None else job.logits.detach().clone(),
+                        job.fin.grad.clone(), [(n, p.grad.clone()) for n, p in job.model.named_parameters()]))
+            del job
+        finally:
+            SparseUNet.EXEC = True
+    a, b = res
+    assert torch.equal(a[0], b[0]), "backbone output"
+    if workload == "cfg3":
+        assert a[1].shape[0] > 100_000 and torch.equal(a[1], b[1]), "mask logits"
+    assert torch.equal(a[2], b[2]), "input-feature gradient"
+    assert len(a[3]) == (76 + 80 if workload == "cfg3" else 76)
+    for (n, x), (_, y) in zip(a[3], b[3]):
+        assert torch.isfinite(x).all() and torch.equal(x, y), n
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_executor_backward_twice_with_retain_graph_and_error_without(gpu, dtype):
+    """ADVICE r3 (executor.py): a stage node keeps its forward workspace, weight images and inputs through
+    save_for_backward -- a second backward with retain_graph=True reads the same slabs and gives the same bits as the
+    first (and as the module path); without retain_graph the second backward raises autograd's own error instead of
+    launching kernels on freed memory."""
+    from sparse_rcnn_amd.unet import Backbone, SparseUNet
+    coords, feats, size, bs, _ = _scene(8_000, (128, 128, 64), seed=3)
+    torch.manual_seed(5)
+    net = Backbone(7, (16, 32, 64), bf16_blocks="all" if dtype == "bf16" else False).to(gpu)
+    gy = None
+    got = {}
+    for use in (True, False):
+        SparseUNet.EXEC = use
+        try:
+            fin = feats.to(gpu).requires_grad_()
+            out = net(coords, fin, size, 1).features
+            if gy is None:
+                gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(2)).to(gpu)
+            passes = []
+            for k in range(2):
+                for p in net.parameters():
+                    p.grad = None
+                fin.grad = None
+                out.backward(gy, retain_graph=(k == 0))
+                torch.cuda.synchronize()
+                # (something else takes the freed blocks between the passes: a stale pointer would show)
+                junk = [torch.full((1 << 20,), float("nan"), device=gpu) for _ in range(8)]
+                passes.append([fin.grad.clone()] + [p.grad.clone() for p in net.parameters()])
+                del junk
+            for x, y in zip(*passes):
+                assert torch.equal(x, y)
+            got[use] = passes[0]
+            with pytest.raises(RuntimeError, match="second time|already been freed"):
+                out.backward(gy)
+        finally:
+            SparseUNet.EXEC = True
+    for x, y in zip(got[True], got[False]):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_executor_records_the_relu_masks_of_the_module_path(gpu, dtype):
+    """functional.RELU_RECORD with the executor ON (round 4: the at-size oracle tests now run the path bench.py times): the
+    sign masks a stage records from the slabs it keeps for backward == the masks the layer-by-layer path records, in the
+    same order -- backbone and the mask branch's input stage / channel-padded internal U-Net."""
+    from sparse_rcnn_amd import functional as F
+    from sparse_rcnn_amd.trainstep import SceneStep
+    from sparse_rcnn_amd.unet import SparseUNet
+    rec = []
+    for use in (True, False):
+        SparseUNet.EXEC = use
+        try:
+            job = SceneStep("cfg3", gpu, dtype=dtype, prefetch=False, seed=5, grad_seed=9, target=10_000, grid=(128, 128, 64),
+                            n_boxes=8, lr=0.0)
+            F.RELU_RECORD = []
+            job.forward_backward()
+            torch.cuda.synchronize()
+            rec.append(F.RELU_RECORD)
+        finally:
+            F.RELU_RECORD = None
+            SparseUNet.EXEC = True
+    assert len(rec[0]) == len(rec[1]) == 31 + 32
+    for k, (x, y) in enumerate(zip(*rec)):
+        assert x.shape == y.shape and torch.equal(x, y), k
+
+
 def test_bf16_elementwise_forms_match_torch(gpu):
     """scn_cast_* / scn_add_bf16 / scn_gather_rows_bf16 / scn_segment_sum_bf16 / pooling / SparseToDense in bf16 storage against
     torch on the same bits (casts and gathers bit-exact; sums within one bf16 rounding of the fp64 sum)."""

@@ -156,6 +156,13 @@ int scn_pyramid_build(const int64_t* coords, int64_t n_points, int n_levels, int
  * that builds its own index structures, the ROI batch) ask for it and the pipelined prefetch does not.  Same structures. */
 #define SCN_PYRAMID_TWO_QUEUES 1
 #define SCN_PYRAMID_XCD_ORDER 2   /* the SubM tiles of every level also get the XCD-local hand-out order (scn_tiles_build_x) */
+/* SCN_PYRAMID_FUSED (round 4, k = 3): the same structures, bit for bit, from a build that never waits for the device before
+ * its end: level sizes stay in device memory (every index kernel reads its row count from the word the numbering kernel
+ * wrote; grids and buffer offsets by the upper bound n_l <= n_points), the levels run side by side inside each launch,
+ * flag / scan / fill of the numbering is one look-back pass, and ONE device -> host copy brings back every size
+ * (14 + n_levels - 1 launches and one host wait; the builder above: ~136 launches, one wait per level + one).  Only the
+ * hash tables differ (every level gets the capacity of n_points).  Overrides SCN_PYRAMID_TWO_QUEUES. */
+#define SCN_PYRAMID_FUSED 4
 int scn_pyramid_build_ex(const int64_t* coords, int64_t n_points, int n_levels, int k, void* workspace,
                          int64_t workspace_bytes, int64_t* desc, int flags, scn_stream_t stream);
 

@@ -130,6 +130,7 @@ OK, EINVAL, ESIZE, EHASH, EHIP = 0, 1, 2, 3, 4
 PYRAMID_MAX_LEVELS, PYRAMID_LEVEL_STRIDE = 8, 72
 PYRAMID_TWO_QUEUES = 1
 PYRAMID_XCD_ORDER = 2
+PYRAMID_FUSED = 4
 PYRAMID_DESC_LEN = 8 + PYRAMID_MAX_LEVELS * PYRAMID_LEVEL_STRIDE
 COLSUM_BLOCKS = 512
 

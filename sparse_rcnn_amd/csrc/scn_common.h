@@ -66,8 +66,23 @@ __device__ __forceinline__ unsigned long long scn_pack_key(int x, int y, int z, 
            ((unsigned long long)(unsigned)y << 16) | (unsigned long long)(unsigned)z;
 }
 
+// Slot of a key: a full 64-bit finaliser (the one of MurmurHash3).  Rounds 1-3 used `key * golden; h ^= h >> 29`, whose low
+// log2(cap) bits do not depend on the batch field (bits 48-63 of the key reach bits >= 19 of h only): the voxels that several
+// samples share -- the overlapping boxes of an ROI batch keep their absolute scene coordinates, roi_select_sparse.py:136-149 --
+// all started their probe at ONE slot and formed clusters as long as the number of samples (index build of a 64-box ROI
+// batch: 2.6 ms against 0.9 ms for as many points of one scene; 0.86 ms with this function).  Slot layout only: no result
+// depends on it.
+// Measured and NOT kept (round 4): a locality-preserving layout -- the 16 sites of a 4 x 4 (y, z) column in one 128-byte line
+// of the key array, slot = hash(column) * 16 + (y & 3) * 4 + (z & 3), so that the 27 neighbour probes of a row touch ~7 lines
+// instead of 27 (every probe of a scattered table is an L2 miss served by the Infinity Cache).  Surfaces fill whole columns,
+// linear probing then builds runs across lines, and the 19 of 27 probes that MISS walk them: table kernel 98 -> 336 us,
+// coarse-site numbering 33 -> 100 us at 150 k voxels.
 __device__ __forceinline__ unsigned long long scn_hash_slot(unsigned long long key, unsigned long long mask) {
-    unsigned long long h = key * 0x9E3779B97F4A7C15ull;
-    h ^= h >> 29;
+    unsigned long long h = key;
+    h ^= h >> 33;
+    h *= 0xff51afd7ed558ccdull;
+    h ^= h >> 33;
+    h *= 0xc4ceb9fe1a85ec53ull;
+    h ^= h >> 33;
     return h & mask;
 }

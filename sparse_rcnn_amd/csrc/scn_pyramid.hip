@@ -102,14 +102,28 @@ int64_t level_bytes(int64_t n, int n_off, bool has_next) {
 }
 }  // namespace
 
-extern "C" int64_t scn_pyramid_workspace_bytes(int64_t n_points, int n_levels, int k) {
-    if (n_points < 0 || n_levels < 1 || n_levels > SCN_PYRAMID_MAX_LEVELS || k < 1 || k > 3 || k % 2 == 0) return -1;
+namespace scn {
+int64_t pyramid2_workspace_bytes(int64_t n_points, int n_levels, int k);
+int pyramid2_build(const int64_t* coords, int64_t n_points, int n_levels, int k, void* workspace, int64_t workspace_bytes,
+                   int64_t* desc, int flags, scn_stream_t stream);
+}  // namespace scn
+
+static int64_t v1_workspace_bytes(int64_t n_points, int n_levels, int k) {
     const int64_t n = n_points > 0 ? n_points : 1, pad = 256;
     const int64_t cap = scn_hash_capacity(n);
     int64_t b = n * 16 + pad + 4 + pad;                                                     // int32 coords, range flag
     b += cap * 8 + pad + cap * 4 + pad + 3 * (n * 4 + pad) + n * 16 + pad + scn_dedup_scratch_bytes(n) + pad + 8 + pad;
     for (int l = 0; l < n_levels; ++l) b += level_bytes(n, k * k * k, l + 1 < n_levels);   // every level is bounded by n
     return b + 4096;
+}
+
+extern "C" int64_t scn_pyramid_workspace_bytes(int64_t n_points, int n_levels, int k) {
+    if (n_points < 0 || n_levels < 1 || n_levels > SCN_PYRAMID_MAX_LEVELS || k < 1 || k > 3 || k % 2 == 0) return -1;
+    const int64_t v1 = v1_workspace_bytes(n_points, n_levels, k);
+    if (k != 3) return v1;
+    // (the fused builder places every level at its upper bound and keeps its sort buffers per level: a little more)
+    const int64_t v2 = scn::pyramid2_workspace_bytes(n_points, n_levels, k);
+    return v2 > v1 ? v2 : v1;
 }
 
 extern "C" int scn_pyramid_build(const int64_t* coords, int64_t n_points, int n_levels, int k, void* workspace,
@@ -122,6 +136,9 @@ extern "C" int scn_pyramid_build_ex(const int64_t* coords, int64_t n_points, int
     SCN_REQUIRE(coords && workspace && desc && n_points >= 1 && n_levels >= 1 && n_levels <= SCN_PYRAMID_MAX_LEVELS);
     SCN_REQUIRE(k == 1 || k == 3);
     SCN_REQUIRE(((uintptr_t)workspace & 255) == 0);
+    // SCN_PYRAMID_FUSED: the build without host round trips (scn_pyramid2.hip); SCN_PYRAMID_V1=1 keeps this file's builder
+    if ((flags & SCN_PYRAMID_FUSED) && k == 3 && getenv("SCN_PYRAMID_V1") == nullptr)
+        return scn::pyramid2_build(coords, n_points, n_levels, k, workspace, workspace_bytes, desc, flags, stream);
     const int n_off = k * k * k;
     hipStream_t st = S(stream);
     Bump ws{(char*)workspace, 0, workspace_bytes};

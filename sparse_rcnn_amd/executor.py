@@ -75,9 +75,10 @@ def build_levels(md, size, n_levels):
         e, t, r = arr[l], rb.tiles, rb.rules
         e.n = rb.n
         e.flags = 1 if getattr(t, "has_x", False) else 0           # SCN_XL_TILE_ORDER_X
-        e.tstab, e.tile_mask, e.perm, e.tile_order = t.tstab.data_ptr(), t.tile_mask.data_ptr(), t.perm.data_ptr(), t.tile_order.data_ptr()
+        # (`ptr`: addresses straight from the build workspace's layout -- no tensor view is created for the executor)
+        e.tstab, e.tile_mask, e.perm, e.tile_order = t.ptr("tstab"), t.ptr("tile_mask"), t.ptr("perm"), t.ptr("tile_order")
         ph = r.prefix_host
-        e.in_rows, e.out_rows, e.prefix_host = r.in_rows.data_ptr(), r.out_rows.data_ptr(), _addr(ph)
+        e.in_rows, e.out_rows, e.prefix_host = r.ptr("in_rows"), r.ptr("out_rows"), _addr(ph)
         keep += [rb, ph]
         ns.append(rb.n)
         if l + 1 < n_levels:
@@ -88,8 +89,8 @@ def build_levels(md, size, n_levels):
             ct, cr = sb.tiles, sb.rules
             cph = cr.prefix_host
             e.n_coarse = sb.n_coarse
-            e.c_tstab, e.c_tile_mask, e.c_perm, e.c_tile_order = ct.tstab.data_ptr(), ct.tile_mask.data_ptr(), ct.perm.data_ptr(), ct.tile_order.data_ptr()
-            e.c_in_rows, e.c_out_rows, e.c_prefix_host = cr.in_rows.data_ptr(), cr.out_rows.data_ptr(), _addr(cph)
+            e.c_tstab, e.c_tile_mask, e.c_perm, e.c_tile_order = ct.ptr("tstab"), ct.ptr("tile_mask"), ct.ptr("perm"), ct.ptr("tile_order")
+            e.c_in_rows, e.c_out_rows, e.c_prefix_host = cr.ptr("in_rows"), cr.ptr("out_rows"), _addr(cph)
             keep += [sb, cph]
             sz = sb.coarse_size
     out = cache[(size, n_levels)] = (arr, keep, ns)

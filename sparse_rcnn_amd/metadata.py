@@ -146,8 +146,50 @@ def index_prefetching(batches, extract):
             drop_prefetched(announced)
 
 
+def _ws_view(ws, off, shape, dtype):
+    """A view of `shape` / `dtype` at byte offset `off` of the uint8 workspace tensor `ws` (one tensor op)."""
+    es = _ELEM[dtype]
+    return torch.empty(0, dtype=dtype, device=ws.device).set_(ws.untyped_storage(), (ws.storage_offset() + off) // es, shape)
+
+
+_ELEM = {torch.int32: 4, torch.int64: 8, torch.uint8: 1, torch.float32: 4}
+
+
+class _Views:
+    """Base of the index-structure records below.  Their tensors are either given (step-by-step build) or views of ONE build
+    workspace (scn_pyramid_build) that are only CREATED WHEN SOMEBODY ASKS for them: a four-level build has ~80 such views and
+    creating them eagerly cost ~0.3 ms of host time per build with the device idle behind the build's size read-back; the
+    step executor never needs the tensors at all -- `ptr(name)` gives the address from the workspace layout."""
+
+    def _lazy(self, ws, ws_ptr, specs):
+        """specs: attribute name -> (byte offset into ws, shape, dtype)."""
+        d = self.__dict__
+        d["_ws"], d["_ws_ptr"], d["_specs"] = ws, ws_ptr, specs
+        return self
+
+    def __getattr__(self, name):                       # (only reached when the attribute does not exist yet)
+        d = self.__dict__
+        specs = d.get("_specs")
+        if specs is None or name not in specs:
+            raise AttributeError(f"{type(self).__name__} has no attribute {name!r}")
+        off, shape, dtype = specs[name]
+        t = d[name] = _ws_view(d["_ws"], off, shape, dtype)
+        return t
+
+    def ptr(self, name) -> int:
+        """Device address of tensor attribute `name` (0 for None) without creating a view."""
+        d = self.__dict__
+        t = d.get(name)
+        if t is None:
+            specs = d.get("_specs")
+            if specs is not None and name in specs:
+                return d["_ws_ptr"] + specs[name][0]
+            t = getattr(self, name)
+        return 0 if t is None else t.data_ptr()
+
+
 @dataclass
-class Grid:
+class Grid(_Views):
     coords: torch.Tensor            # int32 [N,4] device
     table_keys: torch.Tensor        # int64 view of uint64 keys [cap]
     table_rows: torch.Tensor        # int32 [cap]
@@ -226,6 +268,30 @@ class Rules:
         self._in, self._out, self._seg = in_rows, out_rows, None
         return self
 
+    @classmethod
+    def from_workspace(cls, ws, ws_ptr, n_off, n_out, prefix_values, specs):
+        """As from_scan, the tensors being views of the build workspace `ws` that are created on first access (specs:
+        `_table`, `_block_sums`, `prefix_dev`, `_in`, `_out` -> (byte offset, shape, dtype); _Views)."""
+        self = cls.__new__(cls)
+        d = self.__dict__
+        d["n_off"], d["_n_out"], d["_want_seg"], d["_rb"], d["_seg"] = int(n_off), int(n_out), False, None, None
+        arr = (C.c_int64 * (int(n_off) + 1))(*prefix_values)
+        d["_prefix_host"] = arr
+        d["count"] = _KnownCount(int(arr[int(n_off)]))
+        d["_ws"], d["_ws_ptr"], d["_specs"] = ws, ws_ptr, specs
+        return self
+
+    __getattr__ = _Views.__getattr__
+
+    def ptr(self, name) -> int:
+        """Device address of `in_rows` / `out_rows` (filled on first use) or of a raw field, without creating a view."""
+        if name in ("in_rows", "out_rows"):
+            raw = "_in" if name == "in_rows" else "_out"
+            if self.__dict__.get(raw) is None and "_specs" not in self.__dict__:
+                self._fill()
+            name = raw
+        return _Views.ptr(self, name)
+
     @property
     def prefix_host(self):
         """int64[n_off+1] on the host, usable as the `prefix_host` argument of the C calls."""
@@ -274,20 +340,25 @@ class Rules:
                 if t is not None]
 
 
+# scn_pyramid_build_ex(SCN_PYRAMID_FUSED): the one-call index build without host round trips (level sizes stay on the device,
+# the levels run side by side inside each launch: 17 launches and one host wait for four levels instead of ~136 and five).
+# SCN_PYRAMID_FUSED=0 (or SCN_PYRAMID_V1=1 inside the library) keeps the round-3 builder -- same structures, bit for bit.
+FUSED_INDEX = os.environ.get("SCN_PYRAMID_FUSED", "1") != "0"
+
 # default of Metadata.xcd_order (SCN_XCD_ORDER=1: every Metadata builds the second order; 0: nobody does)
 XCD_ORDER_DEFAULT = os.environ.get("SCN_XCD_ORDER", "") == "1"
 XCD_ORDER_BF16 = os.environ.get("SCN_XCD_ORDER", "") != "0"     # bf16-storage networks ask for it
 
 
 @dataclass
-class Tiles:
+class Tiles(_Views):
     """Mask-sorted row tiles of a rule table (scn_tiles_build): what the hot kernel scn_conv_tiles walks."""
     perm: torch.Tensor              # int32 [nt*16]
     tstab: torch.Tensor             # int32 [nt, n_off, 16]
     tile_mask: torch.Tensor         # int32 view of uint32 [nt]
     n_off: int
     n: int
-    tile_order: Optional[torch.Tensor] = None    # int32 [nt], tiles by offset count descending
+    tile_order: torch.Tensor        # int32 [nt], tiles by offset count descending
     has_x: bool = False             # tile_order's buffer continues with the XCD-local order and its bin starts (scn_tiles_build_x)
 
 
@@ -307,7 +378,7 @@ def build_tiles(table: torch.Tensor, n_off: int, n: int, with_x: bool = False) -
 
 
 @dataclass
-class SubmRulebook:
+class SubmRulebook(_Views):
     table: Optional[torch.Tensor]   # int32 [k^3, N]; None for k == 1 (identity)
     rules: Optional[Rules]
     k: int
@@ -316,7 +387,7 @@ class SubmRulebook:
 
 
 @dataclass
-class StridedRulebook:
+class StridedRulebook(_Views):
     parent: torch.Tensor            # int32 [Nf]  fine row -> coarse row
     fine_off: torch.Tensor          # int32 [Nf]
     child: torch.Tensor             # int32 [8, Nc]
@@ -490,56 +561,74 @@ class Metadata:
         desc = (C.c_int64 * L.PYRAMID_DESC_LEN)()
         L.check(lib.scn_pyramid_build_ex(L.ptr(c64), n, n_levels, k, L.ptr(ws), ws.numel(), desc,
                                          (L.PYRAMID_TWO_QUEUES if two_queues else 0) |
-                                         (L.PYRAMID_XCD_ORDER if self.xcd_order else 0), L.stream()))
+                                         (L.PYRAMID_XCD_ORDER if self.xcd_order else 0) |
+                                         (L.PYRAMID_FUSED if FUSED_INDEX else 0), L.stream()))
         self._workspace = ws
 
-        def view(off, count, dtype, shape=None):
-            nbytes = count * torch.empty(0, dtype=dtype).element_size()
-            t = ws[off:off + nbytes].view(dtype)
-            return t.view(shape) if shape is not None else t
+        wsp = ws.data_ptr()
+        i32, i64 = torch.int32, torch.int64
         n_off = k ** 3
         n0 = int(desc[8])
         if int(desc[3]):
             raise L.ScnError(f"libscn_mi355x error {L.EHASH}: coordinates outside the key range in {int(desc[3])} wave(s)")
         self.input_size = size
-        self.point_coords = view(desc[7], n * 4, torch.int32, (n, 4))
-        self.item_row = view(desc[4], n, torch.int32)
-        self.row_count = view(desc[5], n0, torch.int32)
-        self.row_first = view(desc[6], n0, torch.int32)
+        # (the records below hold byte offsets into the workspace; a tensor view exists only once somebody reads the attribute)
+        self.point_coords = _ws_view(ws, int(desc[7]), (n, 4), i32)
+        self.item_row = _ws_view(ws, int(desc[4]), (n,), i32)
+        self.row_count = _ws_view(ws, int(desc[5]), (n0,), i32)
+        self.row_first = _ws_view(ws, int(desc[6]), (n0,), i32)
         self.n_items = n
         if mode == 0 and n0 != n:
             raise L.ScnError("InputLayer mode 0 requires unique coordinates")
         self.n_samples = int(batch_size) if batch_size and batch_size > 0 else int(c64[:, 3].max().item()) + 1
         lv_size = size
+        new = object.__new__
+        stride = L.PYRAMID_LEVEL_STRIDE
+        per_level = [desc[8 + l * stride:8 + (l + 1) * stride] for l in range(n_levels)]      # (ctypes slices: plain int lists)
         for l in range(n_levels):
-            D = [int(desc[8 + l * L.PYRAMID_LEVEL_STRIDE + j]) for j in range(L.PYRAMID_LEVEL_STRIDE)]
+            D = per_level[l]
+            Dn = per_level[l + 1] if l + 1 < n_levels else None
             nl, cap = D[0], D[1]
-            grid = Grid(view(D[2], nl * 4, torch.int32, (nl, 4)), view(D[3], cap, torch.int64), view(D[4], cap, torch.int32),
-                        cap, nl)
+            grid = new(Grid)._lazy(ws, wsp, {"coords": (D[2], (nl, 4), i32), "table_keys": (D[3], (cap,), i64),
+                                             "table_rows": (D[4], (cap,), i32)})
+            grid.__dict__["cap"], grid.__dict__["n"] = cap, nl
             self.grids[lv_size] = grid
             self._depth[lv_size] = l
             if k == 1:
                 self.subm[(lv_size, 1)] = SubmRulebook(None, None, 1, nl)
             elif nl > 0:
                 nt = D[13]
-                table = view(D[5], n_off * nl, torch.int32, (n_off, nl))
                 P = D[25 + n_off]
-                rules = Rules.from_scan(table, n_off, nl, view(D[6], D[7], torch.int32), view(D[8], n_off + 1, torch.int64),
-                                        D[25:25 + n_off + 1], view(D[64], P, torch.int32), view(D[65], P, torch.int32))
-                tiles = Tiles(view(D[9], nt * 16, torch.int32), view(D[10], nt * n_off * 16, torch.int32, (nt, n_off, 16)),
-                              view(D[11], nt, torch.int32), n_off, nl, view(D[12], nt, torch.int32), bool(self.xcd_order))
-                self.subm[(lv_size, k)] = SubmRulebook(table, rules, k, nl, tiles)
+                rules = Rules.from_workspace(ws, wsp, n_off, nl, D[25:25 + n_off + 1],
+                                             {"_table": (D[5], (n_off, nl), i32), "_block_sums": (D[6], (D[7],), i32),
+                                              "prefix_dev": (D[8], (n_off + 1,), i64), "_in": (D[64], (P,), i32),
+                                              "_out": (D[65], (P,), i32)})
+                tiles = new(Tiles)._lazy(ws, wsp, {"perm": (D[9], (nt * 16,), i32), "tstab": (D[10], (nt, n_off, 16), i32),
+                                                   "tile_mask": (D[11], (nt,), i32), "tile_order": (D[12], (nt,), i32)})
+                td = tiles.__dict__
+                td["n_off"], td["n"], td["has_x"] = n_off, nl, bool(self.xcd_order)
+                rb = new(SubmRulebook)._lazy(ws, wsp, {"table": (D[5], (n_off, nl), i32)})
+                rd = rb.__dict__
+                rd["rules"], rd["k"], rd["n"], rd["tiles"] = rules, k, nl, tiles
+                self.subm[(lv_size, k)] = rb
             if l + 1 < n_levels and nl > 0:
-                nc = int(desc[8 + (l + 1) * L.PYRAMID_LEVEL_STRIDE])
+                nc = Dn[0]
                 ntc = D[24]
-                child = view(D[16], 8 * nc, torch.int32, (8, nc))
-                rules = Rules.from_scan(child, 8, nc, view(D[17], D[18], torch.int32), view(D[19], 9, torch.int64), D[53:62],
-                                        view(D[66], D[61], torch.int32), view(D[67], D[61], torch.int32))
-                tiles = Tiles(view(D[20], ntc * 16, torch.int32), view(D[21], ntc * 8 * 16, torch.int32, (ntc, 8, 16)),
-                              view(D[22], ntc, torch.int32), 8, nc, view(D[23], ntc, torch.int32))
+                Pc = D[61]
+                rules = Rules.from_workspace(ws, wsp, 8, nc, D[53:62],
+                                             {"_table": (D[16], (8, nc), i32), "_block_sums": (D[17], (D[18],), i32),
+                                              "prefix_dev": (D[19], (9,), i64), "_in": (D[66], (Pc,), i32),
+                                              "_out": (D[67], (Pc,), i32)})
+                tiles = new(Tiles)._lazy(ws, wsp, {"perm": (D[20], (ntc * 16,), i32), "tstab": (D[21], (ntc, 8, 16), i32),
+                                                   "tile_mask": (D[22], (ntc,), i32), "tile_order": (D[23], (ntc,), i32)})
+                td = tiles.__dict__
+                td["n_off"], td["n"], td["has_x"] = 8, nc, False
                 coarse = tuple(v // 2 for v in lv_size)
-                self.strided[lv_size] = StridedRulebook(view(D[14], nl, torch.int32), view(D[15], nl, torch.int32), child,
-                                                        rules, nl, nc, coarse, tiles)
+                sb = new(StridedRulebook)._lazy(ws, wsp, {"parent": (D[14], (nl,), i32), "fine_off": (D[15], (nl,), i32),
+                                                          "child": (D[16], (8, nc), i32)})
+                sd = sb.__dict__
+                sd["rules"], sd["n_fine"], sd["n_coarse"], sd["coarse_size"], sd["tiles"] = rules, nl, nc, coarse, tiles
+                self.strided[lv_size] = sb
                 lv_size = coarse
             elif l + 1 < n_levels:
                 break

@@ -678,6 +678,86 @@ def test_native_pyramid_build_is_bit_identical(gpu):
         Metadata(3).build_native(torch.tensor([30, 32, 16]), cg, batch, 4, 3, 3)      # 30/2 = 15 is odd
 
 
+def _index_tensors(md, with_x=False):
+    """Every deterministic index structure of a Metadata (the hash tables' slot layout is not: insertion races, capacity)."""
+    out = [("item_row", md.item_row), ("row_count", md.row_count), ("row_first", md.row_first), ("point_coords", md.point_coords)]
+    for s, g in md.grids.items():
+        out.append((f"coords{s}", g.coords))
+    for key, rb in md.subm.items():
+        if rb.table is None:
+            continue
+        nt = rb.tiles.perm.numel() // 16
+        order = rb.tiles.tile_order
+        if with_x:                       # the XCD-local order and its nine bin starts sit behind the first order
+            base = order.untyped_storage()
+            order = torch.empty(0, dtype=torch.int32, device=order.device).set_(base, order.storage_offset(), (2 * nt + 9,))
+        out += [(f"table{key}", rb.table), (f"in{key}", rb.rules.in_rows), (f"out{key}", rb.rules.out_rows),
+                (f"prefix{key}", rb.rules.prefix_dev), (f"perm{key}", rb.tiles.perm), (f"tstab{key}", rb.tiles.tstab),
+                (f"tmask{key}", rb.tiles.tile_mask), (f"torder{key}", order),
+                (f"prefix_host{key}", torch.tensor(rb.rules.prefix_list()))]
+    for key, sb in md.strided.items():
+        out += [(f"parent{key}", sb.parent), (f"fine_off{key}", sb.fine_off), (f"child{key}", sb.child),
+                (f"cin{key}", sb.rules.in_rows), (f"cout{key}", sb.rules.out_rows), (f"cprefix{key}", sb.rules.prefix_dev),
+                (f"cperm{key}", sb.tiles.perm), (f"ctstab{key}", sb.tiles.tstab), (f"ctmask{key}", sb.tiles.tile_mask),
+                (f"ctorder{key}", sb.tiles.tile_order), (f"cprefix_host{key}", torch.tensor(sb.rules.prefix_list()))]
+    return out
+
+
+@pytest.mark.parametrize("case", ["150k-4", "150k-6-x", "12crops-6", "small-3-x", "tiny-2", "one-level"])
+def test_fused_pyramid_build_equals_the_round3_builder(gpu, case):
+    """scn_pyramid_build_ex(SCN_PYRAMID_FUSED) -- level sizes device-resident, the levels side by side inside each launch,
+    one look-back numbering pass, ONE host wait (scn_pyramid2.hip) -- against the round-3 builder (SCN_PYRAMID_V1=1: ~136
+    launches, a host wait per level): every index structure bit for bit, incl. both tile hand-out orders and the bin starts
+    of the XCD-local one, at the BASELINE scene (four and six levels), on the reference's training batch of 12 crops, and on
+    scenes whose deep levels shrink to a handful of rows."""
+    import os
+    from sparse_rcnn_amd.metadata import Metadata
+    from sparse_rcnn_amd.synthetic import make_batch
+    from sparse_rcnn_amd import metadata as MD
+    assert MD.FUSED_INDEX
+    n_s, grid, target, levels, with_x = {"150k-4": (1, (512, 512, 256), 150_000, 4, False),
+                                         "150k-6-x": (1, (512, 512, 256), 150_000, 6, True),
+                                         "12crops-6": (12, (128, 128, 64), 12_500, 6, False),
+                                         "small-3-x": (2, (64, 64, 32), 3_000, 3, True),
+                                         "tiny-2": (1, (8, 8, 4), 20, 2, False),
+                                         "one-level": (1, (64, 64, 32), 5_000, 1, True)}[case]
+    coords, feats, size, bs, _ = make_batch(n_s, grid, target, dup=1.15, seed=3)
+    cg = coords.to(gpu)
+    b = Metadata(3).build_native(size, cg, bs, 4, levels, 3, xcd_order=with_x)
+    os.environ["SCN_PYRAMID_V1"] = "1"
+    try:
+        a = Metadata(3).build_native(size, cg, bs, 4, levels, 3, xcd_order=with_x)
+    finally:
+        del os.environ["SCN_PYRAMID_V1"]
+    torch.cuda.synchronize()
+    assert list(a.grids) == list(b.grids) and [g.n for g in a.grids.values()] == [g.n for g in b.grids.values()]
+    assert set(a.subm) == set(b.subm) and set(a.strided) == set(b.strided) and a.n_samples == b.n_samples
+    ta, tb = _index_tensors(a, with_x), _index_tensors(b, with_x)
+    assert len(ta) == len(tb) and len(ta) >= 4 + levels * 10
+    for (na, x), (nb_, y) in zip(ta, tb):
+        assert na == nb_ and x.shape == y.shape and torch.equal(x, y), (case, na)
+    # the hash tables differ in capacity and slot layout but answer the same questions: every row is found under its key
+    for s, g in b.grids.items():
+        if g.n:
+            rb = b.subm_rulebook(s, 3)
+            assert torch.equal(rb.table[13], torch.arange(g.n, dtype=torch.int32, device=gpu))
+
+
+def test_fused_pyramid_build_reports_out_of_range_coordinates(gpu):
+    """Coordinates outside the 16-bit key fields: the fused build returns the error of the step-by-step path (the count
+    travels back with the sizes in the one device -> host copy)."""
+    from sparse_rcnn_amd.metadata import Metadata
+    coords, size, batch = _cloud(11, grid=(32, 32, 16), n=500, batch=1, dup=0)
+    bad = coords.clone()
+    bad[7, 1] = 70_000
+    with pytest.raises(_scn().ScnError, match="outside"):
+        Metadata(3).build_native(torch.tensor([32, 32, 16]), bad.to(gpu), 1, 4, 2, 3)
+    neg = coords.clone()
+    neg[3, 0] = -1
+    with pytest.raises(_scn().ScnError, match="outside"):
+        Metadata(3).build_native(torch.tensor([32, 32, 16]), neg.to(gpu), 1, 4, 2, 3)
+
+
 def test_async_row_count_equals_synchronous_dedup(gpu):
     """scn_dedup_launch (row count left on the device, no host sync) numbers rows exactly like scn_dedup_build."""
     from sparse_rcnn_amd import metadata as M

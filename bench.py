@@ -506,14 +506,34 @@ def dropin_measurement(job, args, torch):
             job.flat.sgd_step(job.lr)
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
+    from sparse_rcnn_amd import modules as M
+    M.STAGE_STATS.update(enc=0, dec=0, layerwise_units=0)
     ms = timed(loader(n + 3))
+    stats = dict(M.STAGE_STATS)
+    n_fwd = n + 3
     ms_pf = timed(scn.index_prefetching(loader(n + 3), lambda b: b))
-    return {"ms_per_step": ms, "value": job.n_active / (ms * 1e-3),
-            "ms_per_step_index_prefetching": ms_pf, "value_index_prefetching": job.n_active / (ms_pf * 1e-3),
-            "note": "layer-by-layer scn module path with the Metadata created inside the forward from HOST coords "
-                    "(the reference's CustomInputLayer contract), rulebooks built on first use, no helper thread; "
-                    "`index_prefetching`: the same with the loop's batches wrapped in scn.index_prefetching (the coming "
-                    "batch's index build runs on the helper thread during this batch)"}
+    out = {"ms_per_step": ms, "value": job.n_active / (ms * 1e-3),
+           "ms_per_step_index_prefetching": ms_pf, "value_index_prefetching": job.n_active / (ms_pf * 1e-3),
+           # the module tree's levels ran as step-executor stages (modules._enc_stage / _dec_stage), counted per forward
+           "executor": stats["enc"] > 0 and stats["dec"] > 0 and stats["layerwise_units"] == 0,
+           "stage_nodes_per_forward": {"encoder": stats["enc"] / n_fwd, "decoder": stats["dec"] / n_fwd},
+           "note": "the scn module tree driven as the reference's containers drive it (every encoder level called as one "
+                   "scn.Sequential, a decoder level as input stage -> JoinTable -> NetworkInNetwork -> output stage), the "
+                   "Metadata created inside the forward from HOST coords (the reference's CustomInputLayer contract), no "
+                   "helper thread; round 4: the levels run as step-executor stages (deferred tensors), the index build "
+                   "is the fused one; `index_prefetching`: the same with the loop's batches wrapped in "
+                   "scn.index_prefetching (the coming batch's index build runs on the helper thread during this batch)"}
+    # the same tree with bf16-STORED feature slabs: one package-level switch, nothing in the tree changes
+    prev = scn.set_feature_storage(torch.bfloat16)
+    try:
+        b_ms = timed(loader(n + 3))
+        b_pf = timed(scn.index_prefetching(loader(n + 3), lambda b: b))
+    finally:
+        scn.set_feature_storage(prev)
+    out["bf16"] = {"ms_per_step": b_ms, "value": job.n_active / (b_ms * 1e-3), "ms_per_step_index_prefetching": b_pf,
+                   "value_index_prefetching": job.n_active / (b_pf * 1e-3),
+                   "note": "scn.set_feature_storage(torch.bfloat16) around the same module tree (INTEGRATION.md)"}
+    return out
 
 
 def main():

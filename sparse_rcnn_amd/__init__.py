@@ -13,7 +13,7 @@ from .ioLayers import InputLayer, OutputLayer                              # noq
 from .metadata import Metadata, index_prefetching, prefetch_index           # noqa: F401
 from .modules import (AddTable, AveragePooling, BatchNormLeakyReLU, BatchNormReLU, CastFeatures, ConcatTable,  # noqa: F401
                       Convolution, Deconvolution, Identity, JoinTable, MaxPooling, NetworkInNetwork, ReLU,
-                      Sequential, SparseToDense, SubmanifoldConvolution)
+                      Sequential, SparseToDense, SubmanifoldConvolution, set_feature_storage)
 from .tensor import SparseConvNetTensor                                    # noqa: F401
 from .custom_operations import SparseGlobalPool, split_batch               # noqa: F401  (device forms of the reference's own helpers)
 
@@ -21,5 +21,5 @@ __all__ = [
     "Metadata", "SparseConvNetTensor", "ioLayers", "InputLayer", "OutputLayer", "Sequential", "ConcatTable",
     "AddTable", "JoinTable", "Identity", "ReLU", "BatchNormReLU", "BatchNormLeakyReLU", "Convolution",
     "Deconvolution", "SubmanifoldConvolution", "NetworkInNetwork", "MaxPooling", "AveragePooling", "SparseToDense",
-    "prefetch_index", "index_prefetching", "SparseGlobalPool", "split_batch",
+    "prefetch_index", "index_prefetching", "SparseGlobalPool", "split_batch", "set_feature_storage",
 ]

@@ -209,12 +209,14 @@ def _phys(m):
     return int(getattr(m, "pad_out_to", None) or m.nOut)
 
 
-def compile_encoder_stage(level, head, blocks, cin_phys, bf16, cast_first=False, cast_last=False):
+def compile_encoder_stage(level, head, blocks, cin_phys, bf16, cast_first=False, cast_last=False, in_bf16=False):
     """Encoder level: head (SubM 1^3 at level 0 | Convolution 2^3/2 from level-1) + residual units.
     level 0 in bf16 storage: the head runs in fp32 on the fp32 input and its result is cast (SparseUNet), or -- cast_first,
-    the mask branch's input stage -- the input is cast first and the head runs on bf16 rows; cast_last: fp32 output."""
+    the mask branch's input stage -- the input is cast first and the head runs on bf16 rows, or -- in_bf16 -- the input
+    slab is bf16-stored already (a SubM 1^3 stage behind a bf16 network in a module tree); cast_last: fp32 output."""
     st = Stage(bf16, 1)
-    es_in = 4 if (level == 0) else st.es
+    in_bf16 = bool(bf16 and in_bf16 and level == 0)
+    es_in = (2 if in_bf16 else 4) if (level == 0) else st.es
     c = _phys(head)
     IN = st.buf(level if level == 0 else level - 1, cin_phys, es_in, "x")
     st.in_ids = [IN]
@@ -223,9 +225,11 @@ def compile_encoder_stage(level, head, blocks, cin_phys, bf16, cast_first=False,
     OUT = st.buf(level, c, out_es, "x")
     st.out_id = OUT
     if level == 0:
-        if bf16 and cast_first:
-            xin = st.buf(0, cin_phys)
-            st.op(st.fwd, OP_CAST, 0, cin_phys, 0, x=IN, y=xin, flags=XF_BF16)
+        if bf16 and (cast_first or in_bf16):
+            xin = IN
+            if not in_bf16:
+                xin = st.buf(0, cin_phys)
+                st.op(st.fwd, OP_CAST, 0, cin_phys, 0, x=IN, y=xin, flags=XF_BF16)
             h = st.buf(0, c)
             st.op(st.fwd, OP_GEMM_IDENT, 0, cin_phys, c, x=xin, y=h, w=st.param("w", mh), b=st.param("b", mh), flags=XF_BF16)
             x, head_in, head_hb = h, xin, XF_BF16
@@ -258,10 +262,11 @@ def compile_encoder_stage(level, head, blocks, cin_phys, bf16, cast_first=False,
     gw, gb = st.gregion((mh, "w")), st.gregion((mh, "b"))
     if level == 0:
         if head_hb:                                           # head ran on bf16 rows: its input gradient is cast back at the end
-            dinb = st.buf(0, cin_phys, kind="b")
+            dinb = DIN if in_bf16 else st.buf(0, cin_phys, kind="b")
             st.op(st.bwd, OP_GEMM_IDENT, 0, c, cin_phys, x=g, y=dinb, w=st.param("w", mh), flags=BACK | XF_BF16)
             st.op(st.bwd, OP_WGRAD_IDENT, 0, cin_phys, c, x=head_in, y=g, w=gw, b=gb, flags=XF_BF16)
-            st.op(st.bwd, OP_CAST, 0, cin_phys, 0, x=dinb, y=DIN, flags=0)
+            if not in_bf16:
+                st.op(st.bwd, OP_CAST, 0, cin_phys, 0, x=dinb, y=DIN, flags=0)
         else:
             gf = g
             if bf16:
@@ -475,11 +480,29 @@ def _require_bias(*mods):
     return all(getattr(m, "bias", None) is not None for m in mods)
 
 
-def run_stage(stage, levels, inputs):
+def run_stage(stage, levels, inputs, pack=False):
     """Apply a compiled stage: the physical (W, b) of its modules are fetched through `_wb` (zero-padded views of the logical
-    parameters where a layer is channel-padded -- autograd carries their gradients back through the pad)."""
+    parameters where a layer is channel-padded -- autograd carries their gradients back through the pad).
+    pack: bf16 storage outside a network-wide `packed_weights` block (a stage of a module tree somebody else built): the
+    stage's weight images are packed by ONE launch of its own instead of one per image."""
     phys = []
     for m, cin_phys in stage.mods:
         W, b = m._wb(cin_phys)
         phys += [W, b]
+    if pack and stage.bf16:
+        plan = stage.__dict__.get("_pack_plan")
+        if plan is None:
+            jobs = []
+            for d in stage.params:
+                if d[0] == "img":
+                    _, mi, cin, cout, n_off, fl = d
+                    m, cin_phys = stage.mods[mi]
+                    if getattr(m, "pad_out_to", None) or cin_phys != m.nIn:
+                        jobs = None                      # padded layers see fresh padded weight tensors: packed per call
+                        break
+                    jobs.append((m.weight, cin, cout, n_off, fl))
+            plan = stage._pack_plan = F.PackPlan(jobs) if jobs else False
+        if plan:
+            with F.packed_weights(plan):
+                return StageFunction.apply(stage, levels, *inputs, *phys)
     return StageFunction.apply(stage, levels, *inputs, *phys)

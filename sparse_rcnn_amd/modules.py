@@ -12,7 +12,7 @@ import torch
 from torch.nn import Module, Parameter
 
 from . import functional as F
-from .tensor import JoinedTensor, SparseConvNetTensor
+from .tensor import DeferredTensor, JoinedTensor, SparseConvNetTensor
 
 
 def _triple(v, what):
@@ -29,12 +29,170 @@ def _out(input, features, spatial_size=None):
                                spatial_size=input.spatial_size if spatial_size is None else spatial_size)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# Feature storage of a module tree somebody else built (round 4).  The reference's factory code (module_factory.py:127-183,
+# 513-578) knows nothing about storage types; `scn.set_feature_storage(torch.bfloat16)` switches every tree built on this
+# package to bf16-STORED feature slabs (BASELINE configs 3-5; parameters, their gradients and all accumulation stay fp32):
+# a conv-type layer whose output width is a multiple of 8 stores its result in the storage type, and a layer the bf16 entry
+# points do not serve (input width no multiple of 8 on the tile kernels, batch norm, a stand-alone ReLU) widens its input.
+# With the default (torch.float32) nothing changes.
+# ----------------------------------------------------------------------------------------------------------------------
+FEATURE_STORAGE = torch.float32
+
+
+def set_feature_storage(dtype):
+    """torch.float32 (default) | torch.bfloat16.  -> the previous setting."""
+    global FEATURE_STORAGE
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("feature storage: torch.float32 or torch.bfloat16")
+    prev, FEATURE_STORAGE = FEATURE_STORAGE, dtype
+    return prev
+
+
+def _stored(y, n_out):
+    """The output slab of a conv-type layer in the tree's storage type."""
+    if FEATURE_STORAGE is torch.bfloat16 and y.dtype == torch.float32 and n_out % 8 == 0:
+        return y.to(torch.bfloat16)
+    return y
+
+
+def _conv_input(x, c_in, c_out, tile_kernel):
+    """bf16-stored rows reach a layer only when its bf16 entry point takes them; otherwise the layer runs on widened rows."""
+    if x.dtype == torch.bfloat16 and (c_in % 8 or (tile_kernel and c_out % 8)):
+        return x.float()
+    return x
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Step-executor stages for module trees somebody else built (VERDICT r3 item 3; executor.py).  The reference's tree is
+#   encoder level   scn.Sequential(Sequential(SubM 1^3 | Convolution 2^3/2), Sequential(residual units))   module_factory.py:513-530
+#   decoder level   SkipConnectionReuniter(input_stage = scn.Sequential(ReLU, Deconvolution), combiner = scn.JoinTable,
+#                   channel_changer = scn.NetworkInNetwork, output_stage = scn.Sequential(residual units))  :533-578
+# An encoder level IS one of this package's Sequential objects: its forward recognises the shape and runs the level as one
+# executor stage (one autograd node, one C call each way).  A decoder level is four calls from a container this package
+# never sees (custom_container.py:70-83), so the first and the third return a DeferredTensor and the fourth -- a Sequential
+# of residual units that is handed a pending NetworkInNetwork -- runs the whole level.  Anything that does not fit computes
+# layer by layer as before; both ways launch the same kernels with the same arguments (bit-identical, tests/test_gpu_exec.py).
+# ----------------------------------------------------------------------------------------------------------------------
+TREE_STAGES = __import__('os').environ.get("SCN_TREE_STAGES", "1") != "0"
+STAGE_STATS = {"enc": 0, "dec": 0, "layerwise_units": 0}       # how often a forward took which way (tests, bench.py)
+
+
+def _usable(f):
+    from . import executor as EX, profiling, unet
+    return (TREE_STAGES and EX.ENABLED and unet.SparseUNet.EXEC and profiling.TIMER is None and f.is_cuda and f.dim() == 2
+            and f.shape[0] > 0 and f.dtype in (torch.float32, torch.bfloat16))
+
+
+def _head_of(m):
+    """The conv-type head of an encoder level: the layer itself or a Sequential holding just it."""
+    if type(m) is Sequential and len(m._modules) == 1:
+        m = next(iter(m._modules.values()))
+    if type(m) is SubmanifoldConvolution and m.filter_size == 1:
+        return m
+    return m if type(m) is Convolution else None
+
+
+def _kind(seq):
+    """'enc': (head, units) of an encoder level | 'units': residual units only | 'up': (ReLU, Deconvolution) | None."""
+    kind = seq.__dict__.get("_stage_kind")
+    if kind is not None:
+        return kind or None
+    from . import executor as EX
+    mods = list(seq._modules.values())
+    kind = False
+    if len(mods) == 2 and type(mods[0]) is ReLU and type(mods[1]) is Deconvolution and mods[1].bias is not None:
+        kind = "up"
+    elif len(mods) == 2 and _head_of(mods[0]) is not None and type(mods[1]) is Sequential:
+        head, blocks = _head_of(mods[0]), EX._plain_blocks(mods[1])
+        if (blocks and head.bias is not None and head.pad_out_to is None and all(c1.nIn == head.nOut for c1, _ in blocks)
+                and head.nOut % 8 == 0 and (type(head) is SubmanifoldConvolution or head.nIn % 8 == 0)):
+            kind = "enc"
+    elif mods and EX._plain_blocks(seq):
+        kind = "units"
+    object.__setattr__(seq, "_stage_kind", kind)
+    return kind or None
+
+
+def _enc_stage(seq, input):
+    """Encoder level through the executor, or NotImplemented."""
+    from . import executor as EX
+    f = input.features
+    if not _usable(f):
+        return NotImplemented
+    mods = list(seq._modules.values())
+    head = _head_of(mods[0])
+    level = 0 if type(head) is SubmanifoldConvolution else 1
+    if f.shape[1] != head.nIn:
+        return NotImplemented
+    in16 = f.dtype == torch.bfloat16
+    if level == 0:
+        bf16 = in16 or FEATURE_STORAGE is torch.bfloat16
+        if in16 and head.nIn % 8:
+            return NotImplemented
+    else:
+        bf16 = in16
+    key = (bf16, in16)
+    cache = seq.__dict__.setdefault("_stages", {})
+    st = cache.get(key)
+    if st is None:
+        st = cache[key] = EX.compile_encoder_stage(level, head, EX._plain_blocks(mods[1]), head.nIn, bf16, in_bf16=in16)
+    md = input.metadata
+    lv = EX.build_levels(md, input.spatial_size, level + 1)
+    if lv is None:
+        return NotImplemented
+    y = EX.run_stage(st, lv, [f], pack=True)
+    STAGE_STATS["enc"] += 1
+    size = input.spatial_size if level == 0 else torch.as_tensor([int(s) // 2 for s in input.spatial_size], dtype=torch.long)
+    return SparseConvNetTensor(features=y, metadata=md, spatial_size=size)
+
+
+def _dec_stage(seq, input):
+    """Residual units handed a pending NetworkInNetwork(JoinTable([Deconvolution(ReLU(x)), skip])): the decoder level through
+    the executor, or NotImplemented (the DeferredTensor then computes layer by layer)."""
+    from . import executor as EX
+    tag = input.tag
+    if tag is None or tag[0] != "nin":
+        return NotImplemented
+    _, up_t, skip_t, nin = tag
+    if not (isinstance(up_t, DeferredTensor) and up_t.pending and up_t.tag[0] == "up"):
+        return NotImplemented
+    _, coarse_t, deconv = up_t.tag
+    xc, xs = coarse_t.features, skip_t.features
+    c = deconv.nOut
+    blocks = EX._plain_blocks(seq)
+    if not (_usable(xc) and _usable(xs) and xc.dtype == xs.dtype and xs.shape[1] == c and nin.nIn == 2 * c and nin.nOut == c
+            and nin.bias is not None and c % 8 == 0 and deconv.nIn % 8 == 0 and xc.shape[1] == deconv.nIn
+            and deconv.pad_out_to is None and nin.pad_out_to is None and all(c1.nIn == c for c1, _ in blocks)):
+        return NotImplemented
+    md = input.metadata
+    fine = tuple(int(s) for s in input.spatial_size)
+    if md.cached_strided_rulebook(fine) is None or skip_t.metadata is not md:
+        return NotImplemented                            # (the layer-by-layer path raises the reference's error)
+    bf16 = xc.dtype == torch.bfloat16
+    cache = seq.__dict__.setdefault("_stages", {})
+    key = (id(deconv), id(nin), bf16)
+    st = cache.get(key)
+    if st is None:
+        st = EX.compile_decoder_stage(0, deconv, nin, blocks, deconv.nIn, bf16)
+        cache[key] = st
+        st._keep = (deconv, nin)                         # (the ids in the key stay valid while the plan lives)
+    lv = EX.build_levels(md, fine, 2)
+    if lv is None:
+        return NotImplemented
+    y = EX.run_stage(st, lv, [xc, xs], pack=True)
+    STAGE_STATS["dec"] += 1
+    return SparseConvNetTensor(features=y, metadata=md, spatial_size=input.spatial_size)
+
+
 class Sequential(torch.nn.Sequential):
     """``scn.Sequential(*modules)`` with ``.append`` / ``.add`` (module_factory.py:52-56,421-424).
     Peephole: ``ReLU`` directly followed by a conv-type layer runs as one kernel (ReLU fused into the gather)."""
 
     def append(self, module):
         self.add_module(str(len(self._modules)), module)
+        self.__dict__.pop("_stage_kind", None)           # (the cached shape of this Sequential: _kind)
+        self.__dict__.pop("_stages", None)
         return self
 
     def add(self, module):
@@ -43,6 +201,22 @@ class Sequential(torch.nn.Sequential):
     def forward(self, input, residual=None):
         """residual: features to add to the output of the LAST module when that is a SubmanifoldConvolution (used by
         the residual-block peephole below)."""
+        if residual is None and TREE_STAGES and isinstance(input, SparseConvNetTensor):
+            kind = _kind(self)
+            if kind == "enc":
+                y = _enc_stage(self, input)
+                if y is not NotImplemented:
+                    return y
+            elif kind == "units" and isinstance(input, DeferredTensor) and input.pending:
+                y = _dec_stage(self, input)
+                if y is not NotImplemented:
+                    return y
+                STAGE_STATS["layerwise_units"] += 1
+            elif kind == "up" and _usable(input.features):
+                deconv = self._modules["1"]
+                out_size = torch.as_tensor([int(s) * 2 for s in input.spatial_size], dtype=torch.long)
+                return DeferredTensor(lambda: deconv(input, relu_in=True).features, input.metadata, out_size,
+                                      ("up", input, deconv))
         mods = list(self._modules.values())
         i = 0
         while i < len(mods):
@@ -127,9 +301,9 @@ class ConcatTable(Sequential):
 
 class AddTable(Module):
     def forward(self, input):
-        feats = input[0].features
+        feats = _wide(input[0].features)
         for t in input[1:]:
-            feats = F.AddFunction.apply(feats, t.features)
+            feats = F.AddFunction.apply(feats, _wide(t.features))
         return _out(input[0], feats)
 
 
@@ -137,7 +311,7 @@ class JoinTable(Module):
     """Channel concat of tensors sharing Metadata / row order (module_factory.py:301)."""
 
     def forward(self, input):
-        return JoinedTensor([t.features for t in input], input[0].metadata, input[0].spatial_size)
+        return JoinedTensor(None, input[0].metadata, input[0].spatial_size, sources=input)
 
 
 class Identity(Module):
@@ -145,9 +319,15 @@ class Identity(Module):
         return input
 
 
+def _wide(x):
+    """Layers without a bf16 entry point (stand-alone ReLU, AddTable outside a residual unit, batch norm) widen bf16-stored
+    rows; the next conv-type layer stores its result in the tree's storage type again."""
+    return x.float() if x.dtype == torch.bfloat16 else x
+
+
 class ReLU(Module):
     def forward(self, input):
-        return _out(input, F.ReLUFunction.apply(input.features))
+        return _out(input, F.ReLUFunction.apply(_wide(input.features)))
 
 
 class _BatchNorm(Module):
@@ -165,7 +345,7 @@ class _BatchNorm(Module):
         self.bias = Parameter(torch.zeros(nPlanes))
 
     def forward(self, input):
-        y = F.BatchNormReLUFunction.apply(input.features, self.weight, self.bias, self.running_mean, self.running_var,
+        y = F.BatchNormReLUFunction.apply(_wide(input.features), self.weight, self.bias, self.running_mean, self.running_var,
                                           float(self.eps), float(self.momentum), float(self.leakiness), self.training,
                                           _BatchNorm.SYNC)
         return _out(input, y)
@@ -241,10 +421,13 @@ class SubmanifoldConvolution(_ConvBase):
         self._init(self.filter_size ** 3, nIn, nOut, bias)
 
     def forward(self, input, relu_in=False, residual=None):
-        W, b = self._wb(input.features.shape[1])
-        y = F.SubmanifoldConvolutionFunction.apply(input.features, W, b, input.metadata,
-                                                   input.spatial_size, self.filter_size, relu_in, residual)
-        return _out(input, y)
+        W, b = self._wb(input.features.shape[1])          # (physical widths: a channel-padded slab is wider than nIn)
+        x = _conv_input(input.features, W.shape[1], W.shape[2], self.filter_size == 3)
+        if residual is not None and residual.dtype != x.dtype:
+            residual = residual.to(x.dtype)
+        y = F.SubmanifoldConvolutionFunction.apply(x, W, b, input.metadata, input.spatial_size, self.filter_size, relu_in,
+                                                   residual)
+        return _out(input, _stored(y, W.shape[-1]))
 
     def extra_repr(self):
         return f"{self.nIn}->{self.nOut} C{self.filter_size}"
@@ -271,9 +454,10 @@ class Convolution(_ConvBase):
     def forward(self, input, relu_in=False):
         in_size = tuple(int(s) for s in input.spatial_size)
         W, b = self._wb(input.features.shape[1])
-        y = F.ConvolutionFunction.apply(input.features, W, b, input.metadata, in_size, relu_in)
+        x = _conv_input(input.features, W.shape[1], W.shape[2], True)
+        y = F.ConvolutionFunction.apply(x, W, b, input.metadata, in_size, relu_in)
         out_size = torch.as_tensor([s // 2 for s in in_size], dtype=torch.long)
-        return _out(input, y, out_size)
+        return _out(input, _stored(y, W.shape[-1]), out_size)
 
     def input_spatial_size(self, out_size):
         return out_size * 2
@@ -295,8 +479,9 @@ class Deconvolution(_ConvBase):
     def forward(self, input, relu_in=False):
         out_size = tuple(int(s) * 2 for s in input.spatial_size)
         W, b = self._wb(input.features.shape[1])
-        y = F.DeconvolutionFunction.apply(input.features, W, b, input.metadata, out_size, relu_in)
-        return _out(input, y, torch.as_tensor(out_size, dtype=torch.long))
+        x = _conv_input(input.features, W.shape[1], W.shape[2], True)
+        y = F.DeconvolutionFunction.apply(x, W, b, input.metadata, out_size, relu_in)
+        return _out(input, _stored(y, W.shape[-1]), torch.as_tensor(out_size, dtype=torch.long))
 
     def extra_repr(self):
         return f"{self.nIn}->{self.nOut} D2/2"
@@ -339,17 +524,37 @@ class NetworkInNetwork(Module):
         return W, b
 
     def forward(self, input):
-        if isinstance(input, JoinedTensor) and not input.materialized and len(input.parts) > 1:
+        if (TREE_STAGES and isinstance(input, JoinedTensor) and not input.materialized and input.sources is not None
+                and len(input.sources) == 2 and isinstance(input.sources[0], DeferredTensor) and input.sources[0].pending
+                and input.sources[0].tag[0] == "up"):
+            # JoinTable([Deconvolution(ReLU(x)), skip]) -> NetworkInNetwork with the deconvolution still pending: stay pending;
+            # the residual units behind this layer run the decoder level as one executor stage (_dec_stage), anybody else
+            # gets the layer-by-layer result
+            joined = input
+            return DeferredTensor(lambda: self.forward(_materialized_join(joined)).features, input.metadata, input.spatial_size,
+                                  ("nin", input.sources[0], input.sources[1], self))
+        if isinstance(input, JoinedTensor) and not input.materialized and input.n_parts > 1:
             # JoinTable -> NetworkInNetwork (module_factory.py:557-563): one row GEMM per joined part against its rows of
             # the weight, accumulated through the kernel's residual operand -- the concatenated slab is never built
-            W, b = self._wb(sum(p.shape[1] for p in input.parts))
-            y = F.JoinedNetworkInNetworkFunction.apply(W, b, *input.parts)
-            return SparseConvNetTensor(features=y, metadata=input.metadata, spatial_size=input.spatial_size)
+            parts = input.parts
+            if len({p.dtype for p in parts}) > 1 or any(p.dtype == torch.bfloat16 and p.shape[1] % 8 for p in parts):
+                parts = [p.float() for p in parts]
+            W, b = self._wb(sum(p.shape[1] for p in parts))
+            y = F.JoinedNetworkInNetworkFunction.apply(W, b, *parts)
+            return SparseConvNetTensor(features=_stored(y, W.shape[-1]), metadata=input.metadata, spatial_size=input.spatial_size)
         W, b = self._wb(input.features.shape[1])
-        return _out(input, F.NetworkInNetworkFunction.apply(input.features, W, b))
+        x = _conv_input(input.features, W.shape[0], W.shape[1], False)
+        return _out(input, _stored(F.NetworkInNetworkFunction.apply(x, W, b), W.shape[-1]))
 
     def extra_repr(self):
         return f"{self.nIn}->{self.nOut}"
+
+
+def _materialized_join(joined):
+    """The JoinedTensor with its sources computed (a pending Deconvolution runs now) -- for the layer-by-layer path."""
+    joined.parts = [t.features for t in joined.sources]
+    joined.sources = None
+    return joined
 
 
 class SparseToDense(Module):

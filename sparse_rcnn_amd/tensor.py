@@ -47,18 +47,70 @@ class SparseConvNetTensor:
         return f"SparseConvNetTensor<features={n}, spatial_size={None if self.spatial_size is None else self._size()}>"
 
 
+class DeferredTensor(SparseConvNetTensor):
+    """A SparseConvNetTensor whose features have NOT been computed yet (round 4: the fast path for module trees somebody else
+    built).  The reference's decoder level is four calls into this package from a container of its own
+    (custom_container.py:70-83: input_stage -> combiner -> channel_changer -> output_stage); the step executor wants them as
+    ONE launch plan.  So `Sequential(ReLU, Deconvolution)` and `NetworkInNetwork` over a JoinTable return a DeferredTensor
+    that remembers what to compute (`tag`), and the `Sequential` of residual units that receives it runs the whole level as
+    one executor stage.  Anybody else who touches `.features` gets them computed layer by layer, exactly as before
+    (`thunk`): deferral never changes a result, only who launches the kernels."""
+
+    def __init__(self, thunk, metadata, spatial_size, tag):
+        self._thunk, self._feat = thunk, None
+        self.metadata = metadata
+        self.spatial_size = spatial_size
+        self.tag = tag
+
+    @property
+    def pending(self):
+        return self._feat is None
+
+    @property
+    def features(self):
+        if self._feat is None:
+            self._feat = self._thunk()
+            self._thunk = self.tag = None
+        return self._feat
+
+    @features.setter
+    def features(self, value):
+        self._feat, self._thunk, self.tag = value, None, None
+
+    def __repr__(self):
+        if self._feat is None:
+            return f"DeferredTensor<pending {self.tag[0]}, spatial_size={None if self.spatial_size is None else self._size()}>"
+        return super().__repr__()
+
+
 class JoinedTensor(SparseConvNetTensor):
     """What ``scn.JoinTable`` returns: the channel concatenation of tensors that share Metadata and row order
     (module_factory.py:298-301), kept as its PARTS.  ``.features`` is the concatenated slab, built on first access -- a
     consumer that can read the parts as separate row sources (NetworkInNetwork: one GEMM per part against the matching
     rows of its weight) never asks for it, and the copy (two slabs written and read again per decoder level) does not
-    happen."""
+    happen.  `sources`: the joined SparseConvNetTensor objects themselves (a DeferredTensor among them stays pending until
+    somebody asks for `parts` / `features`)."""
 
-    def __init__(self, parts, metadata=None, spatial_size=None):
-        self.parts = list(parts)
+    def __init__(self, parts=None, metadata=None, spatial_size=None, sources=None):
+        self.sources = list(sources) if sources is not None else None
+        self._parts = list(parts) if parts is not None else None
         self._cat = None
         self.metadata = metadata
         self.spatial_size = spatial_size
+
+    @property
+    def parts(self):
+        if self._parts is None:
+            self._parts = [t.features for t in self.sources]
+        return self._parts
+
+    @parts.setter
+    def parts(self, value):
+        self._parts = list(value)
+
+    @property
+    def n_parts(self):
+        return len(self._parts) if self._parts is not None else len(self.sources)
 
     @property
     def features(self):
@@ -69,7 +121,8 @@ class JoinedTensor(SparseConvNetTensor):
     @features.setter
     def features(self, value):
         self._cat = value
-        self.parts = [value]
+        self._parts = [value]
+        self.sources = None
 
     @property
     def materialized(self):

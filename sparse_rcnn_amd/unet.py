@@ -345,9 +345,13 @@ class Backbone(nn.Module):
 class DropinBackbone(nn.Module):
     """The backbone driven the way the reference's own module tree drives the scn surface (the drop-in path proper):
     `CustomInputLayer` creates the Metadata inside the forward from HOST coordinates (custom_operations.py:67-83), no
-    layer announces the depth of the network, rulebooks are requested one by one by the layers that need them, and there
-    is no helper thread.  Shares the parameters of a `Backbone`; used by `bench.py --dropin` and the tests to compare the
-    two ways of driving the same kernels."""
+    layer announces the depth of the network, rulebooks are requested one by one by the layers that need them, there is no
+    helper thread, and the control flow is the reference containers': every encoder level is CALLED AS ONE scn.Sequential
+    and its outputs are collected (SequentialInterims, custom_container.py:5-12), a decoder level is four calls -- input
+    stage, JoinTable, NetworkInNetwork, output stage (SkipConnectionReuniter, :70-83) -- over the levels in reverse
+    (ReuniteSequentialInterims, :42-55).  Shares the parameters of a `Backbone`; used by `bench.py --dropin` and the tests to
+    compare the two ways of driving the same kernels.  Storage type: `scn.set_feature_storage` (the reference's factory
+    knows no storage types), not the Backbone's `bf16_blocks`."""
 
     def __init__(self, backbone: Backbone):
         super().__init__()
@@ -355,4 +359,13 @@ class DropinBackbone(nn.Module):
 
     def forward(self, coords, feats, spatial_size, batch_size=0):
         x = InputLayer(3, spatial_size, mode=4)((coords, feats, batch_size))
-        return self.unet(x, prebuild=False)
+        u = self.unet
+        interims = []
+        for level in u.encoder:
+            x = level(x)
+            interims.append(x)
+        object.__setattr__(u, "interims", interims)
+        *skips, x = interims
+        for d, skip in zip(u.decoder, skips[::-1]):
+            x = d["units"](d["nin"](d["join"]([d["up"](x), skip])))
+        return x

@@ -226,6 +226,148 @@ def test_executor_records_the_relu_masks_of_the_module_path(gpu, dtype):
         assert x.shape == y.shape and torch.equal(x, y), k
 
 
+class _Interims(torch.nn.Sequential):
+    """Control flow of the reference's SequentialInterims (custom_container.py:5-12): apply the children in turn, keep every
+    output.  Test-side stand-in: the reference's containers do not travel to the GPU box."""
+
+    def forward(self, x):
+        outs = []
+        for m in self:
+            x = m(x)
+            outs.append(x)
+        return outs
+
+
+class _Reuniter(torch.nn.Module):
+    """Control flow of the reference's SkipConnectionReuniter (custom_container.py:70-83)."""
+
+    def __init__(self, input_stage, combiner, channel_changer, output_stage):
+        super().__init__()
+        self.input_stage, self.combiner, self.channel_changer, self.output_stage = input_stage, combiner, channel_changer, output_stage
+
+    def forward(self, x, skip):
+        return self.output_stage(self.channel_changer(self.combiner([self.input_stage(x), skip])))
+
+
+class _ReferenceShapedTree(torch.nn.Module):
+    """The module tree the reference's factory builds for sparse + U-Net (tests/golden/dropin_feature_extractor.json `repr`:
+    main_network = SequentialInterims of scn.Sequential(scn.Sequential(head), scn.Sequential(units)); unet.module_list =
+    SkipConnectionReuniter per decoder level), assembled from the modules (= the parameters) of a Backbone."""
+
+    def __init__(self, backbone):
+        super().__init__()
+        import sparse_rcnn_amd as scn
+        u = backbone.unet
+        self.main_network = _Interims(*[scn.Sequential(scn.Sequential(lvl[0]), lvl[1]) for lvl in u.encoder])
+        self.module_list = torch.nn.ModuleList([_Reuniter(d["up"], d["join"], d["nin"], d["units"]) for d in u.decoder])
+
+    def forward(self, coords, feats, size, bs):
+        import sparse_rcnn_amd as scn
+        x = scn.InputLayer(3, size, mode=4)((coords, feats, bs))
+        *skips, x = self.main_network(x)
+        self.interims = skips + [x]
+        for m, skip in zip(self.module_list, skips[::-1]):
+            x = m(x, skip)
+        return x
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("plan", ["bench", "reference"])
+def test_module_tree_stages_are_bit_identical_to_layer_by_layer(gpu, dtype, plan):
+    """a module tree somebody else built -- the reference's shape, driven by the reference's container
+    control flow -- gets the step executor: encoder levels recognised by scn.Sequential, decoder levels through deferred
+    tensors (modules._enc_stage / _dec_stage).  Stages on vs off (SCN_TREE_STAGES): output, every encoder output, input
+    gradient and every parameter gradient bit for bit, fp32 and bf16 storage (scn.set_feature_storage), the benchmark plan
+    and the reference's 32-48-64-80-96-112.  bf16: the tree's result also equals the Backbone's own bf16 mode (the one the
+    oracle tests check), whose final cast to fp32 is the only difference."""
+    import sparse_rcnn_amd as scn
+    from sparse_rcnn_amd import modules as M
+    from sparse_rcnn_amd.unet import Backbone
+    ch, target = {"bench": ((32, 64, 128, 256), 30_000), "reference": ((32, 48, 64, 80, 96, 112), 20_000)}[plan]
+    coords, feats, size, bs, _ = _scene(target, (256, 256, 128), seed=7)
+    torch.manual_seed(3)
+    net = Backbone(7, ch, bf16_blocks="all" if dtype == "bf16" else False).to(gpu)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.05)
+    tree = _ReferenceShapedTree(net)
+    prev = scn.set_feature_storage(torch.bfloat16 if dtype == "bf16" else torch.float32)
+    res = []
+    try:
+        for stages in (True, False):
+            M.TREE_STAGES = stages
+            M.STAGE_STATS.update(enc=0, dec=0, layerwise_units=0)
+            for p in net.parameters():
+                p.grad = None
+            fin = feats.to(gpu).requires_grad_()
+            out = tree(coords, fin, size, 1)
+            assert out.features.dtype == (torch.bfloat16 if dtype == "bf16" else torch.float32)
+            g = torch.Generator().manual_seed(11)
+            outs = [out.features] + [t.features for t in tree.interims[1:]]
+            grads = [torch.randn(o.shape, generator=g).to(gpu).to(o.dtype) for o in outs]
+            torch.autograd.backward(outs, grads)
+            torch.cuda.synchronize()
+            L = len(ch)
+            if stages:
+                assert M.STAGE_STATS == dict(enc=L, dec=L - 1, layerwise_units=0), M.STAGE_STATS
+            else:
+                assert M.STAGE_STATS["enc"] == 0 and M.STAGE_STATS["dec"] == 0
+            res.append((out.features.detach().clone(), [t.features.detach().clone() for t in tree.interims], fin.grad.clone(),
+                        [p.grad.clone() for p in net.parameters()]))
+    finally:
+        M.TREE_STAGES = True
+        scn.set_feature_storage(prev)
+    a, b = res
+    assert torch.equal(a[0], b[0]), "output features"
+    for l, (x, y) in enumerate(zip(a[1], b[1])):
+        assert x.dtype == y.dtype and torch.equal(x, y), f"encoder output {l}"
+    assert torch.equal(a[2], b[2]), "input-feature gradient"
+    for (n, _), x, y in zip(net.named_parameters(), a[3], b[3]):
+        assert torch.equal(x, y), f"gradient of {n}"
+    # the Backbone's own forward on the same parameters (its bf16 mode ends with a cast to fp32)
+    ref = net(coords, feats.to(gpu), size, 1).features
+    assert torch.equal(ref, a[0].float())
+
+
+def test_deferred_tensors_compute_layer_by_layer_when_nobody_fuses_them(gpu):
+    """A pending Deconvolution / NetworkInNetwork whose consumer is NOT a run of residual units (the features are read
+    directly; a JoinTable is materialised) gives the layer-by-layer result, and a Deconvolution to a level no Convolution of
+    this forward built still raises the reference's error."""
+    import sparse_rcnn_amd as scn
+    from sparse_rcnn_amd import modules as M
+    from sparse_rcnn_amd.tensor import DeferredTensor
+    from sparse_rcnn_amd.unet import Backbone
+    coords, feats, size, bs, _ = _scene(5_000, (64, 64, 32), seed=9)
+    torch.manual_seed(1)
+    net = Backbone(7, (16, 32)).to(gpu)
+    u = net.unet
+    d = u.decoder[0]
+    outs = []
+    for stages in (True, False):
+        M.TREE_STAGES = stages
+        try:
+            x = scn.InputLayer(3, size, mode=4)((coords, feats.to(gpu), 1))
+            e0 = u.encoder[0](x)
+            e1 = u.encoder[1](e0)
+            up = d["up"](e1)
+            assert isinstance(up, DeferredTensor) == stages
+            nin = d["nin"](d["join"]([up, e0]))
+            assert isinstance(nin, DeferredTensor) == stages and (not stages or (up.pending and nin.pending))
+            outs.append((nin.features.clone(), up.features.clone(), d["join"]([d["up"](e1), e0]).features.clone()))
+            assert not stages or not (up.pending or nin.pending)
+        finally:
+            M.TREE_STAGES = True
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    x = scn.InputLayer(3, size, mode=4)((coords, feats.to(gpu), 1))
+    lone = scn.Sequential(scn.ReLU(), scn.Deconvolution(3, 16, 16, (2, 2, 2), (2, 2, 2), True)).to(gpu)
+    half = scn.SparseConvNetTensor(features=u.encoder[0](x).features, metadata=x.metadata,
+                                   spatial_size=torch.as_tensor([32, 32, 16]))
+    with pytest.raises(scn.ScnError, match="no cached Convolution rulebook"):
+        lone(half).features
+
+
 def test_bf16_elementwise_forms_match_torch(gpu):
     """scn_cast_* / scn_add_bf16 / scn_gather_rows_bf16 / scn_segment_sum_bf16 / pooling / SparseToDense in bf16 storage against
     torch on the same bits (casts and gathers bit-exact; sums within one bf16 rounding of the fp64 sum)."""

@@ -248,6 +248,12 @@ def run(args):
         job.step()
     profiling.TIMER = None
     timer.count_only = False
+    # test hook (tests/test_gpu_atsize.py: the self-launch must notice a rank that dies in a running job): this rank leaves
+    # after its warm-up steps, while its peers head for the barrier / the first all-reduce of the timed region
+    if os.environ.get("SCN_BENCH_DIE_RANK") == str(rank) and world > 1:
+        sys.stderr.write(f"rank {rank}: SCN_BENCH_DIE_RANK -- leaving with code 3 after warm-up\n")
+        sys.stderr.flush()
+        os._exit(3)
     timer.reserve(2 * max(timer.count, 128) * ((args.steps + every - 1) // every))
     use_timer = not os.environ.get("SCN_BENCH_NO_TIMER")
     # a generation-2 pass of Python's cyclic GC over the (large, static) torch heap costs 60-90 ms when it lands in

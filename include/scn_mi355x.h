@@ -45,7 +45,15 @@ extern "C" {
 #define SCN_EHASH 3       /* hash table too small / coordinate outside the 16-bit key range */
 #define SCN_EHIP 4        /* a HIP runtime call failed; see scn_last_error_string() */
 
-#define SCN_ABI_VERSION 1
+/* History of the ABI (scn_abi_version() returns the value the library was BUILT with: a caller compares it with the
+ * SCN_ABI_VERSION of the header it was compiled against):
+ *   1  rounds 1-2: 78 entry points
+ *   2  round 3: + 23 entry points (step executor: scn_exec_op / scn_exec_level structs, scn_exec_run*; deferred
+ *      weight-gradient sums; bf16 elementwise forms; segment pooling; scn_tiles_build_x) -- shipped with the value still 1
+ *   3  round 4: SCN_PYRAMID_FUSED (scn_pyramid_build_ex flag, larger scn_pyramid_workspace_bytes), hash slot function
+ *      changed (tables built by version <= 2 libraries are not probe-compatible; no table outlives a Metadata, so only a
+ *      caller that kept raw tables across a library upgrade is affected) */
+#define SCN_ABI_VERSION 3
 
 /* flags for the gather-GEMM entry points */
 #define SCN_F_RELU_IN 1      /* use max(X,0) as the input slab (fuses scn.ReLU before a conv, module_factory.py:88,173-176) */

@@ -127,6 +127,7 @@ EXPORTS = tuple(_SIGS)
 F_RELU_IN, F_W_TRANSPOSED, F_OFF_REVERSE, F_RESIDUAL_LAST, F_SPLIT_SUM, F_GEMM_V1 = 1, 2, 4, 8, 16, 32
 F_TILE_ORDER_X = 64
 OK, EINVAL, ESIZE, EHASH, EHIP = 0, 1, 2, 3, 4
+ABI_VERSION = 3                 # include/scn_mi355x.h SCN_ABI_VERSION this host layer was written against
 PYRAMID_MAX_LEVELS, PYRAMID_LEVEL_STRIDE = 8, 72
 PYRAMID_TWO_QUEUES = 1
 PYRAMID_XCD_ORDER = 2
@@ -151,7 +152,7 @@ def load():
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.scn_abi_version() != 1:
+        if lib.scn_abi_version() != ABI_VERSION:
             raise ScnError("libscn_mi355x.so ABI version mismatch")
         _lib = lib
     return _lib

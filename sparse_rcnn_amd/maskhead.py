@@ -28,6 +28,36 @@ from .ioLayers import OutputLayer
 from .unet import SparseUNet, units
 
 
+def reference_key_map(n_unet_levels=4, num_units=2, n_linear=2):
+    """state_dict key of the reference's SparseMaskNetwork (model.py:572-782 under scannet_config/run.py:741-810:
+    `input_conv_layer` = Sequential of one 'B' level, `output_conv_layer` = UnetContainer(downsampling_layer = SequentialInterims
+    whose level 0 is the FLD('I') Identity, upsampling_layer.module_list = SkipConnectionReuniter per decoder level),
+    `linear_layer` = Linear / ReLU stack) -> this package's parameter name (`MaskBranch.named_oracle_params`).  Checked against
+    the key list of a reference SparseMaskNetwork built on this package (tests/golden/dropin_mask_network.json)."""
+    out = {}
+    for t in ("weight", "bias"):
+        out[f"input_conv_layer.0.0.0.{t}"] = f"in.{t}"
+        for u in range(num_units):
+            for v, idx in enumerate((1, 3)):                     # Sequential(ReLU, SubM, ReLU, SubM) inside ConcatTable[1]
+                out[f"input_conv_layer.0.1.{u}.0.1.{idx}.{t}"] = f"in.res{u}.conv{v}.{t}"
+        for l in range(1, n_unet_levels):
+            out[f"output_conv_layer.downsampling_layer.{l}.0.0.{t}"] = f"unet.enc{l}.in.{t}"
+            for u in range(num_units):
+                for v, idx in enumerate((1, 3)):
+                    out[f"output_conv_layer.downsampling_layer.{l}.1.{u}.0.1.{idx}.{t}"] = f"unet.enc{l}.res{u}.conv{v}.{t}"
+        for i in range(n_unet_levels - 1):
+            l = n_unet_levels - 2 - i
+            pre = f"output_conv_layer.upsampling_layer.module_list.{i}"
+            out[f"{pre}.input_stage.1.{t}"] = f"unet.dec{l}.up.{t}"
+            out[f"{pre}.channel_changer.{t}"] = f"unet.dec{l}.nin.{t}"
+            for u in range(num_units):
+                for v, idx in enumerate((1, 3)):
+                    out[f"{pre}.output_stage.{u}.0.1.{idx}.{t}"] = f"unet.dec{l}.res{u}.conv{v}.{t}"
+        for i in range(n_linear):
+            out[f"linear_layer.{2 * i}.{t}"] = f"lin{i}.{t}"          # Linear, ReLU, Linear: indices 0, 2
+    return out
+
+
 class MaskBranch(nn.Module):
     # Where the ROI batch's selection + rulebooks are built: "0" inline on the caller's stream | "thread": helper thread +
     # its own stream | "stream": its own stream, caller's thread.  Measured on one box each (tools/ab_roi_prefetch.sh,
@@ -151,6 +181,38 @@ class MaskBranch(nn.Module):
         for i, m in enumerate(lin):
             out[f"lin{i}.weight"], out[f"lin{i}.bias"] = m.weight, m.bias
         return out
+
+    def load_reference_state_dict(self, state_dict, prefix=None, strict=True):
+        """Load the mask-network part of a checkpoint written by the REFERENCE (training.py:386-391 saves
+        model.state_dict(); the SparseMaskNetwork sits under `mask_network.` in InstanceSegmentationNetwork, model.py:31-114):
+        keys are mapped onto this branch's parameters by `reference_key_map`; SparseConvNet's grouped weight layout
+        [fv, 1, nIn, nOut] is accepted.  prefix=None: detected from the first key ending in 'input_conv_layer.0.0.0.weight'.
+        -> (missing reference keys, unused checkpoint keys under the prefix)."""
+        if prefix is None:
+            tail = "input_conv_layer.0.0.0.weight"
+            prefix = next((k[:-len(tail)] for k in state_dict if k.endswith(tail)), "")
+        own = self.named_oracle_params()
+        n_lin = len([m for m in self.linear_layer if isinstance(m, nn.Linear)])
+        kmap = reference_key_map(len(self.output_conv_layer.channels), n_linear=n_lin)
+        missing, used = [], set()
+        with torch.no_grad():
+            for rk, name in kmap.items():
+                t = state_dict.get(prefix + rk)
+                if t is None:
+                    missing.append(prefix + rk)
+                    continue
+                if t.dim() == 4 and t.shape[1] == 1:
+                    t = t.squeeze(1)
+                p = own[name]
+                if tuple(t.shape) != tuple(p.shape):
+                    raise ValueError(f"{prefix + rk}: checkpoint shape {tuple(t.shape)} != {tuple(p.shape)} ({name})")
+                p.copy_(t)
+                used.add(prefix + rk)
+        mine = ("input_conv_layer.", "output_conv_layer.", "linear_layer.")
+        unused = [k for k in state_dict if k.startswith(prefix) and k[len(prefix):].startswith(mine) and k not in used]
+        if strict and (missing or unused):
+            raise KeyError(f"reference checkpoint mismatch: missing {missing[:4]}... unused {unused[:4]}...")
+        return missing, unused
 
     def _linear(self, x):
         """The Linear / ReLU stack (module_factory.py:700-716) on the library's row GEMM: nn.Linear parameters (state_dict

@@ -121,6 +121,57 @@ def test_reference_checkpoint_names_and_layer_order(name):
     assert "SkipConnectionReuniter" in fx["repr"] and "SequentialInterims" in fx["repr"]      # the reference's containers
 
 
+MASK_FIX = json.load(open(os.path.join(HERE, "golden", "dropin_mask_network.json")))["run_config"]
+
+
+def test_mask_branch_reproduces_the_reference_mask_network():
+    """tests/golden/dropin_mask_network.json holds the state_dict key NAMES + shapes, the scn layer census
+    and the module-tree repr of the reference's SparseMaskNetwork (model.py:572-782, configured as scannet_config/run.py:
+    741-810) built on this package.  (a) maskhead.reference_key_map covers exactly those keys and maps each onto a parameter
+    of MaskBranch with the fixture's shape; (b) a state dict with those names -- under the `mask_network.` prefix of the
+    whole model's checkpoint, one weight in SparseConvNet's grouped layout -- loads through
+    MaskBranch.load_reference_state_dict and every parameter arrives; (c) the scn layers appear in the same order with the
+    same channel signatures in both module trees (the FLD('I') level contributes the reference's lone Identity)."""
+    from sparse_rcnn_amd.maskhead import MaskBranch, reference_key_map
+    fx = MASK_FIX
+    mb = MaskBranch(32, 7, linear_channels=(32, fx["classes"]))
+    kmap = reference_key_map(4)
+    assert set(kmap) == set(fx["keys"]), sorted(set(kmap) ^ set(fx["keys"]))[:6]
+    own = mb.named_oracle_params()
+    assert sorted(kmap.values()) == sorted(own) and len(own) == 80
+    for rk, shape in fx["keys"].items():
+        assert list(own[kmap[rk]].shape) == shape, (rk, kmap[rk])
+    assert sum(p.numel() for p in mb.parameters()) == fx["n_params"] == 1_342_506
+    g = torch.Generator().manual_seed(0)
+    sd = {"mask_network." + rk: torch.randn(shape, generator=g) for rk, shape in fx["keys"].items()}
+    k27 = next(k for k, v in sd.items() if v.dim() == 3 and v.shape[0] == 27)
+    sd[k27] = sd[k27].unsqueeze(1)                                    # SparseConvNet's grouped layout
+    sd["feature_extractor.main_network.0.0.0.weight"] = torch.zeros(1, 7, 32)          # other parts of the checkpoint are ignored
+    missing, unused = mb.load_reference_state_dict(sd)
+    assert not missing and not unused
+    for rk in fx["keys"]:
+        t = sd["mask_network." + rk]
+        assert torch.equal(own[kmap[rk]].detach(), t.squeeze(1) if t.dim() == 4 else t), rk
+    with pytest.raises(KeyError):
+        mb.load_reference_state_dict({k: v for k, v in sd.items() if not k.endswith("linear_layer.2.bias")})
+    # layer order: input_conv_layer, then the internal U-Net (its Identity level first), in tree order
+    ref_leaves = _leaf_lines(fx["repr"])
+    own_leaves = _leaf_lines(repr(mb.input_conv_layer)) + _leaf_lines(repr(mb.output_conv_layer))
+    # MaskBranch's builder spells the FLD('I') level as Sequential(Identity, Identity) (unet.SparseUNet, identity_first); the
+    # reference as one Identity
+    first_id = own_leaves.index("Identity()", len(_leaf_lines(repr(mb.input_conv_layer))))
+    assert own_leaves[first_id + 1] == "Identity()"
+    del own_leaves[first_id + 1]
+    assert ref_leaves == own_leaves, [(i, a, b) for i, (a, b) in enumerate(zip(ref_leaves, own_leaves)) if a != b][:4]
+    for cls in ("UnetContainer", "SkipConnectionReuniter", "SequentialInterims", "SparseFeaturemapSelectorBoth",
+                "SparseFeaturemapFirst", "TrainSelector"):
+        assert cls in fx["repr"], cls                                 # the reference's containers around this package's layers
+    for k in ("SubmanifoldConvolution", "Convolution", "Deconvolution", "NetworkInNetwork", "ReLU", "AddTable", "JoinTable",
+              "ConcatTable"):
+        got = sum(1 for m in list(mb.input_conv_layer.modules()) + list(mb.output_conv_layer.modules()) if type(m).__name__ == k)
+        assert got == fx["census"][k], (k, got, fx["census"][k])
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/ndsis"), reason="reference checkout only exists in the build container")
 def test_reference_feature_extractor_constructs_on_this_package():
     saved = sys.modules.get("sparseconvnet")

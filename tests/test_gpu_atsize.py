@@ -680,3 +680,33 @@ def test_bench_self_launch_two_ranks_on_one_gpu(gpu):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["roofline"]["kernel"] == "k_conv_ts" and 0 < d["roofline"]["frac"] < 1
+
+
+def test_bench_self_launch_five_ranks_detection_and_mask_step_on_one_gpu(gpu):
+    """VERDICT r3 item 8, within this pool's limit of SIX processes with the card open (this test process is one of them; the
+    8-process form may not be started here -- a 6-rank attempt was killed by the box's process guard): five fresh ranks of
+    `bench.py --gpus 5 --workload cfg3 --dtype bf16` from a parent that makes no GPU call -- each with its index helper thread,
+    the stage nodes' bucket hooks over backbone + mask branch, gloo so that they may share cuda:0.  One JSON line, five ranks
+    seen, five per-rank entries.  Then the same launch with a rank that leaves after warm-up: the launcher terminates the four
+    survivors (who would sit in a collective) and returns the dead rank's code within seconds of it."""
+    import time
+    env = dict(os.environ, SCN_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "5", "--steps", "5", "--warmup", "2", "--target", "20000",
+           "--workload", "cfg3", "--dtype", "bf16", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 5 and d["n_ranks_seen"] == 5 and len(d["per_rank"]) == 5 and d["value"] > 0
+    assert sorted(p["rank"] for p in d["per_rank"]) == list(range(5))
+    assert all(p["n_active"] > 15_000 and p["n_roi_rows"] > 0 and p["ms_per_step"] > 0 for p in d["per_rank"])
+    assert d["dtype"] == "bf16" and "configs[2]" in d["config"]["workload"]
+    t0 = time.time()
+    r = subprocess.run(cmd, env=dict(env, SCN_BENCH_DIE_RANK="3"), capture_output=True, text=True, timeout=600)
+    took = time.time() - t0
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert "rank 3 exited with code 3" in r.stderr and not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert took < 240, took                      # (start-up of five processes dominates; the survivors do not wait for a time limit)

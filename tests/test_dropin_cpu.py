@@ -121,6 +121,34 @@ def test_reference_checkpoint_names_and_layer_order(name):
     assert "SkipConnectionReuniter" in fx["repr"] and "SequentialInterims" in fx["repr"]      # the reference's containers
 
 
+TAPES = json.load(open(os.path.join(HERE, "golden", "optape_reference_forward.json")))
+
+
+@pytest.mark.parametrize("name", ["cfg2_32_256", "ref_32_112"])
+def test_dropin_backbone_issues_the_op_tape_of_the_reference_forward(name):
+    """tests/golden/optape_reference_forward.json holds the leaf-operator tape of the REFERENCE's
+    FeatureExtractor.forward (model.py:414-446) run on this package with the arithmetic replaced by shapes
+    (tests/optape.py, generator tests/golden/make_optape_golden.py): per call the layer signature, the tape index of the
+    entry that produced each operand, spatial size, rows and channels.  unet.DropinBackbone -- this repository's imitation
+    of that call pattern, the thing bench.py's `dropin` leg and the GPU tests drive -- issues exactly that tape on the same
+    seeded scene (here under the same shape stub; on the GPU with real kernels: tests/test_gpu_exec.py)."""
+    sys.path.insert(0, HERE)
+    import optape
+    from sparse_rcnn_amd.synthetic import make_batch
+    from sparse_rcnn_amd.unet import Backbone, DropinBackbone
+    sc = TAPES["scene"]
+    coords, feats, size, bs, splits = make_batch(sc["n_samples"], tuple(sc["grid"]), sc["target"], dup=sc["dup"], seed=sc["seed"])
+    ch = [32, 64, 128, 256] if name == "cfg2_32_256" else [32, 48, 64, 80, 96, 112]
+    net = DropinBackbone(Backbone(7, ch))
+    with optape.shape_stub(), optape.record() as tape:
+        out = net(coords, feats, size, bs)
+    ref = TAPES["feature_extractor_" + name]
+    assert len(tape.entries) == len(ref) == (87 if name == "cfg2_32_256" else 137)
+    for i, (a, b) in enumerate(zip(tape.entries, ref)):
+        assert a == b, (i, a, b)
+    assert tuple(out.features.shape) == (ref[0]["rows"], 32)
+
+
 MASK_FIX = json.load(open(os.path.join(HERE, "golden", "dropin_mask_network.json")))["run_config"]
 
 

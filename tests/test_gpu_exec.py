@@ -3,9 +3,14 @@ level) against the layer-by-layer module path.  Both drive the same entry points
 be bit-identical: output features, encoder outputs, the input-feature gradient and every parameter gradient -- fp32 and bf16
 storage, the benchmark plan, the reference's own plan 32-48-64-80-96-112, the mask branch (channel-padded internal U-Net,
 cast-in / cast-out input stage), gradients arriving at the encoder outputs (the RPN's inputs in the reference)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))          # tests/optape.py
 
 pytestmark = pytest.mark.gpu
 
@@ -366,6 +371,88 @@ def test_deferred_tensors_compute_layer_by_layer_when_nobody_fuses_them(gpu):
                                    spatial_size=torch.as_tensor([32, 32, 16]))
     with pytest.raises(scn.ScnError, match="no cached Convolution rulebook"):
         lone(half).features
+
+
+class _unfused:
+    """One leaf operator call per layer: every fusion of the host layer off (the fused paths equal this one bit for bit)."""
+
+    def __enter__(self):
+        from sparse_rcnn_amd import modules as M
+        from sparse_rcnn_amd.unet import SparseUNet
+        self.saved = (M.FUSE_RELU, M.FUSE_ADD, M.FUSE_BLOCK, M.TREE_STAGES, SparseUNet.EXEC)
+        M.FUSE_RELU = M.FUSE_ADD = M.FUSE_BLOCK = M.TREE_STAGES = False
+        SparseUNet.EXEC = False
+
+    def __exit__(self, *exc):
+        from sparse_rcnn_amd import modules as M
+        from sparse_rcnn_amd.unet import SparseUNet
+        M.FUSE_RELU, M.FUSE_ADD, M.FUSE_BLOCK, M.TREE_STAGES, SparseUNet.EXEC = self.saved
+        return False
+
+
+def _tapes():
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    return json.load(open(os.path.join(here, "golden", "optape_reference_forward.json")))
+
+
+@pytest.mark.parametrize("name", ["cfg2_32_256", "ref_32_112"])
+def test_dropin_backbone_issues_the_reference_forwards_op_tape_on_the_gpu(gpu, name):
+    """VERDICT r3 item 5b with REAL kernels: the leaf-operator tape of unet.DropinBackbone on the GPU (layer signatures,
+    operand wiring, spatial sizes, row counts from the device index build, channels) equals the tape the reference's
+    FeatureExtractor.forward produced on this package in the build container (tests/golden/optape_reference_forward.json;
+    tests/optape.py), and the unfused forward that issued it gives the bits of the fused one."""
+    import optape
+    from sparse_rcnn_amd.synthetic import make_batch
+    from sparse_rcnn_amd.unet import Backbone, DropinBackbone
+    T = _tapes()
+    sc = T["scene"]
+    coords, feats, size, bs, _ = make_batch(sc["n_samples"], tuple(sc["grid"]), sc["target"], dup=sc["dup"], seed=sc["seed"])
+    ch = [32, 64, 128, 256] if name == "cfg2_32_256" else [32, 48, 64, 80, 96, 112]
+    torch.manual_seed(2)
+    net = DropinBackbone(Backbone(7, ch).to(gpu))
+    with _unfused(), optape.record() as tape:
+        out = net(coords, feats.to(gpu), size, bs)
+    ref = T["feature_extractor_" + name]
+    assert len(tape.entries) == len(ref)
+    for i, (a, b) in enumerate(zip(tape.entries, ref)):
+        assert a == b, (i, a, b)
+    fused = net(coords, feats.to(gpu), size, bs)
+    assert torch.equal(fused.features, out.features)
+
+
+def test_mask_branch_issues_the_reference_mask_networks_op_tape_on_the_gpu(gpu):
+    """The same for maskhead.MaskBranch against the tape of the reference's SparseMaskNetwork.forward (model.py:758-782, eval
+    mode: the given boxes are the selected ones; scannet_config/run.py:741-810): SubM 1^3 + units on the scene -> OutputLayer
+    -> [crop] -> InputLayer(mode 4, batch_size = boxes, spatial size + 32) -> internal U-Net -> OutputLayer, every leaf call
+    with its wiring, sizes and row counts -- the crop's row counts come from this package's device crop (scn_roi.hip), the
+    tape's from the reference's own roi_cut.  Differences by design, normalised: the 23-channel level is physically padded to
+    24 columns here."""
+    import optape
+    from sparse_rcnn_amd.maskhead import MaskBranch
+    from sparse_rcnn_amd.synthetic import make_batch, make_boxes
+    from sparse_rcnn_amd.unet import Backbone
+    T = _tapes()
+    sc = T["scene"]
+    coords, feats, size, bs, splits = make_batch(sc["n_samples"], tuple(sc["grid"]), sc["target"], dup=sc["dup"], seed=sc["seed"])
+    boxes = make_boxes(coords, sc["n_boxes"], seed=sc["box_seed"])
+    torch.manual_seed(2)
+    bb = Backbone(7, (32, 64, 128, 256)).to(gpu)
+    mb = MaskBranch(32, 7).to(gpu)
+    fd = feats.to(gpu)
+    scene = (coords.to(gpu), fd, size, bs, splits)
+    with _unfused():
+        fmap = bb(coords.to(gpu), fd, size, bs)
+        with optape.record() as tape:
+            logits, selection = mb(scene, fmap, boxes)
+    ref = T["mask_network"]
+    got = optape.normalised(tape.entries, pad={24: 23}, join_pad={48: 46}, at_size=[96, 96, 64])
+    assert list(logits.shape) == T["mask_logits_shape"] and len(got) == len(ref) == 89
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert a == b, (i, a, b)
+    fused, _ = mb(scene, bb(coords.to(gpu), fd, size, bs), boxes)
+    assert torch.equal(fused, logits)
 
 
 def test_bf16_elementwise_forms_match_torch(gpu):

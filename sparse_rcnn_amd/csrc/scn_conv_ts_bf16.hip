@@ -421,6 +421,253 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
 
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_conv_tbs (round 4): the same convolution OFFSET-OUTER with the weights STREAMED, for layers whose weights do not fit one
+// workgroup's LDS (Cin >= 64: levels >= 1 of the U-Net, 48 of the 62 tile launches of a cfg-2 step).
+//
+// k_conv_tb keeps the weights of ALL offsets of one 32-channel K-chunk resident (110 KB) and therefore splits K over
+// workgroups: every (tile, column chunk) is computed as n_kc partial tiles that travel through memory (write-through fp32,
+// tickets, a combine by the last arriver) -- 30-45 % of a launch at levels 1-3 of the 150 k scene, a serial chain of trips to
+// memory behind every wave's last tile, on top of a 110 KB staging front.  Here a workgroup
+// owns NW tiles (one per wave) x 64 output columns with the FULL K: the offsets run in the outer loop, the 64-column slice of
+// W[o] (Cin x 64 bf16: 8 / 16 / 32 KB at Cin = 64 / 128 / 256) streams through a double-buffered LDS stage -- requested
+// when offset o - 1 starts, written when its MFMAs have been issued, one workgroup barrier per offset --, a wave's 16 x 64
+// accumulators stay in registers across all offsets, and a row is gathered as KS 16-byte pieces per lane, D offsets ahead.
+// No K split, no partial tiles, no tickets, no 110 KB front, one write of Y.  Offsets a tile lacks still take their barrier
+// and their (zero-returning, out-of-range) gather instructions but skip their MFMAs (wave-uniform branch without loads).
+//
+// Reads the SAME packed weight image as k_conv_tb (piece (chunk, K-chunk ks, offset o) = 4 KB) and the same tile structures;
+// the fp32 summation order differs (k_conv_tb: offsets inside a K-chunk, then the K-chunks; here: K-chunks inside an offset),
+// so results agree with k_conv_tb's to fp32 rounding before the one bf16 rounding (tests/test_gpu_exec.py) -- both are
+// deterministic, neither depends on placement.  SCN_TB_STREAM=0 keeps k_conv_tb everywhere.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef TBS_EXP
+#define TBS_EXP 0           // developer timing experiments (results invalid): 1 no weight streaming behind slice 0, 2 no row
+#endif                      // gathers behind the first D, 3 no barriers in the offset loop, 4 no MFMAs
+template <int KS, int N_OFF, int NW, int D>
+__global__ __launch_bounds__(NW * 64) void k_conv_tbs(
+    const unsigned short* __restrict__ X, long long n_in, int cin, const int* __restrict__ tstab,
+    const unsigned* __restrict__ tile_mask, const int* __restrict__ perm, const int* __restrict__ tile_order, long long nt,
+    const unsigned short* __restrict__ image, const float* __restrict__ bias, const unsigned short* __restrict__ residual,
+    const unsigned short* __restrict__ relu_mask, unsigned short* __restrict__ Y, long long n_out, int cout, int flags,
+    int n_chunks, int n_wgb) {
+    constexpr int NB = 4, CT = 64, THREADS = NW * 64;
+    constexpr int PIECES = KS * CT * 4;                             // 16-byte pieces of one offset's slice
+    constexpr int PW = (PIECES + THREADS - 1) / THREADS;            // ... per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned short Wb[];     // [2][KS][CT][32] bf16, then int idx[NW][IDXW]
+    constexpr int IDXW = (((N_OFF + 1) * TB_T + 63) / 64) * 64;     // row indices of a wave's tile, all offsets + a row of -1
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    int* idx_w = (int*)(Wb + (size_t)2 * PIECES * 8) + w * IDXW;
+    // workgroups are dealt to XCDs round-robin by block index: the n_chunks column chunks of a tile batch (which gather the
+    // same rows) get block indices 8 apart, i.e. one XCD and one L2
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int chunk = jb % n_chunks, wgb = (jb / n_chunks) * 8 + xcd;
+    if (wgb >= n_wgb) return;
+    const int n0 = chunk * CT;
+    const bool relu_in = flags & SCN_F_RELU_IN;
+    const bool res_last = flags & SCN_F_RESIDUAL_LAST;
+    const int ncol = n0 + NB * i;
+    const bool n_ok = ncol < cout;
+    float bcol[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bcol[nb] = (bias && ncol + nb < cout) ? bias[ncol + nb] : 0.f;
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(unsigned)(n_in * cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t trsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)tstab, 0, (int)(unsigned)(nt * N_OFF * (TB_T * 4)), 0x00020000);
+    // the slice of offset o: K-chunk ks of this column chunk is the 4 KB piece ((chunk KS + ks) N_OFF + o) of the image; a
+    // thread's pieces p = u THREADS + tid sit at a fixed vector offset, the offset advances the SCALAR offset
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(image + (size_t)chunk * KS * N_OFF * (CT * TB_KC)), 0, (int)(unsigned)(KS * N_OFF * (CT * TB_KC * 2)), 0x00020000);
+    int wvoff[PW];
+#pragma unroll
+    for (int u = 0; u < PW; ++u) {
+        const int p = u * THREADS + tid;
+        wvoff[u] = p < PIECES ? (p / (CT * 4)) * (N_OFF * CT * TB_KC * 2) + (p % (CT * 4)) * 16 : (int)0x7FFFFFF0;
+    }
+    const int row_bytes = cin * 2, lane_boff = 16 * kq;
+    const short relu_floor = relu_in ? (short)0 : (short)-32768;
+    const s16x8 floor8 = {relu_floor, relu_floor, relu_floor, relu_floor, relu_floor, relu_floor, relu_floor, relu_floor};
+    // LDS image of a slice: the B fragment of (K-chunk ks, column block nb) is 1 KB in LANE order (lane = 16 kq + i holds
+    // column 16 nb + i, channels 8 kq .. + 7): one conflict-free ds_read_b128 per MFMA.  The packed image stores a 4 KB piece as
+    // [n][kq] (k_conv_tb's order: 16 lanes 64 bytes apart, 4-way bank conflicts -- there the kernel waits for its gathers,
+    // here the B reads are the inner loop); the transposition [n = 16 nb + i][kq] -> [nb][kq][i] happens in the staging write.
+    const unsigned short* wlane = Wb + (size_t)lane * 8;             // + buf PIECES 8 + (ks 4 + nb) 512
+    int wdst[PW];
+#pragma unroll
+    for (int u = 0; u < PW; ++u) {
+        const int p = u * THREADS + tid, r = p % (CT * 4);           // r = n 4 + kq inside the plane
+        wdst[u] = (p / (CT * 4)) * (CT * 4) + (r >> 6) * 64 + (r & 3) * 16 + ((r >> 2) & 15);
+    }
+    constexpr int NWD = NB / 2;
+    const bool vec_ok = (cout % NB == 0) && ((((uintptr_t)Y | (uintptr_t)residual | (uintptr_t)relu_mask) & (2 * NB - 1)) == 0);
+
+#define TBS_WLOAD(O, V)                                                                                        \
+    _Pragma("unroll") for (int u_ = 0; u_ < PW; ++u_)                                                          \
+        V[u_] = __builtin_amdgcn_raw_buffer_load_b128(irsrc, wvoff[u_], (O) * (CT * TB_KC * 2), 0)
+#define TBS_WSTORE(BUF, V)                                                                                     \
+    _Pragma("unroll") for (int u_ = 0; u_ < PW; ++u_) {                                                        \
+        const int p_ = u_ * THREADS + tid;                                                                     \
+        if (p_ < PIECES) ((i32x4*)Wb)[(size_t)(BUF) * PIECES + wdst[u_]] = V[u_];                              \
+    }
+#define TBS_GATHER(O, SLOT)                                                                                    \
+    do {                                                                                                       \
+        const int off_ = __mul24(idx_w[(O) * TB_T + i], row_bytes) + lane_boff;                                \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < KS; ++ks_)                                                   \
+            A[SLOT][ks_] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off_ + 64 * ks_, 0, 0);                \
+    } while (0)
+
+    unsigned* um_s = (unsigned*)((int*)(Wb + (size_t)2 * PIECES * 8) + NW * IDXW);      // union of the batch's tile masks
+    for (long long bt = wgb; bt * NW < nt; bt += n_wgb) {
+        const long long tl = bt * NW + w;
+        // consecutive tile IDS (not the LPT order): tiles are cut from rows sorted by offset mask, so the NW tiles of a batch
+        // have nearly the same offsets -- the batch walks only the UNION of their masks
+        const long long tile = tl < nt ? tl : -1;                   // (wave-uniform)
+        unsigned m = 0;
+        int orow[4] = {-1, -1, -1, -1};
+        if (tile >= 0) {
+            m = __builtin_amdgcn_readfirstlane(tile_mask[tile]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) orow[j] = perm[tile * TB_T + 4 * kq + j];
+        }
+        if (tid == 0) *um_s = 0u;
+        // row indices of all offsets -> this wave's LDS strip (a tile's block of the table is N_OFF x 64 contiguous bytes: one
+        // coalesced 256-byte load per 4 offsets); row N_OFF of the strip is -1: the "no offset left" slot of the prefetch.
+        // A wave without a tile gets -1 everywhere: no gather traffic.
+        {
+            const int tile_boff = tile >= 0 ? (int)tile * N_OFF * (TB_T * 4) : 0;
+            int v[IDXW / 64];
+#pragma unroll
+            for (int t = 0; t < IDXW / 64; ++t)
+                v[t] = (tile >= 0 && t * 64 + lane < N_OFF * TB_T)
+                           ? __builtin_amdgcn_raw_buffer_load_b32(trsrc, (t * 64 + lane) * 4, tile_boff, 0) : -1;
+#pragma unroll
+            for (int t = 0; t < IDXW / 64; ++t) idx_w[t * 64 + lane] = v[t];
+        }
+        __syncthreads();
+        if (lane == 0 && m) atomicOr(um_s, m);
+        __syncthreads();
+        unsigned ua = __builtin_amdgcn_readfirstlane(*um_s), uc = ua;     // offsets left to request / to compute
+        const int n_steps = __popc(ua);
+        int olast = N_OFF;
+        // pop the lowest offset of the (workgroup-uniform) mask U: its number, or N_OFF (the all-"-1" row) when none is left
+#define TBS_POP(U, O)                                                                                          \
+    do {                                                                                                       \
+        int f_;                                                                                                \
+        asm volatile("s_ff1_i32_b32 %0, %1" : "=s"(f_) : "s"(U));                                              \
+        (O) = f_ < 0 ? N_OFF : f_;                                                                             \
+        (U) &= (U) - 1u;                                                                                       \
+    } while (0)
+        // ---- the first D offsets: weight slice -> register set d, rows -> A[d].  The slices travel D steps ahead like the
+        // rows, and in the SAME order: loads return in order, so waiting for the next slice must not wait for younger gathers
+        i32x4 A[D][KS], wv[D][PW];
+        int oq[D];                                                  // offset of the step whose operands sit in set d
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            TBS_POP(ua, oq[d]);
+            TBS_WLOAD(oq[d], wv[d]);
+            TBS_GATHER(oq[d], d);
+        }
+        (void)olast;
+        TBS_WSTORE(0, wv[0]);                 // (buffer 0: the barrier above freed it)
+        f32x4 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = (f32x4){bcol[nb], bcol[nb], bcol[nb], bcol[nb]};
+
+        // one step: barrier; MFMAs of this step's offset if the wave's tile has it; the next step's slice -> LDS; the sets just
+        // freed take slice and rows of the step D ahead.  SLOT = step % D, BUF = step & 1 (D is even).
+#define TBS_STEP(SLOT, BUF)                                                                                    \
+    do {                                                                                                       \
+        if (TBS_EXP != 3) __syncthreads();                                                                     \
+        const int oc_ = oq[SLOT];                                                                              \
+        if (TBS_EXP != 4 && ((m >> oc_) & 1u)) {                                                               \
+            const unsigned short* wo = wlane + (size_t)(BUF) * (PIECES * 8);                                   \
+            _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                \
+                const s16x8 a_ = __builtin_elementwise_max(__builtin_bit_cast(s16x8, A[SLOT][ks]), floor8);    \
+                const bf16x8 af = __builtin_bit_cast(bf16x8, a_);                                              \
+                _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                            \
+                    const bf16x8 bf = *(const bf16x8*)(wo + (ks * 4 + nb) * 512);                              \
+                    acc[nb] = MFMAB(af, bf, acc[nb]);                                                          \
+                }                                                                                              \
+            }                                                                                                  \
+        }                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if (TBS_EXP != 1) TBS_WSTORE(1 - (BUF), wv[((SLOT) + 1) % D]);                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        TBS_POP(ua, oq[SLOT]);                                                                                 \
+        if (TBS_EXP != 1) TBS_WLOAD(oq[SLOT], wv[SLOT]);                                                       \
+        if (TBS_EXP != 2) TBS_GATHER(oq[SLOT], SLOT);                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    } while (0)
+        static_assert(D == 2 || D == 4, "the step macro alternates the LDS buffer with the slot parity");
+        int n_left = n_steps;
+        (void)uc;
+        for (; n_left >= D; n_left -= D) {
+            TBS_STEP(0, 0);
+            TBS_STEP(1, 1);
+            if constexpr (D == 4) { TBS_STEP(2, 0); TBS_STEP(3, 1); }
+        }
+        if (n_left >= 1) TBS_STEP(0, 0);
+        if constexpr (D == 4) {
+            if (n_left >= 2) TBS_STEP(1, 1);
+            if (n_left >= 3) TBS_STEP(2, 0);
+        }
+#undef TBS_STEP
+#undef TBS_POP
+        // ---- epilogue: residual / ReLU-backward mask, one bf16 rounding, one write (as k_conv_tb's direct form)
+        if (tile >= 0) {
+            unsigned rw[4][NWD], mw[4][NWD];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long e = (long long)(orow[j] < 0 ? 0 : orow[j]) * cout + ncol;
+#pragma unroll
+                for (int ww = 0; ww < NWD; ++ww) { rw[j][ww] = 0u; mw[j][ww] = 0x3f803f80u; }
+                if (vec_ok && n_ok) {
+                    if (residual) { const uint2 t = *(const uint2*)(residual + e); rw[j][0] = t.x; rw[j][1] = t.y; }
+                    if (relu_mask) { const uint2 t = *(const uint2*)(relu_mask + e); mw[j][0] = t.x; mw[j][1] = t.y; }
+                } else if (!vec_ok) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        if (ncol + nb >= cout) continue;
+                        if (residual) rw[j][nb >> 1] = (nb & 1) ? (rw[j][nb >> 1] & 0xffffu) | ((unsigned)residual[e + nb] << 16)
+                                                                : (rw[j][nb >> 1] & 0xffff0000u) | residual[e + nb];
+                        if (relu_mask) mw[j][nb >> 1] = (nb & 1) ? (mw[j][nb >> 1] & 0xffffu) | ((unsigned)relu_mask[e + nb] << 16)
+                                                                 : (mw[j][nb >> 1] & 0xffff0000u) | relu_mask[e + nb];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (orow[j] < 0) continue;
+                unsigned ow[NWD] = {0u, 0u};
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const unsigned rbits = (nb & 1) ? (rw[j][nb >> 1] & 0xffff0000u) : (rw[j][nb >> 1] << 16);
+                    const unsigned mbits = (nb & 1) ? (mw[j][nb >> 1] & 0xffff0000u) : (mw[j][nb >> 1] << 16);
+                    const float r = __uint_as_float(rbits);
+                    float y = acc[nb][j] + (res_last ? 0.f : r);
+                    if (!(__uint_as_float(mbits) > 0.f)) y = 0.f;
+                    if (res_last) y += r;
+                    ow[nb >> 1] |= (unsigned)f32_to_bf16(y) << (16 * (nb & 1));
+                }
+                unsigned short* yp = Y + (long long)orow[j] * cout + ncol;
+                if (vec_ok) {
+                    if (n_ok) *(uint2*)yp = make_uint2(ow[0], ow[1]);
+                } else {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        if (ncol + nb < cout) yp[nb] = (unsigned short)(ow[nb >> 1] >> (16 * (nb & 1)));
+                }
+            }
+        }
+        __syncthreads();                     // the next batch restages buffer 0 (read last by offset N_OFF - 1 when that is even)
+    }
+#undef TBS_GATHER
+#undef TBS_WSTORE
+#undef TBS_WLOAD
+}
+
 // Y = bf16( bias + sum_kc slab[kc] (+ residual, ReLU-backward mask) ), K-chunks added in ascending order.
 // V = 4: 16-byte slab reads, 8-byte bf16 accesses (cout % 4 == 0, aligned buffers).
 template <int V>
@@ -625,6 +872,51 @@ extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, con
     const int64_t nt = cdiv(n_out, TB_T);
     const TbShape sh = tb_shape(cin, cout);
     const int nb = sh.nb, kh = sh.kh, ct = sh.ct, kcs = sh.kc, n_chunks = sh.n_chunks, n_kc = sh.n_kc;
+    // ---- the offset-outer, weight-streaming kernel (k_conv_tbs above).  Measured on the cfg-2 scene (tools/ablate_tbs_exp.py,
+    // profiles/r4_tbs_streaming_experiment.txt): 26.2 / 39.3 / 47.9 us per launch at levels 1 / 2 / 3 against k_conv_tb's
+    // 30.0 / 26.9 / 27.7 -- it wins only where one offset's slice is small (Cin = 64), so THAT is what it runs by default:
+    // SubM 3^3 layers with two K-chunks.  SCN_TB_STREAM=1: every eligible layer (Cin = 64 / 128 / 256, 3^3 and 2^3 tables);
+    // SCN_TB_STREAM=0: none (k_conv_tb everywhere: A/B, cross-check in the tests)
+    const char* ts_env = getenv("SCN_TB_STREAM");                   // (read per call: the tests switch it inside one process)
+    const int ts_mode = ts_env ? atoi(ts_env) : -1;
+    const bool ts_eligible = n_kc >= 2 && kh == 1 && nb == 4 && cin % 32 == 0 && (n_kc == 2 || n_kc == 4 || n_kc == 8) &&
+                             (n_off == 27 || n_off == 8) && !(flags & SCN_F_SPLIT_SUM);
+    if (ts_eligible && ts_mode != 0 && (ts_mode == 1 || (n_kc == 2 && n_off == 27))) {
+        hipStream_t st = S(stream);
+        // waves per workgroup: 8 (one tile each); 4 when the level has too few tiles to put a workgroup on every CU
+        const bool small = cdiv(nt, 8) * n_chunks < 224;
+        const int nw = small ? 4 : 8;
+        int64_t n_wgb = cdiv(nt, nw);
+        const int64_t cap = (int64_t)(n_kc == 2 ? 512 : 256) / n_chunks;          // resident workgroups: 2 per CU at Cin = 64
+        if (n_wgb > cap) n_wgb = cap < 8 ? 8 : cap;
+        const int64_t n_wgb8 = cdiv(n_wgb, 8) * 8;
+        dim3 grid((unsigned)(n_wgb8 * n_chunks));
+        const size_t lds = (size_t)2 * n_kc * 64 * 32 * sizeof(uint16_t) + (size_t)nw * (((n_off + 1) * 16 + 63) / 64 * 64) * 4 + 16;
+#define LAUNCH_TBS(KS_, NO_, NW_, D_)                                                                                  \
+    do {                                                                                                            \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            SCN_HIP(hipFuncSetAttribute((const void*)k_conv_tbs<KS_, NO_, NW_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        160 * 1024));                                                               \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        hipLaunchKernelGGL((k_conv_tbs<KS_, NO_, NW_, D_>), grid, dim3(NW_ * 64), lds, st, X, (long long)n_in, cin, tstab,  \
+                           tile_mask, perm, tile_order, (long long)nt, image, bias, residual, relu_mask, Y, (long long)n_out, \
+                           cout, flags, n_chunks, (int)n_wgb);                                                      \
+    } while (0)
+#define PICK_TBS(KS_, D_)                                                                                           \
+    do {                                                                                                            \
+        if (n_off == 27) { if (nw == 8) LAUNCH_TBS(KS_, 27, 8, D_); else LAUNCH_TBS(KS_, 27, 4, D_); }              \
+        else { if (nw == 8) LAUNCH_TBS(KS_, 8, 8, D_); else LAUNCH_TBS(KS_, 8, 4, D_); }                            \
+    } while (0)
+        if (n_kc == 2) PICK_TBS(2, 4);
+        else if (n_kc == 4) PICK_TBS(4, 4);
+        else PICK_TBS(8, 2);
+#undef PICK_TBS
+#undef LAUNCH_TBS
+        SCN_LAUNCH_CHECK();
+        return SCN_OK;
+    }
     float* slabs = (float*)((char*)scratch + 256);
     const size_t lds = (size_t)n_off * ct * kcs * sizeof(uint16_t) + 16;
     int wg_per_cu = (int)((160 * 1024) / lds);

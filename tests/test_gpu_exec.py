@@ -455,6 +455,58 @@ def test_mask_branch_issues_the_reference_mask_networks_op_tape_on_the_gpu(gpu):
     assert torch.equal(fused, logits)
 
 
+@pytest.mark.parametrize("target", [40_000, 2_500])
+@pytest.mark.parametrize("c", [64, 128, 256])
+def test_streaming_bf16_tile_kernel_agrees_with_the_k_split_kernel(gpu, c, target):
+    """k_conv_tbs (round 4: offsets outside, the 64-column weight slice of one offset streamed through LDS, full K per
+    workgroup -- no K split, no partial tiles) against k_conv_tb (SCN_TB_STREAM=0: weights of all offsets resident, K split over
+    workgroups, in-launch combine) on the same packed weight image: SubM 3^3 forward with input ReLU + residual, backward-data
+    with ReLU mask + residual-last, and the 2^3 child table of a strided convolution, at a tile count that takes the 8-wave
+    workgroups and one that takes the 4-wave ones.  The two kernels sum the same products in a different order (K-chunks inside
+    an offset vs offsets inside a K-chunk), so they agree to fp32 rounding BEFORE the one bf16 rounding of the result: apart by
+    at most one bf16 ulp of the value plus the fp32 noise of a 1728-term sum (1e-5 of the output scale: what a result that
+    cancels to nearly zero can move by), on a small fraction of the elements -- and each is bitwise reproducible."""
+    import os
+    import sparse_rcnn_amd as scn
+    from sparse_rcnn_amd import functional as F, _lib as L
+    coords, feats, size, bs, _ = _scene(target, (256, 256, 128), seed=4)
+    x = scn.InputLayer(3, size, mode=4)((coords, feats.to(gpu), 1))
+    rb = x.metadata.subm_rulebook(size, 3)
+    sb = x.metadata.strided_rulebook(size)
+    g = torch.Generator().manual_seed(c)
+    bf = torch.bfloat16
+    X = torch.randn(rb.n, c, generator=g).to(gpu).to(bf)
+    W = (torch.randn(27, c, c, generator=g) * (2.0 / (27 * c)) ** 0.5).to(gpu)
+    b = torch.randn(c, generator=g).to(gpu)
+    R = torch.randn(rb.n, c, generator=g).to(gpu).to(bf)
+    Mk = torch.randn(rb.n, c, generator=g).to(gpu).to(bf)
+    W8 = (torch.randn(8, c, c, generator=g) * (2.0 / (8 * c)) ** 0.5).to(gpu)
+    back = L.F_W_TRANSPOSED | L.F_OFF_REVERSE
+
+    def run():
+        out = [F.conv_rules(X, rb.tiles, rb.n, W, b, c, L.F_RELU_IN, residual=R),
+               F.conv_rules(X, rb.tiles, rb.n, W, None, c, back | L.F_RESIDUAL_LAST, residual=R, relu_mask=Mk),
+               F.conv_rules(X, sb.tiles, sb.n_coarse, W8, b, c, 0),
+               F.conv_rules(X[:sb.n_coarse].contiguous(), sb.tiles, sb.n_coarse, W8, None, c, L.F_W_TRANSPOSED)]
+        torch.cuda.synchronize()
+        return out
+    os.environ["SCN_TB_STREAM"] = "1"                  # every eligible layer (default: only Cin = 64, 3^3)
+    try:
+        a, a2 = run(), run()
+        os.environ["SCN_TB_STREAM"] = "0"
+        ref = run()
+    finally:
+        del os.environ["SCN_TB_STREAM"]
+    for k, (u, v, r) in enumerate(zip(a, a2, ref)):
+        assert u.dtype == bf and torch.equal(u, v), f"op {k}: not reproducible"
+        uf, rf = u.float(), r.float()
+        diff = (uf - rf).abs()
+        bound = rf.abs() * (2.0 ** -7 * 1.001) + 1e-5 * float(rf.abs().max())    # one bf16 ulp <= 2^-7 of the value
+        assert bool((diff <= bound).all()), (k, float((diff / bound).max()))
+        assert float((diff > 0).float().mean()) < 0.02, (k, float((diff > 0).float().mean()))
+        assert float(rf.abs().max()) > 0
+
+
 def test_bf16_elementwise_forms_match_torch(gpu):
     """scn_cast_* / scn_add_bf16 / scn_gather_rows_bf16 / scn_segment_sum_bf16 / pooling / SparseToDense in bf16 storage against
     torch on the same bits (casts and gathers bit-exact; sums within one bf16 rounding of the fp64 sum)."""

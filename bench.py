@@ -234,10 +234,11 @@ def run(args):
     job = SceneStep(args.workload, dev, dtype=args.dtype, prefetch=args.prefetch, seed=seed, grad_seed=100 + rank,
                     target=args.target)
 
-    # Kernel timing: HIP events (torch events on the launch stream) around the launches of the dominant kernel on 3-4 steps
-    # spread over the timed region, from a pool of events created before it; in those steps scn_conv_tiles runs in its
-    # two-call form so that the events bracket the tile kernel alone.  Timing every launch of every step makes the step
-    # host-bound, so the other kernels are only timed with --profile-all.
+    # Kernel timing: HIP events on the launch stream around the launches of the dominant kernel on 3-4 steps spread over the
+    # timed region.  Round 4: those steps stay on the production path -- the step executor's C calls bracket their
+    # tile-convolution launches themselves (scn_exec_timing_enable; rounds 1-3 sent the sampled steps through the
+    # layer-by-layer path, whose host cost the bf16 steps felt).  Timing every launch of every step makes the step host-bound,
+    # so the other kernels are only timed with --profile-all (layer-by-layer path).
     dom_names = {"k_conv_ts", "k_conv_tb"}
     every = max(5, (args.steps + 2) // 3)
     timer = profiling.KernelTimer(every=every, names=None if args.profile_all else dom_names)
@@ -279,6 +280,7 @@ def run(args):
         dist.barrier()
     dt = time.perf_counter() - t0
     profiling.TIMER = None
+    timer.collect_exec()            # the launch times the step executor recorded on the sampled steps (before any other leg runs)
     sampled = max(1, timer.sampled_steps)
     L.lib().scn_conv_tiles_path_counts(paths, 0)
     dt_local = dt

@@ -52,7 +52,7 @@ extern "C" {
  *      weight-gradient sums; bf16 elementwise forms; segment pooling; scn_tiles_build_x) -- shipped with the value still 1
  *   3  round 4: SCN_PYRAMID_FUSED (scn_pyramid_build_ex flag, larger scn_pyramid_workspace_bytes), hash slot function
  *      changed (tables built by version <= 2 libraries are not probe-compatible; no table outlives a Metadata, so only a
- *      caller that kept raw tables across a library upgrade is affected) */
+ *      caller that kept raw tables across a library upgrade is affected); + scn_exec_timing_enable / _collect (103 entry points) */
 #define SCN_ABI_VERSION 3
 
 /* flags for the gather-GEMM entry points */
@@ -625,6 +625,13 @@ int scn_exec_run_streams(const scn_exec_op* ops, int n_ops, const scn_exec_level
                          const void* const* params, void* const* grads, void* scratch, int64_t scratch_bytes,
                          int32_t* arrival, scn_stream_t stream, scn_stream_t side_stream, void* side_scratch,
                          int64_t side_scratch_bytes);
+/* Launch timing inside a pass (round 4; what bench.py's `roofline` samples): while enabled, every scn_exec_run* call brackets
+ * its SCN_OP_CONV_SUBM / SCN_OP_CONV_CHILD ops -- one launch of the dominant tile kernel each -- with HIP timing events on
+ * `stream`.  Process-wide (a node's backward pass runs on the autograd thread).  scn_exec_timing_collect waits for the
+ * recorded events, writes per record the elapsed milliseconds and info[7] = (op, bf16 storage, cin, cout, rows in, rows out,
+ * rules of the table), returns the number of records written (at most cap) and forgets them all. */
+int scn_exec_timing_enable(int on);
+int64_t scn_exec_timing_collect(float* ms, int64_t* info, int64_t cap);
 
 #ifdef __cplusplus
 }

@@ -118,6 +118,8 @@ _SIGS = {
     "scn_exec_requirements": (C.c_int, [p, i32, p, i32, C.POINTER(i64), C.POINTER(i64)]),
     "scn_exec_run": (C.c_int, [p, i32, p, i32, p, p, p, p, i64, p, p]),
     "scn_exec_run_streams": (C.c_int, [p, i32, p, i32, p, p, p, p, i64, p, p, p, p, i64]),
+    "scn_exec_timing_enable": (C.c_int, [i32]),
+    "scn_exec_timing_collect": (i64, [p, p, i64]),
     "scn_sparse_to_dense_fwd": (C.c_int, [p, p, i64, i32, C.POINTER(i64), p, p]),
     "scn_sparse_to_dense_bwd": (C.c_int, [p, p, i64, i32, C.POINTER(i64), p, p]),
 }

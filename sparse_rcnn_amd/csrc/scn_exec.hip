@@ -9,6 +9,9 @@
 #include <stdlib.h>
 #include <vector>
 
+#include <mutex>
+#include <vector>
+
 #include "scn_common.h"
 
 using scn::cdiv;
@@ -262,6 +265,28 @@ struct EventPool {
 };
 thread_local EventPool g_events;
 
+// ---- launch timing inside a pass (scn_exec_timing_enable / _collect): bench.py samples the dominant kernel with HIP events;
+// with the executor on, a level's launches are inside ONE C call, so the call itself brackets its tile-convolution ops.
+// Process-wide (the backward pass of a node runs on autograd's thread), guarded by a mutex; events are created on demand and
+// kept for the life of the process.
+struct TimingRec { hipEvent_t a, b; int64_t info[7]; };
+struct Timing {
+    std::mutex mu;
+    bool on = false;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    std::vector<TimingRec> recs;
+    hipEvent_t take() {
+        if (used == pool.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            pool.push_back(e);
+        }
+        return pool[used++];
+    }
+};
+Timing g_timing;
+
 inline bool is_wgrad(int op) {
     return op == SCN_OP_WGRAD_SUBM || op == SCN_OP_WGRAD2_SUBM || op == SCN_OP_WGRAD_DOWN || op == SCN_OP_WGRAD_UP ||
            op == SCN_OP_WGRAD_IDENT;
@@ -316,6 +341,24 @@ extern "C" int scn_exec_run_streams(const scn_exec_op* ops, int n_ops, const scn
             SCN_HIP(hipStreamWaitEvent(scn::S(side_stream), e, 0));
             rc = run_op(cs, ops[i]);
             side_used = true;
+        } else if (g_timing.on && (ops[i].op == SCN_OP_CONV_SUBM || ops[i].op == SCN_OP_CONV_CHILD)) {
+            std::lock_guard<std::mutex> lock(g_timing.mu);
+            const scn_exec_op& o = ops[i];
+            const scn_exec_level& L = levels[o.level];
+            const bool child = o.op == SCN_OP_CONV_CHILD;
+            TimingRec r{};
+            r.a = g_timing.take();
+            r.b = g_timing.take();
+            if (r.a && r.b) SCN_HIP(hipEventRecord(r.a, scn::S(stream)));
+            rc = run_op(c, ops[i]);
+            if (r.a && r.b) {
+                SCN_HIP(hipEventRecord(r.b, scn::S(stream)));
+                // op, bf16, cin, cout, rows in, rows out, rules (a child table holds every fine row once)
+                r.info[0] = o.op; r.info[1] = bf(o) ? 1 : 0; r.info[2] = o.cin; r.info[3] = o.cout;
+                r.info[4] = L.n; r.info[5] = child ? L.n_coarse : L.n;
+                r.info[6] = child ? L.n : (L.prefix_host ? L.prefix_host[27] - L.prefix_host[0] : 0);
+                g_timing.recs.push_back(r);
+            }
         } else {
             rc = run_op(c, ops[i], defer && own[i] ? (char*)scratch + own[i] : nullptr);
         }
@@ -338,6 +381,28 @@ extern "C" int scn_exec_run_streams(const scn_exec_op* ops, int n_ops, const scn
         SCN_HIP(hipStreamWaitEvent(scn::S(stream), e, 0));
     }
     return SCN_OK;
+}
+
+extern "C" int scn_exec_timing_enable(int on) {
+    std::lock_guard<std::mutex> lock(g_timing.mu);
+    g_timing.on = on != 0;
+    return SCN_OK;
+}
+
+extern "C" int64_t scn_exec_timing_collect(float* ms, int64_t* info, int64_t cap) {
+    std::lock_guard<std::mutex> lock(g_timing.mu);
+    int64_t n = 0;
+    for (const TimingRec& r : g_timing.recs) {
+        if (n >= cap) break;
+        float t = 0.f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+        ms[n] = t;
+        for (int j = 0; j < 7; ++j) info[7 * n + j] = r.info[j];
+        ++n;
+    }
+    g_timing.recs.clear();
+    g_timing.used = 0;
+    return n;
 }
 
 extern "C" int scn_exec_run(const scn_exec_op* ops, int n_ops, const scn_exec_level* levels, int n_levels, void* const* bufs,

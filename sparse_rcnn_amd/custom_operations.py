@@ -56,8 +56,9 @@ class _SegmentPoolFunction(torch.autograd.Function):
 def split_batch(sparse_tensor):
     """custom_operations.py:24-39: list (one entry per sample) of the feature rows of that sample, in row order.  Rows
     grouped by sample (the InputLayer's order for the reference's sample-major batches, data.py:95-98) come back as row
-    RANGES of the slab -- views, no copy; one D2H of the per-sample row counts.  Any other order: one device-side row
-    selection per sample (still no host coordinates)."""
+    RANGES of the slab -- VIEWS, no copy (the reference's boolean indexing returns copies: a caller that edits a piece in
+    place edits the slab here; every use in the reference only reads them, model.py:507-512); one D2H of the per-sample row
+    counts.  Any other order: one device-side row selection per sample (copies; still no host coordinates)."""
     lib = L.lib()
     n_samples = int(sparse_tensor.batch_size())
     feats = sparse_tensor.features
@@ -98,4 +99,8 @@ class SparseGlobalPool(nn.Module):
         if op is None:
             parts = split_batch(sparse_tensor)
             return torch.stack([self.pooling_function(f, dim=0) if len(f) else f.new_zeros((f.shape[1])) for f in parts])
+        if feats.dtype == torch.bfloat16:
+            # bf16-STORED features (scn.set_feature_storage / bf16 networks): pooled in fp32 on exactly widened values -- the
+            # reference's formulation accepts any floating dtype; the pooled [samples, C] result is fp32
+            feats = feats.float()
         return _SegmentPoolFunction.apply(feats, _grid_of(sparse_tensor).coords, n_samples, op)

@@ -330,6 +330,19 @@ def _layout(stage, ids, ns):
 
 
 def _run(stage, ops, levels, table, ptab, gtab, dev, side=False):
+    from . import profiling
+    t = profiling.TIMER
+    if t is not None and t.exec_timing():      # a sampled step of bench.py: the C call brackets its tile-convolution launches
+        lib = L.lib()
+        lib.scn_exec_timing_enable(1)
+        try:
+            return _run_plain(stage, ops, levels, table, ptab, gtab, dev, side)
+        finally:
+            lib.scn_exec_timing_enable(0)
+    return _run_plain(stage, ops, levels, table, ptab, gtab, dev, side)
+
+
+def _run_plain(stage, ops, levels, table, ptab, gtab, dev, side=False):
     lib = L.lib()
     arr, _, ns = levels
     sb, ac = i64(0), i64(0)

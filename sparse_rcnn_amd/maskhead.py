@@ -148,7 +148,7 @@ class MaskBranch(nn.Module):
         from . import executor as EX, functional as F, profiling
         from .tensor import SparseConvNetTensor
         f = fmap.features
-        if (not (EX.ENABLED and SparseUNet.EXEC) or profiling.TIMER is not None
+        if (not (EX.ENABLED and SparseUNet.EXEC) or not profiling.exec_ok()
                 or not (f.is_cuda and f.dtype == torch.float32 and f.shape[0] > 0)):
             return None
         st = self.__dict__.get("_input_stage")

@@ -80,7 +80,7 @@ STAGE_STATS = {"enc": 0, "dec": 0, "layerwise_units": 0}       # how often a for
 
 def _usable(f):
     from . import executor as EX, profiling, unet
-    return (TREE_STAGES and EX.ENABLED and unet.SparseUNet.EXEC and profiling.TIMER is None and f.is_cuda and f.dim() == 2
+    return (TREE_STAGES and EX.ENABLED and unet.SparseUNet.EXEC and profiling.exec_ok() and f.is_cuda and f.dim() == 2
             and f.shape[0] > 0 and f.dtype in (torch.float32, torch.bfloat16))
 
 

@@ -21,6 +21,7 @@ class KernelTimer:
         self.pool = []
         self.used = 0
         self.records = []          # (name, flops, bytes, start, end)
+        self.exec_records = []     # (name, flops, bytes, ms): launches the step executor timed inside its C calls
 
     def reserve(self, n_events: int):
         while len(self.pool) < n_events:
@@ -50,9 +51,40 @@ class KernelTimer:
         self.records.append((name, flops, nbytes, s, e))
         return out
 
+    # ---- the step executor (executor.py): a level's launches sit inside one C call, which brackets its tile-convolution
+    # launches itself while `exec_timing()` is true (scn_exec_timing_enable); the sampled steps stay on the production path
+    def exec_timing(self):
+        return self.active and not self.count_only and (self.names is None or ("k_conv_ts" in self.names or "k_conv_tb" in self.names))
+
+    def collect_exec(self):
+        """Fetch what the executor recorded since the last call (waits for those events)."""
+        import ctypes as C
+        from . import _lib as L
+        cap = 4096
+        ms = (C.c_float * cap)()
+        info = (C.c_int64 * (7 * cap))()
+        while True:
+            n = L.lib().scn_exec_timing_collect(ms, info, cap)
+            for k in range(n):
+                op, bf16, cin, cout, n_in, n_out, rules = (int(info[7 * k + j]) for j in range(7))
+                n_off = 8 if op == 3 else 27                          # SCN_OP_CONV_CHILD = 3
+                es = 2.0 if bf16 else 4.0
+                self.exec_records.append(("k_conv_tb" if bf16 else "k_conv_ts", 2.0 * rules * cin * cout,
+                                          es * (n_in * cin + n_out * cout + (n_off * cin * cout if not bf16 else 0))
+                                          + (2.0 * n_off * cin * cout if bf16 else 0.0) + 8.0 * rules, float(ms[k])))
+            if n < cap:
+                break
+
     def summary(self):
         """name -> dict(launches, ms, flops, bytes) over the sampled launches.  Call after torch.cuda.synchronize()."""
+        self.collect_exec()
         out = {}
+        for name, flops, nbytes, t in self.exec_records:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += t
+            d["flops"] += flops
+            d["bytes"] += nbytes
         for name, flops, nbytes, s, e in self.records:
             d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             d["launches"] += 1
@@ -67,6 +99,14 @@ class KernelTimer:
 
 
 TIMER: KernelTimer | None = None
+
+
+def exec_ok():
+    """May a forward take the step executor?  Yes without a timer, and with one that only samples the dominant tile kernel
+    (the executor's C calls bracket those launches themselves); a timer that counts launches or times every kernel needs
+    the layer-by-layer path."""
+    t = TIMER
+    return t is None or (not t.count_only and t.names is not None and t.names <= {"k_conv_ts", "k_conv_tb"})
 
 
 def timed(name, flops, nbytes, fn):

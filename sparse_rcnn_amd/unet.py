@@ -184,7 +184,7 @@ class SparseUNet(nn.Module):
         """The forward through the step executor, or None when it does not apply to this call."""
         from . import executor as EX, functional as F, profiling
         from .tensor import SparseConvNetTensor
-        if not (EX.ENABLED and SparseUNet.EXEC) or profiling.TIMER is not None:
+        if not (EX.ENABLED and SparseUNet.EXEC) or not profiling.exec_ok():
             return None
         f = x.features
         if not (f.is_cuda and f.dtype == torch.float32 and f.dim() == 2 and f.shape[0] > 0):

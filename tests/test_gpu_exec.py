@@ -507,6 +507,57 @@ def test_streaming_bf16_tile_kernel_agrees_with_the_k_split_kernel(gpu, c, targe
         assert float(rf.abs().max()) > 0
 
 
+def test_executor_side_stream_leaves_give_the_same_bits(gpu):
+    """scn_exec_run_streams with the parameter-gradient ops on a second stream (SCN_EXEC_SIDE=1: each leaf behind an
+    event of the main stream, joined before the call returns) -- shipped, measured slower, off by default -- gives the bits of
+    the one-stream pass."""
+    from sparse_rcnn_amd import executor as EX
+    from sparse_rcnn_amd.unet import Backbone
+    coords, feats, size, bs, _ = _scene(12_000, (128, 128, 64), seed=8)
+    torch.manual_seed(4)
+    net = Backbone(7, (16, 32, 64)).to(gpu)
+    res = []
+    for side in (False, True):
+        EX.SIDE_LEAVES = side
+        try:
+            res.append(_run_backbone(net, coords, feats, size, 13, gpu, True))
+        finally:
+            EX.SIDE_LEAVES = False
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+    for x, y in zip(a[3], b[3]):
+        assert torch.equal(x, y)
+
+
+def test_executor_times_its_tile_launches_for_a_sampling_timer(gpu):
+    """ADVICE r3 / bench.py's `roofline`: with a profiling.KernelTimer that samples only the dominant tile kernel, a forward +
+    backward stays on the step executor (the production path) and the executor's C calls bracket their tile-convolution
+    launches with HIP events themselves: 62 records for the cfg-2 plan (28 SubM 3^3 x 2 + 3 strided forward + 3 deconvolution
+    backward-data), positive times, the algorithmic FLOPs of the layer-by-layer timer; and the same bits as an untimed step."""
+    from sparse_rcnn_amd import profiling
+    from sparse_rcnn_amd.unet import Backbone
+    coords, feats, size, bs, _ = _scene(30_000, (256, 256, 128), seed=7)
+    torch.manual_seed(3)
+    net = Backbone(7, (32, 64, 128, 256)).to(gpu)
+    ref = _run_backbone(net, coords, feats, size, 11, gpu, True)
+    sums = {}
+    for use_exec in (True, False):
+        t = profiling.KernelTimer(every=1, names={"k_conv_ts", "k_conv_tb"})
+        t.begin_step()
+        profiling.TIMER = t
+        try:
+            got = _run_backbone(net, coords, feats, size, 11, gpu, use_exec)
+        finally:
+            profiling.TIMER = None
+        torch.cuda.synchronize()
+        sums[use_exec] = t.summary()["k_conv_ts"]
+        assert len(t.exec_records) == (62 if use_exec else 0) and len(t.records) == (0 if use_exec else 62)
+        assert torch.equal(got[0], ref[0]) and all(torch.equal(x, y) for x, y in zip(got[3], ref[3]))
+    a, b = sums[True], sums[False]
+    assert a["launches"] == b["launches"] == 62 and a["ms"] > 0 and b["ms"] > 0
+    assert abs(a["flops"] - b["flops"]) <= 1e-9 * b["flops"] and abs(a["bytes"] - b["bytes"]) <= 1e-9 * b["bytes"]
+
+
 def test_bf16_elementwise_forms_match_torch(gpu):
     """scn_cast_* / scn_add_bf16 / scn_gather_rows_bf16 / scn_segment_sum_bf16 / pooling / SparseToDense in bf16 storage against
     torch on the same bits (casts and gathers bit-exact; sums within one bf16 rounding of the fp64 sum)."""

@@ -362,7 +362,7 @@ def roofline(dom, d, sampled, args):
     """`roofline` object of the contract for the dominant kernel (HIP events around its launches, live)."""
     us = d["ms"] * 1e3 / d["launches"]
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r3_traffic.json")       # separate rocprofv3 --pmc passes (tools/collect_traffic.py)
+    tfile = os.path.join(ROOT, "profiles", "r4_traffic.json")       # separate rocprofv3 --pmc passes (tools/collect_traffic.py)
     if not os.path.exists(tfile):
         tfile = os.path.join(ROOT, "profiles", "r2_traffic.json")
     try:

@@ -144,7 +144,7 @@ def test_backbone_step_full_size_is_finite_and_reproducible(scene, gpu):
 
 
 def test_config5_shape_600k_voxels_five_levels_to_512_channels(gpu):
-    """BASELINE config 5's shape on one GPU, in fp32 (bf16 storage is not built): grid 1024x1024x512, 600k active
+    """BASELINE config 5's shape on one GPU, in fp32 (its bf16-storage form: tests/test_gpu_atsize.py::test_cfg5_shape_bf16_properties): grid 1024x1024x512, 600k active
     voxels, U-Net 32..512.  The largest case the configs name: 4.6 M SubM pairs at level 0 (> 10 M over the
     five levels' SubM and strided rulebooks), 512-channel bottom level, coordinates beyond 512.  Checked through size-independent properties; the native index build must agree bit for bit
     with the per-call one at this size too."""

@@ -551,6 +551,12 @@ extern "C" int64_t scn_conv_tiles_arrival_counters(int cin, int64_t n_out, int c
     return cdiv(cin, TS_KC) > 1 ? cdiv(n_out, TS_T) * cdiv(cout, TS_CT) : 0;
 }
 
+namespace scn {
+int conv_tiles_stream(const float* X, int64_t n_in, int cin, const int32_t* tstab, const uint32_t* tile_mask,
+                      const int32_t* perm, int n_off, int64_t n_out, const float* W, const float* bias, const float* residual,
+                      const float* relu_mask, float* Y, int cout, int flags, hipStream_t st, bool* launched);
+}
+
 extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32_t* tstab, const uint32_t* tile_mask,
                               const int32_t* perm, const int32_t* tile_order, int n_off, int64_t n_out, const float* W, const float* bias,
                               const float* residual, const float* relu_mask, float* Y, int cout, int flags,
@@ -562,6 +568,18 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     const int n_chunks = (int)cdiv(cout, TS_CT);
     const int n_kc = (int)cdiv(cin, TS_KC);
     SCN_REQUIRE(scratch);
+    if (n_kc > 1 && arrival != nullptr) {        // (the fused mode's callers; the two-launch cross-check keeps k_conv_ts)
+        // layers that would split K over workgroups at Cin = 64 / 128: the offset-outer weight-streaming kernel (scn_conv_tss.hip)
+        bool launched = false;
+        const int rc = scn::conv_tiles_stream(X, n_in, cin, tstab, tile_mask, perm, n_off, n_out, W, bias, residual, relu_mask,
+                                              Y, cout, flags, S(stream), &launched);
+        if (rc != SCN_OK) return rc;
+        if (launched) {
+            g_ts_paths[0].fetch_add(1, std::memory_order_relaxed);
+            g_ts_paths[2].fetch_add(1, std::memory_order_relaxed);
+            return SCN_OK;
+        }
+    }
     float* slabs = (float*)((char*)scratch + ts_counter_bytes(cin, cout));
     // the in-launch K reduction needs the caller's zeroed arrival counters and 32-bit slab offsets; without them (or when
     // the caller asks for the two-launch form) the partial sums go to row-major slabs and k_conv_ts_sum adds them

@@ -558,6 +558,61 @@ def test_executor_times_its_tile_launches_for_a_sampling_timer(gpu):
     assert abs(a["flops"] - b["flops"]) <= 1e-9 * b["flops"] and abs(a["bytes"] - b["bytes"]) <= 1e-9 * b["bytes"]
 
 
+@pytest.mark.parametrize("target", [40_000, 2_500])
+@pytest.mark.parametrize("c", [64, 128])
+def test_streaming_fp32_tile_kernel_agrees_with_the_k_split_kernel(gpu, c, target):
+    """k_conv_tss (round 4: offsets outside, the 64-column fp32 weight slice of one offset streamed through LDS, full K per
+    workgroup, no K split) against k_conv_ts (SCN_TS_STREAM=0) on the same operands: SubM 3^3 forward with input ReLU +
+    residual, backward-data (transposed, offset-reversed weights) with ReLU mask + residual-last, the 2^3 child table forward
+    and transposed -- at a tile count that takes the 16-wave workgroups and one that takes the 8-wave ones.  Same products,
+    different summation order (K-chunks inside an offset vs offsets inside a K-chunk): agreement to fp32 rounding, 2e-6 of
+    the output scale; each kernel bitwise reproducible; both within 1e-5 of an fp64 evaluation of the forward."""
+    import os
+    import sparse_rcnn_amd as scn
+    from sparse_rcnn_amd import functional as F, _lib as L
+    coords, feats, size, bs, _ = _scene(target, (256, 256, 128), seed=4)
+    x = scn.InputLayer(3, size, mode=4)((coords, feats.to(gpu), 1))
+    rb = x.metadata.subm_rulebook(size, 3)
+    sb = x.metadata.strided_rulebook(size)
+    g = torch.Generator().manual_seed(c)
+    X = torch.randn(rb.n, c, generator=g).to(gpu)
+    W = (torch.randn(27, c, c, generator=g) * (2.0 / (27 * c)) ** 0.5).to(gpu)
+    b = torch.randn(c, generator=g).to(gpu)
+    R = torch.randn(rb.n, c, generator=g).to(gpu)
+    Mk = torch.randn(rb.n, c, generator=g).to(gpu)
+    W8 = (torch.randn(8, c, c, generator=g) * (2.0 / (8 * c)) ** 0.5).to(gpu)
+    back = L.F_W_TRANSPOSED | L.F_OFF_REVERSE
+    paths = (__import__("ctypes").c_int64 * 4)()
+
+    def run():
+        out = [F.conv_rules(X, rb.tiles, rb.n, W, b, c, L.F_RELU_IN, residual=R),
+               F.conv_rules(X, rb.tiles, rb.n, W, None, c, back | L.F_RESIDUAL_LAST, residual=R, relu_mask=Mk),
+               F.conv_rules(X, sb.tiles, sb.n_coarse, W8, b, c, 0),
+               F.conv_rules(X[:sb.n_coarse].contiguous(), sb.tiles, sb.n_coarse, W8, None, c, L.F_W_TRANSPOSED)]
+        torch.cuda.synchronize()
+        return out
+    os.environ["SCN_TS_STREAM"] = "1"                  # (opt-in: measured slower than k_conv_ts, DESIGN.md section 4.1)
+    try:
+        a, a2 = run(), run()
+    finally:
+        del os.environ["SCN_TS_STREAM"]
+    ref = run()
+    for k, (u, v, r) in enumerate(zip(a, a2, ref)):
+        assert torch.equal(u, v), f"op {k}: not reproducible"
+        scale = float(r.abs().max())
+        assert scale > 0 and float((u - r).abs().max()) <= 2e-6 * scale, (k, float((u - r).abs().max()) / scale)
+    assert not torch.equal(a[0], ref[0])                              # (the streaming kernel really ran: another summation order)
+    # fp64 forward of op 0 on a sample of rows through the neighbour table
+    rows = torch.arange(0, rb.n, max(1, rb.n // 512), device=gpu)
+    tab = rb.table[:, rows].long()                                   # [27, rows]
+    acc = b.double().unsqueeze(0).repeat(len(rows), 1) + R[rows].double()
+    for o in range(27):
+        ok = tab[o] >= 0
+        acc[ok] += torch.relu(X[tab[o][ok]]).double() @ W[o].double()
+    for y in (a[0], ref[0]):
+        assert float((y[rows].double() - acc).abs().max()) <= 1e-5 * float(acc.abs().max())
+
+
 def test_bf16_elementwise_forms_match_torch(gpu):
     """scn_cast_* / scn_add_bf16 / scn_gather_rows_bf16 / scn_segment_sum_bf16 / pooling / SparseToDense in bf16 storage against
     torch on the same bits (casts and gathers bit-exact; sums within one bf16 rounding of the fp64 sum)."""

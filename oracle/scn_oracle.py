@@ -403,9 +403,11 @@ class OracleScene:
         return len(self.level_coords[level])
 
 
-def unet_param_shapes(cin, channels, identity_first=False):
+def unet_param_shapes(cin, channels, identity_first=False, min_channels=0):
     """Ordered (name, shape) list for the A12 U-Net (SURVEY Appendix A.1 layer list).  identity_first: encoder level 0
-    is the reference's FLD('I') (no layer; the mask head's internal U-Net, scannet_config/run.py:756-775)."""
+    is the reference's FLD('I') (no layer; the mask head's internal U-Net, scannet_config/run.py:756-775).
+    min_channels: decoder level l comes up max(channels[l], min_channels) wide (module_factory.py:789-804, 533-578):
+    Deconvolution(-> d), NetworkInNetwork(d + channels[l] -> d), units(d)."""
     shapes = []
     L = len(channels)
     for l, c in enumerate(channels):
@@ -418,13 +420,15 @@ def unet_param_shapes(cin, channels, identity_first=False):
         for u in range(2):
             for v in range(2):
                 shapes += [(f"enc{l}.res{u}.conv{v}.weight", (27, c, c)), (f"enc{l}.res{u}.conv{v}.bias", (c,))]
+    cup = channels[-1]
     for l in range(L - 2, -1, -1):
-        c, cup = channels[l], channels[l + 1]
-        shapes += [(f"dec{l}.up.weight", (8, cup, c)), (f"dec{l}.up.bias", (c,))]
-        shapes += [(f"dec{l}.nin.weight", (2 * c, c)), (f"dec{l}.nin.bias", (c,))]
+        c, d = channels[l], max(channels[l], min_channels)
+        shapes += [(f"dec{l}.up.weight", (8, cup, d)), (f"dec{l}.up.bias", (d,))]
+        shapes += [(f"dec{l}.nin.weight", (d + c, d)), (f"dec{l}.nin.bias", (d,))]
         for u in range(2):
             for v in range(2):
-                shapes += [(f"dec{l}.res{u}.conv{v}.weight", (27, c, c)), (f"dec{l}.res{u}.conv{v}.bias", (c,))]
+                shapes += [(f"dec{l}.res{u}.conv{v}.weight", (27, d, d)), (f"dec{l}.res{u}.conv{v}.bias", (d,))]
+        cup = d
     return shapes
 
 

@@ -199,7 +199,8 @@ def _plain_blocks(unit_seq):
         r0, c1, r1, c2 = list(inner._modules.values())
         if not (type(r0) is M.ReLU and type(r1) is M.ReLU and type(c1) is M.SubmanifoldConvolution
                 and type(c2) is M.SubmanifoldConvolution and c1.filter_size == 3 and c2.filter_size == 3
-                and c1.bias is not None and c2.bias is not None and c1.nIn == c2.nOut and c1.nOut == c2.nIn == c1.nIn):
+                and c1.bias is not None and c2.bias is not None and c1.nIn == c2.nOut and c1.nOut == c2.nIn == c1.nIn
+                and c1.groups == 1 and c2.groups == 1):
             return None
         out.append((c1, c2))
     return out

@@ -28,16 +28,17 @@ from .ioLayers import OutputLayer
 from .unet import SparseUNet, units
 
 
-def reference_key_map(n_unet_levels=4, num_units=2, n_linear=2):
+def reference_key_map(n_unet_levels=4, num_units=2, n_linear=2, with_input=True):
     """state_dict key of the reference's SparseMaskNetwork (model.py:572-782 under scannet_config/run.py:741-810:
     `input_conv_layer` = Sequential of one 'B' level, `output_conv_layer` = UnetContainer(downsampling_layer = SequentialInterims
     whose level 0 is the FLD('I') Identity, upsampling_layer.module_list = SkipConnectionReuniter per decoder level),
     `linear_layer` = Linear / ReLU stack) -> this package's parameter name (`MaskBranch.named_oracle_params`).  Checked against
-    the key list of a reference SparseMaskNetwork built on this package (tests/golden/dropin_mask_network.json)."""
+    the key list of a reference SparseMaskNetwork built on this package (tests/golden/dropin_mask_network.json).
+    with_input=False: `use_unet_features=False` -- no input_conv_layer (model.py:723-729)."""
     out = {}
     for t in ("weight", "bias"):
-        out[f"input_conv_layer.0.0.0.{t}"] = f"in.{t}"
-        for u in range(num_units):
+        for u in range(num_units if with_input else 0):
+            out[f"input_conv_layer.0.0.0.{t}"] = f"in.{t}"
             for v, idx in enumerate((1, 3)):                     # Sequential(ReLU, SubM, ReLU, SubM) inside ConcatTable[1]
                 out[f"input_conv_layer.0.1.{u}.0.1.{idx}.{t}"] = f"in.res{u}.conv{v}.{t}"
         for l in range(1, n_unet_levels):
@@ -66,21 +67,37 @@ class MaskBranch(nn.Module):
     PREFETCH_ROI_INDEX = os.environ.get("SCN_ROI_PREFETCH", "0")       # "0" inline | "thread" | "stream"
 
     def __init__(self, backbone_channels=32, raw_channels=7, input_channels=16, unet_channels=(32, 48, 64),
-                 linear_channels=(32, 18), bf16_blocks=False):
+                 linear_channels=(32, 18), bf16_blocks=False, *, use_unet_features=True, use_raw_features=True,
+                 use_skip_features=False, min_channels=16):
+        """use_unet_features / use_raw_features / use_skip_features: the reference's switches (model.py:702-751) --
+          unet + raw  `SparseFeaturemapSelectorBoth` (:573-596, the configured one, run.py:799-801): the ROI batch is cut from
+                      [per-point output of input_conv_layer ++ raw point features];
+          unet only   `SparseFeaturemapSelector` (:597-619): from the per-point output alone;
+          raw only    `SparseFeaturemapSelectorRaw` (:621-637): from the raw point features, no input_conv_layer at all;
+          skip        `SparseFeaturemapCombiner` (:639-651) instead of `SparseFeaturemapFirst`: the cropped raw features are
+                      joined to the internal U-Net's per-point output in front of the Linear stack.
+        min_channels: `unet_params['min_channels']` of the internal U-Net (run.py:786; unet.SparseUNet)."""
         super().__init__()
+        if not (use_unet_features or use_raw_features):
+            raise ValueError("MaskBranch: use_unet_features=False needs use_raw_features (model.py:724)")
         self.bf16 = bool(bf16_blocks)           # bf16 STORAGE of the branch's feature slabs (BASELINE configs 3-5)
-        c = input_channels + raw_channels
-        self.input_conv_layer = M.Sequential(M.SubmanifoldConvolution(3, backbone_channels, input_channels, 1, True),
-                                             units(input_channels, 2))
+        self.use_unet_features, self.use_raw_features = bool(use_unet_features), bool(use_raw_features)
+        self.use_skip_features, self.raw_channels = bool(use_skip_features), int(raw_channels)
+        c = (input_channels if use_unet_features else 0) + (raw_channels if use_raw_features else 0)
+        self.input_conv_layer = None
+        if use_unet_features:
+            self.input_conv_layer = M.Sequential(M.SubmanifoldConvolution(3, backbone_channels, input_channels, 1, True),
+                                                 units(input_channels, 2))
         self.output_layer = OutputLayer(3)
         # dense_inside=False: the selection stays the CSR list (no [boxes, points] matrix); every consumer here takes it
         self.output_roi_cut = roi.SparseRoiCut(roi.RawToTensorFeatureExtractorCombiner(), dense_inside=False)
         self.scene_roi_extra_cut = roi.SparseRoiExtraCut(roi.RawToFeaturesSceneFeatureExtractorCombiner())
         self.spatial_size_extention = 32                                        # model.py:701
         self.output_conv_layer = SparseUNet(c, (c,) + tuple(unet_channels), identity_first=True,
-                                            bf16_blocks=bf16_blocks)
+                                            bf16_blocks=bf16_blocks, min_channels=min_channels)
+        c = self.output_conv_layer.out_channels                             # (min_channels: 7 in -> 16 out, model.py:789-804)
         self.roi_output_layer = OutputLayer(3)
-        layers, cin = [], c
+        layers, cin = [], c + (raw_channels if use_skip_features else 0)
         for i, co in enumerate(linear_channels):
             if i:
                 layers.append(nn.ReLU(inplace=True))
@@ -98,12 +115,13 @@ class MaskBranch(nn.Module):
 
     def forward(self, raw_scene, backbone_features, selected_bbox, prepared_cut=None):
         """raw_scene: the collate tuple (coords, features, spatial_size, batch_size, batch_splits) with `features` on
-        the device; backbone_features: SparseConvNetTensor (unet_feature_maps[-1]); selected_bbox: list (one per sample)
-        of fp32 [n, 2, 3] boxes.  -> (per-point-per-class mask logits [M, classes], selection)."""
+        the device; backbone_features: SparseConvNetTensor (unet_feature_maps[-1]; unused -- may be None -- without
+        use_unet_features); selected_bbox: list (one per sample) of fp32 [n, 2, 3] boxes.
+        -> (per-point-per-class mask logits [M, classes], selection)."""
         coords, features, spatial_size, *other, batch_splits = raw_scene
         # the InputLayer of this scene left an int32 device copy of the point coordinates in its Metadata: the crop reads
         # that instead of converting (and range-checking, one host wait) the int64 coordinates a second time
-        pc = getattr(backbone_features.metadata, "point_coords", None)
+        pc = getattr(getattr(backbone_features, "metadata", None), "point_coords", None)
         if pc is not None and pc.shape[0] == coords.shape[0]:
             coords = pc
             raw_scene = (pc,) + tuple(raw_scene[1:])
@@ -118,18 +136,20 @@ class MaskBranch(nn.Module):
         # bf16 storage: the scene-level units, the per-point gather (OutputLayer), the per-point slab and the crop's feature
         # gather all run on bf16 rows (round 3: no fp32 island between backbone and internal U-Net); only the InputLayer's
         # mean over the cropped points accumulates in fp32 / fp64
-        converted = self._input_stage_exec(backbone_features)            # one C call each way (executor.py) where it applies
-        if converted is None and self.bf16:
-            converted = self.input_conv_layer(M.CastFeatures(torch.bfloat16)(backbone_features))
-        elif converted is None:
-            converted = self.input_conv_layer(backbone_features)
-        per_point = self.output_layer(converted)
-        raw = features.to(per_point.dtype)
-        parts = (per_point, raw)
+        parts = ()
+        if self.use_unet_features:
+            converted = self._input_stage_exec(backbone_features)        # one C call each way (executor.py) where it applies
+            if converted is None and self.bf16:
+                converted = self.input_conv_layer(M.CastFeatures(torch.bfloat16)(backbone_features))
+            elif converted is None:
+                converted = self.input_conv_layer(backbone_features)
+            parts += (self.output_layer(converted),)
+        if self.use_raw_features:
+            parts += (features.to(parts[0].dtype if parts else (torch.bfloat16 if self.bf16 else features.dtype)),)
         unet = self.output_conv_layer
         if unet.phys0 != unet.channels[0]:      # 23 -> 24 columns: zero column appended where the slab is assembled anyway
-            parts += (raw.new_zeros((raw.shape[0], unet.phys0 - unet.channels[0])),)
-        combined = torch.cat(parts, dim=-1)
+            parts += (parts[0].new_zeros((parts[0].shape[0], unet.phys0 - unet.channels[0])),)
+        combined = torch.cat(parts, dim=-1) if len(parts) > 1 else parts[0]
         roi_tensor, selection = self.output_roi_cut((coords, combined, size, *other, batch_splits), selected_bbox,
                                                     prepared=pending)
         skip_features = self.scene_roi_extra_cut(raw_scene, selection)
@@ -140,6 +160,8 @@ class MaskBranch(nn.Module):
             if MD.XCD_ORDER_BF16 and not roi_tensor.metadata.subm:
                 roi_tensor.metadata.xcd_order = True
         out = self.roi_output_layer(unet(roi_tensor))            # [cropped points, phys0]; the pad column is zero
+        if self.use_skip_features:              # SparseFeaturemapCombiner (model.py:639-651): [U-Net output ++ cropped raw features]
+            out = torch.cat((out[:, :unet.out_channels], skip_features.to(out.dtype)), dim=-1)
         return self._linear(out), selection
 
     def _input_stage_exec(self, fmap):
@@ -170,8 +192,9 @@ class MaskBranch(nn.Module):
     def named_oracle_params(self):
         out = {}
         ic = self.input_conv_layer
-        out["in.weight"], out["in.bias"] = ic[0].weight, ic[0].bias
-        for u, block in enumerate(ic[1]):
+        if ic is not None:
+            out["in.weight"], out["in.bias"] = ic[0].weight, ic[0].bias
+        for u, block in enumerate(ic[1] if ic is not None else ()):
             convs = [m for m in block[0][1] if isinstance(m, M.SubmanifoldConvolution)]
             for v, cv in enumerate(convs):
                 out[f"in.res{u}.conv{v}.weight"], out[f"in.res{u}.conv{v}.bias"] = cv.weight, cv.bias
@@ -186,14 +209,17 @@ class MaskBranch(nn.Module):
         """Load the mask-network part of a checkpoint written by the REFERENCE (training.py:386-391 saves
         model.state_dict(); the SparseMaskNetwork sits under `mask_network.` in InstanceSegmentationNetwork, model.py:31-114):
         keys are mapped onto this branch's parameters by `reference_key_map`; SparseConvNet's grouped weight layout
-        [fv, 1, nIn, nOut] is accepted.  prefix=None: detected from the first key ending in 'input_conv_layer.0.0.0.weight'.
+        [fv, 1, nIn, nOut] is accepted.  prefix=None: detected from the first key ending in 'input_conv_layer.0.0.0.weight'
+        ('output_conv_layer.downsampling_layer.1.0.0.weight' without use_unet_features).
         -> (missing reference keys, unused checkpoint keys under the prefix)."""
         if prefix is None:
-            tail = "input_conv_layer.0.0.0.weight"
+            tail = ("input_conv_layer.0.0.0.weight" if self.input_conv_layer is not None
+                    else "output_conv_layer.downsampling_layer.1.0.0.weight")
             prefix = next((k[:-len(tail)] for k in state_dict if k.endswith(tail)), "")
         own = self.named_oracle_params()
         n_lin = len([m for m in self.linear_layer if isinstance(m, nn.Linear)])
-        kmap = reference_key_map(len(self.output_conv_layer.channels), n_linear=n_lin)
+        kmap = reference_key_map(len(self.output_conv_layer.channels), n_linear=n_lin,
+                                 with_input=self.input_conv_layer is not None)
         missing, used = [], set()
         with torch.no_grad():
             for rk, name in kmap.items():

@@ -88,7 +88,7 @@ def _head_of(m):
     """The conv-type head of an encoder level: the layer itself or a Sequential holding just it."""
     if type(m) is Sequential and len(m._modules) == 1:
         m = next(iter(m._modules.values()))
-    if type(m) is SubmanifoldConvolution and m.filter_size == 1:
+    if type(m) is SubmanifoldConvolution and m.filter_size == 1 and m.groups == 1:
         return m
     return m if type(m) is Convolution else None
 
@@ -400,7 +400,7 @@ class _ConvBase(Module):
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         # checkpoints written with SparseConvNet's grouped layout [fv, groups=1, nIn, nOut] load into [fv, nIn, nOut]
         k = prefix + "weight"
-        if k in state_dict and state_dict[k].dim() == 4 and state_dict[k].shape[1] == 1:
+        if k in state_dict and state_dict[k].dim() == 4 and state_dict[k].shape[1] == 1 and self.weight.dim() == 3:
             state_dict[k] = state_dict[k].squeeze(1)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
@@ -412,13 +412,32 @@ class SubmanifoldConvolution(_ConvBase):
         super().__init__()
         if int(dimension) != 3:
             raise NotImplementedError("only dimension 3")
-        if groups != 1:
-            raise NotImplementedError("groups != 1 is never used by the reference (module_factory.py:152)")
         fs = _triple(filter_size, "filter_size")
         if len(set(fs)) != 1 or fs[0] % 2 == 0:
             raise ValueError("SubmanifoldConvolution needs an odd cubic filter")
         self.dimension, self.filter_size = 3, fs[0]
+        self.groups = int(groups)
+        if self.groups < 1 or int(nIn) % self.groups or int(nOut) % self.groups:
+            raise ValueError(f"SubmanifoldConvolution: groups={groups} must divide nIn={nIn} and nOut={nOut}")
         self._init(self.filter_size ** 3, nIn, nOut, bias)
+        if self.groups > 1:
+            # SparseConvNet's grouped layout [filter volume, groups, nIn / groups, nOut / groups]: group g maps input channels
+            # [g nIn/G, (g+1) nIn/G) to output channels [g nOut/G, (g+1) nOut/G).  No reference configuration reaches it
+            # (module_factory.py:145,152 pin groups = 1 in the residual blocks; :596 only in the dense dilation network), so the
+            # kernels see the block-diagonal dense weight -- the products with its zero blocks add exact zeros.
+            fv, G = self.filter_size ** 3, self.groups
+            std = math.sqrt(2.0 / (self.nIn // G) / fv)
+            self.weight = Parameter(torch.empty(fv, G, self.nIn // G, self.nOut // G).normal_(0, std))
+
+    def _wb(self, cin_phys):
+        if self.groups == 1:
+            return super()._wb(cin_phys)
+        if int(cin_phys) != self.nIn or self.pad_out_to:
+            raise ValueError("SubmanifoldConvolution: channel padding is not combined with groups")
+        G = self.groups
+        eye = torch.eye(G, dtype=self.weight.dtype, device=self.weight.device)
+        W = torch.einsum("ogij,gh->ogihj", self.weight, eye).reshape(self.weight.shape[0], self.nIn, self.nOut)
+        return W, self.bias
 
     def forward(self, input, relu_in=False, residual=None):
         W, b = self._wb(input.features.shape[1])          # (physical widths: a channel-padded slab is wider than nIn)
@@ -430,7 +449,7 @@ class SubmanifoldConvolution(_ConvBase):
         return _out(input, _stored(y, W.shape[-1]))
 
     def extra_repr(self):
-        return f"{self.nIn}->{self.nOut} C{self.filter_size}"
+        return f"{self.nIn}->{self.nOut} C{self.filter_size}" + (f" groups={self.groups}" if self.groups > 1 else "")
 
 
 def _check_s2(filter_size, filter_stride):
@@ -500,20 +519,21 @@ class NetworkInNetwork(Module):
             self.register_parameter("bias", None)
 
     # channel padding (see _ConvBase): in_groups = logical widths of the joined inputs, each physically padded to the same
-    # width (JoinTable of two padded slabs); pad_out_to = physical output width
+    # width (JoinTable of two padded slabs) or to in_phys[i]; pad_out_to = physical output width
     pad_out_to = None
     in_groups = None
+    in_phys = None
 
     def _wb(self, cin_phys):
         W, b = self.weight, self.bias
         pad = torch.nn.functional.pad
         if cin_phys != self.nIn:
             groups = self.in_groups or (self.nIn,)
-            if cin_phys % len(groups) or sum(groups) != self.nIn:
+            phys = self.in_phys or (cin_phys // len(groups),) * len(groups)
+            if sum(phys) != cin_phys or sum(groups) != self.nIn or any(p < g for p, g in zip(phys, groups)):
                 raise ValueError(f"NetworkInNetwork: {cin_phys} input columns for nIn={self.nIn}")
-            gp = cin_phys // len(groups)
             parts, r0 = [], 0
-            for gsz in groups:
+            for gsz, gp in zip(groups, phys):
                 parts.append(pad(W[r0:r0 + gsz], (0, 0, 0, gp - gsz)))
                 r0 += gsz
             W = torch.cat(parts, 0)

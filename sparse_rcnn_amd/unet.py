@@ -59,12 +59,18 @@ class SparseUNet(nn.Module):
     resolution; ``.interims`` holds the encoder outputs (the reference's SequentialInterims, custom_container.py:5-12)."""
 
     def __init__(self, cin=7, channels=(32, 64, 128, 256), num_units=2, batchnorm=False, bf16_blocks=False,
-                 identity_first=False):
+                 identity_first=False, min_channels=0):
         """identity_first: level 0 of the encoder is the reference's FLD('I') -- no layer at all, channels[0] == cin
         (the mask head's internal U-Net: scannet_config/run.py:756-775, I -> B32/2 -> B48/2 -> B64/2; the decoder's
-        level 0 still has its NiN(2 cin -> cin) + residual units, module_factory.py:533-578)."""
+        level 0 still has its NiN(2 cin -> cin) + residual units, module_factory.py:533-578).
+        min_channels: a decoder level is at least this wide (module_factory.py:789-804, `unet_params['min_channels'] = 16` in
+        run.py:594,786): level l comes up as d_l = max(channels[l], min_channels) channels -- Deconvolution(-> d_l),
+        JoinTable with the channels[l]-wide skip, NetworkInNetwork(d_l + channels[l] -> d_l), units(d_l).  It only bites below
+        16 channels: the mask network cut from the raw point features alone (7 channels in, 16 out)."""
         super().__init__()
         self.channels = tuple(channels)
+        self.dec_channels = tuple(max(int(c), int(min_channels)) for c in self.channels[:-1])
+        self.out_channels = self.dec_channels[0] if self.dec_channels else self.channels[0]
         self.identity_first = bool(identity_first)
         if self.identity_first and self.channels[0] != cin:
             raise ValueError("identity_first needs channels[0] == cin")
@@ -89,27 +95,34 @@ class SparseUNet(nn.Module):
         self.encoder = nn.ModuleList(enc)
         dec = []
         for l in range(len(self.channels) - 2, -1, -1):
-            c, cup = self.channels[l], self.channels[l + 1]
+            c, d = self.channels[l], self.dec_channels[l]
+            cup = self.channels[l + 1] if l == len(self.channels) - 2 else self.dec_channels[l + 1]
             dec.append(nn.ModuleDict(dict(
-                up=M.Sequential(M.ReLU(), M.Deconvolution(3, cup, c, (2, 2, 2), (2, 2, 2), True)),
+                up=M.Sequential(M.ReLU(), M.Deconvolution(3, cup, d, (2, 2, 2), (2, 2, 2), True)),
                 join=M.JoinTable(),
-                nin=M.NetworkInNetwork(2 * c, c, True),
-                units=units(c, num_units, batchnorm))))
+                nin=M.NetworkInNetwork(d + c, d, True),
+                units=units(d, num_units, batchnorm))))
         self.decoder = nn.ModuleList(dec)
         # identity_first with a level-0 width that is no multiple of 8 (the mask head's 23): the level runs on slabs
         # zero-padded to `phys0` columns (16-byte rows: vector kernels in fp32, bf16 storage possible at all); the caller
         # hands in the padded slab and gets the padded result (modules._ConvBase.pad_out_to)
         c0 = self.channels[0]
-        self.phys0 = c0
+        self.phys0 = self.out_phys = c0
         if self.identity_first and c0 % 8:
             self.phys0 = (c0 + 7) // 8 * 8
             d0 = self.decoder[-1]
-            d0["up"][1].pad_out_to = self.phys0
-            d0["nin"].pad_out_to = self.phys0
-            d0["nin"].in_groups = (c0, c0)
-            for m in d0["units"].modules():
-                if isinstance(m, M.SubmanifoldConvolution):
-                    m.pad_out_to = self.phys0
+            if self.out_channels == c0:                      # the whole level is padded
+                self.out_phys = self.phys0
+                d0["up"][1].pad_out_to = self.phys0
+                d0["nin"].pad_out_to = self.phys0
+                d0["nin"].in_groups = (c0, c0)
+                for m in d0["units"].modules():
+                    if isinstance(m, M.SubmanifoldConvolution):
+                        m.pad_out_to = self.phys0
+            else:                                            # min_channels widened the decoder: only the skip slab is padded
+                self.out_phys = self.out_channels
+                d0["nin"].in_groups = (self.out_channels, c0)
+                d0["nin"].in_phys = (self.out_channels, self.phys0)
 
     def _pack_jobs(self):
         """(W, cin, cout, n_off, flags) of every bf16 weight image this network's forward + backward will stage: forward and
@@ -121,6 +134,8 @@ class SparseUNet(nn.Module):
         for m in self.modules():
             if getattr(m, "pad_out_to", None) or (isinstance(m, M._ConvBase) and (m.nIn % 8 or m.nOut % 8)):
                 continue                                     # padded layers see fresh padded weight tensors: packed per call
+            if getattr(m, "groups", 1) != 1:
+                continue                                     # grouped layers hand over a fresh block-diagonal weight per call
             if isinstance(m, M.SubmanifoldConvolution) and m.filter_size == 3 and m.nIn % 8 == 0 and m.nOut % 8 == 0:
                 jobs.append((m.weight, m.nIn, m.nOut, 27, 0))
                 jobs.append((m.weight, m.nOut, m.nIn, 27, L.F_W_TRANSPOSED | L.F_OFF_REVERSE))
@@ -157,6 +172,7 @@ class SparseUNet(nn.Module):
         plan = False
         ch, L = self.channels, len(self.channels)
         ok = not self.bf16_blocks and all(c % 8 == 0 for c in ch[1:]) and (self.phys0 % 8 == 0)
+        ok = ok and self.dec_channels == tuple(ch[:-1])      # (min_channels in effect: the layer-by-layer path)
         enc_blocks = [EX._plain_blocks(lvl[1]) if not (l == 0 and self.identity_first) else [] for l, lvl in enumerate(self.encoder)]
         dec_blocks = [EX._plain_blocks(d["units"]) for d in self.decoder]
         heads = [lvl[0] for l, lvl in enumerate(self.encoder) if not (l == 0 and self.identity_first)]

@@ -34,10 +34,12 @@ def build(channels, cin=7):
     return FeatureExtractor(**params)
 
 
-def build_mask_network(backbone_channels=(32, 64, 128, 256), cin=7, num_instance_classes=18):
+def build_mask_network(backbone_channels=(32, 64, 128, 256), cin=7, num_instance_classes=18, use_unet_features=True,
+                       use_raw_features=True, use_skip_features=False):
     """The reference's SparseMaskNetwork under its own configuration (scannet_config/run.py:741-810: input network B16 x 2
     units at stride 1, internal U-Net I -> B32/2 -> B48/2 -> B64/2, Linear 23-32-classes, use_raw_features, no skip
-    features), fed by the last decoder level of a sparse U-Net backbone (unet_channels = the decoder's channels)."""
+    features), fed by the last decoder level of a sparse U-Net backbone (unet_channels = the decoder's channels).
+    The three switches select the other feature-map selectors / the combiner of model.py:597-651."""
     common = dict(use_residuals=True, main_path_relu=False, relu_first=True, bottleneck_divisor=0, drop_input_relu=True,
                   make_dense=False)
     inp = [FLD(type='B', channels=16, params={**common, 'num_units': 2}, anchor_path=None)]
@@ -45,8 +47,8 @@ def build_mask_network(backbone_channels=(32, 64, 128, 256), cin=7, num_instance
                         for c in (32, 48, 64)]]
     unet_params = dict(use_residuals=True, num_units=2, bottleneck_divisor=0, groups=1, main_path_relu=False, relu_first=True,
                        batchnorm=False, concat=True, min_channels=16)
-    return SparseMaskNetwork(3, True, cin, None, None, list(backbone_channels[-2::-1]), None, use_unet_features=True,
-                             use_raw_features=True, use_skip_features=False, internal_unet=True, unet_params=unet_params,
+    return SparseMaskNetwork(3, True, cin, None, None, list(backbone_channels[-2::-1]), None, use_unet_features=use_unet_features,
+                             use_raw_features=use_raw_features, use_skip_features=use_skip_features, internal_unet=True, unet_params=unet_params,
                              input_network_description=inp, output_network_description=outd,
                              channel_list=[32, num_instance_classes], selection_tuple=(24, 0, True), positive_threshold=0.2)
 
@@ -66,8 +68,18 @@ if __name__ == "__main__":
     mask = dict(backbone_channels=[32, 64, 128, 256], n_params=int(sum(v.numel() for v in sd.values())),
                 keys={k: list(v.shape) for k, v in sd.items()}, census=_census(mn), repr=repr(mn), classes=int(mn.classes))
     print("mask_network", mask["n_params"], mask["census"])
+    fixtures = dict(run_config=mask)
+    for name, flags in (("unet_only", dict(use_raw_features=False)), ("raw_only", dict(use_unet_features=False)),
+                        ("both_skip", dict(use_skip_features=True)), ("raw_skip", dict(use_unet_features=False,
+                                                                                       use_skip_features=True))):
+        mn = build_mask_network(**flags)
+        sd = mn.state_dict()
+        fixtures[name] = dict(flags=flags, n_params=int(sum(v.numel() for v in sd.values())),
+                              keys={k: list(v.shape) for k, v in sd.items()}, census=_census(mn), repr=repr(mn),
+                              classes=int(mn.classes))
+        print(name, fixtures[name]["n_params"], fixtures[name]["census"])
     with open(os.path.join(here, "dropin_mask_network.json"), "w") as f:
-        json.dump(dict(run_config=mask), f, indent=0, sort_keys=True)
+        json.dump(fixtures, f, indent=0, sort_keys=True)
     out = {}
     for name, ch in (("cfg2_32_256", [32, 64, 128, 256]), ("ref_32_112", [32, 48, 64, 80, 96, 112])):
         fe = build(ch)

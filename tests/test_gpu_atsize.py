@@ -307,8 +307,10 @@ def test_dropin_path_equals_backbone_path_at_150k(gpu, scene150k):
 
 
 # ------------------------------------------------------------------------------------------------ cfg 3
-def _oracle_mask_branch(coords_np, raw, bb_feats, mp, boxes_np, assoc, scene, bf16=False, relu=None):
-    """SparseMaskNetwork forward (model.py:758-782) on the oracle ops, reference configuration (run.py:741-810).
+def _oracle_mask_branch(coords_np, raw, bb_feats, mp, boxes_np, assoc, scene, bf16=False, relu=None, use_unet=True,
+                        use_raw=True, use_skip=False):
+    """SparseMaskNetwork forward (model.py:758-782) on the oracle ops, reference configuration (run.py:741-810);
+    use_unet / use_raw / use_skip: the other selectors / the combiner (model.py:597-651).
     bf16: with the storage roundings of the HIP path's bf16 mode (stored slabs -- incl. the per-point slab the crop reads --
     and the tile-kernel layers' weights rounded; InputLayer mean and the Linear stack stay fp32)."""
     relu = torch.relu if relu is None else relu                 # O.FrozenReLU: the masks the HIP forward recorded
@@ -316,30 +318,37 @@ def _oracle_mask_branch(coords_np, raw, bb_feats, mp, boxes_np, assoc, scene, bf
     wq = q                                                      # tile-kernel weights
     kw = dict(storage=O.bf16_storage, tile_weights=O.bf16_storage) if bf16 else {}
     n0 = scene.n(0)
-    ident = [(np.arange(n0, dtype=np.int32),) * 2]
-    x = q(O.conv(q(bb_feats), mp["in.weight"], mp["in.bias"], ident, n0))
-    rules = scene.subm_rules(0, 3)
-    for u in range(2):
-        y = q(O.conv(relu(x), wq(mp[f"in.res{u}.conv0.weight"]), mp[f"in.res{u}.conv0.bias"], rules, n0))
-        y = O.conv(relu(y), wq(mp[f"in.res{u}.conv1.weight"]), mp[f"in.res{u}.conv1.bias"], rules, n0)
-        x = q(x + y)
-    per_point = x[torch.from_numpy(scene.prow)]                              # OutputLayer
-    cat = torch.cat([per_point, q(raw)], 1)                                  # (bf16 storage: the per-point slab is bf16)
+    parts = []
+    if use_unet:
+        ident = [(np.arange(n0, dtype=np.int32),) * 2]
+        x = q(O.conv(q(bb_feats), mp["in.weight"], mp["in.bias"], ident, n0))
+        rules = scene.subm_rules(0, 3)
+        for u in range(2):
+            y = q(O.conv(relu(x), wq(mp[f"in.res{u}.conv0.weight"]), mp[f"in.res{u}.conv0.bias"], rules, n0))
+            y = O.conv(relu(y), wq(mp[f"in.res{u}.conv1.weight"]), mp[f"in.res{u}.conv1.bias"], rules, n0)
+            x = q(x + y)
+        parts.append(x[torch.from_numpy(scene.prow)])                        # OutputLayer
+    if use_raw:
+        parts.append(q(raw))                                                 # (bf16 storage: the per-point slab is bf16)
+    cat = torch.cat(parts, 1)
+    c0 = cat.shape[1]
     src, box_of, inside = O.roi_crop(coords_np, boxes_np, assoc)
     if len(src) == 0:                                    # no box caught a point: the branch ends here (model.py:768-770)
         return None, src, box_of, None
     new_coords = np.concatenate([coords_np[src][:, :3], box_of[:, None]], 1)
     rscene = O.OracleScene(new_coords)
     unet_p = {k[5:]: v for k, v in mp.items() if k.startswith("unet.")}
-    m = O.unet_forward(rscene, cat[torch.from_numpy(src)], unet_p, [23, 32, 48, 64], identity_first=True, relu=relu, **kw)
+    m = O.unet_forward(rscene, cat[torch.from_numpy(src)], unet_p, [c0, 32, 48, 64], identity_first=True, relu=relu, **kw)
     pts = m[torch.from_numpy(rscene.prow)]                                   # OutputLayer over the ROI batch
+    if use_skip:                                                             # SparseFeaturemapCombiner (model.py:639-651)
+        pts = torch.cat([pts, raw[torch.from_numpy(src)]], 1)
     h = relu(pts @ mp["lin0.weight"].t() + mp["lin0.bias"])
     return h @ mp["lin1.weight"].t() + mp["lin1.bias"], src, box_of, rscene
 
 
-def _mask_oracle_params(named, dt=torch.float32):
+def _mask_oracle_params(named, dt=torch.float32, c0=23):
     """MaskBranch.named_oracle_params() tensors (torch or numpy) -> oracle-shaped leaf tensors of dtype dt."""
-    shapes = dict(O.unet_param_shapes(23, [23, 32, 48, 64], identity_first=True))
+    shapes = dict(O.unet_param_shapes(c0, [c0, 32, 48, 64], identity_first=True, min_channels=16))
     mo = {}
     for k, p in named.items():
         t = (torch.from_numpy(np.asarray(p)) if not torch.is_tensor(p) else p.detach().cpu()).clone()
@@ -443,6 +452,68 @@ def test_cfg3_end_to_end_backbone_crop_mask_vs_oracle_at_150k(gpu, dtype):
     assert e_out["rel_to_scale"] <= FEAT_TOL and e_log["rel_to_scale"] <= FEAT_TOL, (e_out, e_log)
     for k in grads:
         _check_grad_frozen(name, "grad " + k, got[k], grads[k].view_as(got[k]), FROZEN_L2_F32)
+
+
+@pytest.mark.parametrize("variant", ["unet_only", "raw_only", "both_skip", "raw_skip"])
+def test_mask_branch_variants_vs_oracle(gpu, variant):
+    """VERDICT r3 missing 4: the other feature-map selectors and the combiner of the reference's SparseMaskNetwork
+    (model.py:597-651) as MaskBranch switches -- `unet_only` SparseFeaturemapSelector (crop of the 16-channel per-point output),
+    `raw_only` SparseFeaturemapSelectorRaw (crop of the 7 raw channels: no input_conv_layer, the internal U-Net's level 0 runs on
+    a 7->8 padded slab and comes up 16 wide, unet_params['min_channels']), `*_skip` SparseFeaturemapCombiner (cropped raw
+    features joined in front of the Linear stack).  Two 20k-voxel samples, 24 boxes each, fp32: logits against the oracle within FEAT_TOL
+    of its scale; every parameter gradient and the gradients of the backbone features / raw features against the oracle with
+    the HIP forward's ReLU masks, FROZEN_L2_F32."""
+    from sparse_rcnn_amd import tensor as T
+    from sparse_rcnn_amd.maskhead import MaskBranch
+    from sparse_rcnn_amd.synthetic import make_batch, make_boxes
+    import sparse_rcnn_amd as scn
+    flags = dict(unet_only=dict(use_raw_features=False), raw_only=dict(use_unet_features=False),
+                 both_skip=dict(use_skip_features=True), raw_skip=dict(use_unet_features=False, use_skip_features=True))[variant]
+    use_unet, use_raw = flags.get("use_unet_features", True), flags.get("use_raw_features", True)
+    use_skip = flags.get("use_skip_features", False)
+    coords, feats, size, bs, splits = make_batch(2, (192, 192, 96), 20_000, seed=11)
+    boxes = make_boxes(coords, 24, seed=5)
+    scene = O.OracleScene(coords.numpy())
+    torch.manual_seed(3)
+    mb = MaskBranch(32, 7, **flags).to(gpu)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(22)
+        for p in mb.parameters():
+            if p.dim() == 1:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    x = scn.InputLayer(3, size, mode=4)((coords, feats.to(gpu), bs))
+    X = torch.randn(scene.n(0), 32, generator=torch.Generator().manual_seed(9))
+    Xd, fd = X.to(gpu).requires_grad_(), feats.to(gpu).requires_grad_()
+    fmap = T.SparseConvNetTensor(features=Xd, metadata=x.metadata, spatial_size=x.spatial_size) if use_unet else None
+    with _record_relu_masks() as masks:
+        logits, selection = mb((coords.to(gpu), fd, size, bs, splits), fmap, boxes)
+    gm = torch.randn(logits.shape, generator=torch.Generator().manual_seed(10))
+    logits.backward(gm.to(gpu))
+    torch.cuda.synchronize()
+    pm = dict(mb.named_oracle_params())
+    c0 = (16 if use_unet else 0) + (7 if use_raw else 0)
+    mo = _mask_oracle_params(pm, c0=c0)
+    Xo, fo = X.clone().requires_grad_(), feats.clone().requires_grad_()
+    boxes_np, cnt, assoc = O.transform_boxes([b.numpy() for b in boxes])
+    fr = O.FrozenReLU(masks)
+    ref, src, box_of, rscene = _oracle_mask_branch(coords.numpy(), fo, Xo, mo, boxes_np, assoc, scene, relu=fr,
+                                                   use_unet=use_unet, use_raw=use_raw, use_skip=use_skip)
+    assert fr.k == len(masks) and len(src) > 2_000 and logits.shape == ref.shape
+    own, _, _, _ = _oracle_mask_branch(coords.numpy(), fo.detach(), Xo.detach(), {k: v.detach() for k, v in mo.items()},
+                                       boxes_np, assoc, scene, use_unet=use_unet, use_raw=use_raw, use_skip=use_skip)
+    name = "mask_branch_" + variant
+    e = _err(logits, own)                                  # forward: against the oracle's OWN ReLU decisions
+    _record(name, "mask logits", e, FEAT_TOL)
+    assert e["rel_to_scale"] <= FEAT_TOL, e
+    ref.backward(gm)
+    for k, p in pm.items():
+        _check_grad_frozen(name, "grad " + k, p.grad, mo[k].grad.view_as(p.grad), FROZEN_L2_F32)
+    if use_raw or use_skip:
+        _check_grad_frozen(name, "grad raw features", fd.grad, fo.grad, FROZEN_L2_F32)
+    else:
+        assert fd.grad is None
+    if use_unet:
+        _check_grad_frozen(name, "grad backbone features", Xd.grad, Xo.grad, FROZEN_L2_F32)
 
 
 def test_tensor_to_tensor_roi_cut_vs_oracle_at_size(gpu, scene150k):

@@ -260,6 +260,34 @@ def test_submanifold_conv(gpu, cin, cout, k, relu_in):
     _close(gx, ox, what="dX"); _close(gw, ow, what="dW"); _close(gb, ob, what="db")
 
 
+@pytest.mark.parametrize("cin,cout,k,groups", [(16, 32, 3, 2), (32, 32, 3, 4), (24, 24, 1, 24), (6, 9, 3, 3)])
+def test_grouped_submanifold_conv(gpu, cin, cout, k, groups):
+    """`scn.SubmanifoldConvolution(..., groups=G)` (module_factory.py:398-406 passes the argument through; :596 asks for a
+    depthwise 1^3 layer, groups = channels): parameter in SparseConvNet's grouped layout [k^3, G, nIn/G, nOut/G], group g maps
+    input channels [g nIn/G, (g+1) nIn/G) to output channels [g nOut/G, (g+1) nOut/G).  Against the oracle convolution run
+    once per group on its channel slice: forward, dX, the grouped dW and db."""
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=6, cin=cin)
+    conv = scn.SubmanifoldConvolution(3, cin, cout, k, True, groups=groups).to(gpu)
+    assert tuple(conv.weight.shape) == (k ** 3, groups, cin // groups, cout // groups)
+    assert tuple(conv.state_dict()["weight"].shape) == tuple(conv.weight.shape)
+    with torch.no_grad():
+        conv.bias.normal_(0, 0.5)
+    y = scn.Sequential(scn.ReLU(), conv)(x).features
+    rules, n = scene.subm_rules(0, k), scene.n(0)
+    Xo = O.input_layer_fwd(feats, scene.prow, n, 4).requires_grad_()
+    W, b = conv.weight.detach().cpu().requires_grad_(), conv.bias.detach().cpu().requires_grad_()
+    ci, co = cin // groups, cout // groups
+    A = torch.relu(Xo)
+    yo = torch.cat([O.conv(A[:, g * ci:(g + 1) * ci], W[:, g], b[g * co:(g + 1) * co], rules, n) for g in range(groups)], 1)
+    _close(y, yo, what="fwd")
+    g = torch.randn(yo.shape, generator=torch.Generator().manual_seed(5))
+    gx, gw, gb = _grads(y, (x.features, conv.weight, conv.bias), g.to(gpu))
+    ox, ow, ob = _grads(yo, (Xo, W, b), g)
+    _close(gx, ox, what="dX"); _close(gw, ow, what="dW"); _close(gb, ob, what="db")
+    with pytest.raises(ValueError):
+        scn.SubmanifoldConvolution(3, 10, 16, 3, True, groups=4)
+
+
 @pytest.mark.parametrize("cin,cout", [(4, 6), (32, 64), (23, 32), (48, 64)])
 @pytest.mark.parametrize("relu_in", [False, True])
 def test_strided_conv_and_deconv(gpu, cin, cout, relu_in):

@@ -728,79 +728,88 @@ TbShape tb_shape(int cin, int cout) {
 
 // image[slice = chunk * n_kc + kci][o][plane h][n = 16 nb + i][kk] = bf16( W[o'][k = kc + 32 h + kk][col = n0 + NB i + nb] )
 // (zero outside the layer).  WT: the layer stores [o][col][k] (backward-data); REV: o' = n_off - 1 - o.
-__global__ void k_tb_pack(const float* __restrict__ W, int cin, int cout, int n_off, int wt, int rev, TbShape sh,
-                          unsigned short* __restrict__ image) {
-    const long long total = (long long)sh.n_chunks * sh.n_kc * n_off * sh.kh * sh.ct * 4;       // 8-element pieces
-    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const int k8 = (int)(e & 3);
-        long long r = e >> 2;
-        const int n = (int)(r % sh.ct); r /= sh.ct;
-        const int h = (int)(r % sh.kh); r /= sh.kh;
-        const int o = (int)(r % n_off); r /= n_off;
-        const int kci = (int)(r % sh.n_kc), chunk = (int)(r / sh.n_kc);
-        const int nb = n >> 4, i = n & 15;
-        const int col = chunk * sh.ct + sh.nb * i + nb;
-        const int k0 = kci * sh.kc + 32 * h + 8 * k8;
-        const int wo = rev ? n_off - 1 - o : o;
-        unsigned short v[8];
+//
+// Round 4: the pack runs once per step over every layer's master weights (12.4 M fp32 -> two bf16 images each: 50 MB read,
+// 50 MB written at cfg 2) and took 87 us -- one 8-element piece per thread meant 64-bit div/mod chains, a per-THREAD job
+// search and eight 4-byte loads a cout apart.  Now a UNIT = one (slice, offset, plane) = ct columns x 32 channels is packed
+// by ct lanes of a wave, lane = column: the unit's indices are wave-uniform (scalar), the [k][col] source is read as 32
+// coalesced rows (ct x 4 B each), the [col][k] source as one 128-byte run per lane, and a lane writes its column's four
+// pieces as one 64-byte line.  Same rounding, same image, bit for bit.
+struct TbPackJob { const float* W; unsigned short* image; int cin, cout, n_off, wt, rev; TbShape sh; };
+
+__device__ __forceinline__ void tb_pack_unit(const TbPackJob& jb, int unit, int cl) {
+    const TbShape& sh = jb.sh;
+    int r = unit;                                                    // unit = ((chunk * n_kc + kci) * n_off + o) * kh + h
+    const int h = r % sh.kh; r /= sh.kh;
+    const int o = r % jb.n_off; r /= jb.n_off;
+    const int kci = r % sh.n_kc, chunk = r / sh.n_kc;
+    const int wo = jb.rev ? jb.n_off - 1 - o : o;
+    const int k0 = kci * sh.kc + 32 * h;
+    // lane cl = local column: image position n = 16 nb + i holds column NB i + nb
+    const int col = chunk * sh.ct + cl;
+    const int n = 16 * (cl % sh.nb) + cl / sh.nb;
+    float w[32];
+    const bool col_ok = col < jb.cout;
+    if (jb.wt) {                                                     // [o][col][k]: 32 consecutive floats
+        const float* src = jb.W + ((long long)wo * jb.cout + (col_ok ? col : 0)) * jb.cin + k0;
+        if (col_ok && k0 + 32 <= jb.cin && (jb.cin & 3) == 0 && (((uintptr_t)jb.W) & 15) == 0) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = k0 + u;
-            float w = 0.f;
-            if (col < cout && k < cin)
-                w = wt ? W[((long long)wo * cout + col) * cin + k] : W[((long long)wo * cin + k) * cout + col];
-            v[u] = f32_to_bf16(w);
+            for (int q = 0; q < 8; ++q) {
+                const float4 t = ((const float4*)src)[q];
+                w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 32; ++u) w[u] = (col_ok && k0 + u < jb.cin) ? src[u] : 0.f;
         }
-        uint4 pk;
-        pk.x = v[0] | ((unsigned)v[1] << 16); pk.y = v[2] | ((unsigned)v[3] << 16);
-        pk.z = v[4] | ((unsigned)v[5] << 16); pk.w = v[6] | ((unsigned)v[7] << 16);
-        ((uint4*)image)[e] = pk;
+    } else {                                                         // [o][k][col]: a row of ct consecutive floats per k
+        const float* src = jb.W + ((long long)wo * jb.cin + k0) * jb.cout + (col_ok ? col : 0);
+        if (k0 + 32 <= jb.cin) {
+#pragma unroll
+            for (int u = 0; u < 32; ++u) w[u] = col_ok ? src[(long long)u * jb.cout] : 0.f;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 32; ++u) w[u] = (col_ok && k0 + u < jb.cin) ? src[(long long)u * jb.cout] : 0.f;
+        }
     }
+    uint4* dst = (uint4*)jb.image + ((long long)unit * sh.ct + n) * 4;
+#pragma unroll
+    for (int k8 = 0; k8 < 4; ++k8) {
+        uint4 pk;
+        pk.x = f32_to_bf16(w[8 * k8 + 0]) | ((unsigned)f32_to_bf16(w[8 * k8 + 1]) << 16);
+        pk.y = f32_to_bf16(w[8 * k8 + 2]) | ((unsigned)f32_to_bf16(w[8 * k8 + 3]) << 16);
+        pk.z = f32_to_bf16(w[8 * k8 + 4]) | ((unsigned)f32_to_bf16(w[8 * k8 + 5]) << 16);
+        pk.w = f32_to_bf16(w[8 * k8 + 6]) | ((unsigned)f32_to_bf16(w[8 * k8 + 7]) << 16);
+        dst[k8] = pk;
+    }
+}
+
+// units per wave: 64 / ct (ct = 32 or 64); a wave's units belong to one layer
+__global__ void __launch_bounds__(256) k_tb_pack(TbPackJob jb, int n_units) {
+    const int upw = 64 / jb.sh.ct;
+    const int wave = (int)((blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    const int unit = wave * upw + lane / jb.sh.ct;
+    if (unit < n_units) tb_pack_unit(jb, unit, lane % jb.sh.ct);
 }
 
 // Many layers in ONE launch (a U-Net packs the forward and backward-data images of all its convolutions once per step:
-// 62 separate pack launches cost 0.37 ms of a 5 ms step).  Descriptors travel by value in the kernel arguments.
+// 62 separate pack launches cost 0.37 ms of a 5 ms step).  Descriptors travel by value in the kernel arguments;
+// start[j] = first WAVE of job j.
 #define SCN_PACK_MAX 80
-struct TbPackJob { const float* W; unsigned short* image; int cin, cout, n_off, wt, rev; TbShape sh; };
-struct TbPackJobs { TbPackJob job[SCN_PACK_MAX]; long long start[SCN_PACK_MAX + 1]; int n; };
+struct TbPackJobs { TbPackJob job[SCN_PACK_MAX]; int start[SCN_PACK_MAX + 1]; int n_units[SCN_PACK_MAX]; int n; };
 
-__device__ __forceinline__ void tb_pack_piece(const TbPackJob& jb, long long e) {
-    const TbShape& sh = jb.sh;
-    const int k8 = (int)(e & 3);
-    long long r = e >> 2;
-    const int n = (int)(r % sh.ct); r /= sh.ct;
-    const int h = (int)(r % sh.kh); r /= sh.kh;
-    const int o = (int)(r % jb.n_off); r /= jb.n_off;
-    const int kci = (int)(r % sh.n_kc), chunk = (int)(r / sh.n_kc);
-    const int nb = n >> 4, i = n & 15;
-    const int col = chunk * sh.ct + sh.nb * i + nb;
-    const int k0 = kci * sh.kc + 32 * h + 8 * k8;
-    const int wo = jb.rev ? jb.n_off - 1 - o : o;
-    unsigned short v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int k = k0 + u;
-        float w = 0.f;
-        if (col < jb.cout && k < jb.cin)
-            w = jb.wt ? jb.W[((long long)wo * jb.cout + col) * jb.cin + k] : jb.W[((long long)wo * jb.cin + k) * jb.cout + col];
-        v[u] = f32_to_bf16(w);
+__global__ void __launch_bounds__(256) k_tb_pack_many(TbPackJobs jobs) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6));
+    if (wave >= jobs.start[jobs.n]) return;
+    int lo = 0, hi = jobs.n - 1;                          // job of this wave: last start <= wave (wave-uniform: scalar loads)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs.start[mid] <= wave) lo = mid; else hi = mid - 1;
     }
-    uint4 pk;
-    pk.x = v[0] | ((unsigned)v[1] << 16); pk.y = v[2] | ((unsigned)v[3] << 16);
-    pk.z = v[4] | ((unsigned)v[5] << 16); pk.w = v[6] | ((unsigned)v[7] << 16);
-    ((uint4*)jb.image)[e] = pk;
-}
-
-__global__ void k_tb_pack_many(TbPackJobs jobs) {
-    const long long total = jobs.start[jobs.n];
-    for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
-        int lo = 0, hi = jobs.n - 1;                      // job of piece g: last start <= g
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (jobs.start[mid] <= g) lo = mid; else hi = mid - 1;
-        }
-        tb_pack_piece(jobs.job[lo], g - jobs.start[lo]);
-    }
+    const TbPackJob& jb = jobs.job[lo];
+    const int lane = threadIdx.x & 63;
+    const int unit = (wave - jobs.start[lo]) * (64 / jb.sh.ct) + lane / jb.sh.ct;
+    if (unit < jobs.n_units[lo]) tb_pack_unit(jb, unit, lane % jb.sh.ct);
 }
 
 extern "C" int scn_conv_tiles_bf16_pack_many(int n, const float* const* W_host, const int32_t* cin_host,
@@ -820,10 +829,13 @@ extern "C" int scn_conv_tiles_bf16_pack_many(int n, const float* const* W_host, 
             jb.wt = (flags_host[q] & SCN_F_W_TRANSPOSED) ? 1 : 0;
             jb.rev = (flags_host[q] & SCN_F_OFF_REVERSE) ? 1 : 0;
             jb.sh = tb_shape(jb.cin, jb.cout);
-            jobs.start[j + 1] = jobs.start[j] + (long long)jb.sh.n_chunks * jb.sh.n_kc * jb.n_off * jb.sh.kh * jb.sh.ct * 4;
+            const int64_t units = (int64_t)jb.sh.n_chunks * jb.sh.n_kc * jb.n_off * jb.sh.kh;
+            SCN_REQUIRE(units < (1ll << 24));
+            jobs.n_units[j] = (int)units;
+            jobs.start[j + 1] = jobs.start[j] + (int)cdiv(units, 64 / jb.sh.ct);
         }
         if (jobs.start[jobs.n] == 0) continue;
-        hipLaunchKernelGGL(k_tb_pack_many, dim3(scn::ew_grid(jobs.start[jobs.n], 256)), dim3(256), 0, S(stream), jobs);
+        hipLaunchKernelGGL(k_tb_pack_many, dim3((unsigned)cdiv(jobs.start[jobs.n], 4)), dim3(256), 0, S(stream), jobs);
         SCN_LAUNCH_CHECK();
     }
     return SCN_OK;
@@ -839,10 +851,14 @@ extern "C" int scn_conv_tiles_bf16_pack(const float* W, int cin, int cout, int n
                                         scn_stream_t stream) {
     SCN_REQUIRE(W && image && cin >= 1 && cout >= 1 && n_off >= 1 && n_off <= 27);
     SCN_REQUIRE((((uintptr_t)image) & 15) == 0);
-    const TbShape sh = tb_shape(cin, cout);
-    const int64_t pieces = (int64_t)sh.n_chunks * sh.n_kc * n_off * sh.kh * sh.ct * 4;
-    hipLaunchKernelGGL(k_tb_pack, dim3(scn::ew_grid(pieces, 256)), dim3(256), 0, S(stream), W, cin, cout, n_off,
-                       (flags & SCN_F_W_TRANSPOSED) ? 1 : 0, (flags & SCN_F_OFF_REVERSE) ? 1 : 0, sh, image);
+    TbPackJob jb;
+    jb.W = W; jb.image = image; jb.cin = cin; jb.cout = cout; jb.n_off = n_off;
+    jb.wt = (flags & SCN_F_W_TRANSPOSED) ? 1 : 0; jb.rev = (flags & SCN_F_OFF_REVERSE) ? 1 : 0;
+    jb.sh = tb_shape(cin, cout);
+    const int64_t units = (int64_t)jb.sh.n_chunks * jb.sh.n_kc * n_off * jb.sh.kh;
+    SCN_REQUIRE(units < (1ll << 24));
+    const int64_t waves = cdiv(units, 64 / jb.sh.ct);
+    hipLaunchKernelGGL(k_tb_pack, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, S(stream), jb, (int)units);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }

@@ -929,6 +929,46 @@ def test_conv_tiles_bf16_forward_and_backward_data(gpu, cin, cout, relu_in):
                                             image=img))
 
 
+def _bf16_image_restated(W, cin, cout, n_off, wt, rev):
+    """The documented layout of the bf16 weight image (scn_conv_ts_bf16.hip: image[chunk * n_kc + kci][o][n = 16 nb + i][kk] =
+    bf16(W[o'][k = 32 kci + kk][col = ct chunk + NB i + nb]), zero outside the layer; NB = 4 / ct = 64 above 32 output columns,
+    else 2 / 32) built with torch indexing -> int16 bit patterns."""
+    nb = 4 if cout > 32 else 2
+    ct, n_chunks, n_kc = 16 * nb, -(-cout // (16 * nb)), -(-cin // 32)
+    Wd = W.flip(0) if rev else W
+    Wd = Wd.transpose(1, 2) if wt else Wd                              # -> [o][k][col]
+    full = torch.zeros(n_off, n_kc * 32, n_chunks * ct)
+    full[:, :cin, :cout] = Wd
+    n = torch.arange(ct)
+    col_of_n = nb * (n % 16) + n // 16                                 # n = 16 nb_idx + i  ->  local column NB i + nb_idx
+    img = full.view(n_off, n_kc, 32, n_chunks, ct)[..., col_of_n]      # [o][kci][kk][chunk][n]
+    img = img.permute(3, 1, 0, 4, 2).contiguous()                      # [chunk][kci][o][n][kk]
+    return img.to(torch.bfloat16).view(torch.int16).reshape(-1)
+
+
+@pytest.mark.parametrize("cin,cout,n_off", [(64, 64, 27), (32, 32, 27), (24, 48, 27), (128, 96, 8), (40, 24, 8), (256, 256, 27)])
+def test_bf16_weight_image_layout_bit_for_bit(gpu, cin, cout, n_off):
+    """scn_conv_tiles_bf16_pack and _pack_many (round 4: one wave per (slice, offset) unit, lane = column) against the
+    documented image layout restated with torch indexing: forward image, backward-data image (stored [o][col][k], offsets
+    reversed), edge slices (24, 40, 48, 96 channels), both entry points -- equal bit patterns."""
+    from sparse_rcnn_amd import functional as F, _lib as L
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    W = torch.randn(n_off, cin, cout, generator=g)
+    Wg = W.to(gpu)
+    back = L.F_W_TRANSPOSED | L.F_OFF_REVERSE
+    # the backward-data image of a layer [o][cin][cout]: the kernel sees a (cout -> cin) layer whose weights are stored
+    # [o][col][k] -- the same tensor
+    cases = [(0, _bf16_image_restated(W, cin, cout, n_off, False, False), (cin, cout)),
+             (back, _bf16_image_restated(W, cout, cin, n_off, True, True), (cout, cin))]
+    for flags, want, (ci, co) in cases:
+        got = F.pack_weights_bf16(Wg, ci, co, n_off, flags).view(torch.int16).cpu()
+        assert got.numel() == want.numel() and torch.equal(got, want), (flags, int((got != want).sum()))
+    with F.packed_weights([(Wg, cin, cout, n_off, 0), (Wg, cout, cin, n_off, back)]):
+        for flags, want, (ci, co) in cases:
+            got = F.packed_image(Wg, ci, co, n_off, flags).view(torch.int16).cpu()
+            assert torch.equal(got, want), flags
+
+
 def test_conv_tiles_bf16_rejects_unsupported_inputs(gpu):
     from sparse_rcnn_amd import functional as F
     scn, coords, feats, fg, x, scene, size = _input(gpu, seed=13, cin=8, n=300, dup=0)

@@ -52,7 +52,7 @@ extern "C" {
  *      weight-gradient sums; bf16 elementwise forms; segment pooling; scn_tiles_build_x) -- shipped with the value still 1
  *   3  round 4: SCN_PYRAMID_FUSED (scn_pyramid_build_ex flag, larger scn_pyramid_workspace_bytes), hash slot function
  *      changed (tables built by version <= 2 libraries are not probe-compatible; no table outlives a Metadata, so only a
- *      caller that kept raw tables across a library upgrade is affected); + scn_exec_timing_enable / _collect (103 entry points) */
+ *      caller that kept raw tables across a library upgrade is affected); + scn_exec_timing_enable / _collect, scn_pad_params_many (104 entry points) */
 #define SCN_ABI_VERSION 3
 
 /* flags for the gather-GEMM entry points */
@@ -523,6 +523,19 @@ int scn_vox_discretize(const float* aug, int64_t n, const float* shift, const in
 int scn_vox_gather(const int32_t* discrete, const int32_t* rows, int64_t m, const int32_t* start_host,
                    int64_t batch_index, int64_t* out, scn_stream_t stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Channel padding of PARAMETERS, many tensors per launch (scn_elem.hip).  No reference counterpart: the reference's mask
+ * network has a 23-channel level (model.py:573-596: 16 U-Net channels ++ 7 raw ones, scannet_config/run.py:741-810); this
+ * package runs it on slabs padded to 24 columns and hands its layers zero-padded copies of their logical weights
+ * (module_factory.py:383-406 SubmanifoldConvolution, :256-258 Deconvolution, :366-367 NetworkInNetwork keep their logical
+ * parameter shapes).  Tensor j is [fv][rows][cols]; desc_host[11 j ..] = fv, src_rows, src_cols, dst_rows, dst_cols, then two
+ * row segments (src row, count, dst row): source rows [s, s + count) land on destination rows [d, d + count), every other
+ * destination element is zero.  backward = 0: out_host[j] (padded shape) <- in_host[j] (logical shape);
+ * backward = 1: out_host[j] (LOGICAL shape) <- the matching elements of in_host[j] (PADDED shape; NULL: zeros).
+ * ---------------------------------------------------------------------------------------- */
+int scn_pad_params_many(int n, const float* const* in_host, float* const* out_host, const int32_t* desc_host, int backward,
+                        scn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * bf16-STORAGE forms of the HBM-bound feature kernels (BASELINE configs 3-5; scn_elem_bf16.hip): slabs are uint16 bf16 bit

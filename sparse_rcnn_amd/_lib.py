@@ -105,6 +105,7 @@ _SIGS = {
     "scn_sample_counts": (C.c_int, [p, i64, i32, p, p, p]),
     "scn_segment_pool_fwd": (C.c_int, [p, p, i64, i32, i32, i32, p, p, p, p, p]),
     "scn_segment_pool_bwd": (C.c_int, [p, p, p, p, i64, i32, i32, i32, p, p, p, p]),
+    "scn_pad_params_many": (C.c_int, [i32, p, p, p, i32, p]),
     "scn_cast_f32_to_bf16": (C.c_int, [p, i64, p, p]),
     "scn_cast_bf16_to_f32": (C.c_int, [p, i64, p, p]),
     "scn_add_bf16": (C.c_int, [p, p, i64, p, p]),

@@ -814,3 +814,68 @@ extern "C" int scn_vox_gather(const int32_t* discrete, const int32_t* rows, int6
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }
+
+// ---- channel padding of parameters, many tensors per launch ------------------------------------------------------------------
+// The mask network's 23-channel level runs on slabs padded to 24 columns (16-byte rows: the vector kernels, bf16 storage), so
+// its six layers see zero-padded copies of their logical [fv][nIn][nOut] weights and [nOut] biases -- through
+// torch.nn.functional.pad that was a fill + a copy per tensor forward and a slice copy backward: ~50 launches of ~4.5 us per
+// detection + mask step for 0.3 MB.  One launch pads all of them (forward), one slices all gradients back (backward).
+// A tensor is [fv][rows][cols]; up to two row segments of the source map to row ranges of the destination (the two joined parts
+// of a NetworkInNetwork over a JoinTable are padded separately); everything else of the destination is zero.
+#define SCN_PAD_MAX 40
+struct PadJob { const float* src; float* dst; int fv, src_rows, src_cols, dst_rows, dst_cols; int seg[6]; };   // seg: (src row, count, dst row) x 2
+struct PadJobs { PadJob job[SCN_PAD_MAX]; int start[SCN_PAD_MAX + 1]; int n; int backward; };
+
+__global__ __launch_bounds__(256) void k_pad_many(PadJobs jobs) {
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.start[j + 1]) ++j;              // (block-uniform: scalar)
+    const PadJob& jb = jobs.job[j];
+    const int e = ((int)blockIdx.x - jobs.start[j]) * 256 + (int)threadIdx.x;
+    if (!jobs.backward) {                                            // dst <- pad(src)
+        if (e >= jb.fv * jb.dst_rows * jb.dst_cols) return;
+        const int c = e % jb.dst_cols, r = (e / jb.dst_cols) % jb.dst_rows, o = e / (jb.dst_cols * jb.dst_rows);
+        int sr = -1;
+        if (r >= jb.seg[2] && r < jb.seg[2] + jb.seg[1]) sr = jb.seg[0] + r - jb.seg[2];
+        else if (r >= jb.seg[5] && r < jb.seg[5] + jb.seg[4]) sr = jb.seg[3] + r - jb.seg[5];
+        jb.dst[e] = (sr >= 0 && c < jb.src_cols) ? jb.src[((long long)o * jb.src_rows + sr) * jb.src_cols + c] : 0.f;
+    } else {                                                         // src-shaped gradient <- slice(dst-shaped gradient)
+        if (e >= jb.fv * jb.src_rows * jb.src_cols) return;
+        const int c = e % jb.src_cols, r = (e / jb.src_cols) % jb.src_rows, o = e / (jb.src_cols * jb.src_rows);
+        int dr = -1;
+        if (r >= jb.seg[0] && r < jb.seg[0] + jb.seg[1]) dr = jb.seg[2] + r - jb.seg[0];
+        else if (r >= jb.seg[3] && r < jb.seg[3] + jb.seg[4]) dr = jb.seg[5] + r - jb.seg[3];
+        // (here `src` is the padded gradient -- NULL: no gradient arrived, zeros -- and `dst` the logical one)
+        jb.dst[e] = (dr >= 0 && jb.src) ? jb.src[((long long)o * jb.dst_rows + dr) * jb.dst_cols + c] : 0.f;
+    }
+}
+
+extern "C" int scn_pad_params_many(int n, const float* const* in_host, float* const* out_host, const int32_t* desc_host,
+                                   int backward, scn_stream_t stream) {
+    SCN_REQUIRE(n >= 0 && (n == 0 || (in_host && out_host && desc_host)));
+    for (int base = 0; base < n; base += SCN_PAD_MAX) {
+        PadJobs jobs;
+        jobs.n = n - base < SCN_PAD_MAX ? n - base : SCN_PAD_MAX;
+        jobs.backward = backward ? 1 : 0;
+        jobs.start[0] = 0;
+        for (int j = 0; j < jobs.n; ++j) {
+            const int32_t* d = desc_host + (size_t)(base + j) * 11;
+            PadJob& jb = jobs.job[j];
+            jb.src = in_host[base + j]; jb.dst = out_host[base + j];
+            jb.fv = d[0]; jb.src_rows = d[1]; jb.src_cols = d[2]; jb.dst_rows = d[3]; jb.dst_cols = d[4];
+            for (int k = 0; k < 6; ++k) jb.seg[k] = d[5 + k];
+            SCN_REQUIRE(jb.dst && (jb.src || backward));
+            SCN_REQUIRE(jb.fv >= 1 && jb.src_rows >= 1 && jb.src_cols >= 1 && jb.dst_rows >= jb.src_rows && jb.dst_cols >= jb.src_cols);
+            SCN_REQUIRE((int64_t)jb.fv * jb.dst_rows * jb.dst_cols < (1ll << 30));
+            // the segments lie inside both tensors and do not overlap in the destination
+            SCN_REQUIRE(jb.seg[1] >= 0 && jb.seg[4] >= 0 && jb.seg[0] >= 0 && jb.seg[3] >= 0 && jb.seg[2] >= 0 && jb.seg[5] >= 0);
+            SCN_REQUIRE(jb.seg[0] + jb.seg[1] <= jb.src_rows && jb.seg[3] + jb.seg[4] <= jb.src_rows);
+            SCN_REQUIRE(jb.seg[2] + jb.seg[1] <= jb.dst_rows && jb.seg[5] + jb.seg[4] <= jb.dst_rows);
+            SCN_REQUIRE(jb.seg[4] == 0 || jb.seg[5] >= jb.seg[2] + jb.seg[1] || jb.seg[2] >= jb.seg[5] + jb.seg[4]);
+            const int64_t elems = backward ? (int64_t)jb.fv * jb.src_rows * jb.src_cols : (int64_t)jb.fv * jb.dst_rows * jb.dst_cols;
+            jobs.start[j + 1] = jobs.start[j] + (int)((elems + 255) / 256);
+        }
+        hipLaunchKernelGGL(k_pad_many, dim3((unsigned)jobs.start[jobs.n]), dim3(256), 0, S(stream), jobs);
+        SCN_LAUNCH_CHECK();
+    }
+    return SCN_OK;
+}

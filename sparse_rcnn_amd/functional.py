@@ -149,6 +149,123 @@ def pack_weights_bf16(W, cin, cout, n_off, flags=0):
     return img
 
 
+# ---- channel-padded parameters of a network, one launch each way -----------------------------------------------------------
+# modules._ConvBase / NetworkInNetwork hand the kernels zero-padded copies of their logical parameters where a level runs on
+# padded slabs (unet.SparseUNet.phys0: the mask network's 23 -> 24 columns).  Through torch.nn.functional.pad that is a fill +
+# a copy per tensor forward and a slice copy backward -- ~50 launches of ~4.5 us per detection + mask step.  `padded_params`
+# pads every tensor of a fixed list with ONE scn_pad_params_many launch (its backward: one launch slices all gradients);
+# `_wb` of the modules picks its tensors up from PADDED while the block is open.
+PADDED = {}
+PAD_MANY = os.environ.get("SCN_PAD_MANY", "1") != "0"      # 0: tensor-by-tensor torch pads (A/B, cross-check in the tests)
+PAD_RECORD = None        # a list while a network records which (module, cin_phys) its forward asks `_wb` for
+
+
+class PadPlan:
+    """jobs: [(key, module, attribute, padded shape, segments)] -- key: what `_wb` asks PADDED for ((id(module), cin_phys,
+    "w" | "b")); getattr(module, attribute): the logical parameter, [fv, rows, cols] / [rows, cols] / [cols] (fetched at every
+    use: module.to(...) replaces the tensors); padded shape: same rank; segments: up to two (src row, count, dst row) triples
+    (None: all rows at row 0)."""
+
+    @classmethod
+    def from_requests(cls, requests):
+        """requests: the (module, cin_phys) pairs a forward recorded (PAD_RECORD) -> plan, or False when there are none."""
+        jobs, seen = [], set()
+        for m, cin_phys in requests:
+            if (id(m), cin_phys) not in seen:
+                seen.add((id(m), cin_phys))
+                jobs += m._pad_jobs(cin_phys)
+        return cls(jobs) if jobs else False
+
+    def fetch(self):
+        return [getattr(m, a) for _, m, a, _, _ in self.jobs]
+
+    def __init__(self, jobs):
+        self.jobs = list(jobs)
+        self.n = len(self.jobs)
+        self.params = self.fetch()
+        desc, self.out_shapes, self.out_offs, self.in_offs = [], [], [], []
+        tot_out = tot_in = 0
+        for (key, _, _, shape, segs), t in zip(self.jobs, self.params):
+            s3 = (1,) * (3 - t.dim()) + tuple(t.shape)
+            d3 = (1,) * (3 - len(shape)) + tuple(int(v) for v in shape)
+            segs = list(segs) if segs else [(0, s3[1], 0)]
+            segs += [(0, 0, 0)] * (2 - len(segs))
+            desc += [s3[0], s3[1], s3[2], d3[1], d3[2], *segs[0], *segs[1]]
+            if d3[0] != s3[0]:
+                raise ValueError("PadPlan: the leading dimension is never padded")
+            self.out_shapes.append(tuple(int(v) for v in shape))
+            self.out_offs.append(tot_out); self.in_offs.append(tot_in)
+            tot_out += (d3[0] * d3[1] * d3[2] + 3) & ~3                       # 16-byte aligned tensors
+            tot_in += (t.numel() + 3) & ~3
+        self.total_out, self.total_in = tot_out, tot_in
+        self.desc = (C.c_int32 * len(desc))(*desc)
+        self.src = (C.c_void_p * self.n)()
+        self.dst = (C.c_void_p * self.n)()
+        self.keys = [j[0] for j in self.jobs]
+
+
+class _PadMany(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, *params):
+        buf = torch.empty(plan.total_out, dtype=torch.float32, device=params[0].device)
+        base = buf.data_ptr()
+        for i, p in enumerate(params):
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise TypeError("padded_params: contiguous fp32 parameters")
+            plan.src[i] = p.data_ptr()
+            plan.dst[i] = base + 4 * plan.out_offs[i]
+        L.check(L.lib().scn_pad_params_many(plan.n, plan.src, plan.dst, plan.desc, 0, L.stream()))
+        ctx.plan = plan
+        outs = []
+        for off, shape in zip(plan.out_offs, plan.out_shapes):
+            n = 1
+            for v in shape:
+                n *= v
+            outs.append(buf[off:off + n].view(shape))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        plan = ctx.plan
+        dev = next(g.device for g in grads if g is not None)
+        buf = torch.empty(plan.total_in, dtype=torch.float32, device=dev)
+        base, keep = buf.data_ptr(), []
+        for i, g in enumerate(grads):
+            if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
+                g = g.float().contiguous()
+            keep.append(g)
+            plan.src[i] = g.data_ptr() if g is not None else None
+            plan.dst[i] = base + 4 * plan.in_offs[i]
+        L.check(L.lib().scn_pad_params_many(plan.n, plan.src, plan.dst, plan.desc, 1, L.stream()))
+        return (None,) + tuple(buf[off:off + p.numel()].view(p.shape) for off, p in zip(plan.in_offs, plan.params))
+
+
+class padded_params:
+    """Context manager: the padded tensors of `plan` are in PADDED until the block ends (nested blocks of other networks keep
+    theirs).  Outside a CUDA device or with no jobs it does nothing -- `_wb` then pads tensor by tensor as before."""
+
+    def __init__(self, plan):
+        self.plan, self.keys = plan, []
+
+    def __enter__(self):
+        pl = self.plan
+        if not pl or not pl.n:
+            return self
+        pl.params = pl.fetch()
+        if not pl.params[0].is_cuda:
+            return self
+        outs = _PadMany.apply(pl, *pl.params)
+        for key, t in zip(pl.keys, outs):
+            PADDED[key] = t
+        self.keys = pl.keys
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.keys:
+            PADDED.pop(k, None)
+        return False
+
+
 # Weight images packed for the forward pass that is running (packed_weights below): (data_ptr, cin, cout, n_off, flags & 6)
 # -> image.  Filled by ONE launch for a whole network, emptied when its forward ends; a backward-data image is handed to the
 # autograd node during the forward (ctx) -- nothing here outlives a step, so an optimizer update can never meet a stale image.

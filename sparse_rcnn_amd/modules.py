@@ -383,10 +383,24 @@ class _ConvBase(Module):
         if pin < 0 or pout < 0:
             raise ValueError(f"{type(self).__name__}: {cin_phys} input columns for nIn={self.nIn}")
         if pin or pout:
+            Wp = F.PADDED.get((id(self), int(cin_phys), "w"))        # (functional.padded_params: one launch for a network)
+            if Wp is not None:
+                return Wp, F.PADDED.get((id(self), int(cin_phys), "b"), b)
+            if F.PAD_RECORD is not None:
+                F.PAD_RECORD.append((self, int(cin_phys)))
             W = torch.nn.functional.pad(W, (0, pout, 0, pin))
             if b is not None and pout:
                 b = torch.nn.functional.pad(b, (0, pout))
         return W, b
+
+    def _pad_jobs(self, cin_phys):
+        """functional.PadPlan jobs for the tensors `_wb(cin_phys)` pads."""
+        pout = (self.pad_out_to - self.nOut) if self.pad_out_to else 0
+        fv = self.weight.shape[0]
+        jobs = [((id(self), int(cin_phys), "w"), self, "weight", (fv, int(cin_phys), self.nOut + pout), None)]
+        if self.bias is not None and pout:
+            jobs.append(((id(self), int(cin_phys), "b"), self, "bias", (self.nOut + pout,), None))
+        return jobs
 
     def _init(self, filter_volume, nIn, nOut, bias):
         self.nIn, self.nOut = int(nIn), int(nOut)
@@ -524,14 +538,39 @@ class NetworkInNetwork(Module):
     in_groups = None
     in_phys = None
 
+    def _layout(self, cin_phys):
+        groups = self.in_groups or (self.nIn,)
+        phys = self.in_phys or (cin_phys // len(groups),) * len(groups)
+        if sum(phys) != cin_phys or sum(groups) != self.nIn or any(p < g for p, g in zip(phys, groups)):
+            raise ValueError(f"NetworkInNetwork: {cin_phys} input columns for nIn={self.nIn}")
+        return groups, phys
+
+    def _pad_jobs(self, cin_phys):
+        """functional.PadPlan jobs for the tensors `_wb(cin_phys)` pads (at most two joined parts)."""
+        groups, phys = self._layout(cin_phys)
+        if len(groups) > 2:
+            return []
+        pout = (self.pad_out_to - self.nOut) if self.pad_out_to else 0
+        segs, r0, d0 = [], 0, 0
+        for gsz, gp in zip(groups, phys):
+            segs.append((r0, gsz, d0))
+            r0, d0 = r0 + gsz, d0 + gp
+        jobs = [((id(self), int(cin_phys), "w"), self, "weight", (int(cin_phys), self.nOut + pout), segs)]
+        if self.bias is not None and pout:
+            jobs.append(((id(self), int(cin_phys), "b"), self, "bias", (self.nOut + pout,), None))
+        return jobs
+
     def _wb(self, cin_phys):
         W, b = self.weight, self.bias
         pad = torch.nn.functional.pad
+        if cin_phys != self.nIn or self.pad_out_to:
+            Wp = F.PADDED.get((id(self), int(cin_phys), "w"))
+            if Wp is not None:
+                return Wp, F.PADDED.get((id(self), int(cin_phys), "b"), b)
+            if F.PAD_RECORD is not None and (cin_phys != self.nIn or self.pad_out_to != self.nOut):
+                F.PAD_RECORD.append((self, int(cin_phys)))
         if cin_phys != self.nIn:
-            groups = self.in_groups or (self.nIn,)
-            phys = self.in_phys or (cin_phys // len(groups),) * len(groups)
-            if sum(phys) != cin_phys or sum(groups) != self.nIn or any(p < g for p, g in zip(phys, groups)):
-                raise ValueError(f"NetworkInNetwork: {cin_phys} input columns for nIn={self.nIn}")
+            groups, phys = self._layout(cin_phys)
             parts, r0 = [], 0
             for gsz, gp in zip(groups, phys):
                 parts.append(pad(W[r0:r0 + gsz], (0, 0, 0, gp - gsz)))

@@ -148,6 +148,22 @@ class SparseUNet(nn.Module):
     def forward(self, x, prebuild=True):
         """prebuild=False: no up-front index build -- every rulebook is requested by the first layer that needs it, the
         way the reference's module tree drives the scn surface (DropinBackbone)."""
+        from . import functional as F
+        # channel-padded layers (phys0): their zero-padded parameter copies come from ONE launch (functional.padded_params);
+        # the first forward records which (layer, physical input width) pairs ask for one
+        pads = self.__dict__.get("_pad_plan") if F.PAD_MANY else False
+        if pads is None and F.PAD_RECORD is None:
+            F.PAD_RECORD = rec = []
+            try:
+                y = self._forward_packed(x, prebuild)
+            finally:
+                F.PAD_RECORD = None
+            object.__setattr__(self, "_pad_plan", F.PadPlan.from_requests(rec))
+            return y
+        with F.padded_params(pads):
+            return self._forward_packed(x, prebuild)
+
+    def _forward_packed(self, x, prebuild):
         if self.bf16_all or self.bf16_blocks:
             from . import functional as F
             plan = self.__dict__.get("_pack_plan")

@@ -851,3 +851,64 @@ def test_xcd_local_tile_order_is_a_valid_second_order_and_changes_no_bit(gpu):
                 del os.environ["SCN_TB_NO_XORDER"]
             assert torch.equal(a, b) and torch.equal(a, c)
             assert float(a.float().abs().max()) > 0
+
+
+def test_padded_parameters_in_one_launch_equal_the_tensor_by_tensor_pads(gpu):
+    """functional.padded_params (round 4): the zero-padded parameter copies of the mask network's 23 -> 24-column level (Deconvolution
+    out, NetworkInNetwork over two padded parts, four SubM 3^3, the Convolution reading the padded slab) from ONE
+    scn_pad_params_many launch and their gradients sliced back by one more -- against torch.nn.functional.pad tensor by tensor
+    (SCN_PAD_MANY=0): logits, every parameter gradient and both input gradients bit for bit, for the configured network and for
+    the raw-only variant (7 -> 8 columns under a 16-wide decoder level: unequal joined parts).  Plus the entry point alone on a
+    two-segment job against torch indexing."""
+    import ctypes as C
+    from sparse_rcnn_amd import functional as F, _lib as L, tensor as T
+    from sparse_rcnn_amd.maskhead import MaskBranch
+    from sparse_rcnn_amd.synthetic import make_batch, make_boxes
+    import sparse_rcnn_amd as scn
+    # -- the entry point alone: [2][5][3] -> [2][9][4], rows 0-1 -> 0-1 and 2-4 -> 5-7
+    src = torch.randn(2, 5, 3, device=gpu)
+    dst = torch.full((2, 9, 4), 7.0, device=gpu)
+    desc = (C.c_int32 * 11)(2, 5, 3, 9, 4, 0, 2, 0, 2, 3, 5)
+    a, b = (C.c_void_p * 1)(src.data_ptr()), (C.c_void_p * 1)(dst.data_ptr())
+    L.check(L.lib().scn_pad_params_many(1, a, b, desc, 0, L.stream()))
+    want = torch.zeros(2, 9, 4, device=gpu)
+    want[:, 0:2, :3], want[:, 5:8, :3] = src[:, 0:2], src[:, 2:5]
+    assert torch.equal(dst, want)
+    g = torch.randn(2, 9, 4, device=gpu)
+    back = torch.full((2, 5, 3), 7.0, device=gpu)
+    a, b = (C.c_void_p * 1)(g.data_ptr()), (C.c_void_p * 1)(back.data_ptr())
+    L.check(L.lib().scn_pad_params_many(1, a, b, desc, 1, L.stream()))
+    assert torch.equal(back, torch.cat([g[:, 0:2, :3], g[:, 5:8, :3]], 1))
+    a[0] = None
+    L.check(L.lib().scn_pad_params_many(1, a, b, desc, 1, L.stream()))
+    assert not back.any()
+    # -- the mask network
+    coords, feats, size, bs, splits = make_batch(2, (128, 128, 64), 8_000, seed=5)
+    boxes = make_boxes(coords, 12, seed=6)
+    for flags in (dict(), dict(use_unet_features=False)):
+        torch.manual_seed(4)
+        mb = MaskBranch(32, 7, **flags).to(gpu)
+        x = scn.InputLayer(3, size, mode=4)((coords, feats.to(gpu), bs))
+        X = torch.randn(x.features.shape[0], 32, generator=torch.Generator().manual_seed(1)).to(gpu)
+        gm = None
+        res = []
+        for many in (True, False):
+            F.PAD_MANY = many
+            object.__setattr__(mb.output_conv_layer, "_pad_plan", None)
+            try:
+                for rep in range(2):                       # (first forward of a network records, the second uses the plan)
+                    mb.zero_grad()
+                    Xd, fd = X.clone().requires_grad_(), feats.to(gpu).requires_grad_()
+                    fmap = T.SparseConvNetTensor(features=Xd, metadata=x.metadata, spatial_size=x.spatial_size)
+                    logits, _ = mb((coords.to(gpu), fd, size, bs, splits), fmap if mb.use_unet_features else None, boxes)
+                    gm = torch.randn(logits.shape, generator=torch.Generator().manual_seed(2)).to(gpu) if gm is None else gm
+                    logits.backward(gm)
+            finally:
+                F.PAD_MANY = True
+            plan = mb.output_conv_layer.__dict__.get("_pad_plan")
+            assert bool(plan) == many and (not many or plan.n == (13 if mb.use_unet_features else 2))
+            res.append([logits.detach()] + [p.grad.clone() for p in mb.parameters()] + [fd.grad.clone()]
+                       + ([Xd.grad.clone()] if mb.use_unet_features else []))
+        assert not F.PADDED
+        for u, v in zip(*res):
+            assert torch.equal(u, v)

@@ -64,7 +64,10 @@ class MaskBranch(nn.Module):
     # its own stream | "stream": its own stream, caller's thread.  Measured on one box each (tools/ab_roi_prefetch.sh,
     # profiles/r2_ab_roi_prefetch.log): fp32 12.1-12.9 ms whichever way; bf16 9.6-10.2 ms inline, 9.7-12.8 with the helper
     # thread (two Python threads issuing launches share one interpreter lock), 10.0-11.6 on the side stream -> inline.
-    PREFETCH_ROI_INDEX = os.environ.get("SCN_ROI_PREFETCH", "0")       # "0" inline | "thread" | "stream"
+    # Round 4, "split": the selection's count pass is queued on the index stream when the forward starts, the scene-level input
+    # stage is queued on the caller's stream, and only then the caller waits (selected rows; level sizes of the ROI batch) --
+    # the GPU runs the input stage through both waits (tools/ab_env.py SCN_ROI_PREFETCH).
+    PREFETCH_ROI_INDEX = os.environ.get("SCN_ROI_PREFETCH", "0")       # "0" inline | "thread" | "stream" | "split"
 
     def __init__(self, backbone_channels=32, raw_channels=7, input_channels=16, unet_channels=(32, 48, 64),
                  linear_channels=(32, 18), bf16_blocks=False, *, use_unet_features=True, use_raw_features=True,
@@ -132,7 +135,10 @@ class MaskBranch(nn.Module):
         how = {True: "thread", False: "0", "1": "thread"}.get(how, how)
         pending = prepared_cut
         if pending is None and how != "0":
-            pending = self.output_roi_cut.prepare_cut_in_thread(coords, size, selected_bbox, in_thread=how == "thread")
+            from . import metadata as MD
+            pending = self.output_roi_cut.prepare_cut_in_thread(
+                coords, size, selected_bbox, in_thread=how == "thread", split=how == "split",
+                xcd_order=True if (self.bf16 and MD.XCD_ORDER_BF16) else None)
         # bf16 storage: the scene-level units, the per-point gather (OutputLayer), the per-point slab and the crop's feature
         # gather all run on bf16 rows (round 3: no fp32 island between backbone and internal U-Net); only the InputLayer's
         # mean over the cropped points accumulates in fp32 / fp64

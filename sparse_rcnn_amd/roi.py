@@ -109,29 +109,47 @@ class RoiSelection:
         return self.n_boxes
 
 
+class _SelectStarted:
+    """roi_select after its count pass has been queued: `finish()` waits for the per-box counts and queues the fill."""
+
+    def __init__(self, coords_i32, boxes_i32, want_coords=True):
+        lib = L.lib()
+        self.coords, self.boxes, self.want_coords = coords_i32, boxes_i32, want_coords
+        n, bb = coords_i32.shape[0], boxes_i32.shape[0]
+        self.readback = None
+        if bb == 0 or n == 0:
+            return
+        dev = coords_i32.device
+        self.offsets = torch.empty(bb * lib.scn_roi_units(n) + bb, dtype=torch.int32, device=dev)
+        self.prefix_dev = torch.empty(bb + 1, dtype=torch.int64, device=dev)
+        L.check(lib.scn_roi_count(L.ptr(coords_i32), n, L.ptr(boxes_i32), bb, L.ptr(self.offsets), L.ptr(self.prefix_dev), None,
+                                  L.stream()))
+        self.readback = _Readback(self.prefix_dev)
+
+    def finish(self) -> "RoiSelection":
+        lib = L.lib()
+        coords_i32, boxes_i32 = self.coords, self.boxes
+        n, bb = coords_i32.shape[0], boxes_i32.shape[0]
+        dev = coords_i32.device
+        if self.readback is None:
+            e = torch.zeros(0, dtype=torch.int32, device=dev)
+            return RoiSelection(e, e, [0] * (bb + 1), n, bb, torch.zeros((0, 4), dtype=torch.int64, device=dev))
+        prefix = self.readback.get()[0].tolist()
+        m = int(prefix[bb])
+        if m >= 2 ** 31 - 1:
+            raise L.ScnError("ROI selection exceeds int32 rows")
+        src_row = torch.empty(m, dtype=torch.int32, device=dev)
+        box_of = torch.empty(m, dtype=torch.int32, device=dev)
+        new_coords = torch.empty((m, 4), dtype=torch.int64, device=dev) if self.want_coords else None
+        if m:
+            L.check(lib.scn_roi_fill(L.ptr(coords_i32), n, L.ptr(boxes_i32), bb, L.ptr(self.offsets), L.ptr(self.prefix_dev),
+                                     L.ptr(src_row), L.ptr(box_of), L.ptr(new_coords), L.stream()))
+        return RoiSelection(src_row, box_of, prefix, n, bb, new_coords)
+
+
 def roi_select(coords_i32: torch.Tensor, boxes_i32: torch.Tensor, want_coords=True) -> RoiSelection:
     """count -> scan -> scatter.  One host wait (for the per-box row counts, M = prefix[BB])."""
-    lib = L.lib()
-    n, bb = coords_i32.shape[0], boxes_i32.shape[0]
-    dev = coords_i32.device
-    if bb == 0 or n == 0:
-        e = torch.zeros(0, dtype=torch.int32, device=dev)
-        return RoiSelection(e, e, [0] * (bb + 1), n, bb, torch.zeros((0, 4), dtype=torch.int64, device=dev))
-    offsets = torch.empty(bb * lib.scn_roi_units(n) + bb, dtype=torch.int32, device=dev)
-    prefix_dev = torch.empty(bb + 1, dtype=torch.int64, device=dev)
-    L.check(lib.scn_roi_count(L.ptr(coords_i32), n, L.ptr(boxes_i32), bb, L.ptr(offsets), L.ptr(prefix_dev), None,
-                              L.stream()))
-    prefix = _Readback(prefix_dev).get()[0].tolist()
-    m = int(prefix[bb])
-    if m >= 2 ** 31 - 1:
-        raise L.ScnError("ROI selection exceeds int32 rows")
-    src_row = torch.empty(m, dtype=torch.int32, device=dev)
-    box_of = torch.empty(m, dtype=torch.int32, device=dev)
-    new_coords = torch.empty((m, 4), dtype=torch.int64, device=dev) if want_coords else None
-    if m:
-        L.check(lib.scn_roi_fill(L.ptr(coords_i32), n, L.ptr(boxes_i32), bb, L.ptr(offsets), L.ptr(prefix_dev),
-                                 L.ptr(src_row), L.ptr(box_of), L.ptr(new_coords), L.stream()))
-    return RoiSelection(src_row, box_of, prefix, n, bb, new_coords)
+    return _SelectStarted(coords_i32, boxes_i32, want_coords).finish()
 
 
 def _coords_to_device(coords):
@@ -283,17 +301,22 @@ class SparseRoiCut(torch.nn.Module):
             box_features = fec.combine(new_coords, new_features, spatial_size, sel.n_boxes)
         return box_features, (sel.is_inside() if self.dense_inside else sel, counts, batch_splits)
 
-    def prepare_cut_in_thread(self, coords, spatial_size, bbox_batch, n_levels=0, in_thread=True):
+    def prepare_cut_in_thread(self, coords, spatial_size, bbox_batch, n_levels=0, in_thread=True, split=False, xcd_order=None):
         """Start building what the cut needs from coordinates and boxes alone -- the selection list and, for the
         RawToTensor combiner, the InputLayer rules + rulebook pyramid of the ROI batch (n_levels; 0: the depth the last
         network over this spatial size used, Metadata.LEVELS_HINT) -- on its own high-priority stream, so that the host
         waits of the build (row counts) wait for index kernels only and not for whatever the caller has queued before.
         in_thread: on a helper thread as well (False: on the caller's thread, which then blocks for the build's own
-        ~1 ms while the GPU works through the caller's queue).  Returns a handle for `forward(..., prepared=)`."""
+        ~1 ms while the GPU works through the caller's queue).
+        split (caller's thread): only the part WITHOUT host waits runs now -- boxes to the device, the selection's count pass
+        queued behind what the caller's stream holds at this moment; the two waits (selected rows, level sizes) and the
+        launches between them happen inside `result()`.  A caller that queues independent work in between (the mask
+        branch: its scene-level input stage) keeps the GPU busy through both waits.
+        Returns a handle for `forward(..., prepared=)`."""
         from concurrent.futures import ThreadPoolExecutor
         global _roi_pool, _roi_stream
         dev = torch.device("cuda", torch.cuda.current_device())
-        if _roi_pool is None:
+        if _roi_pool is None and in_thread and not split:
             _roi_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="scn-roi-index")
         if _roi_stream.get(dev) is None:
             _roi_stream[dev] = torch.cuda.Stream(device=dev, priority=-1)
@@ -305,12 +328,17 @@ class SparseRoiCut(torch.nn.Module):
         mode = getattr(self.feature_extractor_combiner, "MODE", 4)
         clip, resize = self.clip_boxes, self.resize_boxes
 
-        def fn():
+        def start():
             torch.cuda.set_device(dev)
-            side.wait_stream(main)                       # the coordinates may have been produced on the caller's stream
             with torch.cuda.stream(side):
-                boxes, counts, _ = transform_boxes(bbox_batch, size, clip, resize)
-                sel = roi_select(_coords_to_device(coords), boxes)
+                boxes, counts, _ = transform_boxes(bbox_batch, size, clip, resize)     # (host boxes: nothing of `main` needed)
+                side.wait_stream(main)                   # the coordinates may have been produced on the caller's stream
+                started = _SelectStarted(_coords_to_device(coords), boxes)
+            return boxes, counts, started
+
+        def finish(boxes, counts, started):
+            with torch.cuda.stream(side):
+                sel = started.finish()
                 md = None
                 if want_md and sel.src_row.shape[0]:
                     levels = n_levels or Metadata.LEVELS_HINT.get(size, 1)
@@ -319,7 +347,7 @@ class SparseRoiCut(torch.nn.Module):
                         lv, ok = tuple(v // 2 for v in lv), ok + 1
                     md = Metadata(3)
                     md._prepared_for = (sel.new_coords, sel.new_coords._version)
-                    md.build_native(size, sel.new_coords, sel.n_boxes, mode, ok, 3)
+                    md.build_native(size, sel.new_coords, sel.n_boxes, mode, ok, 3, xcd_order=xcd_order)
                     md._unrequested = set(md.strided)
                     md.ready_event = torch.cuda.Event()
                     md.ready_event.record(side)
@@ -330,11 +358,19 @@ class SparseRoiCut(torch.nn.Module):
                 ev.record(side)
             return boxes, counts, sel, md, ev
 
-        if in_thread:
-            fut = _roi_pool.submit(fn)
+        if split:
+            begun = start()
+            done = []
+
+            def get():
+                if not done:
+                    done.append(finish(*begun))
+                return done[0]
+        elif in_thread:
+            fut = _roi_pool.submit(lambda: finish(*start()))
             get = fut.result
         else:
-            done = fn()
+            done = finish(*start())
             get = lambda: done
 
         class _Pending:

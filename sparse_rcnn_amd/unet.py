@@ -124,25 +124,61 @@ class SparseUNet(nn.Module):
                 d0["nin"].in_groups = (self.out_channels, c0)
                 d0["nin"].in_phys = (self.out_channels, self.phys0)
 
-    def _pack_jobs(self):
+    def _pack_jobs(self, pad_requests=()):
         """(W, cin, cout, n_off, flags) of every bf16 weight image this network's forward + backward will stage: forward and
         backward-data images of the SubM 3^3 layers, forward of the strided convolutions, backward-data of the
-        deconvolutions (the other directions of the strided layers run on the rule-list GEMMs)."""
+        deconvolutions (the other directions of the strided layers run on the rule-list GEMMs).
+        pad_requests: the (layer, physical input width) pairs of the channel-padded layers (functional.PAD_RECORD).  The image
+        of a zero-padded weight IS the image of the logical weight -- the pack zero-fills outside the layer and padding to the
+        next multiple of 8 never crosses a slice boundary -- so those layers join the one pack launch with their logical
+        parameters, and `aliases` = [(pad key, (cin_phys, cout_phys, n_off, flags), job index)] lets the forward register
+        the image under the padded tensor it hands the kernels.  -> jobs (and the aliases as the attribute `_pack_aliases`)."""
         from . import functional as F
         from . import _lib as L
-        jobs = []
+        lib = L.lib()
+        jobs, aliases = [], []
+        back = L.F_W_TRANSPOSED | L.F_OFF_REVERSE
+        padded = {}
+        for m, cin_phys in pad_requests:
+            padded.setdefault(id(m), []).append(int(cin_phys))
+
+        def add(m, W, cin, cout, n_off, fl, phys=None):
+            if phys is not None:
+                pc, po, key = phys
+                if (pc % 8 or po % 8 or (cout > 32) != (po > 32) or -(-cin // 32) != -(-pc // 32)
+                        or lib.scn_conv_tiles_bf16_image_bytes(cin, cout, n_off) != lib.scn_conv_tiles_bf16_image_bytes(pc, po, n_off)):
+                    return                                   # (not the same image: packed per call as before)
+                aliases.append((key, (pc, po, n_off, fl & back), len(jobs)))
+            jobs.append((W, cin, cout, n_off, fl))
+
         for m in self.modules():
-            if getattr(m, "pad_out_to", None) or (isinstance(m, M._ConvBase) and (m.nIn % 8 or m.nOut % 8)):
-                continue                                     # padded layers see fresh padded weight tensors: packed per call
             if getattr(m, "groups", 1) != 1:
                 continue                                     # grouped layers hand over a fresh block-diagonal weight per call
-            if isinstance(m, M.SubmanifoldConvolution) and m.filter_size == 3 and m.nIn % 8 == 0 and m.nOut % 8 == 0:
-                jobs.append((m.weight, m.nIn, m.nOut, 27, 0))
-                jobs.append((m.weight, m.nOut, m.nIn, 27, L.F_W_TRANSPOSED | L.F_OFF_REVERSE))
-            elif isinstance(m, M.Convolution) and m.nIn % 8 == 0:
-                jobs.append((m.weight, m.nIn, m.nOut, 8, 0))
-            elif isinstance(m, M.Deconvolution) and m.nOut % 8 == 0:
-                jobs.append((m.weight, m.nOut, m.nIn, 8, L.F_W_TRANSPOSED))
+            if not isinstance(m, M._ConvBase):
+                continue
+            is_padded = bool(getattr(m, "pad_out_to", None)) or id(m) in padded
+            if is_padded:
+                pout = m.pad_out_to or m.nOut
+                for pin in padded.get(id(m), []):
+                    key = (id(m), pin, "w")
+                    if isinstance(m, M.SubmanifoldConvolution) and m.filter_size == 3:
+                        add(m, m.weight, m.nIn, m.nOut, 27, 0, (pin, pout, key))
+                        add(m, m.weight, m.nOut, m.nIn, 27, back, (pout, pin, key))
+                    elif isinstance(m, M.Convolution):
+                        add(m, m.weight, m.nIn, m.nOut, 8, 0, (pin, pout, key))
+                    elif isinstance(m, M.Deconvolution):
+                        add(m, m.weight, m.nOut, m.nIn, 8, L.F_W_TRANSPOSED, (pout, pin, key))
+                continue
+            if m.nIn % 8 or m.nOut % 8:
+                continue                                     # (rows that are no 16-byte multiples: not on the bf16 tile kernels)
+            if isinstance(m, M.SubmanifoldConvolution) and m.filter_size == 3:
+                add(m, m.weight, m.nIn, m.nOut, 27, 0)
+                add(m, m.weight, m.nOut, m.nIn, 27, back)
+            elif isinstance(m, M.Convolution):
+                add(m, m.weight, m.nIn, m.nOut, 8, 0)
+            elif isinstance(m, M.Deconvolution):
+                add(m, m.weight, m.nOut, m.nIn, 8, L.F_W_TRANSPOSED)
+        object.__setattr__(self, "_pack_aliases", aliases)
         return jobs
 
     def forward(self, x, prebuild=True):
@@ -159,6 +195,8 @@ class SparseUNet(nn.Module):
             finally:
                 F.PAD_RECORD = None
             object.__setattr__(self, "_pad_plan", F.PadPlan.from_requests(rec))
+            object.__setattr__(self, "_pad_requests", [(m, c) for m, c in rec if isinstance(m, M._ConvBase)])
+            object.__setattr__(self, "_pack_plan", None)     # (rebuilt with the padded layers' images in it)
             return y
         with F.padded_params(pads):
             return self._forward_packed(x, prebuild)
@@ -168,9 +206,16 @@ class SparseUNet(nn.Module):
             from . import functional as F
             plan = self.__dict__.get("_pack_plan")
             if plan is None:                                 # host-side tables of the pack call: built once
-                plan = F.PackPlan(self._pack_jobs())
+                use_pads = F.PAD_MANY and bool(self.__dict__.get("_pad_plan"))
+                plan = F.PackPlan(self._pack_jobs(self.__dict__.get("_pad_requests", ()) if use_pads else ()))
                 object.__setattr__(self, "_pack_plan", plan)
-            with F.packed_weights(plan):                     # one pack launch for the whole network, gone after the forward
+            with F.packed_weights(plan) as pw:               # one pack launch for the whole network, gone after the forward
+                for pad_key, dims, j in self.__dict__.get("_pack_aliases", ()):
+                    Wp = F.PADDED.get(pad_key)               # this forward's padded tensor -> the image of its logical weight
+                    if Wp is not None:
+                        key = (Wp.data_ptr(),) + dims
+                        F.PACKED[key] = F.PACKED[plan.keys[j]]
+                        pw.keys = pw.keys + [key]
                 return self._forward(x, prebuild)
         return self._forward(x, prebuild)
 

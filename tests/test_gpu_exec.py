@@ -858,7 +858,8 @@ def test_padded_parameters_in_one_launch_equal_the_tensor_by_tensor_pads(gpu):
     out, NetworkInNetwork over two padded parts, four SubM 3^3, the Convolution reading the padded slab) from ONE
     scn_pad_params_many launch and their gradients sliced back by one more -- against torch.nn.functional.pad tensor by tensor
     (SCN_PAD_MANY=0): logits, every parameter gradient and both input gradients bit for bit, for the configured network and for
-    the raw-only variant (7 -> 8 columns under a 16-wide decoder level: unequal joined parts).  Plus the entry point alone on a
+    the raw-only variant (7 -> 8 columns under a 16-wide decoder level: unequal joined parts), and in bf16 storage, where the
+    padded layers' weight images are packed from the LOGICAL weights by the network's one pack launch.  Plus the entry point alone on a
     two-segment job against torch indexing."""
     import ctypes as C
     from sparse_rcnn_amd import functional as F, _lib as L, tensor as T
@@ -885,7 +886,7 @@ def test_padded_parameters_in_one_launch_equal_the_tensor_by_tensor_pads(gpu):
     # -- the mask network
     coords, feats, size, bs, splits = make_batch(2, (128, 128, 64), 8_000, seed=5)
     boxes = make_boxes(coords, 12, seed=6)
-    for flags in (dict(), dict(use_unet_features=False)):
+    for flags in (dict(), dict(use_unet_features=False), dict(bf16_blocks="all")):
         torch.manual_seed(4)
         mb = MaskBranch(32, 7, **flags).to(gpu)
         x = scn.InputLayer(3, size, mode=4)((coords, feats.to(gpu), bs))
@@ -912,3 +913,48 @@ def test_padded_parameters_in_one_launch_equal_the_tensor_by_tensor_pads(gpu):
         assert not F.PADDED
         for u, v in zip(*res):
             assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_roi_cut_preparation_modes_give_the_inline_result(gpu, bf16):
+    """MaskBranch.PREFETCH_ROI_INDEX: "0" (the crop's selection and the ROI batch's index build inline, on the caller's stream),
+    "split" (round 4: count pass queued on the index stream first, the scene-level input stage queued on the caller's stream,
+    THEN the two host waits), "stream" and "thread" (everything on the index stream, from the caller's / a helper thread) and
+    MaskBranch.prepare_cut + forward(prepared_cut=) -- the same logits, selection and gradients bit for bit (bf16: the prepared
+    index carries the XCD-local tile order the inline path asks for, so the same kernels run)."""
+    import sparse_rcnn_amd as scn
+    from sparse_rcnn_amd import tensor as T
+    from sparse_rcnn_amd.maskhead import MaskBranch
+    from sparse_rcnn_amd.synthetic import make_batch, make_boxes
+    coords, feats, size, bs, splits = make_batch(2, (128, 128, 64), 10_000, seed=8)
+    boxes = make_boxes(coords, 10, seed=9)
+    torch.manual_seed(5)
+    mb = MaskBranch(32, 7, bf16_blocks="all" if bf16 else False).to(gpu)
+    x = scn.InputLayer(3, size, mode=4)((coords, feats.to(gpu), bs))
+    X = torch.randn(x.features.shape[0], 32, generator=torch.Generator().manual_seed(1)).to(gpu)
+    gm = None
+    res = {}
+    saved = MaskBranch.PREFETCH_ROI_INDEX
+    try:
+        for how in ("0", "split", "stream", "thread", "prepared"):
+            MaskBranch.PREFETCH_ROI_INDEX = "0" if how == "prepared" else how
+            for rep in range(2):
+                mb.zero_grad()
+                Xd, fd = X.clone().requires_grad_(), feats.to(gpu).requires_grad_()
+                fmap = T.SparseConvNetTensor(features=Xd, metadata=x.metadata, spatial_size=x.spatial_size)
+                scene = (coords.to(gpu), fd, size, bs, splits)
+                cut = mb.prepare_cut(coords.to(gpu), size, boxes) if how == "prepared" else None
+                logits, sel = mb(scene, fmap, boxes, prepared_cut=cut)
+                gm = torch.randn(logits.shape, generator=torch.Generator().manual_seed(2)).to(gpu) if gm is None else gm
+                logits.backward(gm)
+            torch.cuda.synchronize()
+            res[how] = [logits.detach(), sel[0].src_row, sel[0].box_of, fd.grad, Xd.grad] + [p.grad.clone() for p in mb.parameters()]
+    finally:
+        MaskBranch.PREFETCH_ROI_INDEX = saved
+    for how, r in res.items():
+        if bf16 and how in ("stream", "thread", "prepared"):
+            # (these hand over an index without the XCD-local order: another hand-out order of the same tiles -- same sums per
+            # tile, so still the same bits)
+            pass
+        for u, v in zip(res["0"], r):
+            assert torch.equal(u, v), how

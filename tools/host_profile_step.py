@@ -24,3 +24,6 @@ torch.cuda.synchronize()
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(45)
 print(s.getvalue()[:9000])
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats("sparse_rcnn_amd|bench", 40)
+print(s.getvalue()[:9000])

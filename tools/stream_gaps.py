@@ -9,7 +9,7 @@ key = 'Stream_Id' if 'Stream_Id' in rows[0] else 'Queue_Id'
 by = collections.defaultdict(list)
 for r in rows:
     by[r[key]].append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
-main = max(by, key=lambda q: sum('k_conv_ts<' in k[2] for k in by[q]))
+main = max(by, key=lambda q: sum(('k_conv_ts<' in k[2]) or ('k_conv_tb' in k[2]) for k in by[q]))
 ks = sorted(by[main])
 print("streams/queues:", {q: len(v) for q, v in by.items()}, "compute:", main)
 # steps: split at the SGD update (multi_tensor_apply) kernels

@@ -180,6 +180,13 @@ class Stage:
         self.bwd_arr = (ExecOp * len(self.bwd))(*self.bwd)
         self.fwd_ws = [i for i, b in enumerate(self.bufs) if b[3] == "f"]
         self.bwd_ws = [i for i, b in enumerate(self.bufs) if b[3] == "b"]
+        # host-side tables of a call, built once (the per-call Python is what a host-bound step feels: DESIGN.md section 5)
+        self.fwd_specs = [(self.bufs[i][0], self.bufs[i][1] * self.bufs[i][2]) for i in self.fwd_ws]     # (level, row bytes)
+        self.bwd_specs = [(self.bufs[i][0], self.bufs[i][1] * self.bufs[i][2]) for i in self.bwd_ws]
+        self.w_entries = [(k, 2 * d[1]) for k, d in enumerate(self.params) if d[0] == "w"]
+        self.b_entries = [(k, 2 * d[1] + 1) for k, d in enumerate(self.params) if d[0] == "b"]
+        self.img_entries = [(k, 2 * d[1]) + tuple(d[2:]) for k, d in enumerate(self.params) if d[0] not in ("w", "b")]
+        self.grad_views = {}                              # tuple of parameter shapes -> (region offsets, total, views)
         covered = sorted(m for reg in self.gregions for m in reg)
         want = sorted((i, k) for i in range(len(self.mods)) for k in ("w", "b"))
         if covered != want:
@@ -321,12 +328,11 @@ def compile_decoder_stage(level, up, nin, blocks, c_coarse, bf16):
 # ----------------------------------------------------------------------------------------------------------------------
 # run time
 # ----------------------------------------------------------------------------------------------------------------------
-def _layout(stage, ids, ns):
+def _layout(specs, ns):
     offs, tot = [], 0
-    for i in ids:
-        lv, ch, es, _ = stage.bufs[i]
+    for lv, row_bytes in specs:
         offs.append(tot)
-        tot += (ns[lv] * ch * es + 255) & ~255
+        tot += (ns[lv] * row_bytes + 255) & ~255
     return offs, tot
 
 
@@ -375,7 +381,7 @@ class StageFunction(torch.autograd.Function):
         phys = ts[n_in:]
         dev = inputs[0].device
         ns = levels[2]
-        offs, total = _layout(stage, stage.fwd_ws, ns)
+        offs, total = _layout(stage.fwd_specs, ns)
         ws = torch.empty(max(total, 256), dtype=torch.uint8, device=dev)
         lv, ch, es, _ = stage.bufs[stage.out_id]
         out = torch.empty((ns[lv], ch), dtype=torch.float32 if es == 4 else torch.bfloat16, device=dev)
@@ -391,25 +397,25 @@ class StageFunction(torch.autograd.Function):
         table[stage.out_id] = out.data_ptr()
         ptab = (vp * max(len(stage.params), 1))()
         images = []
-        for k, d in enumerate(stage.params):
-            if d[0] == "w":
-                ptab[k] = F._f32(phys[2 * d[1]]).data_ptr()
-            elif d[0] == "b":
-                b = phys[2 * d[1] + 1]
-                ptab[k] = 0 if b is None else F._f32(b).data_ptr()
-            else:
-                _, mi, cin, cout, n_off, fl = d
-                W = phys[2 * mi]
-                img = F.packed_image(W, cin, cout, n_off, fl)
-                if img is None:
-                    img = F.pack_weights_bf16(W.detach(), cin, cout, n_off, fl)
-                images.append(img)
-                ptab[k] = img.data_ptr()
+        f32 = torch.float32
+        for k, j in stage.w_entries:
+            t = phys[j]
+            ptab[k] = (t if (t.dtype is f32 and t.is_contiguous()) else F._f32(t)).data_ptr()
+        for k, j in stage.b_entries:
+            t = phys[j]
+            ptab[k] = 0 if t is None else (t if (t.dtype is f32 and t.is_contiguous()) else F._f32(t)).data_ptr()
+        for k, j, cin, cout, n_off, fl in stage.img_entries:
+            W = phys[j]
+            img = F.packed_image(W, cin, cout, n_off, fl)
+            if img is None:
+                img = F.pack_weights_bf16(W.detach(), cin, cout, n_off, fl)
+            images.append(img)
+            ptab[k] = img.data_ptr()
         _run(stage, stage.fwd_arr, levels, table, ptab, None, dev)
         if F.RELU_RECORD is not None:
             _record_relu_masks(stage, ns, ws, offs, inputs, out)
         ctx.stage, ctx.levels, ctx.table, ctx.ptab = stage, levels, table, ptab
-        ctx.phys_shapes = [None if t is None else tuple(t.shape) for t in phys]
+        ctx.phys_shapes = tuple(None if t is None else tuple(t.shape) for t in phys)
         # Everything the pointer tables name travels through save_for_backward: the parameter tensors, the forward workspace,
         # the packed weight images and the input slabs.  They stay alive exactly as long as autograd keeps the graph
         # (retain_graph=True: a second backward reads the same slabs; otherwise they are released when backward ends and a
@@ -428,7 +434,7 @@ class StageFunction(torch.autograd.Function):
         dout = dout.contiguous()
         if dout.element_size() != es:
             dout = dout.to(torch.float32 if es == 4 else torch.bfloat16)
-        offs, total = _layout(stage, stage.bwd_ws, ns)
+        offs, total = _layout(stage.bwd_specs, ns)
         ws = torch.empty(max(total, 256), dtype=torch.uint8, device=dev)
         base = ws.data_ptr()
         for i, o in zip(stage.bwd_ws, offs):
@@ -442,21 +448,25 @@ class StageFunction(torch.autograd.Function):
             table[i] = t.data_ptr()
         # gradient regions back to back in one fp32 buffer; the returned gradients are views of it
         shapes = ctx.phys_shapes
-        goffs, gtot, views = [], 0, [None] * len(shapes)
-        for reg in stage.gregions:
-            goffs.append(gtot)
-            start = gtot
-            for mi, kind in reg:
-                sh = shapes[2 * mi + (kind == "b")]
-                if sh is not None:
-                    n = 1
-                    for s in sh:
-                        n *= s
-                    views[2 * mi + (kind == "b")] = (gtot, n, sh)
-                    gtot += n
-            if gtot == start:                    # (plans are only compiled for layers WITH bias: _require_bias)
-                raise L.ScnError("executor: a gradient region without a tensor (bias=None layer in a compiled stage)")
-            gtot = (gtot + 63) & ~63
+        cached = stage.grad_views.get(shapes)
+        if cached is None:
+            goffs, gtot, views = [], 0, [None] * len(shapes)
+            for reg in stage.gregions:
+                goffs.append(gtot)
+                start = gtot
+                for mi, kind in reg:
+                    sh = shapes[2 * mi + (kind == "b")]
+                    if sh is not None:
+                        n = 1
+                        for v in sh:
+                            n *= v
+                        views[2 * mi + (kind == "b")] = (gtot, n, sh)
+                        gtot += n
+                if gtot == start:                    # (plans are only compiled for layers WITH bias: _require_bias)
+                    raise L.ScnError("executor: a gradient region without a tensor (bias=None layer in a compiled stage)")
+                gtot = (gtot + 63) & ~63
+            cached = stage.grad_views[shapes] = (goffs, gtot, views)
+        goffs, gtot, views = cached
         flat = torch.empty(max(gtot, 1), dtype=torch.float32, device=dev)
         gtab = (vp * max(len(stage.gregions), 1))()
         gb = flat.data_ptr()

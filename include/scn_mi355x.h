@@ -52,7 +52,7 @@ extern "C" {
  *      weight-gradient sums; bf16 elementwise forms; segment pooling; scn_tiles_build_x) -- shipped with the value still 1
  *   3  round 4: SCN_PYRAMID_FUSED (scn_pyramid_build_ex flag, larger scn_pyramid_workspace_bytes), hash slot function
  *      changed (tables built by version <= 2 libraries are not probe-compatible; no table outlives a Metadata, so only a
- *      caller that kept raw tables across a library upgrade is affected); + scn_exec_timing_enable / _collect, scn_pad_params_many (104 entry points) */
+ *      caller that kept raw tables across a library upgrade is affected); + scn_exec_timing_enable / _collect, scn_pad_params_many, scn_conv_tiles_split_count (105 entry points) */
 #define SCN_ABI_VERSION 3
 
 /* flags for the gather-GEMM entry points */
@@ -270,6 +270,10 @@ int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32_t* tstab, 
  * reduction to a second launch.  reset != 0 zeroes the counters after reading.  (bench.py reports it as `fast_path`: a
  * workload that outgrows the fast path's limits changes kernels, and the JSON line says so.) */
 void scn_conv_tiles_path_counts(int64_t out[4], int reset);
+/* Launches (a subset of out[0]) that took the four-waves-per-tile loop of latency-bound levels: fewer (tile, slice) pairs
+ * than half the chip's waves -- the coarse levels of the reference's six-level plan (scannet_config/run.py:539-549: 2 983 /
+ * 734 / 180 rows), deep levels of an ROI batch.  Same arithmetic per product, an element's sum associated by wave share. */
+int64_t scn_conv_tiles_split_count(int reset);
 /* Second half of a scn_conv_tiles call made with SCN_F_SPLIT_SUM: adds the K-chunk slabs (no-op when cin <= 32: the
  * tile kernel has written Y).  Same arguments as that call. */
 int scn_conv_tiles_finish(int cin, int64_t n_out, const float* bias, const float* residual, const float* relu_mask,

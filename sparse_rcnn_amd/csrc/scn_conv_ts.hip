@@ -74,7 +74,7 @@ __device__ __forceinline__ int ts_ws_off(int o, int k, int n) { return (o * TS_K
 // numbered class by class: [full slices][column-tail slices][K-tail slices][the corner slice].
 struct TsSlices { int g_full, g_ntail, g_ktail, g_both; };
 
-template <bool WT, bool VEC, bool VECN, bool FULLK, bool PART, bool FUSED, bool TAIL = false>
+template <bool WT, bool VEC, bool VECN, bool FULLK, bool PART, bool FUSED, bool TAIL = false, int SPLIT = 1>
 __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     const float* __restrict__ X, long long n_in, int cin, const int* __restrict__ tstab,
     const unsigned* __restrict__ tile_mask,
@@ -135,7 +135,8 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     };
     const int i = lane & 15, kq = lane >> 4;
     // first tile: id, mask and output rows are requested before the weight slice is staged
-    long long tile_next = grab();
+    // (SPLIT > 1, scn_conv_ts_small.inc: tiles are dealt to wave groups by round, nothing to grab)
+    long long tile_next = SPLIT == 1 ? grab() : -1;
     unsigned m_next = 0;
     int orow_next[4] = {-1, -1, -1, -1};
     if (tile_next >= 0) {
@@ -453,32 +454,52 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         if (kh && nh) {
 #define TS_KH 1
 #define TS_NH 1
+if constexpr (SPLIT == 1) {
 #include "scn_conv_ts_loop.inc"
+        } else {
+#include "scn_conv_ts_small.inc"
+        }
 #undef TS_KH
 #undef TS_NH
         } else if (kh) {
 #define TS_KH 1
 #define TS_NH 0
+if constexpr (SPLIT == 1) {
 #include "scn_conv_ts_loop.inc"
+        } else {
+#include "scn_conv_ts_small.inc"
+        }
 #undef TS_KH
 #undef TS_NH
         } else if (nh) {
 #define TS_KH 0
 #define TS_NH 1
+if constexpr (SPLIT == 1) {
 #include "scn_conv_ts_loop.inc"
+        } else {
+#include "scn_conv_ts_small.inc"
+        }
 #undef TS_KH
 #undef TS_NH
         } else {
 #define TS_KH 0
 #define TS_NH 0
+if constexpr (SPLIT == 1) {
 #include "scn_conv_ts_loop.inc"
+        } else {
+#include "scn_conv_ts_small.inc"
+        }
 #undef TS_KH
 #undef TS_NH
         }
     } else {
 #define TS_KH 0
 #define TS_NH 0
+if constexpr (SPLIT == 1) {
 #include "scn_conv_ts_loop.inc"
+        } else {
+#include "scn_conv_ts_small.inc"
+        }
 #undef TS_KH
 #undef TS_NH
     }
@@ -542,6 +563,9 @@ extern "C" int64_t scn_conv_tiles_scratch_bytes(int cin, int64_t n_out, int cout
 }
 
 static std::atomic<int64_t> g_ts_paths[4];
+static std::atomic<int64_t> g_ts_split;            // launches of the four-waves-per-tile loop (scn_conv_ts_small.inc)
+
+extern "C" int64_t scn_conv_tiles_split_count(int reset) { return reset ? g_ts_split.exchange(0) : g_ts_split.load(); }
 
 extern "C" void scn_conv_tiles_path_counts(int64_t out[4], int reset) {
     for (int i = 0; i < 4; ++i) out[i] = reset ? g_ts_paths[i].exchange(0) : g_ts_paths[i].load();
@@ -586,20 +610,28 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     const bool fused = n_kc > 1 && arrival != nullptr && !(flags & SCN_F_SPLIT_SUM) &&
                        nt * n_chunks * n_kc * (int64_t)(TS_T * TS_CT * 4) < (1ll << 31);
     int* counters = (int*)arrival;
-    const size_t lds = (size_t)n_off * TS_KC * TS_CT * sizeof(float) + 16;
-    int wg_per_cu = (int)((160 * 1024) / lds);
-    if (wg_per_cu > 2) wg_per_cu = 2;                  // 16 waves each: 2 workgroups fill a CU
-    if (wg_per_cu < 1) wg_per_cu = 1;
-    // grid sized to the chip: workgroups per (column chunk, K-chunk) slice; a workgroup should see at least ~16 tiles
-    int64_t n_tg = (256 * wg_per_cu) / ((int64_t)n_chunks * n_kc);
-    if (n_tg > cdiv(nt, TS_NW)) n_tg = cdiv(nt, TS_NW);
-    if (n_tg < 1) n_tg = 1;
     const bool wt = flags & SCN_F_W_TRANSPOSED;
     const bool vec = (cin % 4 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0);
     const bool vecn = (cout % 4 == 0) && (((uintptr_t)W & 15) == 0);
     // the fast path addresses X through a raw buffer descriptor: 32-bit byte offsets, 24-bit row indices
     const bool fullk = vec && n_in < (1ll << 23) && n_in * cin * 4 < (1ll << 32) - (1ll << 24) &&
                        n_out < (1ll << 23) && n_out * cout * 4 < (1ll << 32) - (1ll << 24);
+    // Latency-bound levels (scn_conv_ts_small.inc): with fewer (tile, slice) pairs than half the chip's waves a launch is ONE
+    // tile's serial chain of up to 27 dependent gathers, so four waves share a tile.  Decided from the tile and slice counts
+    // alone: every form of a layer (fused / two-launch K reduction, TAIL / padded slices) takes the same loop.
+    // SCN_TS_SPLIT=0: never (A/B; the cross-check in the tests -- the two loops associate an element's sum differently).
+    const char* sp_env = getenv("SCN_TS_SPLIT");                        // (read per call: the tests switch it inside one process)
+    static const int64_t sp_max = getenv("SCN_TS_SPLIT_MAX") ? atoll(getenv("SCN_TS_SPLIT_MAX")) : 2048;   // (developer switch)
+    const bool split4 = fullk && nt * n_chunks * n_kc <= sp_max && !(sp_env && atoi(sp_env) == 0);
+    const int tiles_per_round = split4 ? TS_NW / 4 : TS_NW;
+    const size_t lds = (size_t)n_off * TS_KC * TS_CT * sizeof(float) + 16 + (split4 ? (size_t)TS_NW * 2 * 64 * 16 : 0);
+    int wg_per_cu = (int)((160 * 1024) / lds);
+    if (wg_per_cu > 2) wg_per_cu = 2;                  // 16 waves each: 2 workgroups fill a CU
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    // grid sized to the chip: workgroups per (column chunk, K-chunk) slice; a workgroup should see at least ~16 tiles
+    int64_t n_tg = (256 * wg_per_cu) / ((int64_t)n_chunks * n_kc);
+    if (n_tg > cdiv(nt, tiles_per_round)) n_tg = cdiv(nt, tiles_per_round);
+    if (n_tg < 1) n_tg = 1;
     const bool part = cin % TS_KC != 0;
     // TAIL: a dead K half or a dead column block exists (the reference's 48 / 80 / 112-channel layers): those MFMAs are
     // skipped and the slices get workgroups in proportion to their cost.  Estimated cost of a tile step relative to a
@@ -616,7 +648,7 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
         const int ncf = n_chunks - (n_tail ? 1 : 0), nkf = n_kc - (k_tail ? 1 : 0);
         const double wsum = (double)nkf * ncf + (n_tail ? nkf * w_half : 0.0) + (k_tail ? ncf * w_half : 0.0) +
                             (n_tail && k_tail ? w_both : 0.0);
-        const int64_t total_wg = 256 * wg_per_cu, cap = cdiv(nt, TS_NW);   // a workgroup should see at least ~16 tiles
+        const int64_t total_wg = 256 * wg_per_cu, cap = cdiv(nt, tiles_per_round);   // a workgroup should see at least ~16 tiles
         auto share = [&](double w) { int64_t g = (int64_t)(total_wg * w / wsum); return (int)(g > cap ? cap : (g < 1 ? 1 : g)); };
         slices.g_full = share(1.0);
         slices.g_ntail = n_tail ? share(w_half) : 0;
@@ -626,45 +658,51 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     }
     g_ts_paths[fullk ? 0 : 1].fetch_add(1, std::memory_order_relaxed);
     if (n_kc > 1) g_ts_paths[fused ? 2 : 3].fetch_add(1, std::memory_order_relaxed);
+    if (split4) g_ts_split.fetch_add(1, std::memory_order_relaxed);
     dim3 grid((unsigned)grid_x);
     hipStream_t st = S(stream);
-#define LAUNCH_TS_F(T, V, VN, FK, PT, FU, TL)                                                                       \
+#define LAUNCH_TS_F(T, V, VN, FK, PT, FU, TL, SP)                                                                   \
     do {                                                                                                            \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
-            SCN_HIP(hipFuncSetAttribute((const void*)k_conv_ts<T, V, VN, FK, PT, FU, TL>,                           \
+            SCN_HIP(hipFuncSetAttribute((const void*)k_conv_ts<T, V, VN, FK, PT, FU, TL, SP>,                       \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((k_conv_ts<T, V, VN, FK, PT, FU, TL>), grid, dim3(TS_NW * 64), lds, st, X, (long long)n_in, cin, tstab, tile_mask, \
+        hipLaunchKernelGGL((k_conv_ts<T, V, VN, FK, PT, FU, TL, SP>), grid, dim3(TS_NW * 64), lds, st, X, (long long)n_in, cin, tstab, tile_mask, \
                            perm, tile_order, n_off, (long long)nt, W, bias, residual, relu_mask, Y, slabs,                      \
                            (long long)n_out, cout, flags, n_chunks, n_kc, counters, slices);                        \
     } while (0)
 #define LAUNCH_TS(T, V, VN, FK, PT)                                                                                 \
     do {                                                                                                            \
-        if (fused) LAUNCH_TS_F(T, V, VN, FK, PT, true, false); else LAUNCH_TS_F(T, V, VN, FK, PT, false, false);    \
+        if (fused) LAUNCH_TS_F(T, V, VN, FK, PT, true, false, 1); else LAUNCH_TS_F(T, V, VN, FK, PT, false, false, 1); \
     } while (0)
-#define LAUNCH_TS_TAIL(T, VN, PT)                                                                                   \
+    // the raw-buffer fast path (FULLK), plain or TAIL slices, one tile per wave or four waves per tile
+#define LAUNCH_TS_FK(T, VN, PT, TL)                                                                                 \
     do {                                                                                                            \
-        if (fused) LAUNCH_TS_F(T, true, VN, true, PT, true, true); else LAUNCH_TS_F(T, true, VN, true, PT, false, true); \
+        if (split4) {                                                                                               \
+            if (fused) LAUNCH_TS_F(T, true, VN, true, PT, true, TL, 4); else LAUNCH_TS_F(T, true, VN, true, PT, false, TL, 4); \
+        } else {                                                                                                    \
+            if (fused) LAUNCH_TS_F(T, true, VN, true, PT, true, TL, 1); else LAUNCH_TS_F(T, true, VN, true, PT, false, TL, 1); \
+        }                                                                                                           \
     } while (0)
-    if (tail && wt && part) LAUNCH_TS_TAIL(true, true, true);
-    else if (tail && wt) LAUNCH_TS_TAIL(true, true, false);
-    else if (tail && vecn && part) LAUNCH_TS_TAIL(false, true, true);
-    else if (tail && vecn) LAUNCH_TS_TAIL(false, true, false);
-    else if (tail && part) LAUNCH_TS_TAIL(false, false, true);
-    else if (tail) LAUNCH_TS_TAIL(false, false, false);
-    else if (fullk && wt && part) LAUNCH_TS(true, true, true, true, true);
-    else if (fullk && wt) LAUNCH_TS(true, true, true, true, false);
-    else if (fullk && vecn && part) LAUNCH_TS(false, true, true, true, true);
-    else if (fullk && vecn) LAUNCH_TS(false, true, true, true, false);
-    else if (fullk && part) LAUNCH_TS(false, true, false, true, true);
-    else if (fullk) LAUNCH_TS(false, true, false, true, false);
+    if (tail && wt && part) LAUNCH_TS_FK(true, true, true, true);
+    else if (tail && wt) LAUNCH_TS_FK(true, true, false, true);
+    else if (tail && vecn && part) LAUNCH_TS_FK(false, true, true, true);
+    else if (tail && vecn) LAUNCH_TS_FK(false, true, false, true);
+    else if (tail && part) LAUNCH_TS_FK(false, false, true, true);
+    else if (tail) LAUNCH_TS_FK(false, false, false, true);
+    else if (fullk && wt && part) LAUNCH_TS_FK(true, true, true, false);
+    else if (fullk && wt) LAUNCH_TS_FK(true, true, false, false);
+    else if (fullk && vecn && part) LAUNCH_TS_FK(false, true, true, false);
+    else if (fullk && vecn) LAUNCH_TS_FK(false, true, false, false);
+    else if (fullk && part) LAUNCH_TS_FK(false, false, true, false);
+    else if (fullk) LAUNCH_TS_FK(false, false, false, false);
     else if (wt) LAUNCH_TS(true, false, true, false, false);
     else if (vecn) LAUNCH_TS(false, false, true, false, false);
     else LAUNCH_TS(false, false, false, false, false);
 #undef LAUNCH_TS
-#undef LAUNCH_TS_TAIL
+#undef LAUNCH_TS_FK
 #undef LAUNCH_TS_F
     SCN_LAUNCH_CHECK();
     if (fused || (flags & SCN_F_SPLIT_SUM)) return SCN_OK;

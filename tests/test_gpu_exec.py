@@ -958,3 +958,73 @@ def test_roi_cut_preparation_modes_give_the_inline_result(gpu, bf16):
             pass
         for u, v in zip(res["0"], r):
             assert torch.equal(u, v), how
+
+
+@pytest.mark.parametrize("c,target", [(80, 2_900), (96, 700), (112, 180), (64, 1_500), (128, 400), (32, 300)])
+def test_four_waves_per_tile_loop_agrees_with_the_plain_loop(gpu, c, target):
+    """scn_conv_ts_small.inc (round 4): where a level has fewer (tile, slice) pairs than half the chip's waves -- the coarse
+    levels of the reference's plan, 80 / 96 / 112 channels on ~2 900 / 700 / 180 rows -- four waves share a tile (offsets dealt
+    by rank among the mask's set bits, all of a wave's gathers in flight at once, partial tiles added in LDS in ascending share
+    order).  Against the plain loop (SCN_TS_SPLIT=0) on the same operands: SubM 3^3 forward with input ReLU + residual,
+    backward-data with ReLU mask + residual-last, the 2^3 child table forward and transposed, the K reduction inside the launch
+    and as a second launch (functional.FUSED_K = False; bit-equal to the in-launch form in BOTH loops), TAIL slices (80, 112) and the
+    padded kernel (SCN_TS_NO_TAIL=1: bit-equal in both loops).  The two loops associate an element's sum differently: 2e-6 of
+    the output scale; each bitwise reproducible; both within 1e-5 of an fp64 forward; and the split loop really ran."""
+    import os
+    import sparse_rcnn_amd as scn
+    from sparse_rcnn_amd import functional as F, _lib as L
+    coords, feats, size, bs, _ = _scene(target, (96, 96, 48), seed=7)
+    x = scn.InputLayer(3, size, mode=4)((coords, feats.to(gpu), 1))
+    rb = x.metadata.subm_rulebook(size, 3)
+    sb = x.metadata.strided_rulebook(size)
+    g = torch.Generator().manual_seed(c)
+    X = torch.randn(rb.n, c, generator=g).to(gpu)
+    W = (torch.randn(27, c, c, generator=g) * (2.0 / (27 * c)) ** 0.5).to(gpu)
+    b = torch.randn(c, generator=g).to(gpu)
+    R = torch.randn(rb.n, c, generator=g).to(gpu)
+    Mk = torch.randn(rb.n, c, generator=g).to(gpu)
+    W8 = (torch.randn(8, c, c, generator=g) * (2.0 / (8 * c)) ** 0.5).to(gpu)
+    back = L.F_W_TRANSPOSED | L.F_OFF_REVERSE
+    lib = L.lib()
+
+    def run(fused=True):
+        F.FUSED_K = fused                                                 # False: the K-chunk slabs are added by a second launch
+        try:
+            out = [F.conv_rules(X, rb.tiles, rb.n, W, b, c, L.F_RELU_IN, residual=R),
+                   F.conv_rules(X, rb.tiles, rb.n, W, None, c, back | L.F_RESIDUAL_LAST, residual=R, relu_mask=Mk),
+                   F.conv_rules(X, sb.tiles, sb.n_coarse, W8, b, c, 0),
+                   F.conv_rules(X[:sb.n_coarse].contiguous(), sb.tiles, sb.n_coarse, W8, None, c, L.F_W_TRANSPOSED)]
+        finally:
+            F.FUSED_K = True
+        torch.cuda.synchronize()
+        return out
+    lib.scn_conv_tiles_split_count(1)
+    a, a2 = run(), run()
+    assert lib.scn_conv_tiles_split_count(1) == 8                         # every launch took the four-waves-per-tile loop
+    two = run(False)                                                      # (cin <= 32: nothing to add, same launch)
+    os.environ["SCN_TS_NO_TAIL"] = "1"
+    try:
+        padded = run()
+    finally:
+        del os.environ["SCN_TS_NO_TAIL"]
+    lib.scn_conv_tiles_split_count(1)
+    os.environ["SCN_TS_SPLIT"] = "0"
+    try:
+        ref = run()
+        ref_two = run(False)
+    finally:
+        del os.environ["SCN_TS_SPLIT"]
+    assert lib.scn_conv_tiles_split_count(1) == 0
+    for k in range(4):
+        assert torch.equal(a[k], a2[k]) and torch.equal(a[k], two[k]) and torch.equal(a[k], padded[k]), k
+        assert torch.equal(ref[k], ref_two[k]), k
+        scale = float(ref[k].abs().max())
+        assert scale > 0 and float((a[k] - ref[k]).abs().max()) <= 2e-6 * scale, (k, float((a[k] - ref[k]).abs().max()) / scale)
+    rows = torch.arange(0, rb.n, max(1, rb.n // 256), device=gpu)
+    tab = rb.table[:, rows].long()
+    acc = b.double().unsqueeze(0).repeat(len(rows), 1) + R[rows].double()
+    for o in range(27):
+        ok = tab[o] >= 0
+        acc[ok] += torch.relu(X[tab[o][ok]]).double() @ W[o].double()
+    for y in (a[0], ref[0]):
+        assert float((y[rows].double() - acc).abs().max()) <= 1e-5 * float(acc.abs().max())

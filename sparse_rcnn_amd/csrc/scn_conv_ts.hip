@@ -624,7 +624,7 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     static const int64_t sp_max = getenv("SCN_TS_SPLIT_MAX") ? atoll(getenv("SCN_TS_SPLIT_MAX")) : 2048;   // (developer switch)
     const bool split4 = fullk && nt * n_chunks * n_kc <= sp_max && !(sp_env && atoi(sp_env) == 0);
     const int tiles_per_round = split4 ? TS_NW / 4 : TS_NW;
-    const size_t lds = (size_t)n_off * TS_KC * TS_CT * sizeof(float) + 16 + (split4 ? (size_t)TS_NW * 2 * 64 * 16 : 0);
+    const size_t lds = (size_t)n_off * TS_KC * TS_CT * sizeof(float) + 16 + (split4 ? (size_t)2 * (TS_NW / 4) * 3 * 2 * 64 * 16 : 0);   // two buffers of partial tiles
     int wg_per_cu = (int)((160 * 1024) / lds);
     if (wg_per_cu > 2) wg_per_cu = 2;                  // 16 waves each: 2 workgroups fill a CU
     if (wg_per_cu < 1) wg_per_cu = 1;

@@ -25,6 +25,9 @@
 #ifndef TS_EXP
 #define TS_EXP 0
 #endif
+#ifndef TS_DEPTH
+#define TS_DEPTH 3          // row gathers this many offsets ahead of the MFMAs (3: indices 5 ahead; 5: indices 7 ahead)
+#endif
 #ifndef TS_TIMELINE
 #define TS_TIMELINE 0       // 1: per-wave wall_clock64 stamps appended to the scratch buffer (tools/ts_timeline.py)
 #endif
@@ -326,7 +329,8 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
                 if (!TS_NH) c1 = MFMA16(a1_[e_], bh_[4 + e_], c1);                                   \
             }                                                                                        \
         }                                                                                            \
-        oq0 = oq1; oq1 = oq2; oq2 = oq3; oq3 = oq4; oq4 = o4_;                                       \
+        oq0 = oq1; oq1 = oq2; oq2 = oq3; oq3 = oq4;                                                  \
+        if (TS_DEPTH == 3) oq4 = o4_; else ts_o4_ = o4_;     /* (depth 5: the caller shifts the longer queue) */ \
     } while (0)
 
     // ---- epilogue pieces --------------------------------------------------------------------------------------------
@@ -392,6 +396,7 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     // in flight (tk_v holds it in lane 0); -1 = none.  Callers drain the wave's memory operations first.
     long long q1 = -1, q2 = -1;
     int tk_v = 0;
+    int ts_o4_ = -1;                                   // (TS_DEPTH 5: the offset a step popped, handed to the longer queue)
     int orow_q1[4] = {-1, -1, -1, -1}, orow_q2[4] = {-1, -1, -1, -1};     // output rows of the tiles q1 / q2 (FULLK)
     auto ts_publish = [&](long long t, const f32x4& c0, const f32x4& c1) {
         const int sb = (int)((t * n_chunks + chunk) * n_kc + kci) * (TS_T * TS_CT * 4) + lane * 16;

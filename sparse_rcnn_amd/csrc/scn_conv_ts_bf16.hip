@@ -151,7 +151,7 @@ __global__ __launch_bounds__(TB_NW * 64) __attribute__((amdgpu_waves_per_eu(NB =
     const int row_bytes = cin * 2, lane_boff = (kc + 8 * kq) * 2;
     const unsigned short* wlane = Wb + (size_t)i * TB_KC + 8 * kq;   // + ((o KH + plane) CT + 16 nb) 32
     // Round 3d: the step below is ISSUE-bound (four 16-cycle MFMAs against ~16 vector and ~12 scalar instructions of
-    // bookkeeping in the first version; SQ counters in profiles/r3_pmc_conv_tb.txt), so every piece of bookkeeping is
+    // bookkeeping in the first version; SQ counters in profiles/r3_tb_where_the_time_goes.txt), so every piece of bookkeeping is
     // written for its instruction count:
     //   * row-index loads through a raw buffer descriptor of the tile table with a SCALAR offset (tile base + 64 offset):
     //     no vector address arithmetic (was a 64-bit shift-add pair per load);

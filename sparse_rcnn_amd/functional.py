@@ -230,13 +230,14 @@ class _PadMany(torch.autograd.Function):
         dev = next(g.device for g in grads if g is not None)
         buf = torch.empty(plan.total_in, dtype=torch.float32, device=dev)
         base, keep = buf.data_ptr(), []
+        src, dst = (C.c_void_p * plan.n)(), (C.c_void_p * plan.n)()      # (own tables: backward runs on autograd's thread)
         for i, g in enumerate(grads):
             if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
                 g = g.float().contiguous()
             keep.append(g)
-            plan.src[i] = g.data_ptr() if g is not None else None
-            plan.dst[i] = base + 4 * plan.in_offs[i]
-        L.check(L.lib().scn_pad_params_many(plan.n, plan.src, plan.dst, plan.desc, 1, L.stream()))
+            src[i] = g.data_ptr() if g is not None else None
+            dst[i] = base + 4 * plan.in_offs[i]
+        L.check(L.lib().scn_pad_params_many(plan.n, src, dst, plan.desc, 1, L.stream()))
         return (None,) + tuple(buf[off:off + p.numel()].view(p.shape) for off, p in zip(plan.in_offs, plan.params))
 
 

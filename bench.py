@@ -340,6 +340,9 @@ def run(args):
             dom = max((k for k in ks if k in dom_names), key=lambda k: ks[k]["ms"], default=max(ks, key=lambda k: ks[k]["ms"]))
             d = ks[dom]
             out["roofline"] = roofline(dom, d, sampled, args)
+            shapes = [r for r in timer.by_shape(sampled) if r["bf16"] == (dom == "k_conv_tb")]
+            if shapes:                      # the dominant kernel's launches by layer shape (the level that sets the average)
+                out["roofline"]["by_shape"] = shapes
             out["kernels"] = {k: {"ms_per_step": v["ms"] / sampled, "launches_per_step": v["launches"] / sampled,
                                   "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else None,
                                   "algorithmic_GBps": v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] else None}
@@ -473,6 +476,9 @@ def bf16_side_leg(args, dev, torch):
     if "k_conv_tb" in ks:
         out["roofline"] = roofline("k_conv_tb", ks["k_conv_tb"], max(1, timer.sampled_steps),
                                    argparse.Namespace(workload="cfg2", dtype="bf16"))
+        shapes = [r for r in timer.by_shape(max(1, timer.sampled_steps)) if r["bf16"]]
+        if shapes:
+            out["roofline"]["by_shape"] = shapes
     del job
     torch.cuda.empty_cache()
     return out

@@ -22,6 +22,7 @@ class KernelTimer:
         self.used = 0
         self.records = []          # (name, flops, bytes, start, end)
         self.exec_records = []     # (name, flops, bytes, ms): launches the step executor timed inside its C calls
+        self.exec_shapes = {}      # (op, bf16, cin, cout, rows out) -> [launches, ms, flops]: the same launches by layer shape
 
     def reserve(self, n_events: int):
         while len(self.pool) < n_events:
@@ -69,6 +70,10 @@ class KernelTimer:
                 op, bf16, cin, cout, n_in, n_out, rules = (int(info[7 * k + j]) for j in range(7))
                 n_off = 8 if op == 3 else 27                          # SCN_OP_CONV_CHILD = 3
                 es = 2.0 if bf16 else 4.0
+                sh = self.exec_shapes.setdefault((op, bf16, cin, cout, n_out), [0, 0.0, 0.0])
+                sh[0] += 1
+                sh[1] += float(ms[k])
+                sh[2] += 2.0 * rules * cin * cout
                 self.exec_records.append(("k_conv_tb" if bf16 else "k_conv_ts", 2.0 * rules * cin * cout,
                                           es * (n_in * cin + n_out * cout + (n_off * cin * cout if not bf16 else 0))
                                           + (2.0 * n_off * cin * cout if bf16 else 0.0) + 8.0 * rules, float(ms[k])))
@@ -91,6 +96,16 @@ class KernelTimer:
             d["ms"] += s.elapsed_time(e)
             d["flops"] += flops() if callable(flops) else flops
             d["bytes"] += nbytes() if callable(nbytes) else nbytes
+        return out
+
+    def by_shape(self, steps):
+        """The executor-timed tile-convolution launches by layer shape, largest level first: launches and us per step, us per
+        launch and useful TFLOP/s (HIP events inside the C calls; bench.py reports it as roofline.by_shape)."""
+        out = []
+        for (op, bf16, cin, cout, n_out), (c, ms, fl) in sorted(self.exec_shapes.items(), key=lambda kv: (-kv[0][4], kv[0])):
+            out.append(dict(table="child 2^3" if op == 3 else "subm 3^3", bf16=bool(bf16), cin=cin, cout=cout, rows_out=n_out,
+                            launches_per_step=c / steps, us_per_launch=ms * 1e3 / c, us_per_step=ms * 1e3 / steps,
+                            useful_tflops=fl / (ms * 1e-3) / 1e12 if ms else None))
         return out
 
     @property

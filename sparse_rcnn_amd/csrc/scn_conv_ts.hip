@@ -41,7 +41,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static constexpr int TS_KC = 32;        // channels per K-chunk
 static constexpr int TS_CT = 32;        // output columns per workgroup
 static constexpr int TS_T = 16;         // rows per tile
-static constexpr int TS_NW = 16;        // waves per workgroup
+#ifndef TS_NW_V
+#define TS_NW_V 16
+#endif
+static constexpr int TS_NW = TS_NW_V;   // waves per workgroup (16; -DTS_NW_V=12: the co-residency experiment of DESIGN.md section 4.1)
 
 // LDS image of a weight slice: Ws[o][k][n], n contiguous (the layer's own layout: staging is a straight 16-byte copy),
 // columns XOR-ed with 16 on every other group of 4 channels: the B fragment of MFMA step (half, e) is read by lane

@@ -52,7 +52,8 @@ extern "C" {
  *      weight-gradient sums; bf16 elementwise forms; segment pooling; scn_tiles_build_x) -- shipped with the value still 1
  *   3  round 4: SCN_PYRAMID_FUSED (scn_pyramid_build_ex flag, larger scn_pyramid_workspace_bytes), hash slot function
  *      changed (tables built by version <= 2 libraries are not probe-compatible; no table outlives a Metadata, so only a
- *      caller that kept raw tables across a library upgrade is affected); + scn_exec_timing_enable / _collect, scn_pad_params_many, scn_conv_tiles_split_count (105 entry points) */
+ *      caller that kept raw tables across a library upgrade is affected); + scn_exec_timing_enable / _collect, scn_pad_params_many, scn_conv_tiles_split_count, scn_dedup_launch_div, scn_child_table_div (107 entry points);
+ *      scn_pool_fwd / _bwd (+ _bf16): `average` carries the pool volume above bit 8 (0 = the 2^3 of every configuration) */
 #define SCN_ABI_VERSION 3
 
 /* flags for the gather-GEMM entry points */
@@ -119,6 +120,15 @@ int scn_subm_table(const int32_t* coords, int64_t n, const uint64_t* table_keys,
  * and offset o = ((x&1)*2 + (y&1))*2 + (z&1), or -1.  Also writes fine_off[n_fine] = that offset. */
 int scn_child_table(const int32_t* fine_coords, const int32_t* parent, int64_t n_fine, int64_t n_coarse,
                     int32_t* child, int32_t* fine_off, scn_stream_t stream);
+/* The same two steps for ANY filter_size = filter_stride = (sx, sy, sz) -- `get_downsampler(stride=...)` /
+ * `get_upsampler` hand an int or one entry per axis to scn.Convolution / scn.Deconvolution (module_factory.py:221-258; every
+ * shipped configuration uses 2): coarse site = (x / sx, y / sy, z / sz), numbered by first occurrence like scn_dedup_launch;
+ * child table [sx sy sz][n_coarse] with offset o = ((x % sx) sy + y % sy) sz + z % sz, which is the 2^3 numbering for 2. */
+int scn_dedup_launch_div(const int32_t* coords, int64_t n, int sx, int sy, int sz, uint64_t* table_keys, int32_t* table_rows,
+                         int64_t cap, int32_t* item_row, int32_t* row_count, int32_t* row_first, int32_t* row_coords,
+                         void* scratch, int64_t* n_rows_dev, scn_stream_t stream);
+int scn_child_table_div(const int32_t* fine_coords, const int32_t* parent, int64_t n_fine, int64_t n_coarse, int sx, int sy,
+                        int sz, int32_t* child, int32_t* fine_off, scn_stream_t stream);
 
 /* Compaction of a rule table into (in,out) pairs -- wave ballot + prefix sum.
  * Phase 1: counts; block_sums must hold scn_rules_blocks(n_off, n_out) int32; writes prefix (device, int64[n_off+1])

@@ -174,24 +174,27 @@ def subm_rulebook(coords: np.ndarray, k: int = 3):
     return nbr, rules
 
 
-def strided_rulebook(coords: np.ndarray, s: int = 2):
+def strided_rulebook(coords: np.ndarray, s=2):
     """Fine coords [Nf,4] -> dict(coarse coords, parent, off, child table, rules).
 
-    size = stride = s.  Coarse site = floor(p/s); offset o = ((x%s)*s + y%s)*s + z%s.
+    size = stride = s (an int, or one entry per axis: `get_downsampler(stride=...)`, module_factory.py:221-241).
+    Coarse site = floor(p/s); offset o = ((x%sx)*sy + y%sy)*sz + z%sz.
     Coarse rows numbered by first occurrence scanning fine rows ascending.
     rules[o] = (fine rows, coarse rows), coarse ascending.
     """
+    st = np.asarray((s, s, s) if np.isscalar(s) else tuple(s), dtype=np.int64)
     coords = np.asarray(coords, dtype=np.int64).reshape(-1, 4)
     cc = coords.copy()
-    cc[:, :3] //= s
+    cc[:, :3] //= st
     parent, first = _first_occurrence_rows(pack_keys(cc))
     nc = len(first)
-    r = coords[:, :3] % s
-    off = ((r[:, 0] * s + r[:, 1]) * s + r[:, 2]).astype(np.int32)
-    child = np.full((s ** 3, nc), -1, np.int32)
+    r = coords[:, :3] % st
+    off = ((r[:, 0] * st[1] + r[:, 1]) * st[2] + r[:, 2]).astype(np.int32)
+    n_off = int(st.prod())
+    child = np.full((n_off, nc), -1, np.int32)
     child[off, parent] = np.arange(len(coords), dtype=np.int32)
     rules = []
-    for o in range(s ** 3):
+    for o in range(n_off):
         out = np.nonzero(child[o] >= 0)[0].astype(np.int32)
         rules.append((child[o][out].astype(np.int32), out))
     return dict(coords=cc[first], parent=parent.astype(np.int32), off=off, child=child, rules=rules)
@@ -284,16 +287,18 @@ def batchnorm_relu_fwd(X, gamma, beta, running_mean, running_var, eps=1e-4, mome
 
 
 def pool_fwd(X, child, average):
-    """MaxPooling / AveragePooling 2^3 stride 2 on the child table [8, Nc] ([UPSTREAM-SCN]):
-    max: zero-initialised output, max over existing children;  avg: sum over existing children / 8."""
+    """MaxPooling / AveragePooling, pool size = stride, on the child table [n_off, Nc] ([UPSTREAM-SCN]; the
+    reference's poolings are 2^3 / 2: n_off = 8):
+    max: zero-initialised output, max over existing children;  avg: sum over existing children / n_off."""
     nc = child.shape[1]
+    n_off = child.shape[0]
     Y = torch.zeros(nc, X.shape[1], dtype=X.dtype)
-    for o in range(8):
+    for o in range(n_off):
         rows = np.nonzero(child[o] >= 0)[0]
         if len(rows):
             src = X[_t(child[o][rows])]
             if average:
-                Y.index_add_(0, _t(rows), src / 8.0)
+                Y.index_add_(0, _t(rows), src / float(n_off))
             else:
                 Y[_t(rows)] = torch.maximum(Y[_t(rows)], src)
     return Y

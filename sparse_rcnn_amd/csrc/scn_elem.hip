@@ -483,15 +483,16 @@ __global__ void k_pool_fwd(const float* __restrict__ X, const int* __restrict__ 
         const long long r = i / c;
         const int ch = (int)(i - r * c);
         float acc = 0.f;
-#pragma unroll
-        for (int o = 0; o < 8; ++o) {
+        const int n_off = (avg >> 8) ? (avg >> 8) : 8;                  // `average` carries the pool volume above bit 8 (0: 2^3)
+        const bool mean = avg & 1;
+        for (int o = 0; o < n_off; ++o) {
             const int f = child[(long long)o * n_coarse + r];
             if (f >= 0) {
                 const float v = X[(long long)f * c + ch];
-                acc = avg ? acc + v : fmaxf(acc, v);
+                acc = mean ? acc + v : fmaxf(acc, v);
             }
         }
-        Y[i] = avg ? acc * 0.125f : acc;
+        Y[i] = mean ? acc * (1.0f / (float)n_off) : acc;
     }
 }
 
@@ -502,7 +503,8 @@ __global__ void k_pool_bwd(const float* __restrict__ X, const float* __restrict_
         const long long f = i / c;
         const int ch = (int)(i - f * c);
         const long long o = (long long)parent[f] * c + ch;
-        dX[i] = avg ? dY[o] * 0.125f : (X[i] == Y[o] ? dY[o] : 0.f);
+        const int n_off = (avg >> 8) ? (avg >> 8) : 8;
+        dX[i] = (avg & 1) ? dY[o] * (1.0f / (float)n_off) : (X[i] == Y[o] ? dY[o] : 0.f);
     }
 }
 

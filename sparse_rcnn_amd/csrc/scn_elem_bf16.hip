@@ -94,15 +94,16 @@ __global__ void k_pool_fwd_b(const us* __restrict__ X, const int* __restrict__ c
         const long long r = i / c;
         const int ch = (int)(i - r * c);
         float acc = 0.f;
-#pragma unroll
-        for (int o = 0; o < 8; ++o) {
+        const int n_off = (avg >> 8) ? (avg >> 8) : 8;                  // `average` carries the pool volume above bit 8 (0: 2^3)
+        const bool mean = avg & 1;
+        for (int o = 0; o < n_off; ++o) {
             const int f = child[(long long)o * n_coarse + r];
             if (f >= 0) {
                 const float v = bw(X[(long long)f * c + ch]);
-                acc = avg ? acc + v : fmaxf(acc, v);
+                acc = mean ? acc + v : fmaxf(acc, v);
             }
         }
-        Y[i] = bn(avg ? acc * 0.125f : acc);
+        Y[i] = bn(mean ? acc * (1.0f / (float)n_off) : acc);
     }
 }
 
@@ -113,7 +114,8 @@ __global__ void k_pool_bwd_b(const us* __restrict__ X, const us* __restrict__ Y,
         const long long f = i / c;
         const long long o = (long long)parent[f] * c + (int)(i - f * c);
         // max: a stored maximum IS one of the stored inputs (a maximum is not rounded), so the bit patterns compare
-        dX[i] = avg ? bn(bw(dY[o]) * 0.125f) : (X[i] == Y[o] ? dY[o] : (us)0);
+        const int n_off = (avg >> 8) ? (avg >> 8) : 8;
+        dX[i] = (avg & 1) ? bn(bw(dY[o]) * (1.0f / (float)n_off)) : (X[i] == Y[o] ? dY[o] : (us)0);
     }
 }
 

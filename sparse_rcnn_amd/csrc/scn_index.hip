@@ -218,14 +218,23 @@ __global__ void k_table_init(unsigned long long* __restrict__ keys, int* __restr
     }
 }
 
-__global__ void k_hash_insert_min(const int4* __restrict__ coords, long long n, int shift,
+// How a fine coordinate becomes its coarse site: x >> shift (size = stride = 2^shift: the reference's 2^3/2 layers) or, with
+// dx > 0, (x / dx, y / dy, z / dz) -- any filter_size = filter_stride the reference's `get_downsampler(stride=...)` can ask for
+// (module_factory.py:221-241: an int or one entry per axis).  Coordinates are non-negative.
+struct Coarsen { int shift, dx, dy, dz; };
+__device__ __forceinline__ int4 scn_coarse(int4 c, Coarsen cs) {
+    if (cs.dx == 0) return make_int4(c.x >> cs.shift, c.y >> cs.shift, c.z >> cs.shift, c.w);
+    return make_int4(c.x / cs.dx, c.y / cs.dy, c.z / cs.dz, c.w);
+}
+
+__global__ void k_hash_insert_min(const int4* __restrict__ coords, long long n, Coarsen cs,
                                   unsigned long long* __restrict__ keys, int* __restrict__ tmin, long long cap,
                                   int* __restrict__ slot_of) {
     const unsigned long long mask = (unsigned long long)cap - 1ull;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
-        int4 c = coords[i];
-        unsigned long long key = scn_pack_key(c.x >> shift, c.y >> shift, c.z >> shift, c.w);
+        const int4 c = scn_coarse(coords[i], cs);
+        unsigned long long key = scn_pack_key(c.x, c.y, c.z, c.w);
         unsigned long long slot = scn_hash_slot(key, mask);
         int found = -1;
         for (long long probe = 0; probe < cap; ++probe) {
@@ -254,7 +263,7 @@ __global__ void k_flag_first(const int* __restrict__ slot_of, const int* __restr
 __global__ __launch_bounds__(SCAN_T) void k_assign_rows(const int* __restrict__ first, long long n,
                                                         const int* __restrict__ block_offs,
                                                         const int* __restrict__ slot_of,
-                                                        const int4* __restrict__ coords, int shift,
+                                                        const int4* __restrict__ coords, Coarsen cs,
                                                         int* __restrict__ table_rows, int* __restrict__ row_first,
                                                         int4* __restrict__ row_coords) {
     const long long base = (long long)blockIdx.x * SCAN_TILE;
@@ -267,8 +276,7 @@ __global__ __launch_bounds__(SCAN_T) void k_assign_rows(const int* __restrict__ 
             int i = vals[it];
             table_rows[slot_of[i]] = pos[it];
             if (row_first) row_first[pos[it]] = i;
-            int4 c = coords[i];
-            row_coords[pos[it]] = make_int4(c.x >> shift, c.y >> shift, c.z >> shift, c.w);
+            row_coords[pos[it]] = scn_coarse(coords[i], cs);
         }
     }
 }
@@ -290,12 +298,13 @@ extern "C" int64_t scn_dedup_scratch_bytes(int64_t n) {
     return align256(4 * n) * 2 + align256(4 * blocks) + 256;
 }
 
-static int dedup_impl(const int32_t* coords, int64_t n, int shift, uint64_t* table_keys,
+static int dedup_impl(const int32_t* coords, int64_t n, Coarsen cs, uint64_t* table_keys,
                       int32_t* table_rows, int64_t cap, int32_t* item_row, int32_t* row_count,
                       int32_t* row_first, int32_t* row_coords, void* scratch, int64_t* n_rows_host,
                       int64_t* n_rows_dev, scn_stream_t stream) {
-    SCN_REQUIRE(n >= 0 && shift >= 0 && shift < 16 && table_keys && table_rows && (n_rows_host || n_rows_dev) &&
+    SCN_REQUIRE(n >= 0 && cs.shift >= 0 && cs.shift < 16 && table_keys && table_rows && (n_rows_host || n_rows_dev) &&
                 scratch);
+    SCN_REQUIRE(cs.dx == 0 || (cs.dx >= 1 && cs.dy >= 1 && cs.dz >= 1));
     SCN_REQUIRE(cap >= 2 * n && (cap & (cap - 1)) == 0);
     SCN_REQUIRE(n < 2147483647LL);
     hipStream_t st = S(stream);
@@ -315,7 +324,7 @@ static int dedup_impl(const int32_t* coords, int64_t n, int shift, uint64_t* tab
     int* block_sums = (int*)p;              p += align256(4 * blocks);
     long long* prefix = (long long*)p;      // [2]
     const int g = scn::ew_grid(n, 256);
-    hipLaunchKernelGGL(k_hash_insert_min, dim3(g), dim3(256), 0, st, (const int4*)coords, (long long)n, shift,
+    hipLaunchKernelGGL(k_hash_insert_min, dim3(g), dim3(256), 0, st, (const int4*)coords, (long long)n, cs,
                        (unsigned long long*)table_keys, table_rows, (long long)cap, slot_of);
     SCN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_flag_first, dim3(g), dim3(256), 0, st, slot_of, table_rows, (long long)n, first);
@@ -323,7 +332,7 @@ static int dedup_impl(const int32_t* coords, int64_t n, int shift, uint64_t* tab
     int rc = scan_launch(first, 1, n, block_sums, (int64_t*)prefix, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_assign_rows, dim3((unsigned)blocks), dim3(SCAN_T), 0, st, first, (long long)n, block_sums,
-                       slot_of, (const int4*)coords, shift, table_rows, row_first, (int4*)row_coords);
+                       slot_of, (const int4*)coords, cs, table_rows, row_first, (int4*)row_coords);
     SCN_LAUNCH_CHECK();
     if (row_count) SCN_HIP(hipMemsetAsync(row_count, 0, sizeof(int32_t) * n, st));
     hipLaunchKernelGGL(k_item_rows, dim3(g), dim3(256), 0, st, slot_of, table_rows, (long long)n, item_row, row_count);
@@ -344,7 +353,7 @@ extern "C" int scn_dedup_build(const int32_t* coords, int64_t n, int shift, uint
                                int32_t* row_first, int32_t* row_coords, void* scratch, int64_t* n_rows_host,
                                scn_stream_t stream) {
     SCN_REQUIRE(n_rows_host);
-    return dedup_impl(coords, n, shift, table_keys, table_rows, cap, item_row, row_count, row_first, row_coords,
+    return dedup_impl(coords, n, Coarsen{shift, 0, 0, 0}, table_keys, table_rows, cap, item_row, row_count, row_first, row_coords,
                       scratch, n_rows_host, nullptr, stream);
 }
 
@@ -353,7 +362,16 @@ extern "C" int scn_dedup_launch(const int32_t* coords, int64_t n, int shift, uin
                                 int32_t* row_first, int32_t* row_coords, void* scratch, int64_t* n_rows_dev,
                                 scn_stream_t stream) {
     SCN_REQUIRE(n_rows_dev);
-    return dedup_impl(coords, n, shift, table_keys, table_rows, cap, item_row, row_count, row_first, row_coords,
+    return dedup_impl(coords, n, Coarsen{shift, 0, 0, 0}, table_keys, table_rows, cap, item_row, row_count, row_first, row_coords,
+                      scratch, nullptr, n_rows_dev, stream);
+}
+
+extern "C" int scn_dedup_launch_div(const int32_t* coords, int64_t n, int sx, int sy, int sz, uint64_t* table_keys,
+                                    int32_t* table_rows, int64_t cap, int32_t* item_row, int32_t* row_count,
+                                    int32_t* row_first, int32_t* row_coords, void* scratch, int64_t* n_rows_dev,
+                                    scn_stream_t stream) {
+    SCN_REQUIRE(n_rows_dev && sx >= 1 && sy >= 1 && sz >= 1);
+    return dedup_impl(coords, n, Coarsen{0, sx, sy, sz}, table_keys, table_rows, cap, item_row, row_count, row_first, row_coords,
                       scratch, nullptr, n_rows_dev, stream);
 }
 
@@ -414,6 +432,33 @@ __global__ void k_child_table(const int4* __restrict__ fine, const int* __restri
         child[(long long)o * n_coarse + parent[i]] = (int)i;
         fine_off[i] = o;
     }
+}
+
+// size = stride = (sx, sy, sz): child[o][coarse row] = fine row, o = ((x % sx) sy + y % sy) sz + z % sz (the 2^3 numbering above
+// for sx = sy = sz = 2)
+__global__ void k_child_table_div(const int4* __restrict__ fine, const int* __restrict__ parent, long long n,
+                                  long long n_coarse, int sx, int sy, int sz, int* __restrict__ child,
+                                  int* __restrict__ fine_off) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int4 c = fine[i];
+        const int o = ((c.x % sx) * sy + c.y % sy) * sz + c.z % sz;
+        child[(long long)o * n_coarse + parent[i]] = (int)i;
+        fine_off[i] = o;
+    }
+}
+
+extern "C" int scn_child_table_div(const int32_t* fine_coords, const int32_t* parent, int64_t n_fine, int64_t n_coarse,
+                                   int sx, int sy, int sz, int32_t* child, int32_t* fine_off, scn_stream_t stream) {
+    SCN_REQUIRE(n_fine >= 0 && n_coarse >= 0 && n_coarse <= n_fine && sx >= 1 && sy >= 1 && sz >= 1);
+    SCN_REQUIRE((int64_t)sx * sy * sz <= 4096);
+    if (n_fine == 0) return SCN_OK;
+    SCN_REQUIRE(fine_coords && parent && child && fine_off);
+    SCN_HIP(hipMemsetAsync(child, 0xFF, sizeof(int32_t) * (size_t)sx * sy * sz * n_coarse, S(stream)));
+    hipLaunchKernelGGL(k_child_table_div, dim3(scn::ew_grid(n_fine, 256)), dim3(256), 0, S(stream),
+                       (const int4*)fine_coords, parent, (long long)n_fine, (long long)n_coarse, sx, sy, sz, child, fine_off);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
 }
 
 extern "C" int scn_child_table(const int32_t* fine_coords, const int32_t* parent, int64_t n_fine, int64_t n_coarse,

@@ -394,14 +394,29 @@ def gemm_rules(X, in_rows, out_rows, prefix_host, n_off, n_out, W, bias, cout, f
     entry = lib.scn_gemm_rules_bf16 if _is_bf16(X) else lib.scn_gemm_rules
 
     def run():
-        L.check(entry(L.ptr(X), cin, L.ptr(in_rows), L.ptr(out_rows), prefix_host, n_off, L.ptr(W),
-                      L.ptr(bias), L.ptr(relu_mask), L.ptr(Y), cout, flags, L.stream()))
+        # the entry point takes up to 32 offsets per call; every output row occurs in exactly one rule (the callers: Deconvolution
+        # forward, Convolution backward-data), so the chunks of a larger filter (a 4^3 stride: 64) write disjoint rows of one Y
+        for o0 in range(0, n_off, 32):
+            k = min(32, n_off - o0)
+            ph = _offset_chunk(prefix_host, o0)
+            Wp = L.ptr(W) + 4 * o0 * W.shape[1] * W.shape[2] if o0 else L.ptr(W)
+            L.check(entry(L.ptr(X), cin, L.ptr(in_rows), L.ptr(out_rows), ph, k, Wp,
+                          L.ptr(bias), L.ptr(relu_mask), L.ptr(Y), cout, flags, L.stream()))
     profiling.timed("k_gemm_rules", 2.0 * P * cin * cout, _conv_bytes(X.shape[0], cin, n_out, cout, n_off, P), run)
     return Y
 
 
+def _offset_chunk(prefix_host, o0):
+    """`prefix_host` advanced by o0 offsets (the rule-list entry points take up to 32 offsets per call; rule rows are addressed
+    through the absolute prefix, so a chunk is the same arrays with a later prefix pointer)."""
+    return prefix_host if o0 == 0 else C.cast(C.addressof(prefix_host.contents) + 8 * o0, C.POINTER(C.c_int64))
+
+
 def wgrad_rules_bf16(X, dY, in_rows, out_rows, prefix_host, n_off, flags=0):
     """scn_wgrad_rules_bf16: dW (fp32) from bf16-stored X and dY -- the weight gradient of the bf16 storage path."""
+    if n_off > 32:          # (a 4^3 stride, a 5^3 filter: chunks of 32 offsets)
+        return torch.cat([wgrad_rules_bf16(X, dY, in_rows, out_rows, _offset_chunk(prefix_host, o0), min(32, n_off - o0), flags)
+                          for o0 in range(0, n_off, 32)], 0)
     lib = L.lib()
     for t in (X, dY):
         if t.dtype != torch.bfloat16 or not t.is_contiguous():
@@ -421,6 +436,9 @@ def wgrad_rules_bf16(X, dY, in_rows, out_rows, prefix_host, n_off, flags=0):
 def wgrad_rules(X, dY, in_rows, out_rows, prefix_host, n_off, flags=0):
     if _is_bf16(X):
         return wgrad_rules_bf16(X, dY, in_rows, out_rows, prefix_host, n_off, flags)
+    if n_off > 32:
+        return torch.cat([wgrad_rules(X, dY, in_rows, out_rows, _offset_chunk(prefix_host, o0), min(32, n_off - o0), flags)
+                          for o0 in range(0, n_off, 32)], 0)
     lib = L.lib()
     cin, cout = X.shape[1], dY.shape[1]
     nbytes = lib.scn_wgrad_scratch_bytes(cin, cout, prefix_host, n_off)
@@ -540,7 +558,7 @@ class SubmanifoldConvolutionFunction(torch.autograd.Function):
         R = _feat(residual) if residual is not None else None
         if relu_in:
             _rec_relu(X)
-        if USE_TILES and rb.rules is not None:
+        if USE_TILES and rb.rules is not None and rb.tiles is not None:
             Y = conv_rules(X, rb.tiles, rb.n, W, b, cout, L.F_RELU_IN if relu_in else 0, residual=R,
                            n_rules=rb.rules.count)
         else:
@@ -561,7 +579,7 @@ class SubmanifoldConvolutionFunction(torch.autograd.Function):
         fl = L.F_RELU_IN if ctx.relu_in else 0
         dX = dW = db = None
         if ctx.needs_input_grad[0]:
-            if USE_TILES and rb.rules is not None:
+            if USE_TILES and rb.rules is not None and rb.tiles is not None:
                 dX = conv_rules(dY, rb.tiles, rb.n, W, None, cin, L.F_W_TRANSPOSED | L.F_OFF_REVERSE,
                                 relu_mask=X if ctx.relu_in else None, n_rules=rb.rules.count, image=ctx.bwd_image)
             else:
@@ -574,10 +592,12 @@ class SubmanifoldConvolutionFunction(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 ir, orr = (None, None) if rb.k == 1 else (rb.rules.in_rows, rb.rules.out_rows)
                 ph = _identity_prefix(rb.n) if rb.k == 1 else rb.rules.prefix_host
-                if want_b:      # the centre offset lists every row once: bias gradient from the same pass
+                if want_b and n_off <= 32:      # the centre offset lists every row once: bias gradient from the same pass
                     dW, db = wgrad_bias_rules(X, dY, ir, orr, ph, n_off, 1 << (n_off // 2), fl)
                 else:
                     dW = wgrad_rules(X, dY, ir, orr, ph, n_off, fl)
+                    if want_b:
+                        db = colsum(dY)
                 dW = dW.view_as(W)
             elif want_b:
                 db = colsum(dY)
@@ -715,17 +735,17 @@ class ResidualBlockFunctionBF16(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------------
 class ConvolutionFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, features, weight, bias, metadata: Metadata, in_size, relu_in=False):
+    def forward(ctx, features, weight, bias, metadata: Metadata, in_size, relu_in=False, stride=(2, 2, 2)):
         X, W = _feat(features), _f32(weight)
-        rb = metadata.strided_rulebook(in_size)
+        rb = metadata.strided_rulebook(in_size, stride)
         b = _f32(bias) if bias is not None else None
         if relu_in:
             _rec_relu(X)
-        if USE_TILES:
+        if USE_TILES and rb.tiles is not None:
             Y = conv_rules(X, rb.tiles, rb.n_coarse, W, b, W.shape[-1], L.F_RELU_IN if relu_in else 0,
                            n_rules=rb.n_fine)
-        else:
-            Y = gemm_table(X, rb.child, 8, rb.n_coarse, W, b, W.shape[-1], L.F_RELU_IN if relu_in else 0,
+        else:                   # (more than 27 offsets -- a 4^3 filter -- : the table-walk GEMM; fp32 rows)
+            Y = gemm_table(X, rb.child, rb.n_off, rb.n_coarse, W, b, W.shape[-1], L.F_RELU_IN if relu_in else 0,
                            n_rules=rb.n_fine)
         ctx.save_for_backward(X, W)
         ctx.rb, ctx.has_bias, ctx.relu_in = rb, bias is not None, relu_in
@@ -739,28 +759,28 @@ class ConvolutionFunction(torch.autograd.Function):
         fl = L.F_RELU_IN if ctx.relu_in else 0
         dX = dW = db = None
         if ctx.needs_input_grad[0]:      # dX[f] = dY[parent f] . W[off f]^T : rule list with roles swapped
-            dX = gemm_rules(dY, r.out_rows, r.in_rows, r.prefix_host, 8, rb.n_fine, W, None, X.shape[1],
+            dX = gemm_rules(dY, r.out_rows, r.in_rows, r.prefix_host, rb.n_off, rb.n_fine, W, None, X.shape[1],
                             L.F_W_TRANSPOSED, relu_mask=X if ctx.relu_in else None)
         def leaves():
             dW = db = None
             if ctx.needs_input_grad[1]:
-                dW = wgrad_rules(X, dY, r.in_rows, r.out_rows, r.prefix_host, 8, fl).view_as(W)
+                dW = wgrad_rules(X, dY, r.in_rows, r.out_rows, r.prefix_host, rb.n_off, fl).view_as(W)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = colsum(dY)
             return dW, db
         dW, db = _on_leaf_stream(dY, leaves)
-        return dX, dW, db, None, None, None
+        return dX, dW, db, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------
-# A7 Deconvolution size=stride=2 back to the cached fine level  (module_factory.py:256-258)
+# A7 Deconvolution size=stride back to the cached fine level  (module_factory.py:256-258)
 # ------------------------------------------------------------------------------------------------------
 class DeconvolutionFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, features, weight, bias, metadata: Metadata, out_size, relu_in=False):
+    def forward(ctx, features, weight, bias, metadata: Metadata, out_size, relu_in=False, stride=(2, 2, 2)):
         X, W = _feat(features), _f32(weight)
         out_size = tuple(int(s) for s in out_size)
-        rb = metadata.cached_strided_rulebook(out_size)
+        rb = metadata.cached_strided_rulebook(out_size, stride)
         if rb is None:
             raise L.ScnError(f"Deconvolution: no cached Convolution rulebook from spatial size {out_size}; the "
                              "reference only deconvolves back to an encoder level (custom_container.py:70-83)")
@@ -768,11 +788,11 @@ class DeconvolutionFunction(torch.autograd.Function):
         b = _f32(bias) if bias is not None else None
         if relu_in:
             _rec_relu(X)
-        Y = gemm_rules(X, r.out_rows, r.in_rows, r.prefix_host, 8, rb.n_fine, W, b, W.shape[-1],
+        Y = gemm_rules(X, r.out_rows, r.in_rows, r.prefix_host, rb.n_off, rb.n_fine, W, b, W.shape[-1],
                        L.F_RELU_IN if relu_in else 0)
         ctx.save_for_backward(X, W)
         ctx.rb, ctx.has_bias, ctx.relu_in = rb, bias is not None, relu_in
-        ctx.bwd_image = packed_image(W, W.shape[-1], X.shape[1], 8, L.F_W_TRANSPOSED) if _is_bf16(X) else None
+        ctx.bwd_image = packed_image(W, W.shape[-1], X.shape[1], rb.n_off, L.F_W_TRANSPOSED) if _is_bf16(X) else None
         return Y
 
     @staticmethod
@@ -783,26 +803,28 @@ class DeconvolutionFunction(torch.autograd.Function):
         fl = L.F_RELU_IN if ctx.relu_in else 0
         dX = dW = db = None
         if ctx.needs_input_grad[0]:      # dX[c] = sum_o dY[child[o][c]] . W[o]^T
-            if USE_TILES:
+            if USE_TILES and rb.tiles is not None:
                 dX = conv_rules(dY, rb.tiles, rb.n_coarse, W, None, X.shape[1], L.F_W_TRANSPOSED,
                                 relu_mask=X if ctx.relu_in else None, n_rules=rb.n_fine, image=ctx.bwd_image)
             else:
-                dX = gemm_table(dY, rb.child, 8, rb.n_coarse, W, None, X.shape[1], L.F_W_TRANSPOSED,
+                dX = gemm_table(dY, rb.child, rb.n_off, rb.n_coarse, W, None, X.shape[1], L.F_W_TRANSPOSED,
                                 relu_mask=X if ctx.relu_in else None, n_rules=rb.n_fine)
         def leaves():
             dW = db = None
             want_b = ctx.has_bias and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
-                if want_b:      # every fine (output) row occurs in exactly one of the 8 rule lists
-                    dW, db = wgrad_bias_rules(X, dY, r.out_rows, r.in_rows, r.prefix_host, 8, 0xFF, fl)
+                if want_b and rb.n_off <= 27:      # every fine (output) row occurs in exactly one of the rule lists
+                    dW, db = wgrad_bias_rules(X, dY, r.out_rows, r.in_rows, r.prefix_host, rb.n_off, (1 << rb.n_off) - 1, fl)
                 else:
-                    dW = wgrad_rules(X, dY, r.out_rows, r.in_rows, r.prefix_host, 8, fl)
+                    dW = wgrad_rules(X, dY, r.out_rows, r.in_rows, r.prefix_host, rb.n_off, fl)
+                    if want_b:
+                        db = colsum(dY)
                 dW = dW.view_as(W)
             elif want_b:
                 db = colsum(dY)
             return dW, db
         dW, db = _on_leaf_stream(dY, leaves)
-        return dX, dW, db, None, None, None
+        return dX, dW, db, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -1153,15 +1175,16 @@ class SparseToDenseFunction(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------------
 class PoolingFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, features, metadata: Metadata, in_size, average):
+    def forward(ctx, features, metadata: Metadata, in_size, average, stride=(2, 2, 2)):
         X = _feat(features)                     # fp32, or bf16 storage
-        rb = metadata.strided_rulebook(in_size)
+        rb = metadata.strided_rulebook(in_size, stride)
         c = X.shape[1]
         Y = _new((rb.n_coarse, c), X, X.dtype)
+        mode = int(bool(average)) | ((rb.n_off << 8) if rb.n_off != 8 else 0)     # pool volume above bit 8 (0: the 2^3 default)
         fwd = L.lib().scn_pool_fwd_bf16 if _is_bf16(X) else L.lib().scn_pool_fwd
-        L.check(fwd(L.ptr(X), L.ptr(rb.child), rb.n_coarse, c, int(average), L.ptr(Y), L.stream()))
+        L.check(fwd(L.ptr(X), L.ptr(rb.child), rb.n_coarse, c, mode, L.ptr(Y), L.stream()))
         ctx.save_for_backward(X, Y)
-        ctx.rb, ctx.average = rb, int(average)
+        ctx.rb, ctx.average = rb, mode
         return Y
 
     @staticmethod
@@ -1173,4 +1196,4 @@ class PoolingFunction(torch.autograd.Function):
         bwd = L.lib().scn_pool_bwd_bf16 if hb else L.lib().scn_pool_bwd
         L.check(bwd(L.ptr(X), L.ptr(Y), L.ptr(dY), L.ptr(ctx.rb.parent), X.shape[0], X.shape[1], ctx.average, L.ptr(dX),
                     L.stream()))
-        return dX, None, None, None
+        return dX, None, None, None, None

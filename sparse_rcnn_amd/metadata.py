@@ -390,12 +390,14 @@ class SubmRulebook(_Views):
 class StridedRulebook(_Views):
     parent: torch.Tensor            # int32 [Nf]  fine row -> coarse row
     fine_off: torch.Tensor          # int32 [Nf]
-    child: torch.Tensor             # int32 [8, Nc]
+    child: torch.Tensor             # int32 [n_off, Nc]
     rules: Rules                    # in = fine rows, out = coarse rows
     n_fine: int
     n_coarse: int
     coarse_size: Tuple[int, ...]
-    tiles: Optional[Tiles] = None
+    tiles: Optional[Tiles] = None   # None above 27 offsets (the tile kernels' 32-bit masks): the table-walk GEMM serves those
+    n_off: int = 8                  # filter volume = sx * sy * sz
+    stride: Tuple[int, ...] = (2, 2, 2)
 
 
 def compact_rules(table: torch.Tensor, n_off: int, n_out: int, want_seg=False):
@@ -405,7 +407,9 @@ def compact_rules(table: torch.Tensor, n_off: int, n_out: int, want_seg=False):
 
 
 class _Dedup:
-    """A queued scn_dedup_launch; `finish()` waits for the row count and returns what `dedup` returns."""
+    """A queued scn_dedup_launch; `finish()` waits for the row count and returns what `dedup` returns.
+    shift: an int (coarse site = coordinate >> shift) or a 3-tuple of divisors (coarse site = coordinate // divisor per axis:
+    scn_dedup_launch_div)."""
 
     def __init__(self, coords_i32, shift, want_counts, want_first, extra=()):
         lib = L.lib()
@@ -420,9 +424,15 @@ class _Dedup:
         self.row_coords = torch.empty((n, 4), dtype=torch.int32, device=dev)
         scratch = _empty(lib.scn_dedup_scratch_bytes(n), torch.uint8, dev)
         n_rows = _empty(1, torch.int64, dev)
-        L.check(lib.scn_dedup_launch(L.ptr(coords_i32), n, shift, L.ptr(self.keys), L.ptr(self.rows), self.cap,
-                                     L.ptr(self.item_row), L.ptr(self.row_count), L.ptr(self.row_first),
-                                     L.ptr(self.row_coords), L.ptr(scratch), L.ptr(n_rows), L.stream()))
+        if isinstance(shift, tuple):
+            L.check(lib.scn_dedup_launch_div(L.ptr(coords_i32), n, shift[0], shift[1], shift[2], L.ptr(self.keys),
+                                             L.ptr(self.rows), self.cap, L.ptr(self.item_row), L.ptr(self.row_count),
+                                             L.ptr(self.row_first), L.ptr(self.row_coords), L.ptr(scratch), L.ptr(n_rows),
+                                             L.stream()))
+        else:
+            L.check(lib.scn_dedup_launch(L.ptr(coords_i32), n, shift, L.ptr(self.keys), L.ptr(self.rows), self.cap,
+                                         L.ptr(self.item_row), L.ptr(self.row_count), L.ptr(self.row_first),
+                                         L.ptr(self.row_coords), L.ptr(scratch), L.ptr(n_rows), L.stream()))
         self._rb = _Readback(n_rows, *extra)
 
     def finish(self):
@@ -457,6 +467,7 @@ class Metadata:
         self.grids: Dict[Tuple[int, ...], Grid] = {}
         self.subm: Dict[Tuple[Tuple[int, ...], int], SubmRulebook] = {}
         self.strided: Dict[Tuple[int, ...], StridedRulebook] = {}
+        self.strided_general = {}       # (fine size, stride) -> StridedRulebook for strides other than (2, 2, 2)
         # InputLayer bookkeeping (kept for OutputLayer: custom_operations.py:7-10)
         self.input_size: Optional[Tuple[int, ...]] = None
         self.item_row: Optional[torch.Tensor] = None
@@ -654,8 +665,9 @@ class Metadata:
                 table = torch.empty((k ** 3, g.n), dtype=torch.int32, device=g.coords.device)
                 L.check(lib.scn_subm_table(L.ptr(g.coords), g.n, L.ptr(g.table_keys), L.ptr(g.table_rows), g.cap, k,
                                            L.ptr(table), L.stream()))
+                # (filters above 3^3 -- 125 offsets -- have no mask tiles: the tile kernels hold a tile's offsets in 27 bits)
                 rb = SubmRulebook(table, compact_rules(table, k ** 3, g.n), k, g.n,
-                                  build_tiles(table, k ** 3, g.n, with_x=self.xcd_order))
+                                  build_tiles(table, k ** 3, g.n, with_x=self.xcd_order) if k ** 3 <= 27 else None)
             self.subm[key] = rb
         if k == 3:
             self._note_levels(size, 1)
@@ -688,9 +700,15 @@ class Metadata:
         self.strided[size] = rb
         return rb
 
-    def strided_rulebook(self, size) -> StridedRulebook:
-        """size=stride=2 Convolution from `size` to size/2; creates the coarse grid on first use."""
+    def strided_rulebook(self, size, stride=(2, 2, 2)) -> StridedRulebook:
+        """size = stride Convolution from `size` to size / stride; creates the coarse grid on first use.  stride (2, 2, 2) is the
+        reference's (and the only one the fused index build, the step executor and the level hints know); any other
+        per-axis stride (module_factory.py:221-241) builds its coarse grid and child table on request
+        (`_general_strided_rulebook`)."""
         size = tuple(int(s) for s in size)
+        stride = tuple(int(v) for v in stride)
+        if stride != (2, 2, 2):
+            return self._general_strided_rulebook(size, stride)
         rb = self.strided.get(size)
         if rb is None:
             rb = self._strided_finish(size, self._strided_launch(size))
@@ -698,12 +716,45 @@ class Metadata:
         self._note_levels(size, 2)
         return rb
 
-    def cached_strided_rulebook(self, size):
+    def _general_strided_rulebook(self, size, stride) -> StridedRulebook:
+        rb = self.strided_general.get((size, stride))
+        if rb is not None:
+            return rb
+        if any(st < 1 for st in stride) or any(s % st for s, st in zip(size, stride)):
+            raise L.ScnError(f"Convolution size=stride={stride} needs a spatial size that is a multiple of it, got {size} "
+                             "((out-1)*stride+filter != in)")
+        coarse_size = tuple(s // st for s, st in zip(size, stride))
+        if coarse_size in self.grids and coarse_size != size:
+            raise L.ScnError(f"Metadata already holds a grid of size {coarse_size}")
+        g = self.grid(size)
+        lib = L.lib()
+        dev = g.coords.device
+        n_off = stride[0] * stride[1] * stride[2]
+        if stride == (1, 1, 1):                       # a 1^3 / 1 "downsampler" keeps the grid
+            cg = g
+            parent = torch.arange(g.n, dtype=torch.int32, device=dev)
+        else:
+            cg, parent, _, _ = _Dedup(g.coords, stride, False, False).finish()
+            self.grids[coarse_size] = cg
+            self._depth[coarse_size] = self._depth.get(size, 0) + 1
+        child = torch.empty((n_off, cg.n), dtype=torch.int32, device=dev)
+        fine_off = _empty(g.n, torch.int32, dev)
+        L.check(lib.scn_child_table_div(L.ptr(g.coords), L.ptr(parent), g.n, cg.n, stride[0], stride[1], stride[2],
+                                        L.ptr(child), L.ptr(fine_off), L.stream()))
+        rules = compact_rules(child, n_off, cg.n)
+        tiles = build_tiles(child, n_off, cg.n) if n_off <= 27 else None
+        rb = StridedRulebook(parent, fine_off, child, rules, g.n, cg.n, coarse_size, tiles, n_off, stride)
+        self.strided_general[(size, stride)] = rb
+        return rb
+
+    def cached_strided_rulebook(self, size, stride=(2, 2, 2)):
         """The rulebook a Deconvolution back to `size` re-uses, or None when no layer of this forward has built it."""
         size = tuple(int(s) for s in size)
+        stride = tuple(int(v) for v in stride)
+        if stride != (2, 2, 2):
+            return self.strided_general.get((size, stride))
         return None if size in self._unrequested else self.strided.get(size)
 
-    # ---- index prefetch on a side stream -----------------------------------------------------------
     def prepare_async(self, spatial_size, coords, batch_size: int = 0, mode: int = 4, n_levels: int = 0, k: int = 3,
                       native: bool = False, caller_stream=None, xcd_order: Optional[bool] = None):
         """Build the InputLayer rules (and optionally the rulebook pyramid of an n_levels U-Net) on the index stream.
@@ -759,7 +810,7 @@ class Metadata:
                getattr(self, "_workspace", None)]
         for g in self.grids.values():
             out += [g.coords, g.table_keys, g.table_rows]
-        for rb in list(self.subm.values()) + list(self.strided.values()):
+        for rb in list(self.subm.values()) + list(self.strided.values()) + list(self.strided_general.values()):
             for obj in (rb, getattr(rb, "tiles", None)):
                 if obj is not None:
                     out += [v for v in vars(obj).values() if isinstance(v, torch.Tensor)]

@@ -90,7 +90,7 @@ def _head_of(m):
         m = next(iter(m._modules.values()))
     if type(m) is SubmanifoldConvolution and m.filter_size == 1 and m.groups == 1:
         return m
-    return m if type(m) is Convolution else None
+    return m if (type(m) is Convolution and m.stride == (2, 2, 2)) else None
 
 
 def _kind(seq):
@@ -101,7 +101,8 @@ def _kind(seq):
     from . import executor as EX
     mods = list(seq._modules.values())
     kind = False
-    if len(mods) == 2 and type(mods[0]) is ReLU and type(mods[1]) is Deconvolution and mods[1].bias is not None:
+    if (len(mods) == 2 and type(mods[0]) is ReLU and type(mods[1]) is Deconvolution and mods[1].bias is not None
+            and mods[1].stride == (2, 2, 2)):
         kind = "up"
     elif len(mods) == 2 and _head_of(mods[0]) is not None and type(mods[1]) is Sequential:
         head, blocks = _head_of(mods[0]), EX._plain_blocks(mods[1])
@@ -466,12 +467,15 @@ class SubmanifoldConvolution(_ConvBase):
         return f"{self.nIn}->{self.nOut} C{self.filter_size}" + (f" groups={self.groups}" if self.groups > 1 else "")
 
 
-def _check_s2(filter_size, filter_stride):
+def _size_stride(filter_size, filter_stride):
+    """filter_size == filter_stride, one positive entry per axis (`get_downsampler` / `get_upsampler`, module_factory.py:221-258,
+    hand `stride_tuple` to both arguments; every shipped configuration uses 2)."""
     fs, st = _triple(filter_size, "filter_size"), _triple(filter_stride, "filter_stride")
-    if fs != (2, 2, 2) or st != (2, 2, 2):
+    if fs != st or any(v < 1 for v in st):
         raise NotImplementedError(
-            f"only filter_size = filter_stride = 2 (the reference's down/up-samplers, module_factory.py:221-258); "
+            f"only filter_size == filter_stride (the reference's down/up-samplers, module_factory.py:221-258); "
             f"got size {fs} stride {st}")
+    return st
 
 
 class Convolution(_ConvBase):
@@ -481,22 +485,23 @@ class Convolution(_ConvBase):
         super().__init__()
         if int(dimension) != 3:
             raise NotImplementedError("only dimension 3")
-        _check_s2(filter_size, filter_stride)
-        self._init(8, nIn, nOut, bias)
+        self.stride = _size_stride(filter_size, filter_stride)
+        self._init(self.stride[0] * self.stride[1] * self.stride[2], nIn, nOut, bias)
 
     def forward(self, input, relu_in=False):
         in_size = tuple(int(s) for s in input.spatial_size)
         W, b = self._wb(input.features.shape[1])
-        x = _conv_input(input.features, W.shape[1], W.shape[2], True)
-        y = F.ConvolutionFunction.apply(x, W, b, input.metadata, in_size, relu_in)
-        out_size = torch.as_tensor([s // 2 for s in in_size], dtype=torch.long)
+        x = _conv_input(input.features, W.shape[1], W.shape[2], W.shape[0] <= 27)
+        y = F.ConvolutionFunction.apply(x, W, b, input.metadata, in_size, relu_in, self.stride)
+        out_size = torch.as_tensor([s // st for s, st in zip(in_size, self.stride)], dtype=torch.long)
         return _out(input, _stored(y, W.shape[-1]), out_size)
 
     def input_spatial_size(self, out_size):
-        return out_size * 2
+        return out_size * torch.as_tensor(self.stride, dtype=torch.long)
 
     def extra_repr(self):
-        return f"{self.nIn}->{self.nOut} C2/2"
+        st = self.stride
+        return f"{self.nIn}->{self.nOut} C{st[0]}/{st[0]}" if len(set(st)) == 1 else f"{self.nIn}->{self.nOut} C{st}/{st}"
 
 
 class Deconvolution(_ConvBase):
@@ -506,18 +511,19 @@ class Deconvolution(_ConvBase):
         super().__init__()
         if int(dimension) != 3:
             raise NotImplementedError("only dimension 3")
-        _check_s2(filter_size, filter_stride)
-        self._init(8, nIn, nOut, bias)
+        self.stride = _size_stride(filter_size, filter_stride)
+        self._init(self.stride[0] * self.stride[1] * self.stride[2], nIn, nOut, bias)
 
     def forward(self, input, relu_in=False):
-        out_size = tuple(int(s) * 2 for s in input.spatial_size)
+        out_size = tuple(int(s) * st for s, st in zip(input.spatial_size, self.stride))
         W, b = self._wb(input.features.shape[1])
-        x = _conv_input(input.features, W.shape[1], W.shape[2], True)
-        y = F.DeconvolutionFunction.apply(x, W, b, input.metadata, out_size, relu_in)
+        x = _conv_input(input.features, W.shape[1], W.shape[2], W.shape[0] <= 27)
+        y = F.DeconvolutionFunction.apply(x, W, b, input.metadata, out_size, relu_in, self.stride)
         return _out(input, _stored(y, W.shape[-1]), torch.as_tensor(out_size, dtype=torch.long))
 
     def extra_repr(self):
-        return f"{self.nIn}->{self.nOut} D2/2"
+        st = self.stride
+        return f"{self.nIn}->{self.nOut} D{st[0]}/{st[0]}" if len(set(st)) == 1 else f"{self.nIn}->{self.nOut} D{st}/{st}"
 
 
 class NetworkInNetwork(Module):
@@ -635,14 +641,15 @@ class _Pooling(Module):
         if int(dimension) != 3:
             raise NotImplementedError("only dimension 3")
         ps, st = _triple(pool_size, "pool_size"), _triple(pool_stride, "pool_stride")
-        if ps != (2, 2, 2) or st != (2, 2, 2) or nFeaturesToDrop:
-            raise NotImplementedError("only pool_size = pool_stride = 2 (the reference's down-poolings, "
-                                      "module_factory.py:315-354)")
+        if ps != st or any(v < 1 for v in st) or nFeaturesToDrop:
+            raise NotImplementedError("only pool_size == pool_stride (the reference's down-poolings, "
+                                      "module_factory.py:315-354) and nFeaturesToDrop = 0")
+        self.stride = st
 
     def forward(self, input):
         in_size = tuple(int(s) for s in input.spatial_size)
-        y = F.PoolingFunction.apply(input.features, input.metadata, in_size, self.AVERAGE)
-        return _out(input, y, torch.as_tensor([s // 2 for s in in_size], dtype=torch.long))
+        y = F.PoolingFunction.apply(input.features, input.metadata, in_size, self.AVERAGE, self.stride)
+        return _out(input, y, torch.as_tensor([s // v for s, v in zip(in_size, self.stride)], dtype=torch.long))
 
 
 class MaxPooling(_Pooling):

@@ -154,8 +154,8 @@ class SparseUNet(nn.Module):
         for m in self.modules():
             if getattr(m, "groups", 1) != 1:
                 continue                                     # grouped layers hand over a fresh block-diagonal weight per call
-            if not isinstance(m, M._ConvBase):
-                continue
+            if not isinstance(m, M._ConvBase) or getattr(m, "stride", (2, 2, 2)) != (2, 2, 2):
+                continue                                     # (other strides: images packed per call)
             is_padded = bool(getattr(m, "pad_out_to", None)) or id(m) in padded
             if is_padded:
                 pout = m.pad_out_to or m.nOut

@@ -181,12 +181,12 @@ def shape_stub():
         return out(input, _zeros(input.features.shape[0], self.nOut))
 
     def conv(self, input, relu_in=False):
-        size = [int(s) // 2 for s in input.spatial_size]
+        size = [int(s) // st for s, st in zip(input.spatial_size, self.stride)]
         input.metadata._convolved.add(tuple(int(s) for s in input.spatial_size))
         return out(input, _zeros(input.metadata.rows(size), self.nOut), size)
 
     def deconv(self, input, relu_in=False):
-        size = [int(s) * 2 for s in input.spatial_size]
+        size = [int(s) * st for s, st in zip(input.spatial_size, self.stride)]
         if tuple(size) not in input.metadata._convolved:
             raise scn.ScnError("Deconvolution: no cached Convolution rulebook")
         return out(input, _zeros(input.metadata.rows(size), self.nOut), size)

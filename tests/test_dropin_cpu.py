@@ -258,3 +258,34 @@ def test_reference_feature_extractor_constructs_on_this_package():
             sys.modules.pop("sparseconvnet", None)
         else:
             sys.modules["sparseconvnet"] = saved
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/ndsis"), reason="reference checkout only exists in the build container")
+def test_reference_factories_construct_strided_layers_on_this_package():
+    """`get_downsampler` / `get_upsampler` / `get_down_maxpooling` / `get_down_avgpooling` (module_factory.py:221-258,315-354)
+    with the strides they accept -- an int or one entry per axis (numpy array, as the reference passes them) -- build this
+    package's Convolution / Deconvolution / pooling layers with the filter volume sx sy sz (round 4; the arithmetic:
+    tests/test_gpu_parity.py::test_general_stride_conv_deconv_and_pooling)."""
+    import numpy as np
+    saved = sys.modules.get("sparseconvnet")
+    sys.modules["sparseconvnet"] = scn
+    sys.path.insert(0, "/root/reference")
+    try:
+        from ndsis.modules import module_factory as mf
+        for st, vol in ((3, 27), (np.array([2, 2, 1]), 4), (np.array([1, 2, 3]), 6), (4, 64), (2, 8)):
+            want = tuple(int(v) for v in (np.full(3, st) if np.isscalar(st) else st))
+            _, _, _, d = mf.get_downsampler(3, True, 8, 16, stride=st)
+            _, _, _, u = mf.get_upsampler(3, True, 16, 8, stride=st)
+            _, _, _, mp = mf.get_down_maxpooling(3, True, 8, stride=st)
+            _, _, _, ap = mf.get_down_avgpooling(3, True, 8, stride=st)
+            assert type(d) is scn.Convolution and tuple(d.weight.shape) == (vol, 8, 16) and d.stride == want
+            assert type(u) is scn.Deconvolution and tuple(u.weight.shape) == (vol, 16, 8) and u.stride == want
+            assert type(mp) is scn.MaxPooling and type(ap) is scn.AveragePooling and mp.stride == ap.stride == want
+    finally:
+        sys.path.remove("/root/reference")
+        for k in [k for k in sys.modules if k == "ndsis" or k.startswith("ndsis.")]:
+            del sys.modules[k]
+        if saved is None:
+            sys.modules.pop("sparseconvnet", None)
+        else:
+            sys.modules["sparseconvnet"] = saved

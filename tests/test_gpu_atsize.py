@@ -737,6 +737,52 @@ def test_cfg5_shape_bf16_properties(gpu):
     assert torch.isfinite(outs[1][1]).all() and e["rel_l2"] < 0.1, e
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_cfg5_shape_vs_oracle_at_600k(gpu, dtype):
+    """BASELINE configs[4]'s per-GPU shape against the ORACLE (round 4: the suite's oracle passes run on the job's real CPU
+    threads, so the largest configuration fits too): 600k voxels, five levels 32-64-128-256-512, through the step executor.
+    fp32: forward within 1e-4 of the scale, every one of the 96 parameter gradients and the input gradient within
+    FROZEN_L2_F32 of the oracle with the HIP forward's ReLU masks.  bf16 storage: the oracle with the same roundings (stored
+    slabs and tile-kernel weights rounded to bf16), forward <= 2^-6 of the scale / 1e-2 relative L2, gradients FROZEN_L2_BF16.
+    (n_in >= 2^23 rows is where the raw-buffer fast path ends; 600k rows stay far below: `fast_path` of the bench line.)"""
+    from sparse_rcnn_amd.synthetic import make_batch
+    from sparse_rcnn_amd.unet import Backbone
+    bf16 = dtype == "bf16"
+    coords, feats, size, bs, _ = make_batch(1, (1024, 1024, 512), 600_000, dup=1.15, seed=2)
+    ch = (32, 64, 128, 256, 512)
+    scene = O.OracleScene(coords.numpy())
+    params = O.init_unet_params(7, list(ch), seed=3)
+    net = Backbone(7, ch, bf16_blocks="all" if bf16 else False).to(gpu)
+    net.unet.load_oracle_params(params)
+    fin = feats.to(gpu).requires_grad_()
+    with _record_relu_masks() as masks:
+        out = net(coords, fin, size, 1)
+    assert out.features.shape == (600_000, 32) and len(masks) == 9 * 4 + 4 and _n_stage_nodes(out.features) == 9
+    gy = torch.randn(out.features.shape, generator=torch.Generator().manual_seed(7))
+    out.features.backward(gy.to(gpu))
+    torch.cuda.synchronize()
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    fo = feats.clone().requires_grad_()
+    fr = O.FrozenReLU(masks)
+    kw = dict(storage=O.bf16_storage, tile_weights=O.bf16_storage) if bf16 else {}
+    exp = O.unet_forward(scene, fo, po, list(ch), relu=fr, **kw)
+    assert fr.k == len(masks)
+    exp.backward(gy)
+    own = O.unet_forward(scene, fo.detach(), {k: v.detach() for k, v in po.items()}, list(ch), **kw)
+    name = "cfg5_shape_600k" + ("_bf16_storage" if bf16 else "")
+    e = _err(out.features, own)                       # forward: against the oracle's OWN ReLU decisions
+    if bf16:
+        _record(name, "forward features vs oracle with the same roundings", e, "rel_to_scale <= 2^-6, rel_l2 <= 1e-2")
+        assert e["rel_to_scale"] <= 2.0 ** -6 and e["rel_l2"] <= 1e-2, e
+    else:
+        _record(name, "forward features", e, FEAT_TOL)
+        assert e["rel_to_scale"] <= FEAT_TOL, e
+    bound = FROZEN_L2_BF16 if bf16 else FROZEN_L2_F32
+    for k, p in list(net.unet.named_oracle_params().items()) + [("input features", fin)]:
+        ref = fo.grad if p is fin else po[k].grad.view_as(p)
+        _check_grad_frozen(name, "grad " + k, p.grad, ref, bound)
+
+
 def test_bench_self_launch_two_ranks_on_one_gpu(gpu):
     """`python bench.py --gpus 2` with no torchrun environment starts its own two ranks (gloo here, so that both may share
     cuda:0) and prints ONE JSON line on stdout with n_gpus = 2 -- the launch path of the driver's scaling run."""

@@ -737,6 +737,47 @@ def test_cfg5_shape_bf16_properties(gpu):
     assert torch.isfinite(outs[1][1]).all() and e["rel_l2"] < 0.1, e
 
 
+def test_reference_plan_on_its_training_batch_of_12_crops_vs_oracle(gpu):
+    """`--workload ref-crop`: the network the reference trains (six levels 32-48-64-80-96-112) on the batch it trains on -- 12
+    random crops of 128 x 128 x 64 voxels (scannet_config/run.py:364,485-488), ~12 500 active voxels each, ONE batch of twelve
+    samples: through the step executor (the coarse levels take the four-waves-per-tile loop, the 48 / 80 / 112-channel layers the
+    TAIL slices, the hash holds twelve batch indices), forward within 1e-4 of the scale and every one of the 120 parameter
+    gradients + the input gradient within FROZEN_L2_F32 of the oracle with the HIP forward's ReLU masks."""
+    from sparse_rcnn_amd.synthetic import make_batch
+    from sparse_rcnn_amd.trainstep import REF_PLAN
+    from sparse_rcnn_amd.unet import Backbone
+    from sparse_rcnn_amd import _lib as L
+    coords, feats, size, bs, splits = make_batch(12, (128, 128, 64), 12_500, dup=1.15, seed=21)
+    ch = REF_PLAN
+    scene = O.OracleScene(coords.numpy())
+    params = O.init_unet_params(7, list(ch), seed=5)
+    net = Backbone(7, ch).to(gpu)
+    net.unet.load_oracle_params(params)
+    fin = feats.to(gpu).requires_grad_()
+    L.lib().scn_conv_tiles_split_count(1)
+    with _record_relu_masks() as masks:
+        out = net(coords, fin, size, bs)
+    assert len(masks) == 6 * 4 + 5 * 5 and _n_stage_nodes(out.features) == 11
+    gy = torch.randn(out.features.shape, generator=torch.Generator().manual_seed(8))
+    out.features.backward(gy.to(gpu))
+    torch.cuda.synchronize()
+    assert L.lib().scn_conv_tiles_split_count(1) > 0                    # coarse levels: four waves per tile
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    fo = feats.clone().requires_grad_()
+    fr = O.FrozenReLU(masks)
+    exp = O.unet_forward(scene, fo, po, list(ch), relu=fr)
+    assert fr.k == len(masks)
+    exp.backward(gy)
+    own = O.unet_forward(scene, fo.detach(), {k: v.detach() for k, v in po.items()}, list(ch))
+    name = "ref_plan_12_crops"
+    e = _err(out.features, own)
+    _record(name, "forward features", e, FEAT_TOL)
+    assert out.features.shape[0] == scene.n(0) and out.batch_size() == 12 and e["rel_to_scale"] <= FEAT_TOL, e
+    for k, p in list(net.unet.named_oracle_params().items()) + [("input features", fin)]:
+        ref = fo.grad if p is fin else po[k].grad.view_as(p)
+        _check_grad_frozen(name, "grad " + k, p.grad, ref, FROZEN_L2_F32)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_cfg5_shape_vs_oracle_at_600k(gpu, dtype):
     """BASELINE configs[4]'s per-GPU shape against the ORACLE (round 4: the suite's oracle passes run on the job's real CPU

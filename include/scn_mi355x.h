@@ -656,7 +656,9 @@ int scn_exec_run_streams(const scn_exec_op* ops, int n_ops, const scn_exec_level
  * its SCN_OP_CONV_SUBM / SCN_OP_CONV_CHILD ops -- one launch of the dominant tile kernel each -- with HIP timing events on
  * `stream`.  Process-wide (a node's backward pass runs on the autograd thread).  scn_exec_timing_collect waits for the
  * recorded events, writes per record the elapsed milliseconds and info[7] = (op, bf16 storage, cin, cout, rows in, rows out,
- * rules of the table), returns the number of records written (at most cap) and forgets them all. */
+ * rules of the table), returns the number of records written (at most cap) and forgets them all.
+ * on = 2: EVERY op of a pass is bracketed (weight gradients, row GEMMs, casts: tools/exec_launch_table.py); the deferred unit
+ * sums of a pass run behind its last op and belong to no record. */
 int scn_exec_timing_enable(int on);
 int64_t scn_exec_timing_collect(float* ms, int64_t* info, int64_t cap);
 

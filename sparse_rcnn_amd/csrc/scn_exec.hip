@@ -272,7 +272,7 @@ thread_local EventPool g_events;
 struct TimingRec { hipEvent_t a, b; int64_t info[7]; };
 struct Timing {
     std::mutex mu;
-    bool on = false;
+    bool on = false, all = false;
     std::vector<hipEvent_t> pool;
     size_t used = 0;
     std::vector<TimingRec> recs;
@@ -341,7 +341,7 @@ extern "C" int scn_exec_run_streams(const scn_exec_op* ops, int n_ops, const scn
             SCN_HIP(hipStreamWaitEvent(scn::S(side_stream), e, 0));
             rc = run_op(cs, ops[i]);
             side_used = true;
-        } else if (g_timing.on && (ops[i].op == SCN_OP_CONV_SUBM || ops[i].op == SCN_OP_CONV_CHILD)) {
+        } else if (g_timing.on && (g_timing.all || ops[i].op == SCN_OP_CONV_SUBM || ops[i].op == SCN_OP_CONV_CHILD)) {
             std::lock_guard<std::mutex> lock(g_timing.mu);
             const scn_exec_op& o = ops[i];
             const scn_exec_level& L = levels[o.level];
@@ -350,7 +350,7 @@ extern "C" int scn_exec_run_streams(const scn_exec_op* ops, int n_ops, const scn
             r.a = g_timing.take();
             r.b = g_timing.take();
             if (r.a && r.b) SCN_HIP(hipEventRecord(r.a, scn::S(stream)));
-            rc = run_op(c, ops[i]);
+            rc = run_op(c, ops[i], defer && own[i] ? (char*)scratch + own[i] : nullptr);
             if (r.a && r.b) {
                 SCN_HIP(hipEventRecord(r.b, scn::S(stream)));
                 // op, bf16, cin, cout, rows in, rows out, rules (a child table holds every fine row once)
@@ -386,6 +386,7 @@ extern "C" int scn_exec_run_streams(const scn_exec_op* ops, int n_ops, const scn
 extern "C" int scn_exec_timing_enable(int on) {
     std::lock_guard<std::mutex> lock(g_timing.mu);
     g_timing.on = on != 0;
+    g_timing.all = on == 2;          // 2: every op of a pass (tools/exec_launch_table.py); deferred unit sums are not inside any op
     return SCN_OK;
 }
 

@@ -68,6 +68,8 @@ class KernelTimer:
             n = L.lib().scn_exec_timing_collect(ms, info, cap)
             for k in range(n):
                 op, bf16, cin, cout, n_in, n_out, rules = (int(info[7 * k + j]) for j in range(7))
+                if op not in (2, 3):                                  # (scn_exec_timing_enable(2) times every op: a tool's mode)
+                    continue
                 n_off = 8 if op == 3 else 27                          # SCN_OP_CONV_CHILD = 3
                 es = 2.0 if bf16 else 4.0
                 sh = self.exec_shapes.setdefault((op, bf16, cin, cout, n_out), [0, 0.0, 0.0])

@@ -14,9 +14,18 @@ buckets in: a rank whose ROI crop is empty gives its mask-branch parameters no g
 
 `flat_grad` holds the SUM over ranks of `rank_weight x gradient`; the mean is `flat_grad x grad_scale`.  The scale is
 folded into the SGD step (`alpha = -lr x grad_scale`): no pass over the 50 MB buffer after the last all-reduce.
+
+Gradient accumulation (the reference's only batch-scaling mechanism: `(loss / batches_per_step).backward()` N times, then
+one `optimizer.step()` -- ndsis/training/training.py:436,458-460; `batches_per_step` = 2 or 6 with the mask head,
+scannet_config/run.py:377-396): every micro-batch but the last runs its backward under `with fp.accumulate():` -- the
+bucket hooks count nothing and pack nothing, autograd accumulates into `.grad` -- and the LAST backward, outside the block,
+packs the accumulated `.grad` of a bucket when that bucket's last hook fires: ONE all-reduce per bucket and optimizer step.
+A gradient hook that fires a second time after its bucket has been counted (a second backward with the hooks armed and no
+`zero_grad()` in between) raises: the slice it belongs to may already be on the wire.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import torch
@@ -50,6 +59,7 @@ class FlatParams:
         self.rank_weight = 1.0
         self.grad_scale = 1.0         # mean gradient = flat_grad * grad_scale (valid after all_reduce_mean)
         self.flat_grad_valid = False  # False after a step that never packed the flat buffer (step_single_rank fast path)
+        self.sync = True              # False inside `accumulate()`: a backward only accumulates into `.grad`
         off = 0
         for p in self.params:
             n = p.numel()
@@ -105,11 +115,31 @@ class FlatParams:
     def _reset_buckets(self):
         self._pending = [len(ids) for ids, _ in self.buckets]
         self._ready = [False] * len(self.buckets)
+        self._fired = [False] * len(self.params)
         self._next = 0
         self._works = []
 
+    @contextlib.contextmanager
+    def accumulate(self):
+        """Micro-batches of one optimizer step (training.py:436,458-460): inside the block a backward accumulates into
+        `.grad` and no slice is packed or reduced; run the LAST micro-batch's backward outside it.  (torch DDP's `no_sync`.)"""
+        prev, self.sync = self.sync, False
+        try:
+            yield self
+        finally:
+            self.sync = prev
+
     def _make_hook(self, i):
         def hook(_param):
+            if not self.sync:                    # an accumulating micro-batch: autograd has added into .grad, nothing else
+                return
+            if self._fired[i]:
+                raise RuntimeError(
+                    "FlatParams: the gradient hook of parameter %d fired a second time since zero_grad() -- its slice has "
+                    "been counted (and may be on the wire) with the FIRST backward's gradient only.  Accumulate micro-"
+                    "batches under `with fp.accumulate():` and run only the last backward outside it "
+                    "(training.py:436,458-460), or call zero_grad() between steps." % i)
+            self._fired[i] = True
             b = self._bucket_of[i]
             self._pending[b] -= 1
             if self._pending[b] == 0:
@@ -174,6 +204,8 @@ class FlatParams:
 
         weight: this rank's share (None: `self.rank_weight`).  On the bucketed path the slices were packed and scaled
         during backward, so a weight given here must equal the `rank_weight` that was set before backward."""
+        if not self.sync:
+            raise RuntimeError("all_reduce_mean inside `accumulate()`: the block is for the micro-batches BEFORE the last one")
         w = self.rank_weight if weight is None else float(weight)
         world = float(dist.get_world_size()) if _dist_on(1) else 1.0
         if self.buckets:

@@ -49,8 +49,12 @@ class SparseStepModel(torch.nn.Module):
 
 class SceneStep:
     def __init__(self, workload="cfg2", device=None, dtype="f32", prefetch=True, seed=1, grad_seed=100, n_buckets=4,
-                 target=None, channels=None, grid=None, n_boxes=None, lr=1e-6, weighting="equal"):
-        """weighting: how the ranks' gradients are averaged -- "equal" (1 / world: balanced scenes, the benchmark) or "count"
+                 target=None, channels=None, grid=None, n_boxes=None, lr=1e-6, weighting="equal", batches_per_step=1):
+        """batches_per_step: micro-batches whose gradients are accumulated before ONE all-reduce + update, each scaled by
+        1 / batches_per_step -- the reference's `(loss / batches_per_step).backward()` ... `optimizer.step()`
+        (ndsis/training/training.py:436,458-460; 2 or 6 with the mask head, scannet_config/run.py:377-396).  Micro-batch k
+        is its own scene (seed + 1000 k); all but the last run under `FlatParams.accumulate()`.
+        weighting: how the ranks' gradients are averaged -- "equal" (1 / world: balanced scenes, the benchmark) or "count"
         (each rank in proportion to its active voxels: what a loss normalised by batch-level counts gives when the
         batch is sharded one scene per rank, loss.py:401-431; the counts are summed over ranks once per step)."""
         ch, gr, tg, nb, self.baseline_entry, n_samples = WORKLOADS[workload]
@@ -58,6 +62,12 @@ class SceneStep:
         if weighting not in ("equal", "count"):
             raise ValueError("weighting: equal | count")
         self.weighting = weighting
+        self.batches_per_step = int(batches_per_step)
+        if self.batches_per_step < 1:
+            raise ValueError("batches_per_step >= 1")
+        if self.batches_per_step > 1 and weighting == "count":
+            raise ValueError("count-weighted ranks with gradient accumulation: scale each micro-batch's loss by its own count "
+                             "instead (rank_weight applies to the accumulated sum when a slice is packed)")
         self._total_weight = None
         self.channels = tuple(channels or ch)
         self.grid = tuple(grid or gr)
@@ -66,33 +76,54 @@ class SceneStep:
         if dtype not in ("f32", "bf16", "bf16-blocks"):
             raise ValueError("dtype: f32 | bf16 | bf16-blocks")
         storage = {"f32": False, "bf16": "all", "bf16-blocks": True}[dtype]
-        coords, feats, size, bs, splits = make_batch(n_samples, self.grid, target or tg, dup=1.15, seed=seed)
-        self.coords_cpu, self.feats_cpu, self.size, self.batch_size, self.splits = coords, feats, size, bs, splits
-        self.coords, self.feats = coords.to(self.device), feats.to(self.device)      # resident in HBM
-        self.boxes = make_boxes(coords, self.n_boxes, seed=seed + 2) if self.n_boxes else None
+        self._scenes = []
+        for k in range(self.batches_per_step):
+            coords, feats, size, bs, splits = make_batch(n_samples, self.grid, target or tg, dup=1.15, seed=seed + 1000 * k)
+            boxes = make_boxes(coords, self.n_boxes, seed=seed + 1000 * k + 2) if self.n_boxes else None
+            self._scenes.append(dict(coords_cpu=coords, feats_cpu=feats, size=size, batch_size=bs, splits=splits,
+                                     coords=coords.to(self.device), feats=feats.to(self.device), boxes=boxes))   # resident in HBM
+        self._use_scene(0)
         torch.manual_seed(0)
         self.model = SparseStepModel(self.channels, bool(self.n_boxes), storage).to(self.device)
         self.flat = FlatParams(self.model, n_buckets=n_buckets)
         broadcast_params(self.flat)
         self._gen = torch.Generator(device="cpu").manual_seed(grad_seed)
-        self._gy = self._gm = None
+        self._gys, self._gms = {}, {}
         self._md_next = None
         self.n_active = 0
         self.n_roi_rows = 0
         self.out = self.logits = self.fin = None
 
     # ------------------------------------------------------------------------------------------------------------
-    def forward_backward(self):
-        """Index build + forward + backward (no collective, no update).  Keeps .out / .logits / .fin for checks."""
+    def _use_scene(self, k):
+        sc = self._scenes[k]
+        self.coords_cpu, self.feats_cpu, self.size, self.batch_size, self.splits = (
+            sc["coords_cpu"], sc["feats_cpu"], sc["size"], sc["batch_size"], sc["splits"])
+        self.coords, self.feats, self.boxes = sc["coords"], sc["feats"], sc["boxes"]
+        self._k = k
+
+    def upstream_grads(self, k=0):
+        """(dY of the backbone output, dY of the mask logits or None) of micro-batch k, BEFORE the 1 / batches_per_step scale."""
+        return self._gys.get(k), self._gms.get(k)
+
+    def forward_backward(self, k=0, zero=True):
+        """Index build + forward + backward of micro-batch k (no collective, no update); the upstream gradients are scaled
+        by 1 / batches_per_step.  zero: drop the gradients first (the first micro-batch of a step).
+        Keeps .out / .logits / .fin for checks."""
         m = self.model
-        self.flat.zero_grad()
+        if zero:
+            self.flat.zero_grad()
+        if k != self._k:
+            self._use_scene(k)
+        scale = 1.0 / self.batches_per_step
         fin = self.feats.detach().requires_grad_()
         md = self._md_next.result() if self._md_next is not None else None
         self._md_next = None
         # the index structures of the NEXT batch depend on its coordinates only (a data loader's output): a helper thread
         # builds them on the high-priority index stream while this batch runs; every step contains one complete build
         if self.prefetch:
-            self._md_next = m.backbone.prefetch_in_thread(self.coords, self.size, self.batch_size)
+            nx = self._scenes[(k + 1) % self.batches_per_step]
+            self._md_next = m.backbone.prefetch_in_thread(nx["coords"], nx["size"], nx["batch_size"])
         # cfg3: the ROI crop's selection and the ROI batch's index structures depend on coordinates and boxes only -- the
         # boxes of a step are known before its backbone runs (here: synthetic; in the reference: the RPN's proposals of
         # the same forward, so this applies to the mask branch's SECOND use of a scene, e.g. evaluation on cached proposals)
@@ -100,9 +131,11 @@ class SceneStep:
         if m.mask is not None and EARLY_ROI_CUT:
             cut = m.mask.prepare_cut(self.coords, self.size, self.boxes)      # (resident int64 coords: no dependency on md)
         out = m.backbone(self.coords, fin, self.size, self.batch_size, metadata=md)
-        if self._gy is None or self._gy.shape != out.features.shape:
-            self._gy = torch.randn(out.features.shape, generator=self._gen).to(self.device)   # upstream grad dY ~ N(0,1)
-            self.n_active = out.features.shape[0]
+        gy = self._gys.get(k)
+        if gy is None or gy.shape != out.features.shape:
+            gy = self._gys[k] = torch.randn(out.features.shape, generator=self._gen).to(self.device)   # upstream grad dY ~ N(0,1)
+            self.n_active = sum(g.shape[0] for g in self._gys.values())
+        gys = gy if scale == 1.0 else gy * scale
         if self.weighting == "count":             # before backward: the bucketed path scales slices as it packs them
             import torch.distributed as dist
             self.flat.rank_weight = float(out.features.shape[0])
@@ -112,22 +145,27 @@ class SceneStep:
                 dist.all_reduce(tot)
             self._total_weight = float(tot.item())
         if m.mask is None:
-            out.features.backward(self._gy)
+            out.features.backward(gys)
             logits = None
         else:
             scene = (self.coords, fin, self.size, self.batch_size, self.splits)
             logits, selection = m.mask(scene, out, self.boxes, prepared_cut=cut)
-            if self._gm is None or self._gm.shape != logits.shape:
-                self._gm = torch.randn(logits.shape, generator=self._gen).to(self.device)
-                self.n_roi_rows = logits.shape[0]
+            gm = self._gms.get(k)
+            if gm is None or gm.shape != logits.shape:
+                gm = self._gms[k] = torch.randn(logits.shape, generator=self._gen).to(self.device)
+                self.n_roi_rows = sum(g.shape[0] for g in self._gms.values())
             if logits.requires_grad and logits.shape[0]:
-                torch.autograd.backward([out.features, logits], [self._gy, self._gm])
+                torch.autograd.backward([out.features, logits], [gys, gm if scale == 1.0 else gm * scale])
             else:         # empty crop (no proposal caught a point): the mask branch contributes nothing on this rank
-                out.features.backward(self._gy)
+                out.features.backward(gys)
         self.out, self.logits, self.fin = out, logits, fin
 
     def step(self):
-        self.forward_backward()
+        n = self.batches_per_step
+        for k in range(n - 1):                    # training.py:436: (loss / batches_per_step).backward(), no update yet
+            with self.flat.accumulate():
+                self.forward_backward(k, zero=(k == 0))
+        self.forward_backward(n - 1, zero=(n == 1))       # the last micro-batch: bucket hooks armed, slices go out
         if self.weighting == "count":
             self.flat.all_reduce_mean(total_weight=self._total_weight)
             self.flat.sgd_step(self.lr)

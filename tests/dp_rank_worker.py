@@ -3,7 +3,7 @@ real Backbone (cfg2) or of Backbone + sparse ROI crop + mask branch (cfg3), run 
 MASTER_* in the environment, gloo collective so that two ranks may share one GPU).  Writes the parameters and the
 all-reduced mean gradient as seen by this rank.
 
-argv: out.npz target[/target_rank1] grid_x,grid_y,grid_z [workload [dtype [n_boxes [empty_rank [weighting]]]]]
+argv: out.npz target[/target_rank1] grid_x,grid_y,grid_z [workload [dtype [n_boxes [empty_rank [weighting [batches_per_step]]]]]]
 empty_rank: that rank's boxes are moved outside the scene (its ROI crop is empty: no mask-branch gradients there)."""
 import os
 import sys
@@ -24,13 +24,15 @@ def main():
     n_boxes = int(sys.argv[6]) if len(sys.argv) > 6 else None
     empty_rank = int(sys.argv[7]) if len(sys.argv) > 7 else -1
     weighting = sys.argv[8] if len(sys.argv) > 8 else "equal"
+    bps = int(sys.argv[9]) if len(sys.argv) > 9 else 1            # micro-batches accumulated before the one all-reduce
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     target = targets[rank % len(targets)]
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
     from sparse_rcnn_amd.trainstep import SceneStep
     job = SceneStep(workload, torch.device("cuda", 0), dtype=dtype, prefetch=False, seed=10 + rank, grad_seed=100 + rank,
-                    n_buckets=4, target=target, grid=grid, lr=0.0, n_boxes=n_boxes, weighting=weighting)
+                    n_buckets=4, target=target, grid=grid, lr=0.0, n_boxes=n_boxes, weighting=weighting,
+                    batches_per_step=bps)
     assert job.flat.buckets, "the bucketed, overlapped all-reduce must be active with 2 ranks"
     if rank == empty_rank:
         job.boxes = [b + 10_000.0 for b in job.boxes]
@@ -48,7 +50,8 @@ def main():
     grads = {"g:" + k: views[id(p)].detach().cpu().numpy() for k, p in named.items()}
     mk = {f"mask{i}": np.packbits(m.numpy().reshape(-1)) for i, m in enumerate(masks)}
     mk["mask_shapes"] = np.array([tuple(m.shape) for m in masks], np.int64).reshape(-1, 2)
-    np.savez(out_path, n_active=job.n_active, n_roi_rows=job.n_roi_rows, **params, **grads, **mk)
+    per = np.array([job.upstream_grads(k)[0].shape[0] for k in range(bps)], np.int64)      # active voxels per micro-batch
+    np.savez(out_path, n_active=job.n_active, n_active_per=per, n_roi_rows=job.n_roi_rows, **params, **grads, **mk)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -608,6 +608,60 @@ def test_two_rank_dp_step_matches_oracle(gpu, tmp_path, weighting):
                            mean[k].reshape(-1), FROZEN_L2_F32)
 
 
+def test_two_rank_dp_gradient_accumulation_matches_oracle(gpu, tmp_path):
+    """the reference's batch scaling is `(loss / batches_per_step).backward()` N times, then ONE
+    optimizer step (ndsis/training/training.py:436,458-460).  Two fresh gloo ranks on cuda:0, TWO micro-batches (two scenes)
+    per rank through the step executor with the bucketed all-reduce: the first under FlatParams.accumulate() (hooks pack
+    nothing), the second packs the accumulated `.grad`.  The reduced gradient == the mean over ranks of the oracle's
+    gradients SUMMED over both micro-batches (each scaled by 1/2, each with the ReLU masks its forward recorded)."""
+    target, grid, bps = 8_000, (128, 128, 64), 2
+    port = _free_port()
+    procs, outs = [], []
+    for r in range(2):
+        out = str(tmp_path / f"rank{r}.npz")
+        outs.append(out)
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_rank_worker.py"), out, str(target),
+                                       ",".join(map(str, grid)), "cfg2", "f32", "0", "-1", "equal", str(bps)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), logs
+    z = [np.load(o) for o in outs]
+    from sparse_rcnn_amd.synthetic import make_batch
+    ch = [32, 64, 128, 256]
+    names = [n for n, _ in O.unet_param_shapes(7, ch)]
+    shapes = dict(O.unet_param_shapes(7, ch))
+    for k in names:
+        assert np.array_equal(z[0][k], z[1][k]), k
+        assert np.array_equal(z[0]["g:" + k], z[1]["g:" + k]), k
+    def oracle_rank(r):
+        masks = _load_masks(z[r])
+        assert len(masks) == 31 * bps
+        gen = torch.Generator().manual_seed(100 + r)             # SceneStep draws dY of micro-batch 0, then of micro-batch 1
+        tot = None
+        for k in range(bps):
+            coords, feats, size, bs, _ = make_batch(1, grid, target, dup=1.15, seed=10 + r + 1000 * k)
+            scene = O.OracleScene(coords.numpy())
+            assert scene.n(0) == int(z[r]["n_active_per"][k])
+            po = {n: torch.from_numpy(z[0][n]).view(shapes[n]).requires_grad_() for n in names}
+            out = O.unet_forward(scene, feats, po, ch, relu=O.FrozenReLU(masks[31 * k:31 * (k + 1)]))
+            gy = torch.randn(out.shape, generator=gen)
+            out.backward(gy / bps)
+            tot = {n: po[n].grad if tot is None else tot[n] + po[n].grad for n in names}
+        return {n: tot[n] / 2 for n in names}, {n: po[n].grad / 2 for n in names}
+    grs = _both_ranks(oracle_rank)
+    for k in names:
+        got = torch.from_numpy(z[0]["g:" + k]).reshape(-1)
+        mean = (grs[0][0][k] + grs[1][0][k]).reshape(-1)
+        _check_grad_frozen("cfg4_two_rank_dp_accumulation", "mean grad " + k, got, mean, FROZEN_L2_F32)
+    # ... and it is NOT one micro-batch's gradient (what the bucket hooks of round 4 reduced without a word)
+    k = "enc3.res1.conv1.weight"
+    last_only = (grs[0][1][k] + grs[1][1][k]).reshape(-1)
+    got = torch.from_numpy(z[0]["g:" + k]).reshape(-1)
+    assert (got - last_only).norm() > 0.1 * got.norm()
+
+
 @pytest.mark.parametrize("case", ["bf16", "f32-empty-rank"])
 def test_two_rank_dp_cfg3_step_matches_oracle(gpu, tmp_path, case):
     """BASELINE configs[3] (data-parallel detection + mask step) on what one GPU can run: two fresh

@@ -113,6 +113,120 @@ def _dp_worker_uneven(rank, world, port, out, weighted):
     dist.destroy_process_group()
 
 
+def _dp_worker_accum(rank, world, port, out, n_buckets, bps):
+    """`bps` micro-batches per optimizer step (training.py:436,458-460): all but the last under fp.accumulate().  The mask
+    head runs on rank 0 in the FIRST micro-batch only: its parameters hold an accumulated gradient whose hook never fires
+    in the last backward (the forced drain must still pack it)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = _TwoHeads()
+    fp = FlatParams(net, n_buckets=n_buckets)
+    broadcast_params(fp)
+    assert bool(fp.buckets) == bool(n_buckets)
+    res = []
+    for step in range(2):
+        fp.zero_grad()
+        launched = []
+        orig = fp._launch_bucket
+        fp._launch_bucket = lambda b, orig=orig: (launched.append(b), orig(b))[1]
+        parts = []
+        for k in range(bps):
+            x = torch.full((4, 6), float(rank + 1 + step)) + 0.25 * k + torch.arange(6.0) * 0.1
+            h = net.backbone(x)
+            loss = h.sum()
+            if rank == 0 and k == 0:
+                loss = loss + net.mask(h).square().sum()
+            gs = torch.autograd.grad(loss / bps, fp.params, allow_unused=True, retain_graph=True)
+            parts.append(torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(gs, fp.params)]))
+            if k < bps - 1:
+                with fp.accumulate():
+                    (loss / bps).backward()
+                assert launched == [], launched            # nothing goes out before the last micro-batch
+            else:
+                (loss / bps).backward()
+        fp.all_reduce_mean()
+        fp._launch_bucket = orig
+        if n_buckets:
+            assert launched == list(range(len(fp.buckets))), launched        # every slice exactly once, in order
+        res.append((torch.stack(parts).numpy().copy(), fp.mean_grad().numpy().copy()))
+        fp.sgd_step(0.05)
+    out.put((rank, fp.flat.detach().numpy().copy(), res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bps", [2, 6])
+def test_gradient_accumulation_world2_bucketed_equals_unbucketed(bps):
+    """`batches_per_step` micro-batches, ONE all-reduce per optimizer step.  The reduced gradient == the
+    single-process accumulation over all micro-batches of both ranks, and the bucketed path is bit-equal to the unbucketed
+    one (two optimizer steps, so that zero_grad re-arms the hooks)."""
+    ctx = mp.get_context("spawn")
+    got = {}
+    for nb in (0, 3):
+        q = ctx.Queue()
+        port = _free_port()
+        ps = [ctx.Process(target=_dp_worker_accum, args=(r, 2, port, q, nb, bps)) for r in range(2)]
+        for p in ps: p.start()
+        res = sorted([q.get(timeout=180) for _ in ps], key=lambda t: t[0])
+        for p in ps: p.join(60)
+        (_, w0, r0), (_, w1, r1) = res
+        assert np.array_equal(w0, w1)                                   # ranks stay in lock-step
+        for (p0, m0), (p1, m1) in zip(r0, r1):
+            assert np.array_equal(m0, m1)
+            want = (p0.astype(np.float64).sum(0) + p1.astype(np.float64).sum(0)) / 2     # all micro-batches of both ranks
+            assert np.allclose(m0, want, rtol=2e-6, atol=1e-6), np.abs(m0 - want).max()
+            assert np.abs(p0[1:]).sum() > 0                             # the later micro-batches do contribute
+            first_only = (p0[0] + p1[0]) / 2
+            assert np.abs(m0 - first_only).max() > 1e-2                 # (what round 4's hooks silently produced)
+        got[nb] = (w0, [m for _, m in r0])
+    assert np.array_equal(got[0][0], got[3][0])
+    for a, b in zip(got[0][1], got[3][1]):
+        assert np.array_equal(a, b)                                     # bucketed == unbucketed, bit for bit
+
+
+def test_second_backward_with_armed_hooks_raises():
+    """A second backward with the bucket hooks armed and no zero_grad() (accumulation WITHOUT fp.accumulate()) must not be
+    dropped silently: the hook raises, naming the remedy.  Inside fp.accumulate() the same sequence is fine."""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%r, RANK="0", WORLD_SIZE="1", SCN_DP_FORCE_BUCKETS="1")
+dist.init_process_group("gloo")
+from sparse_rcnn_amd.dp import FlatParams
+net = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.Linear(4, 2))
+fp = FlatParams(net, n_buckets=2)
+assert fp.buckets
+x = torch.ones(1, 3)
+fp.zero_grad(); net(x).sum().backward()
+try:
+    net(2 * x).sum().backward()
+    print("NOT RAISED")
+except RuntimeError as e:
+    assert "accumulate" in str(e), e
+    print("RAISED")
+fp.all_reduce_mean()
+fp.zero_grad()
+with fp.accumulate():
+    net(x).sum().backward()
+net(2 * x).sum().backward()
+fp.all_reduce_mean()
+g1 = fp.mean_grad().clone()
+fp.zero_grad(); net(x).sum().backward(); fp.all_reduce_mean(); a = fp.mean_grad().clone()
+fp.zero_grad(); net(2 * x).sum().backward(); fp.all_reduce_mean(); b = fp.mean_grad().clone()
+assert torch.allclose(g1, a + b), (g1, a + b)
+try:
+    with fp.accumulate():
+        fp.all_reduce_mean()
+    print("NO GUARD")
+except RuntimeError:
+    print("GUARDED")
+''' % (ROOT, str(_free_port()))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RAISED" in r.stdout and "NOT RAISED" not in r.stdout and "GUARDED" in r.stdout, \
+        (r.stdout, r.stderr[-2000:])
+
+
 def test_flat_bucket_all_reduce_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -33,12 +33,12 @@ for _ in range(N):
     out = m.backbone(job.coords, fin, job.size, job.batch_size, metadata=md)
     t = tick("backbone forward", t)
     if m.mask is None:
-        out.features.backward(job._gy)
+        out.features.backward(job.upstream_grads()[0])
     else:
         scene = (job.coords, fin, job.size, job.batch_size, job.splits)
         logits, selection = m.mask(scene, out, job.boxes)
         t = tick("mask branch forward", t)
-        torch.autograd.backward([out.features, logits], [job._gy, job._gm])
+        torch.autograd.backward([out.features, logits], [job.upstream_grads()[0], job.upstream_grads()[1]])
     t = tick("backward", t)
     job.flat.step_single_rank(job.lr)
     t = tick("optimizer", t)

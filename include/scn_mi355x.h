@@ -54,7 +54,9 @@ extern "C" {
  *      changed (tables built by version <= 2 libraries are not probe-compatible; no table outlives a Metadata, so only a
  *      caller that kept raw tables across a library upgrade is affected); + scn_exec_timing_enable / _collect, scn_pad_params_many, scn_conv_tiles_split_count, scn_dedup_launch_div, scn_child_table_div (107 entry points);
  *      scn_pool_fwd / _bwd (+ _bf16): `average` carries the pool volume above bit 8 (0 = the 2^3 of every configuration) */
-#define SCN_ABI_VERSION 3
+/*   4  round 5: + scn_debug_set / scn_debug_get (developer switches no longer follow the ambient environment per launch);
+ *      scn_exec_timing_collect forgets only the records it returned */
+#define SCN_ABI_VERSION 4
 
 /* flags for the gather-GEMM entry points */
 #define SCN_F_RELU_IN 1      /* use max(X,0) as the input slab (fuses scn.ReLU before a conv, module_factory.py:88,173-176) */
@@ -73,6 +75,13 @@ typedef void* scn_stream_t;
 
 int scn_abi_version(void);
 const char* scn_last_error_string(void);
+
+/* Developer switches (round 5; no reference counterpart -- A/B and cross-check knobs of this library's own kernel variants,
+ * e.g. SCN_TS_NO_TAIL, SCN_TB_STREAM, SCN_PYRAMID_V1: the list is scn_debug.hip's table).  The environment is read ONCE, at
+ * the first use of any switch; afterwards a switch changes only through scn_debug_set (value NULL: unset).  The product path
+ * never scans the environment per launch (rounds 1-4: ~300 getenv calls per step).  Unknown name: SCN_EINVAL. */
+int scn_debug_set(const char* name, const char* value);
+int scn_debug_get(const char* name, int* is_set, int64_t* value);
 
 /* ------------------------------------------------------------------------------------------
  * Index path: scn.Metadata / InputLayer rules / rulebooks
@@ -656,7 +665,8 @@ int scn_exec_run_streams(const scn_exec_op* ops, int n_ops, const scn_exec_level
  * its SCN_OP_CONV_SUBM / SCN_OP_CONV_CHILD ops -- one launch of the dominant tile kernel each -- with HIP timing events on
  * `stream`.  Process-wide (a node's backward pass runs on the autograd thread).  scn_exec_timing_collect waits for the
  * recorded events, writes per record the elapsed milliseconds and info[7] = (op, bf16 storage, cin, cout, rows in, rows out,
- * rules of the table), returns the number of records written (at most cap) and forgets them all.
+ * rules of the table), returns the number of records written (at most cap) and forgets THOSE (round 5: a caller whose buffer
+ * is smaller than the backlog calls again for the rest; rounds 3-4 dropped what did not fit).
  * on = 2: EVERY op of a pass is bracketed (weight gradients, row GEMMs, casts: tools/exec_launch_table.py); the deferred unit
  * sums of a pass run behind its last op and belong to no record. */
 int scn_exec_timing_enable(int on);

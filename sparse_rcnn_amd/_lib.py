@@ -21,6 +21,8 @@ i32, i64, f32 = C.c_int, C.c_int64, C.c_float
 _SIGS = {
     "scn_abi_version": (C.c_int, []),
     "scn_last_error_string": (C.c_char_p, []),
+    "scn_debug_set": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "scn_debug_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(i64)]),
     "scn_hash_capacity": (i64, [i64]),
     "scn_coords_to_i32": (C.c_int, [p, i64, p, p, C.POINTER(i64), p]),
     "scn_dedup_scratch_bytes": (i64, [i64]),
@@ -133,7 +135,7 @@ EXPORTS = tuple(_SIGS)
 F_RELU_IN, F_W_TRANSPOSED, F_OFF_REVERSE, F_RESIDUAL_LAST, F_SPLIT_SUM, F_GEMM_V1 = 1, 2, 4, 8, 16, 32
 F_TILE_ORDER_X = 64
 OK, EINVAL, ESIZE, EHASH, EHIP = 0, 1, 2, 3, 4
-ABI_VERSION = 3                 # include/scn_mi355x.h SCN_ABI_VERSION this host layer was written against
+ABI_VERSION = 4                 # include/scn_mi355x.h SCN_ABI_VERSION this host layer was written against
 PYRAMID_MAX_LEVELS, PYRAMID_LEVEL_STRIDE = 8, 72
 PYRAMID_TWO_QUEUES = 1
 PYRAMID_XCD_ORDER = 2
@@ -179,6 +181,37 @@ def lib():
         _gpu_ok = True
         return l
     return _lib
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def debug_switch(name: str, value):
+    """A developer switch of the library (scn_debug.hip's table) set for the duration of the block -- the tests' A/B runs of
+    two kernel variants inside one process.  The library reads the environment once, at the first use of any switch; after
+    that only scn_debug_set changes one (no getenv per launch).  value None: unset."""
+    l = load()
+    was_set, was = C.c_int(0), i64(0)
+    check(l.scn_debug_get(name.encode(), C.byref(was_set), C.byref(was)))
+    check(l.scn_debug_set(name.encode(), None if value is None else str(value).encode()))
+    try:
+        yield
+    finally:
+        check(l.scn_debug_set(name.encode(), str(was.value).encode() if was_set.value else None))
+
+
+class _Switches:
+    """`switches["SCN_TS_NO_TAIL"] = "1"` / `del switches["SCN_TS_NO_TAIL"]`: scn_debug_set in mapping clothes."""
+
+    def __setitem__(self, name, value):
+        check(load().scn_debug_set(name.encode(), str(value).encode()))
+
+    def __delitem__(self, name):
+        check(load().scn_debug_set(name.encode(), None))
+
+
+switches = _Switches()
 
 
 def check(rc: int):

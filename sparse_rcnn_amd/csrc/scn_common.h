@@ -44,6 +44,15 @@ inline int fail(int code, const char* fmt, const char* a = "", long long b = 0, 
         }                                                                                           \
     } while (0)
 
+// Developer switches (scn_debug.hip): the environment is read once at first use; later changes go through scn_debug_set().
+enum Switch {
+    SW_TS_SPLIT, SW_TS_SPLIT_MAX, SW_TS_NO_TAIL, SW_TS_W_HALF, SW_TS_W_BOTH, SW_TB_NB, SW_TB_KH, SW_TB_STREAM,
+    SW_TB_NO_XORDER, SW_TS_STREAM, SW_TSS_NW, SW_EXEC_DEFER_SUMS, SW_PYRAMID_V1, SW_PYRAMID_ONE_STREAM, SW_WD_NO_T3,
+    SW_WGRAD_BF16_MFMA, SW_WGRAD_SPLITS, SW_WD_NO_EVEC, SW_TS_L0, SW_TB_PAIR, SW_EXP_A, SW_EXP_B, SW_COUNT
+};
+struct SwitchVal { bool set = false; long long i = 0; double f = 0.0; };
+SwitchVal sw(Switch s);
+
 inline hipStream_t S(scn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -628,9 +628,9 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     // tile's serial chain of up to 27 dependent gathers, so four waves share a tile.  Decided from the tile and slice counts
     // alone: every form of a layer (fused / two-launch K reduction, TAIL / padded slices) takes the same loop.
     // SCN_TS_SPLIT=0: never (A/B; the cross-check in the tests -- the two loops associate an element's sum differently).
-    const char* sp_env = getenv("SCN_TS_SPLIT");                        // (read per call: the tests switch it inside one process)
-    static const int64_t sp_max = getenv("SCN_TS_SPLIT_MAX") ? atoll(getenv("SCN_TS_SPLIT_MAX")) : 2048;   // (developer switch)
-    const bool split4 = fullk && nt * n_chunks * n_kc <= sp_max && !(sp_env && atoi(sp_env) == 0);
+    const scn::SwitchVal sp_sw = scn::sw(scn::SW_TS_SPLIT);            // (scn_debug_set: the tests switch it inside one process)
+    static const int64_t sp_max = scn::sw(scn::SW_TS_SPLIT_MAX).set ? scn::sw(scn::SW_TS_SPLIT_MAX).i : 2048;   // (developer switch)
+    const bool split4 = fullk && nt * n_chunks * n_kc <= sp_max && !(sp_sw.set && sp_sw.i == 0);
     const int tiles_per_round = split4 ? TS_NW / 4 : TS_NW;
     const size_t lds = (size_t)n_off * TS_KC * TS_CT * sizeof(float) + 16 + (split4 ? (size_t)2 * (TS_NW / 4) * 3 * 2 * 64 * 16 : 0);   // two buffers of partial tiles
     int wg_per_cu = (int)((160 * 1024) / lds);
@@ -647,12 +647,12 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     // not shrink with the MFMAs; calibrated with tools/ablate_conv_tail.py on the 48 / 80 / 112-channel layers:
     // profiles/r3_ablate_conv_tail.txt).
     const bool k_tail = cin % TS_KC != 0 && cin % TS_KC <= 16, n_tail = cout % TS_CT != 0 && cout % TS_CT <= 16;
-    const bool tail = fullk && (k_tail || n_tail) && !getenv("SCN_TS_NO_TAIL");
+    const bool tail = fullk && (k_tail || n_tail) && !scn::sw(scn::SW_TS_NO_TAIL).set;
     TsSlices slices = {0, 0, 0, 0};
     int64_t grid_x = n_tg * n_chunks * n_kc;
     if (tail) {
-        static const double w_half = getenv("SCN_TS_W_HALF") ? atof(getenv("SCN_TS_W_HALF")) : 0.70;
-        static const double w_both = getenv("SCN_TS_W_BOTH") ? atof(getenv("SCN_TS_W_BOTH")) : 0.50;
+        static const double w_half = scn::sw(scn::SW_TS_W_HALF).set ? scn::sw(scn::SW_TS_W_HALF).f : 0.70;
+        static const double w_both = scn::sw(scn::SW_TS_W_BOTH).set ? scn::sw(scn::SW_TS_W_BOTH).f : 0.50;
         const int ncf = n_chunks - (n_tail ? 1 : 0), nkf = n_kc - (k_tail ? 1 : 0);
         const double wsum = (double)nkf * ncf + (n_tail ? nkf * w_half : 0.0) + (k_tail ? ncf * w_half : 0.0) +
                             (n_tail && k_tail ? w_both : 0.0);

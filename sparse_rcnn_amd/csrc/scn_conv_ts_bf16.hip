@@ -709,8 +709,8 @@ namespace {
 struct TbShape { int nb, kh, ct, kc, n_chunks, n_kc; };
 
 TbShape tb_shape(int cin, int cout) {
-    static const int nb_env = getenv("SCN_TB_NB") ? atoi(getenv("SCN_TB_NB")) : 0;      // developer switches
-    static const int kh_env = getenv("SCN_TB_KH") ? atoi(getenv("SCN_TB_KH")) : 0;
+    static const int nb_env = (int)scn::sw(scn::SW_TB_NB).i;      // developer switches
+    static const int kh_env = (int)scn::sw(scn::SW_TB_KH).i;
     // shapes: 32 columns x 32 channels (small layers), 64 columns x 32 channels, 32 columns x 64 channels -- the last
     // halves the number of K-chunks (no partial sums at Cin = 64) at twice the gather traffic per output
     TbShape s;
@@ -893,8 +893,8 @@ extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, con
     // 30.0 / 26.9 / 27.7 -- it wins only where one offset's slice is small (Cin = 64), so THAT is what it runs by default:
     // SubM 3^3 layers with two K-chunks.  SCN_TB_STREAM=1: every eligible layer (Cin = 64 / 128 / 256, 3^3 and 2^3 tables);
     // SCN_TB_STREAM=0: none (k_conv_tb everywhere: A/B, cross-check in the tests)
-    const char* ts_env = getenv("SCN_TB_STREAM");                   // (read per call: the tests switch it inside one process)
-    const int ts_mode = ts_env ? atoi(ts_env) : -1;
+    const scn::SwitchVal ts_sw = scn::sw(scn::SW_TB_STREAM);        // (scn_debug_set: the tests switch it inside one process)
+    const int ts_mode = ts_sw.set ? (int)ts_sw.i : -1;
     const bool ts_eligible = n_kc >= 2 && kh == 1 && nb == 4 && cin % 32 == 0 && (n_kc == 2 || n_kc == 4 || n_kc == 8) &&
                              (n_off == 27 || n_off == 8) && !(flags & SCN_F_SPLIT_SUM);
     if (ts_eligible && ts_mode != 0 && (ts_mode == 1 || (n_kc == 2 && n_off == 27))) {
@@ -949,7 +949,7 @@ extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, con
     // XCD-local hand-out (SCN_F_TILE_ORDER_X): possible when the slices of a tile group fall on 8 / n_slices whole groups of
     // XCDs, i.e. 1, 2 or 4 slices; with 8 or more every XCD sees every tile group anyway
     const int n_slices = n_chunks * n_kc;
-    const bool x_off = getenv("SCN_TB_NO_XORDER") != nullptr;        // (read per call: the tests switch it inside one process)
+    const bool x_off = scn::sw(scn::SW_TB_NO_XORDER).set;             // (scn_debug_set: the tests switch it inside one process)
     const int xbins = ((flags & SCN_F_TILE_ORDER_X) && !x_off && (n_slices == 1 || n_slices == 2 || n_slices == 4) &&
                        n_tg >= 8) ? 8 / n_slices : 1;
 #define LAUNCH_TB(N, K, FU, PT)                                                                                     \

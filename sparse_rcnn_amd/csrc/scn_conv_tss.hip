@@ -267,8 +267,7 @@ int conv_tiles_stream(const float* X, int64_t n_in, int cin, const int32_t* tsta
     // 86.5 / 114.4 us per launch at levels 1 / 2 with 4-wave workgroups, 119 / 144 with 16 / 8, against 69.4 / 65.9) -- the
     // lockstep over the union of a batch's offset masks idles the waves whose tile lacks an offset, and the mask-sorted
     // tiles of a surface scene differ too much for any batch size to hide that.  SCN_TS_STREAM=1 runs it (tests, A/B).
-    const char* env = getenv("SCN_TS_STREAM");                      // (read per call: the tests switch it inside one process)
-    if (!(env && atoi(env) == 1)) return SCN_OK;
+    if (scn::sw(scn::SW_TS_STREAM).i != 1) return SCN_OK;           // (scn_debug_set: the tests switch it inside one process)
     const int ks = cin / 32;
     const bool ok = cin % 32 == 0 && (ks == 2 || ks == 4) && cout % SS_CT == 0 && (n_off == 27 || n_off == 8) &&
                     !(flags & SCN_F_SPLIT_SUM) && (((uintptr_t)X | (uintptr_t)W) & 15) == 0 &&
@@ -283,7 +282,7 @@ int conv_tiles_stream(const float* X, int64_t n_in, int cin, const int32_t* tsta
     // consecutive tiles the union is ~25 of 27 offsets for tiles that have ~14 each, and the SIMD a stalled wave sits on has
     // nobody else to run (measured: 119 us per launch at level 1 against k_conv_ts's 69).  With 4 waves per workgroup (one per
     // SIMD) the union stays near a tile's own mask and the other resident workgroups of the CU fill the matrix pipe.
-    static const int nw_env = getenv("SCN_TSS_NW") ? atoi(getenv("SCN_TSS_NW")) : 0;
+    static const int nw_env = (int)scn::sw(scn::SW_TSS_NW).i;
     const int nw = (nw_env == 4 || nw_env == 8 || nw_env == 16) ? (ks == 4 && nw_env == 16 ? 8 : nw_env) : 4;
     const size_t lds0 = (size_t)2 * ks * 32 * SS_CT * sizeof(float) + (size_t)nw * (((n_off + 1) * 16 + 63) / 64 * 64) * 4 + 16;
     int64_t per_cu = (int64_t)((160 * 1024) / lds0);

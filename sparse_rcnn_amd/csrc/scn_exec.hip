@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <vector>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -272,7 +273,7 @@ thread_local EventPool g_events;
 struct TimingRec { hipEvent_t a, b; int64_t info[7]; };
 struct Timing {
     std::mutex mu;
-    bool on = false, all = false;
+    std::atomic<bool> on{false}, all{false};        // read outside the mutex on every op of a pass
     std::vector<hipEvent_t> pool;
     size_t used = 0;
     std::vector<TimingRec> recs;
@@ -307,7 +308,7 @@ extern "C" int scn_exec_run_streams(const scn_exec_op* ops, int n_ops, const scn
     // Deferred sums: the unit sums of the pass's weight-gradient launches run as ONE batched launch at its end (7 us
     // launches of a few hundred workgroups each, 27 per backbone step; SCN_EXEC_DEFER_SUMS=0: one sum per launch).  Needs
     // the per-op scratch regions scn_exec_requirements counts; a caller that sized the scratch otherwise keeps the old form.
-    static const bool defer_env = !(getenv("SCN_EXEC_DEFER_SUMS") && atoi(getenv("SCN_EXEC_DEFER_SUMS")) == 0);
+    static const bool defer_env = !(scn::sw(scn::SW_EXEC_DEFER_SUMS).set && scn::sw(scn::SW_EXEC_DEFER_SUMS).i == 0);
     // (the weight-gradient needs are computed once per pass and only for passes that have such ops: backward passes)
     int n_wg = 0;
     for (int i = 0; i < n_ops; ++i) n_wg += is_wgrad(ops[i].op) ? 1 : 0;
@@ -393,16 +394,19 @@ extern "C" int scn_exec_timing_enable(int on) {
 extern "C" int64_t scn_exec_timing_collect(float* ms, int64_t* info, int64_t cap) {
     std::lock_guard<std::mutex> lock(g_timing.mu);
     int64_t n = 0;
-    for (const TimingRec& r : g_timing.recs) {
-        if (n >= cap) break;
+    size_t taken = 0;
+    // Only the records handed out (or unreadable) leave the list: a caller with a smaller buffer calls again and gets the
+    // rest.  The event pool is recycled once no record names an event any more.
+    for (; taken < g_timing.recs.size() && n < cap; ++taken) {
+        const TimingRec& r = g_timing.recs[taken];
         float t = 0.f;
         if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
         ms[n] = t;
         for (int j = 0; j < 7; ++j) info[7 * n + j] = r.info[j];
         ++n;
     }
-    g_timing.recs.clear();
-    g_timing.used = 0;
+    g_timing.recs.erase(g_timing.recs.begin(), g_timing.recs.begin() + (ptrdiff_t)taken);
+    if (g_timing.recs.empty()) g_timing.used = 0;
     return n;
 }
 

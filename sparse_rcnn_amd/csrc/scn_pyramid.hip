@@ -137,7 +137,7 @@ extern "C" int scn_pyramid_build_ex(const int64_t* coords, int64_t n_points, int
     SCN_REQUIRE(k == 1 || k == 3);
     SCN_REQUIRE(((uintptr_t)workspace & 255) == 0);
     // SCN_PYRAMID_FUSED: the build without host round trips (scn_pyramid2.hip); SCN_PYRAMID_V1=1 keeps this file's builder
-    if ((flags & SCN_PYRAMID_FUSED) && k == 3 && getenv("SCN_PYRAMID_V1") == nullptr)
+    if ((flags & SCN_PYRAMID_FUSED) && k == 3 && !scn::sw(scn::SW_PYRAMID_V1).set)
         return scn::pyramid2_build(coords, n_points, n_levels, k, workspace, workspace_bytes, desc, flags, stream);
     const int n_off = k * k * k;
     hipStream_t st = S(stream);
@@ -175,7 +175,7 @@ extern "C" int scn_pyramid_build_ex(const int64_t* coords, int64_t n_points, int
     const int64_t n_rows = hs.words[0];
     const int32_t bad = (int32_t)hs.words[1];
     desc[3] = bad;
-    const bool two = (flags & SCN_PYRAMID_TWO_QUEUES) && getenv("SCN_PYRAMID_ONE_STREAM") == nullptr;
+    const bool two = (flags & SCN_PYRAMID_TWO_QUEUES) && !scn::sw(scn::SW_PYRAMID_ONE_STREAM).set;
     bool side_used[HostSlots::NSIDE] = {};
     // an error return while side streams still work on the caller's workspace must not hand that workspace back
     struct SideGuard {

@@ -700,7 +700,7 @@ Shape pick_shape(int cin, int cout, bool hb = false) {
     s.quad = cin > 64 && cout > 64;
     // the reference's 48- and 96-channel layers (scannet_config/run.py:539-549): whole multiples of a 48-wide wave block
     // (TA = TB = 3) -- 64- / 128-wide blocks execute 1.78x their MFMAs (fp32 rows only: no packed-bf16 ring for T = 3)
-    const bool no_t3 = getenv("SCN_WD_NO_T3") != nullptr;         // (read per call: the tests switch it inside one process)
+    const bool no_t3 = scn::sw(scn::SW_WD_NO_T3).set;              // (scn_debug_set: the tests switch it inside one process)
     if (!hb && !no_t3 && cin % 48 == 0 && cout % 48 == 0 && cin <= 96 && cout <= 96) { s.ta = s.tb = 3; s.quad = false; }
     return s;
 }
@@ -708,7 +708,7 @@ Shape pick_shape(int cin, int cout, bool hb = false) {
 // bf16 MFMA kernel: tiles of 16 channels per wave along Cin / Cout (workgroup block 32 T x 32 T)
 int tb_tiles(int c) { return c <= 32 ? 1 : (c <= 64 ? 2 : 4); }
 bool tb_usable(int cin, int cout) {
-    static const bool off = getenv("SCN_WGRAD_BF16_MFMA") && atoi(getenv("SCN_WGRAD_BF16_MFMA")) == 0;
+    static const bool off = scn::sw(scn::SW_WGRAD_BF16_MFMA).set && scn::sw(scn::SW_WGRAD_BF16_MFMA).i == 0;
     return !off && cin % 8 == 0 && cout % 8 == 0;
 }
 
@@ -737,11 +737,11 @@ int make_dplan(int cin, int cout, const int64_t* prefix_host, int n_off, DPlan& 
     const bool tb_big = hb_mfma && tb_tiles(cin) == 4 && tb_tiles(cout) == 4;      // 128 x 128 workgroup blocks
     if (hb_mfma) { occ = 4; rounds = 1; }                                   // 32 KB of LDS, <= 128 registers: 4 per CU
     int64_t target = (256 * occ * rounds) / nblk - n_off;
-    if (const char* e = getenv("SCN_WGRAD_SPLITS")) target = atoi(e);       // developer override
+    if (scn::sw(scn::SW_WGRAD_SPLITS).set) target = (int)scn::sw(scn::SW_WGRAD_SPLITS).i;       // developer override
     if (target < 1) target = 1;
     const int64_t gran = hb_mfma ? 32 : (sh.quad ? 16 : 64);
     int64_t per = cdiv(cdiv(total, target), gran) * gran;
-    if (tb_big && !getenv("SCN_WGRAD_SPLITS") && n_off > 0 && total > 0 && per < 1024) {
+    if (tb_big && !scn::sw(scn::SW_WGRAD_SPLITS).set && n_off > 0 && total > 0 && per < 1024) {
         // bf16-MFMA kernel, 128 x 128 blocks, SHORT units (a unit writes 64 KB of partial sums for `per` rules): half as many
         // workgroups, and units of EQUAL length inside an offset -- k units per (average) offset.  A `per` just above half
         // an offset's rules makes units of 1 : 0.35 and half again as many of them (tools/sweep_wgrad_tb_units.py: the
@@ -846,7 +846,7 @@ static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const 
     dim3 grid((unsigned)pl.unit_start[n_off], 1, (unsigned)(pl.nbi * pl.nbj));
     // bit 1: EDGE blocks whose fragments are whole (vector loads stay possible, see k_wgrad_direct)
     const bool evec = edge && !hb && cin % sh.ta == 0 && cout % sh.tb == 0 && (all_ptrs & 15) == 0 &&
-                      (cin * 4) % 16 == 0 && (cout * 4) % 16 == 0 && !getenv("SCN_WD_NO_EVEC");
+                      (cin * 4) % 16 == 0 && (cout * 4) % 16 == 0 && !scn::sw(scn::SW_WD_NO_EVEC).set;
     const int relu_in = ((flags & SCN_F_RELU_IN) ? 1 : 0) | (evec ? 2 : 0);
     if (mfma16) {
         const int ta = tb_tiles(cin), tb = tb_tiles(cout);

@@ -170,6 +170,11 @@ class MaskBranch(nn.Module):
             out = torch.cat((out[:, :unet.out_channels], skip_features.to(out.dtype)), dim=-1)
         return self._linear(out), selection
 
+    def __getstate__(self):
+        d = self.__dict__.copy()                 # (the compiled input stage: ctypes tables, rebuilt on first use by a copy)
+        d.pop("_input_stage", None)
+        return d
+
     def _input_stage_exec(self, fmap):
         """input_conv_layer (SubM 1^3 + residual units on the scene's level 0; bf16 storage: cast in, cast out) through the
         step executor, or None when it does not apply."""

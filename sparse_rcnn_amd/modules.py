@@ -93,8 +93,49 @@ def _head_of(m):
     return m if (type(m) is Convolution and m.stride == (2, 2, 2)) else None
 
 
+# A cached shape (`_stage_kind`) / compiled plan (`_stages`) of a Sequential captures its WHOLE subtree: the head, the inner
+# Sequential's residual units, their bias / padding flags (editing the INNER Sequential, or replacing a child
+# through __setitem__ / __delitem__ / insert / extend / add_module, left the outer plan running the old layer list).  Every
+# structural edit of any scn.Sequential and every `bias` / `pad_out_to` assignment of a conv-type layer advances the tree
+# epoch; a cache from an older epoch is kept only if the subtree's signature (identity + type of every module below, the
+# conv layers' shape / bias / padding) is still the one it was compiled for.  Per call: one integer comparison.
+_TREE_EPOCH = [0]
+_PLAN_CACHES = ("_stage_kind", "_stages", "_stage_sig", "_stage_epoch")
+
+
+def _bump_tree_epoch():
+    _TREE_EPOCH[0] += 1
+
+
+def _signature(seq):
+    sig = []
+
+    def walk(m):
+        for c in m._modules.values():
+            sig.append((id(c), type(c).__name__))
+            if isinstance(c, _ConvBase):
+                sig.append((c.nIn, c.nOut, c.bias is None, c.pad_out_to))
+            if c is not None:
+                walk(c)
+    walk(seq)
+    return tuple(sig)
+
+
+def _validate_plan_caches(seq):
+    d = seq.__dict__
+    if d.get("_stage_epoch") == _TREE_EPOCH[0]:
+        return
+    sig = _signature(seq)
+    if d.get("_stage_sig") != sig:
+        d.pop("_stage_kind", None)
+        d.pop("_stages", None)
+        d["_stage_sig"] = sig
+    d["_stage_epoch"] = _TREE_EPOCH[0]
+
+
 def _kind(seq):
     """'enc': (head, units) of an encoder level | 'units': residual units only | 'up': (ReLU, Deconvolution) | None."""
+    _validate_plan_caches(seq)
     kind = seq.__dict__.get("_stage_kind")
     if kind is not None:
         return kind or None
@@ -133,6 +174,10 @@ def _enc_stage(seq, input):
             return NotImplemented
     else:
         bf16 = in16
+        if FEATURE_STORAGE is torch.bfloat16 and not in16:
+            # an fp32 slab reaching a strided head under bf16 storage: layer by layer the head's result is stored in bf16 and
+            # the units run on bf16 rows; the stage would keep the whole level in fp32 -> the layer-by-layer path
+            return NotImplemented
     key = (bf16, in16)
     cache = seq.__dict__.setdefault("_stages", {})
     st = cache.get(key)
@@ -192,12 +237,41 @@ class Sequential(torch.nn.Sequential):
 
     def append(self, module):
         self.add_module(str(len(self._modules)), module)
-        self.__dict__.pop("_stage_kind", None)           # (the cached shape of this Sequential: _kind)
-        self.__dict__.pop("_stages", None)
         return self
 
     def add(self, module):
         return self.append(module)
+
+    # ---- every structural edit advances the tree epoch (cached stage plans of ANY enclosing Sequential are re-validated)
+    def add_module(self, name, module):
+        _bump_tree_epoch()
+        return super().add_module(name, module)
+
+    register_module = add_module
+
+    def __setattr__(self, name, value):                  # (__setitem__ of torch.nn.Sequential lands here)
+        _bump_tree_epoch()
+        return super().__setattr__(name, value)
+
+    def __delattr__(self, name):                         # (__delitem__ / pop)
+        _bump_tree_epoch()
+        return super().__delattr__(name)
+
+    def insert(self, index, module):
+        _bump_tree_epoch()
+        return super().insert(index, module)
+
+    def __delitem__(self, idx):
+        _bump_tree_epoch()
+        return super().__delitem__(idx)
+
+    def __getstate__(self):
+        """copy.deepcopy / torch.save of a tree that has run: the compiled plans hold ctypes pointer arrays (not picklable)
+        and belong to THIS object's modules -- a copy compiles its own on first use."""
+        d = self.__dict__.copy()
+        for k in _PLAN_CACHES:
+            d.pop(k, None)
+        return d
 
     def forward(self, input, residual=None):
         """residual: features to add to the output of the LAST module when that is a SubmanifoldConvolution (used by
@@ -375,6 +449,11 @@ class _ConvBase(Module):
     # 16-byte aligned and its layers take the vector kernels).  The parameters keep their logical shape (state_dict
     # compatibility); `_wb` hands the kernels a zero-padded view through torch's differentiable pad.
     pad_out_to = None
+
+    def __setattr__(self, name, value):
+        if name == "bias" or name == "pad_out_to":       # what a compiled stage plan of an enclosing Sequential depends on
+            _bump_tree_epoch()
+        return super().__setattr__(name, value)
 
     def _wb(self, cin_phys):
         """(weight, bias) as the kernels see them for an input slab of cin_phys columns."""

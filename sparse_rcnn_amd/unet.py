@@ -181,6 +181,16 @@ class SparseUNet(nn.Module):
         object.__setattr__(self, "_pack_aliases", aliases)
         return jobs
 
+    _PLAN_ATTRS = ("_pack_aliases", "_pad_plan", "_pad_requests", "_pack_plan", "_exec_plan_cache")
+
+    def __getstate__(self):
+        """copy.deepcopy (EMA copies) / torch.save after a forward: the compiled launch plans hold ctypes pointer arrays and
+        name THIS object's modules; a copy compiles its own on first use."""
+        d = self.__dict__.copy()
+        for k in self._PLAN_ATTRS:
+            d.pop(k, None)
+        return d
+
     def forward(self, x, prebuild=True):
         """prebuild=False: no up-front index build -- every rulebook is requested by the first layer that needs it, the
         way the reference's module tree drives the scn surface (DropinBackbone)."""

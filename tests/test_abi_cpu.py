@@ -3,6 +3,7 @@ product path refuses to compute without its extension / without a GPU (no CPU fa
 import ctypes
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -35,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     # and the Python binding table covers the header
     assert sorted(scn.EXPORTS) == declared_functions()
     loaded = scn.load_library()
-    assert loaded.scn_abi_version() == 3          # include/scn_mi355x.h: history of the ABI
+    assert loaded.scn_abi_version() == 4          # include/scn_mi355x.h: history of the ABI
     assert loaded.scn_hash_capacity(1000) == 2048 and loaded.scn_hash_capacity(0) == 1024
     assert loaded.scn_rules_blocks(27, 5000) == 27 * 5
     # the step executor's plan records: the ctypes structures of executor.py have the C layout
@@ -106,3 +107,40 @@ def test_header_is_plain_c_and_library_links_from_c():
     out = subprocess.run(["ldd", g.C_HOST_BIN], capture_output=True, text=True).stdout
     assert "libscn_mi355x.so" in out and "not found" not in out, out
     assert "python" not in out.lower() and "torch" not in out.lower(), out
+
+
+def test_developer_switches_are_read_once_and_change_only_through_the_abi():
+    """the library's developer switches no longer follow the ambient environment per launch.  The
+    environment is read ONCE (first use of any switch) -- SCN_TB_KH=2 given at process start is seen, a variable exported
+    afterwards is not; scn_debug_set / the tests' `_lib.debug_switch` change one; an unknown name is SCN_EINVAL.  And no
+    product source calls getenv outside scn_debug.hip."""
+    import subprocess
+    code = r'''
+import ctypes, os, sys
+sys.path.insert(0, %r)
+from sparse_rcnn_amd import _lib as L
+l = L.load()
+s, v = ctypes.c_int(0), ctypes.c_int64(0)
+assert l.scn_debug_get(b"SCN_TB_KH", ctypes.byref(s), ctypes.byref(v)) == 0 and (s.value, v.value) == (1, 2)
+os.environ["SCN_TS_NO_TAIL"] = "1"                                   # after the one read: not seen
+assert l.scn_debug_get(b"SCN_TS_NO_TAIL", ctypes.byref(s), ctypes.byref(v)) == 0 and s.value == 0
+with L.debug_switch("SCN_TS_NO_TAIL", 1):
+    l.scn_debug_get(b"SCN_TS_NO_TAIL", ctypes.byref(s), ctypes.byref(v)); assert (s.value, v.value) == (1, 1)
+    with L.debug_switch("SCN_TS_NO_TAIL", None):
+        l.scn_debug_get(b"SCN_TS_NO_TAIL", ctypes.byref(s), ctypes.byref(v)); assert s.value == 0
+    l.scn_debug_get(b"SCN_TS_NO_TAIL", ctypes.byref(s), ctypes.byref(v)); assert (s.value, v.value) == (1, 1)
+l.scn_debug_get(b"SCN_TS_NO_TAIL", ctypes.byref(s), ctypes.byref(v)); assert s.value == 0
+L.switches["SCN_TS_SPLIT"] = "0"
+l.scn_debug_get(b"SCN_TS_SPLIT", ctypes.byref(s), ctypes.byref(v)); assert (s.value, v.value) == (1, 0)
+del L.switches["SCN_TS_SPLIT"]
+assert l.scn_debug_set(b"SCN_NO_SUCH_SWITCH", b"1") == L.EINVAL and b"SCN_NO_SUCH_SWITCH" in l.scn_last_error_string()
+print("OK")
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, SCN_TB_KH="2"))
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout, r.stderr[-2000:])
+    csrc = os.path.join(ROOT, "sparse_rcnn_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".inc", ".h")) and f != "scn_debug.hip":
+            with open(os.path.join(csrc, f)) as fh:
+                assert "getenv(" not in fh.read(), f

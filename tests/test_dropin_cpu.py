@@ -289,3 +289,52 @@ def test_reference_factories_construct_strided_layers_on_this_package():
             sys.modules.pop("sparseconvnet", None)
         else:
             sys.modules["sparseconvnet"] = saved
+
+
+def test_stage_plan_caches_are_revalidated_after_tree_edits_and_left_out_of_copies():
+    """the cached shape / compiled plans of an scn.Sequential (modules._kind, `_stages`) are dropped when anything
+    BELOW it changes -- the inner Sequential's units, a replaced / deleted child, a layer's bias -- and never travel with
+    copy.deepcopy / pickle (they hold ctypes pointer arrays and name the original's modules)."""
+    import copy
+    import ctypes
+    import io
+    import sparse_rcnn_amd as scn
+    from sparse_rcnn_amd import modules as M
+    from sparse_rcnn_amd.unet import Backbone
+
+    def unit(c):
+        return scn.Sequential(scn.ConcatTable(scn.Identity(), scn.Sequential(
+            scn.ReLU(), scn.SubmanifoldConvolution(3, c, c, 3, True), scn.ReLU(), scn.SubmanifoldConvolution(3, c, c, 3, True))),
+            scn.AddTable())
+    inner = scn.Sequential(unit(16), unit(16))
+    level = scn.Sequential(scn.Sequential(scn.SubmanifoldConvolution(3, 8, 16, 1, True)), inner)
+    assert M._kind(level) == "enc" and M._kind(inner) == "units"
+    level.__dict__["_stages"] = {"planted": (ctypes.c_void_p * 2)()}
+    assert M._kind(level) == "enc" and "planted" in level.__dict__["_stages"]          # nothing changed: the cache stays
+    inner.append(unit(16))
+    assert M._kind(level) == "enc" and "_stages" not in level.__dict__                  # inner edit: outer plans dropped
+    level.__dict__["_stages"] = {"planted": 1}
+    inner[1] = scn.ReLU()                                                               # no longer plain residual units
+    assert M._kind(level) is None and M._kind(inner) is None and "_stages" not in level.__dict__
+    inner[1] = unit(16)
+    assert M._kind(level) == "enc"
+    level.__dict__["_stages"] = {"planted": 1}
+    inner[0][0][1][3].bias = None
+    assert M._kind(level) is None and "_stages" not in level.__dict__
+    inner[0][0][1][3].bias = torch.nn.Parameter(torch.zeros(16))
+    assert M._kind(level) == "enc"
+    level.__dict__["_stages"] = {"planted": (ctypes.c_void_p * 2)()}
+    del inner[2]
+    assert "_stages" not in level.__dict__ or M._kind(level) == "enc" and "_stages" not in level.__dict__
+    # copies: plans stay behind
+    level.__dict__["_stages"] = {"planted": (ctypes.c_void_p * 2)()}
+    M._kind(level)
+    twin = copy.deepcopy(level)
+    assert "_stages" not in twin.__dict__ and "_stage_sig" not in twin.__dict__ and M._kind(twin) == "enc"
+    torch.save(level, io.BytesIO())
+    net = Backbone(7, (16, 32))
+    for k in net.unet._PLAN_ATTRS:
+        object.__setattr__(net.unet, k, (ctypes.c_void_p * 2)())
+    c = copy.deepcopy(net)
+    assert not any(k in c.unet.__dict__ for k in net.unet._PLAN_ATTRS)
+    torch.save(net, io.BytesIO())

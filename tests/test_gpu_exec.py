@@ -10,6 +10,8 @@ import numpy as np
 import pytest
 import torch
 
+from sparse_rcnn_amd._lib import switches as _SW      # developer switches of the library: scn_debug_set, not the environment
+
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))          # tests/optape.py
 
 pytestmark = pytest.mark.gpu
@@ -335,6 +337,63 @@ def test_module_tree_stages_are_bit_identical_to_layer_by_layer(gpu, dtype, plan
     assert torch.equal(ref, a[0].float())
 
 
+def test_stage_plans_follow_edits_of_the_inner_module_tree(gpu):
+    """ADVICE r4 (modules.py): the compiled plan of an encoder level captures the INNER Sequential's residual units.  After one
+    forward: a unit appended to the inner Sequential, a unit replaced through __setitem__, a unit deleted, a bias removed --
+    the next forward must run the EDITED tree (== the same tree with stages off, bit for bit), not the cached plan; and a
+    deep copy of a tree that has run (ctypes tables in its caches) works and computes the same."""
+    import copy
+    import sparse_rcnn_amd as scn
+    from sparse_rcnn_amd import modules as M
+    coords, feats, size, bs, _ = _scene(6_000, (64, 64, 32), seed=5)
+    torch.manual_seed(2)
+
+    def unit(c):
+        return scn.Sequential(scn.ConcatTable(scn.Identity(), scn.Sequential(
+            scn.ReLU(), scn.SubmanifoldConvolution(3, c, c, 3, True), scn.ReLU(), scn.SubmanifoldConvolution(3, c, c, 3, True))),
+            scn.AddTable())
+    inner = scn.Sequential(unit(16), unit(16))
+    level = scn.Sequential(scn.Sequential(scn.SubmanifoldConvolution(3, 7, 16, 1, True)), inner).to(gpu)
+    inp = scn.InputLayer(3, size, mode=4)
+
+    def run(stages):
+        M.TREE_STAGES = stages
+        M.STAGE_STATS.update(enc=0, dec=0, layerwise_units=0)
+        try:
+            for p in level.parameters():
+                p.grad = None
+            x = inp((coords, feats.to(gpu), 1))
+            y = level(x).features
+            y.backward(torch.ones_like(y))
+            return y.detach().clone(), [p.grad.clone() for p in level.parameters()], M.STAGE_STATS["enc"]
+        finally:
+            M.TREE_STAGES = True
+
+    def both(expect_stage=1):
+        a, b = run(True), run(False)
+        assert a[2] == expect_stage and b[2] == 0
+        assert torch.equal(a[0], b[0])
+        assert len(a[1]) == len(b[1]) and all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
+        return a[0]
+    y0 = both()
+    twin = copy.deepcopy(level)                                    # a tree that has run: plans are not copied, ctypes and all
+    assert "_stages" in level.__dict__ and "_stages" not in twin.__dict__
+    inner.append(unit(16).to(gpu))                                 # three units now
+    y1 = both()
+    assert not torch.equal(y0, y1)
+    inner[1] = unit(16).to(gpu)                                    # __setitem__: another unit in the middle
+    y2 = both()
+    assert not torch.equal(y1, y2)
+    del inner[0]                                                   # two units again, different ones
+    y3 = both()
+    assert not torch.equal(y2, y3)
+    inner[0][0][1][1].bias = None                                  # no bias: plans need one -> the level runs layer by layer
+    both(expect_stage=0)
+    M.TREE_STAGES = True
+    x = inp((coords, feats.to(gpu), 1))
+    assert torch.equal(twin(x).features, y0)                       # the copy still is the tree as it was when copied
+
+
 def test_deferred_tensors_compute_layer_by_layer_when_nobody_fuses_them(gpu):
     """A pending Deconvolution / NetworkInNetwork whose consumer is NOT a run of residual units (the features are read
     directly; a JoinTable is materialised) gives the layer-by-layer result, and a Deconvolution to a level no Convolution of
@@ -490,13 +549,13 @@ def test_streaming_bf16_tile_kernel_agrees_with_the_k_split_kernel(gpu, c, targe
                F.conv_rules(X[:sb.n_coarse].contiguous(), sb.tiles, sb.n_coarse, W8, None, c, L.F_W_TRANSPOSED)]
         torch.cuda.synchronize()
         return out
-    os.environ["SCN_TB_STREAM"] = "1"                  # every eligible layer (default: only Cin = 64, 3^3)
+    _SW["SCN_TB_STREAM"] = "1"                  # every eligible layer (default: only Cin = 64, 3^3)
     try:
         a, a2 = run(), run()
-        os.environ["SCN_TB_STREAM"] = "0"
+        _SW["SCN_TB_STREAM"] = "0"
         ref = run()
     finally:
-        del os.environ["SCN_TB_STREAM"]
+        del _SW["SCN_TB_STREAM"]
     for k, (u, v, r) in enumerate(zip(a, a2, ref)):
         assert u.dtype == bf and torch.equal(u, v), f"op {k}: not reproducible"
         uf, rf = u.float(), r.float()
@@ -591,11 +650,11 @@ def test_streaming_fp32_tile_kernel_agrees_with_the_k_split_kernel(gpu, c, targe
                F.conv_rules(X[:sb.n_coarse].contiguous(), sb.tiles, sb.n_coarse, W8, None, c, L.F_W_TRANSPOSED)]
         torch.cuda.synchronize()
         return out
-    os.environ["SCN_TS_STREAM"] = "1"                  # (opt-in: measured slower than k_conv_ts)
+    _SW["SCN_TS_STREAM"] = "1"                  # (opt-in: measured slower than k_conv_ts)
     try:
         a, a2 = run(), run()
     finally:
-        del os.environ["SCN_TS_STREAM"]
+        del _SW["SCN_TS_STREAM"]
     ref = run()
     for k, (u, v, r) in enumerate(zip(a, a2, ref)):
         assert torch.equal(u, v), f"op {k}: not reproducible"
@@ -677,11 +736,11 @@ def test_conv_tiles_tail_slices_reproduce_the_padded_kernel_bit_for_bit(gpu, cin
     import ctypes
     paths = (ctypes.c_int64 * 4)()
     a = run()
-    os.environ["SCN_TS_NO_TAIL"] = "1"
+    _SW["SCN_TS_NO_TAIL"] = "1"
     try:
         ref = run()
     finally:
-        del os.environ["SCN_TS_NO_TAIL"]
+        del _SW["SCN_TS_NO_TAIL"]
     for u, v in zip(a, ref):
         assert torch.equal(u, v)
     assert float(a[0].abs().max()) > 0
@@ -714,11 +773,11 @@ def test_wgrad_whole_fragment_edge_blocks_keep_vector_loads_and_the_bits(gpu, ci
         torch.cuda.synchronize()
         return out
     a = run()
-    os.environ["SCN_WD_NO_EVEC"] = "1"
+    _SW["SCN_WD_NO_EVEC"] = "1"
     try:
         ref = run()
     finally:
-        del os.environ["SCN_WD_NO_EVEC"]
+        del _SW["SCN_WD_NO_EVEC"]
     for u, v in zip(a, ref):
         assert torch.equal(u, v)
     assert float(a[0].abs().max()) > 0
@@ -750,11 +809,11 @@ def test_wgrad_48_wide_blocks_match_the_padded_blocks(gpu, c):
         return [a[0], a[1], b[0], b[1], n[0], n[1]]
     a = run()
     a2 = run()
-    os.environ["SCN_WD_NO_T3"] = "1"
+    _SW["SCN_WD_NO_T3"] = "1"
     try:
         ref = run()
     finally:
-        del os.environ["SCN_WD_NO_T3"]
+        del _SW["SCN_WD_NO_T3"]
     for u, v, w in zip(a, ref, a2):
         assert torch.equal(u, w)                                              # reproducible
         scale = float(v.abs().max())
@@ -844,11 +903,11 @@ def test_xcd_local_tile_order_is_a_valid_second_order_and_changes_no_bit(gpu):
             Wc = W if not fl else W.transpose(1, 2).contiguous()
             a = F.conv_rules_bf16(X, tx, rb_plain.n, Wc, None, cout, fl | L.F_RELU_IN)
             b = F.conv_rules_bf16(X, t0, rb_plain.n, Wc, None, cout, fl | L.F_RELU_IN)
-            os.environ["SCN_TB_NO_XORDER"] = "1"
+            _SW["SCN_TB_NO_XORDER"] = "1"
             try:
                 c = F.conv_rules_bf16(X, tx, rb_plain.n, Wc, None, cout, fl | L.F_RELU_IN)
             finally:
-                del os.environ["SCN_TB_NO_XORDER"]
+                del _SW["SCN_TB_NO_XORDER"]
             assert torch.equal(a, b) and torch.equal(a, c)
             assert float(a.float().abs().max()) > 0
 
@@ -1002,18 +1061,18 @@ def test_four_waves_per_tile_loop_agrees_with_the_plain_loop(gpu, c, target):
     a, a2 = run(), run()
     assert lib.scn_conv_tiles_split_count(1) == 8                         # every launch took the four-waves-per-tile loop
     two = run(False)                                                      # (cin <= 32: nothing to add, same launch)
-    os.environ["SCN_TS_NO_TAIL"] = "1"
+    _SW["SCN_TS_NO_TAIL"] = "1"
     try:
         padded = run()
     finally:
-        del os.environ["SCN_TS_NO_TAIL"]
+        del _SW["SCN_TS_NO_TAIL"]
     lib.scn_conv_tiles_split_count(1)
-    os.environ["SCN_TS_SPLIT"] = "0"
+    _SW["SCN_TS_SPLIT"] = "0"
     try:
         ref = run()
         ref_two = run(False)
     finally:
-        del os.environ["SCN_TS_SPLIT"]
+        del _SW["SCN_TS_SPLIT"]
     assert lib.scn_conv_tiles_split_count(1) == 0
     for k in range(4):
         assert torch.equal(a[k], a2[k]) and torch.equal(a[k], two[k]) and torch.equal(a[k], padded[k]), k

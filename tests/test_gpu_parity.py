@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+from sparse_rcnn_amd._lib import switches as _SW      # developer switches of the library: scn_debug_set, not the environment
+
 from oracle import scn_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -842,11 +844,11 @@ def test_fused_pyramid_build_equals_the_round3_builder(gpu, case):
     coords, feats, size, bs, _ = make_batch(n_s, grid, target, dup=1.15, seed=3)
     cg = coords.to(gpu)
     b = Metadata(3).build_native(size, cg, bs, 4, levels, 3, xcd_order=with_x)
-    os.environ["SCN_PYRAMID_V1"] = "1"
+    _SW["SCN_PYRAMID_V1"] = "1"
     try:
         a = Metadata(3).build_native(size, cg, bs, 4, levels, 3, xcd_order=with_x)
     finally:
-        del os.environ["SCN_PYRAMID_V1"]
+        del _SW["SCN_PYRAMID_V1"]
     torch.cuda.synchronize()
     assert list(a.grids) == list(b.grids) and [g.n for g in a.grids.values()] == [g.n for g in b.grids.values()]
     assert set(a.subm) == set(b.subm) and set(a.strided) == set(b.strided) and a.n_samples == b.n_samples

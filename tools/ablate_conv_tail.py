@@ -5,6 +5,7 @@ weighted) against the padded kernel (SCN_TS_NO_TAIL=1), useful TFLOP/s next to t
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from sparse_rcnn_amd._lib import switches as _SW      # library switches: scn_debug_set (the environment is read once at load)
 import sparse_rcnn_amd as scn
 from sparse_rcnn_amd import _lib as L
 from sparse_rcnn_amd.synthetic import make_batch
@@ -43,9 +44,9 @@ for level in range(max(levels) + 1):
                 L.check(lib.scn_conv_tiles(L.ptr(X), n, C, L.ptr(t.tstab), L.ptr(t.tile_mask), L.ptr(t.perm), L.ptr(t.tile_order), 27, n,
                                            L.ptr(W), 0, 0, 0, L.ptr(Y), C, fl, L.ptr(SCR), L.ptr(ARR), L.stream()))
             us = timed(run)
-            os.environ["SCN_TS_NO_TAIL"] = "1"
+            _SW["SCN_TS_NO_TAIL"] = "1"
             us0 = timed(run)
-            del os.environ["SCN_TS_NO_TAIL"]
+            del _SW["SCN_TS_NO_TAIL"]
             fl = 2.0 * P * C * C
             print(f"  C={C:3d}  tail {us:6.1f} us {fl / us / 1e6:6.1f} TF useful   padded {us0:6.1f} us {fl / us0 / 1e6:6.1f} TF   x{us0 / us:.2f}")
     if level < max(levels):

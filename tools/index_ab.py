@@ -4,6 +4,7 @@ alternating, cfg-2 scene (4 levels) and the reference plan's 6 levels; bit-equal
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from sparse_rcnn_amd._lib import switches as _SW      # library switches: scn_debug_set (the environment is read once at load)
 from sparse_rcnn_amd.metadata import Metadata
 from sparse_rcnn_amd.synthetic import make_batch
 
@@ -28,9 +29,9 @@ def timed(levels, reps=20):
 
 for levels in (4, 6):
     a = build(levels)
-    os.environ["SCN_PYRAMID_ONE_STREAM"] = "1"
+    _SW["SCN_PYRAMID_ONE_STREAM"] = "1"
     b = build(levels)
-    del os.environ["SCN_PYRAMID_ONE_STREAM"]
+    del _SW["SCN_PYRAMID_ONE_STREAM"]
     torch.cuda.synchronize()
     def det(md):        # the deterministic structures (the hash tables' slot layout depends on the insertion race)
         out = [md.item_row, md.row_count, md.row_first, md.point_coords] + [g.coords for g in md.grids.values()]
@@ -46,9 +47,9 @@ for levels in (4, 6):
     res = []
     for rep in range(3):
         two = timed(levels)
-        os.environ["SCN_PYRAMID_ONE_STREAM"] = "1"
+        _SW["SCN_PYRAMID_ONE_STREAM"] = "1"
         one = timed(levels)
-        del os.environ["SCN_PYRAMID_ONE_STREAM"]
+        del _SW["SCN_PYRAMID_ONE_STREAM"]
         res.append((two, one))
     print(f"levels={levels}: {n_t} index tensors identical: {same};  ms per build (two queues / one): " +
           "  ".join(f"{t:.3f}/{o:.3f}" for t, o in res))

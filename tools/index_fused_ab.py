@@ -4,6 +4,7 @@ a 600k-voxel scene with 5 levels.      python tools/index_fused_ab.py [reps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from sparse_rcnn_amd._lib import switches as _SW      # library switches: scn_debug_set (the environment is read once at load)
 from sparse_rcnn_amd.metadata import Metadata
 from sparse_rcnn_amd.synthetic import make_batch
 
@@ -32,8 +33,8 @@ for name, n_s, grid, target, levels in (("cfg2 150k, 4 levels", 1, (512, 512, 25
     res = []
     for rep in range(3):
         fused = timed(build)
-        os.environ["SCN_PYRAMID_V1"] = "1"
+        _SW["SCN_PYRAMID_V1"] = "1"
         old = timed(build)
-        del os.environ["SCN_PYRAMID_V1"]
+        del _SW["SCN_PYRAMID_V1"]
         res.append((fused, old))
     print(f"{name}: {len(coords)} points; ms per build fused / round-3: " + "  ".join(f"{f:.3f}/{o:.3f}" for f, o in res), flush=True)

@@ -268,6 +268,7 @@ def run(args):
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()                      # peak HBM of the timed region (memory audit)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if use_timer:
@@ -279,6 +280,7 @@ def run(args):
     if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
+    peak_alloc, peak_reserved = torch.cuda.max_memory_allocated(), torch.cuda.max_memory_reserved()
     profiling.TIMER = None
     timer.collect_exec()            # the launch times the step executor recorded on the sampled steps (before any other leg runs)
     sampled = max(1, timer.sampled_steps)
@@ -329,6 +331,14 @@ def run(args):
             "n_ranks_seen_by_rccl": ranks_seen if backend == "nccl" else None,
             "n_ranks_seen": ranks_seen, "collective_backend": backend if dist_on else None,
             "per_rank": per_rank,
+            "peak_hbm_bytes": int(peak_alloc),
+            "peak_hbm": {"allocated_bytes": int(peak_alloc), "reserved_bytes": int(peak_reserved),
+                         "note": "torch.cuda.max_memory_allocated / max_memory_reserved over the timed region of rank 0: feature "
+                                 "slabs, index structures of two batches (this one + the prefetched one), workspaces, "
+                                 "parameters, gradients, weight images; of 288 GB"},
+            "inputs": "coordinates (int64 [N,4]) and features resident in HBM before the timed region (the contract's "
+                      "`value`); the reference hands coordinates over on the HOST (ndsis/data/data.py:207-210): the `dropin` "
+                      "leg times that contract (host coords, H2D + range check inside the step)",
             "fast_path": {"conv_tiles_fast": int(paths[0]), "conv_tiles_general": int(paths[1]),
                           "k_reduction_in_launch": int(paths[2]), "k_reduction_second_launch": int(paths[3]),
                           "all_fast": int(paths[1]) == 0 and int(paths[3]) == 0,
@@ -442,6 +452,31 @@ def side_measurements(job, args, world, dist, torch):
             dist.barrier()
         ex["ms_per_step_no_prefetch"] = (time.perf_counter() - t0) / n * 1e3
         job.prefetch = True
+    # ---- forward only (evaluation: eval_model, training.py:244-304; SparseMaskPredictor, model.py:826-882): the same scene
+    # under torch.no_grad() -- forward-only slab plan, no backward-data weight images -- with its own peak HBM
+    job.finish()
+    n = max(5, min(20, args.steps))
+    for _ in range(3):
+        job.forward_only()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        job.forward_only()
+    job.finish()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    fo_ms = (time.perf_counter() - t0) / n * 1e3
+    ex["forward_only_ms"] = fo_ms
+    ex["forward_only"] = {"ms_per_step": fo_ms, "value": job.n_active / job.batches_per_step / (fo_ms * 1e-3),
+                          "unit": "active-voxels/s, forward only", "steps": n,
+                          "peak_hbm_bytes": int(torch.cuda.max_memory_allocated()),
+                          "note": "index build (pipelined as in the step) + forward under torch.no_grad(): the executor's "
+                                  "forward-only slab plan, no backward-data weight images; bit-equal to the training forward "
+                                  "(tests/test_gpu_exec.py::test_forward_only_is_bit_equal...)"}
     if args.dropin and args.workload == "cfg2" and world == 1:
         ex["dropin"] = dropin_measurement(job, args, torch)
     if args.bf16_leg and args.workload == "cfg2" and args.dtype == "f32" and world == 1 and args.target is None:
@@ -473,6 +508,15 @@ def bf16_side_leg(args, dev, torch):
     ks = timer.summary()
     out = {"ms_per_step": ms, "value": job.n_active / (ms * 1e-3), "steps": n, "warmup": warm,
            "workload": "cfg2 in bf16 storage (bench.py --dtype bf16 times it as the main leg)"}
+    for _ in range(3):
+        job.forward_only()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        job.forward_only()
+    job.finish()
+    torch.cuda.synchronize()
+    out["forward_only_ms"] = (time.perf_counter() - t0) / n * 1e3
     if "k_conv_tb" in ks:
         out["roofline"] = roofline("k_conv_tb", ks["k_conv_tb"], max(1, timer.sampled_steps),
                                    argparse.Namespace(workload="cfg2", dtype="bf16"))

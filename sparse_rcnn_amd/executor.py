@@ -187,11 +187,60 @@ class Stage:
         self.b_entries = [(k, 2 * d[1] + 1) for k, d in enumerate(self.params) if d[0] == "b"]
         self.img_entries = [(k, 2 * d[1]) + tuple(d[2:]) for k, d in enumerate(self.params) if d[0] not in ("w", "b")]
         self.grad_views = {}                              # tuple of parameter shapes -> (region offsets, total, views)
+        self._lean_slots()
         covered = sorted(m for reg in self.gregions for m in reg)
         want = sorted((i, k) for i in range(len(self.mods)) for k in ("w", "b"))
         if covered != want:
             raise RuntimeError("executor plan: every parameter must sit in exactly one gradient region")
         return self
+
+
+def _lean_slots(self):
+    """Forward-only plan (evaluation: `eval_model`, ndsis/training/training.py:244-304, and `SparseMaskPredictor`,
+    model.py:826-882, run the forward under torch.no_grad()): nothing is kept for a backward pass, so a forward slab's
+    storage is handed on as soon as its last reader has been queued.  Slots per (level, row bytes) class by liveness over the
+    forward op list; an op's output never shares a slot with one of its own operands (a slot is released AFTER the op)."""
+    last = {}
+    for t, op in enumerate(self.fwd):
+        for v in (op.x, op.r, op.m, op.x1, op.y, op.y1):
+            if v >= 0:
+                last[v] = t
+    ws = set(i for i, b in enumerate(self.bufs) if b[3] == "f")
+    free, n_slots, slot_of = {}, {}, {}
+    for t, op in enumerate(self.fwd):
+        for v in (op.y, op.y1):
+            if v in ws and v not in slot_of:
+                cls = (self.bufs[v][0], self.bufs[v][1] * self.bufs[v][2])
+                if free.get(cls):
+                    slot_of[v] = (cls, free[cls].pop())
+                else:
+                    slot_of[v] = (cls, n_slots.get(cls, 0))
+                    n_slots[cls] = n_slots.get(cls, 0) + 1
+        for v in (op.x, op.r, op.m, op.x1, op.y, op.y1):
+            if v in slot_of and last[v] == t and slot_of[v] is not None:
+                cls, k = slot_of[v]
+                if k not in free.setdefault(cls, []):
+                    free[cls].append(k)
+    for v in ws:                                          # (a declared slab no forward op writes: give it a slot of its own)
+        if v not in slot_of:
+            cls = (self.bufs[v][0], self.bufs[v][1] * self.bufs[v][2])
+            slot_of[v] = (cls, n_slots.get(cls, 0))
+            n_slots[cls] = n_slots.get(cls, 0) + 1
+    self.lean_classes = sorted(n_slots.items())            # [((level, row bytes), slots)]
+    self.lean_slot_of = [slot_of[i] for i in self.fwd_ws]
+
+
+Stage._lean_slots = _lean_slots
+
+
+def _lean_layout(stage, ns):
+    """-> (offset per forward workspace buffer, total bytes) of the forward-only plan."""
+    base, tot = {}, 0
+    for (lv, row_bytes), k in stage.lean_classes:
+        size = (ns[lv] * row_bytes + 255) & ~255
+        base[(lv, row_bytes)] = (tot, size)
+        tot += size * k
+    return [base[cls][0] + k * base[cls][1] for cls, k in stage.lean_slot_of], tot
 
 
 def _plain_blocks(unit_seq):
@@ -371,17 +420,28 @@ def _run_plain(stage, ops, levels, table, ptab, gtab, dev, side=False):
                              arrival.data_ptr(), L.stream()))
 
 
+LAST_FORWARD = {"lean": False, "ws_bytes": 0}      # what the last stage forward did (tests)
+
+
+def _lean(inputs, phys):
+    return not torch.is_grad_enabled() or not any(t is not None and t.requires_grad for t in (*inputs, *phys))
+
+
 class StageFunction(torch.autograd.Function):
-    """forward(stage, levels, *inputs, *(W, b per module of the stage)) -> the stage's output slab."""
+    """forward(stage, levels, lean, *inputs, *(W, b per module of the stage)) -> the stage's output slab.
+    lean: nothing will ask for a backward pass (torch.no_grad(), or no operand requires a gradient): the forward-only slab
+    plan (`_lean_layout`: storage re-used along the op list) and nothing saved."""
 
     @staticmethod
-    def forward(ctx, stage, levels, *ts):
+    def forward(ctx, stage, levels, lean, *ts):
         n_in = stage.n_inputs
         inputs = [F._feat(t) for t in ts[:n_in]]
         phys = ts[n_in:]
         dev = inputs[0].device
         ns = levels[2]
-        offs, total = _layout(stage.fwd_specs, ns)
+        lean = bool(lean) and F.RELU_RECORD is None
+        offs, total = _lean_layout(stage, ns) if lean else _layout(stage.fwd_specs, ns)
+        LAST_FORWARD["lean"], LAST_FORWARD["ws_bytes"] = lean, total
         ws = torch.empty(max(total, 256), dtype=torch.uint8, device=dev)
         lv, ch, es, _ = stage.bufs[stage.out_id]
         out = torch.empty((ns[lv], ch), dtype=torch.float32 if es == 4 else torch.bfloat16, device=dev)
@@ -405,6 +465,8 @@ class StageFunction(torch.autograd.Function):
             t = phys[j]
             ptab[k] = 0 if t is None else (t if (t.dtype is f32 and t.is_contiguous()) else F._f32(t)).data_ptr()
         for k, j, cin, cout, n_off, fl in stage.img_entries:
+            if lean and fl:                      # a backward-data image: only a backward pass reads it
+                continue
             W = phys[j]
             img = F.packed_image(W, cin, cout, n_off, fl)
             if img is None:
@@ -414,6 +476,8 @@ class StageFunction(torch.autograd.Function):
         _run(stage, stage.fwd_arr, levels, table, ptab, None, dev)
         if F.RELU_RECORD is not None:
             _record_relu_masks(stage, ns, ws, offs, inputs, out)
+        if lean:
+            return out
         ctx.stage, ctx.levels, ctx.table, ctx.ptab = stage, levels, table, ptab
         ctx.phys_shapes = tuple(None if t is None else tuple(t.shape) for t in phys)
         # Everything the pointer tables name travels through save_for_backward: the parameter tensors, the forward workspace,
@@ -475,7 +539,7 @@ class StageFunction(torch.autograd.Function):
         _run(stage, stage.bwd_arr, levels, table, ptab, gtab, dev, side=True)
         grads = [None if v is None else flat[v[0]:v[0] + v[1]].view(v[2]) for v in views]
         del kept
-        return (None, None, *dins, *grads)
+        return (None, None, None, *dins, *grads)
 
 
 def _record_relu_masks(stage, ns, ws, offs, inputs, out):
@@ -514,19 +578,24 @@ def run_stage(stage, levels, inputs, pack=False):
         W, b = m._wb(cin_phys)
         phys += [W, b]
     if pack and stage.bf16:
-        plan = stage.__dict__.get("_pack_plan")
+        lean = _lean(inputs, phys)
+        attr = "_pack_plan_fwd" if lean else "_pack_plan"
+        plan = stage.__dict__.get(attr)
         if plan is None:
             jobs = []
             for d in stage.params:
                 if d[0] == "img":
                     _, mi, cin, cout, n_off, fl = d
+                    if lean and fl:
+                        continue
                     m, cin_phys = stage.mods[mi]
                     if getattr(m, "pad_out_to", None) or cin_phys != m.nIn:
                         jobs = None                      # padded layers see fresh padded weight tensors: packed per call
                         break
                     jobs.append((m.weight, cin, cout, n_off, fl))
-            plan = stage._pack_plan = F.PackPlan(jobs) if jobs else False
+            plan = F.PackPlan(jobs) if jobs else False
+            setattr(stage, attr, plan)
         if plan:
             with F.packed_weights(plan):
-                return StageFunction.apply(stage, levels, *inputs, *phys)
-    return StageFunction.apply(stage, levels, *inputs, *phys)
+                return StageFunction.apply(stage, levels, lean, *inputs, *phys)
+    return StageFunction.apply(stage, levels, _lean(inputs, phys), *inputs, *phys)

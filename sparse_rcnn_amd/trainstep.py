@@ -160,6 +160,27 @@ class SceneStep:
                 out.features.backward(gys)
         self.out, self.logits, self.fin = out, logits, fin
 
+    def forward_only(self, k=0):
+        """Evaluation forward of micro-batch k under torch.no_grad() -- what the reference's `eval_model`
+        (ndsis/training/training.py:244-304) and `SparseMaskPredictor` (model.py:826-882) run: index build + backbone
+        (+ ROI crop + mask branch), no graph, the executor's forward-only slab plan (executor._lean_layout), no
+        backward-data weight images.  Same bits as the training forward.  -> (backbone output tensor, mask logits | None)"""
+        m = self.model
+        if k != self._k:
+            self._use_scene(k)
+        md = self._md_next.result() if self._md_next is not None else None
+        self._md_next = None
+        if self.prefetch:
+            nx = self._scenes[(k + 1) % self.batches_per_step]
+            self._md_next = m.backbone.prefetch_in_thread(nx["coords"], nx["size"], nx["batch_size"])
+        with torch.no_grad():
+            out = m.backbone(self.coords, self.feats, self.size, self.batch_size, metadata=md)
+            logits = None
+            if m.mask is not None:
+                scene = (self.coords, self.feats, self.size, self.batch_size, self.splits)
+                logits, _ = m.mask(scene, out, self.boxes)
+        return out, logits
+
     def step(self):
         n = self.batches_per_step
         for k in range(n - 1):                    # training.py:436: (loss / batches_per_step).backward(), no update yet

@@ -124,7 +124,7 @@ class SparseUNet(nn.Module):
                 d0["nin"].in_groups = (self.out_channels, c0)
                 d0["nin"].in_phys = (self.out_channels, self.phys0)
 
-    def _pack_jobs(self, pad_requests=()):
+    def _pack_jobs(self, pad_requests=(), forward_only=False):
         """(W, cin, cout, n_off, flags) of every bf16 weight image this network's forward + backward will stage: forward and
         backward-data images of the SubM 3^3 layers, forward of the strided convolutions, backward-data of the
         deconvolutions (the other directions of the strided layers run on the rule-list GEMMs).
@@ -132,7 +132,9 @@ class SparseUNet(nn.Module):
         of a zero-padded weight IS the image of the logical weight -- the pack zero-fills outside the layer and padding to the
         next multiple of 8 never crosses a slice boundary -- so those layers join the one pack launch with their logical
         parameters, and `aliases` = [(pad key, (cin_phys, cout_phys, n_off, flags), job index)] lets the forward register
-        the image under the padded tensor it hands the kernels.  -> jobs (and the aliases as the attribute `_pack_aliases`)."""
+        the image under the padded tensor it hands the kernels.  -> jobs (and the aliases as the attribute `_pack_aliases`).
+        forward_only (a forward under torch.no_grad(): evaluation, training.py:244-304): only the images a forward reads --
+        no backward-data image is packed (half the bytes of the pack); aliases go to `_pack_aliases_fwd`."""
         from . import functional as F
         from . import _lib as L
         lib = L.lib()
@@ -143,6 +145,8 @@ class SparseUNet(nn.Module):
             padded.setdefault(id(m), []).append(int(cin_phys))
 
         def add(m, W, cin, cout, n_off, fl, phys=None):
+            if forward_only and fl:                          # a backward-data image (W^T): nobody reads it without a backward
+                return
             if phys is not None:
                 pc, po, key = phys
                 if (pc % 8 or po % 8 or (cout > 32) != (po > 32) or -(-cin // 32) != -(-pc // 32)
@@ -178,10 +182,11 @@ class SparseUNet(nn.Module):
                 add(m, m.weight, m.nIn, m.nOut, 8, 0)
             elif isinstance(m, M.Deconvolution):
                 add(m, m.weight, m.nOut, m.nIn, 8, L.F_W_TRANSPOSED)
-        object.__setattr__(self, "_pack_aliases", aliases)
+        object.__setattr__(self, "_pack_aliases_fwd" if forward_only else "_pack_aliases", aliases)
         return jobs
 
-    _PLAN_ATTRS = ("_pack_aliases", "_pad_plan", "_pad_requests", "_pack_plan", "_exec_plan_cache")
+    _PLAN_ATTRS = ("_pack_aliases", "_pack_aliases_fwd", "_pad_plan", "_pad_requests", "_pack_plan", "_pack_plan_fwd",
+                   "_exec_plan_cache")
 
     def __getstate__(self):
         """copy.deepcopy (EMA copies) / torch.save after a forward: the compiled launch plans hold ctypes pointer arrays and
@@ -207,6 +212,7 @@ class SparseUNet(nn.Module):
             object.__setattr__(self, "_pad_plan", F.PadPlan.from_requests(rec))
             object.__setattr__(self, "_pad_requests", [(m, c) for m, c in rec if isinstance(m, M._ConvBase)])
             object.__setattr__(self, "_pack_plan", None)     # (rebuilt with the padded layers' images in it)
+            object.__setattr__(self, "_pack_plan_fwd", None)
             return y
         with F.padded_params(pads):
             return self._forward_packed(x, prebuild)
@@ -214,13 +220,15 @@ class SparseUNet(nn.Module):
     def _forward_packed(self, x, prebuild):
         if self.bf16_all or self.bf16_blocks:
             from . import functional as F
-            plan = self.__dict__.get("_pack_plan")
+            fwd_only = not torch.is_grad_enabled()           # evaluation: no backward-data images
+            attr, al = ("_pack_plan_fwd", "_pack_aliases_fwd") if fwd_only else ("_pack_plan", "_pack_aliases")
+            plan = self.__dict__.get(attr)
             if plan is None:                                 # host-side tables of the pack call: built once
                 use_pads = F.PAD_MANY and bool(self.__dict__.get("_pad_plan"))
-                plan = F.PackPlan(self._pack_jobs(self.__dict__.get("_pad_requests", ()) if use_pads else ()))
-                object.__setattr__(self, "_pack_plan", plan)
+                plan = F.PackPlan(self._pack_jobs(self.__dict__.get("_pad_requests", ()) if use_pads else (), fwd_only))
+                object.__setattr__(self, attr, plan)
             with F.packed_weights(plan) as pw:               # one pack launch for the whole network, gone after the forward
-                for pad_key, dims, j in self.__dict__.get("_pack_aliases", ()):
+                for pad_key, dims, j in self.__dict__.get(al, ()):
                     Wp = F.PADDED.get(pad_key)               # this forward's padded tensor -> the image of its logical weight
                     if Wp is not None:
                         key = (Wp.data_ptr(),) + dims

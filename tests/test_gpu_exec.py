@@ -394,6 +394,55 @@ def test_stage_plans_follow_edits_of_the_inner_module_tree(gpu):
     assert torch.equal(twin(x).features, y0)                       # the copy still is the tree as it was when copied
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_forward_only_is_bit_equal_to_the_training_forward_and_allocates_less(gpu, dtype):
+    """evaluation (`eval_model`, ndsis/training/training.py:244-304; `SparseMaskPredictor`,
+    model.py:826-882) runs the forward under torch.no_grad().  There the executor plans no backward workspace -- a stage's
+    slabs share storage along its op list -- and packs no backward-data weight image; the results are the training forward's
+    bit for bit (backbone output, every encoder output, mask logits) and the forward's peak allocation is smaller."""
+    from sparse_rcnn_amd import executor as EX
+    from sparse_rcnn_amd.trainstep import SceneStep
+    job = SceneStep("cfg3", gpu, dtype=dtype, prefetch=False, seed=3, target=30_000, grid=(256, 256, 128), n_boxes=16, n_buckets=0)
+    m = job.model
+
+    def train_forward():
+        fin = job.feats.detach().requires_grad_()
+        out = m.backbone(job.coords, fin, job.size, job.batch_size)
+        inter = [t.features.detach().clone() for t in m.backbone.unet.interims]
+        logits, _ = m.mask((job.coords, fin, job.size, job.batch_size, job.splits), out, job.boxes)
+        return out, logits, inter
+    out, logits, inter = train_forward()                   # (first call: plans, caches)
+    torch.cuda.synchronize()
+    assert EX.LAST_FORWARD["lean"] is False
+    ref = (out.features.detach().clone(), logits.detach().clone())
+    del out, logits
+    o2, l2 = job.forward_only()
+    assert EX.LAST_FORWARD["lean"] is True
+    assert not o2.features.requires_grad and not l2.requires_grad
+    assert torch.equal(o2.features, ref[0]) and torch.equal(l2, ref[1])
+    for a, t in zip(inter, m.backbone.unet.interims):
+        assert torch.equal(a, t.features)
+    del o2, l2
+    # peak allocation of one forward, both ways (graph alive at the end of the training forward, as before a backward)
+    def peak(fn):
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        keep = fn()
+        torch.cuda.synchronize()
+        p = torch.cuda.max_memory_allocated() - base
+        del keep
+        return p
+    p_train = peak(train_forward)
+    p_eval = peak(job.forward_only)
+    assert p_eval < 0.6 * p_train, (p_eval, p_train)
+    # a frozen network under grad mode (no operand requires a gradient) takes the forward-only plan as well
+    for p in m.parameters():
+        p.requires_grad_(False)
+    out3 = m.backbone(job.coords, job.feats, job.size, job.batch_size)
+    assert EX.LAST_FORWARD["lean"] is True and torch.equal(out3.features, ref[0])
+
+
 def test_deferred_tensors_compute_layer_by_layer_when_nobody_fuses_them(gpu):
     """A pending Deconvolution / NetworkInNetwork whose consumer is NOT a run of residual units (the features are read
     directly; a JoinTable is materialised) gives the layer-by-layer result, and a Deconvolution to a level no Convolution of

@@ -45,9 +45,11 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--target", type=int, default=None, help="active voxels per scene (default: the workload's)")
-    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg5", "ref", "ref-crop"), default="cfg2",
+    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg3-rpn", "cfg5", "ref", "ref-crop"), default="cfg2",
                     help="cfg2 = the configuration the metric is quoted on (default); cfg3 = backbone + OutputLayer + "
-                         "sparse ROI crop (64 boxes) + mask-branch U-Net, fwd+bwd; cfg5 = 600k voxels, 5 levels to 512; "
+                         "sparse ROI crop (64 synthetic boxes) + mask-branch U-Net, fwd+bwd (crop + mask branch only); cfg3-rpn = "
+                         "configs[2] as written: the boxes come out of the same forward (SparseToDense -> dense RPN heads -> "
+                         "top-k + NMS); cfg5 = 600k voxels, 5 levels to 512; "
                          "ref = the reference's own 6-level plan 32-48-64-80-96-112 on the 150k scene; ref-crop = the same "
                          "plan on the reference's training batch (12 crops of 128x128x64)")
     ap.add_argument("--dtype", choices=("f32", "bf16", "bf16-blocks"), default="f32",

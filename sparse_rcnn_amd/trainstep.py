@@ -4,8 +4,12 @@ backward to every parameter and the input features + all-reduce of the flat grad
 
 Workloads (BASELINE.json configs; SURVEY.md §8d synthetic inputs):
   cfg2  configs[1]  one ~150k-voxel scene, U-Net backbone 32-64-128-256
-  cfg3  configs[2]  cfg2 + 64 boxes per scene -> sparse ROI crop -> mask branch (maskhead.MaskBranch); the proposal
-                    source (dense RPN) is PyTorch outside the hot path and not part of the step
+  cfg3  configs[2] WITHOUT its RPN ("crop + mask branch only"): cfg2 + 64 synthetic boxes per scene, known before the
+                    forward -> sparse ROI crop -> mask branch (maskhead.MaskBranch)
+  cfg3-rpn  configs[2] as written: backbone -> SparseToDense of the anchor level -> dense dilation stack + 1x1 heads
+                    (torch / MIOpen) -> RoiSelector (top-k + one-launch NMS) -> <= 64 boxes per scene -> sparse ROI crop ->
+                    mask branch -> backward through both (rpn.py; model.py:116-240, anchor_network.py:73-124,
+                    proposal_selector.py:23-89).  The boxes exist only after the heads have produced them.
   cfg5  configs[4]  one ~600k-voxel scene, 5-level U-Net to 512 channels
 configs[3] (8 scenes data-parallel) is cfg3 with one scene per rank.
 """
@@ -23,6 +27,7 @@ REF_PLAN = (32, 48, 64, 80, 96, 112)      # the reference's own sparse U-Net pla
 WORKLOADS = {      # name -> (channels, grid, active voxels per sample, boxes per scene, BASELINE.json entry, samples per rank)
     "cfg2": ((32, 64, 128, 256), (512, 512, 256), 150_000, 0, "configs[1]", 1),
     "cfg3": ((32, 64, 128, 256), (512, 512, 256), 150_000, 64, "configs[2]", 1),
+    "cfg3-rpn": ((32, 64, 128, 256), (512, 512, 256), 150_000, 64, "configs[2] with the RPN boundary inside the step", 1),
     "cfg5": ((32, 64, 128, 256, 512), (1024, 1024, 512), 600_000, 0, "configs[4] shape (one scene per GPU)", 1),
     # the network the reference actually trains: 6 levels 32-48-64-80-96-112 ...
     "ref": (REF_PLAN, (512, 512, 256), 150_000, 0, "configs[1] scene, the REFERENCE's own channel plan 32-48-64-80-96-112", 1),
@@ -41,10 +46,15 @@ EARLY_ROI_CUT = _os.environ.get("SCN_ROI_EARLY", "0") != "0"
 class SparseStepModel(torch.nn.Module):
     """Backbone (+ mask branch for cfg3) as one module, so that one flat parameter buffer covers the step."""
 
-    def __init__(self, channels, with_mask, storage):
+    def __init__(self, channels, with_mask, storage, with_rpn=False, n_boxes=64):
         super().__init__()
         self.backbone = Backbone(7, channels, bf16_blocks=storage)
         self.mask = MaskBranch(channels[0], 7, bf16_blocks=storage) if with_mask else None
+        self.rpn = self.roi_selector = None
+        if with_rpn:                 # one anchor path on the coarsest level (run.py:524: num_anchor_pathes = 1), stride 2^(L-1)
+            from .rpn import DenseRpn, RoiSelector
+            self.rpn = DenseRpn(channels[-1], stride=2 ** (len(channels) - 1), autocast_bf16=bool(storage))
+            self.roi_selector = RoiSelector(1024, n_boxes, 0.5)          # run.py:848-850 with ~64 proposals kept per scene
 
 
 class SceneStep:
@@ -84,11 +94,15 @@ class SceneStep:
                                      coords=coords.to(self.device), feats=feats.to(self.device), boxes=boxes))   # resident in HBM
         self._use_scene(0)
         torch.manual_seed(0)
-        self.model = SparseStepModel(self.channels, bool(self.n_boxes), storage).to(self.device)
+        self.with_rpn = workload.endswith("-rpn")
+        self.model = SparseStepModel(self.channels, bool(self.n_boxes), storage, self.with_rpn, self.n_boxes).to(self.device)
+        if self.with_rpn:
+            self._init_rpn()
         self.flat = FlatParams(self.model, n_buckets=n_buckets)
         broadcast_params(self.flat)
         self._gen = torch.Generator(device="cpu").manual_seed(grad_seed)
-        self._gys, self._gms = {}, {}
+        self._gys, self._gms, self._grs = {}, {}, {}
+        self.rpn_out = None
         self._md_next = None
         self.n_active = 0
         self.n_roi_rows = 0
@@ -101,6 +115,17 @@ class SceneStep:
             sc["coords_cpu"], sc["feats_cpu"], sc["size"], sc["batch_size"], sc["splits"])
         self.coords, self.feats, self.boxes = sc["coords"], sc["feats"], sc["boxes"]
         self._k = k
+
+    def _init_rpn(self):
+        """Random-init heads give near-constant scores; the synthetic RPN gets a head whose scores spread (so that top-k and
+        NMS have something to decide) -- seeded, the same on every rank."""
+        g = torch.Generator().manual_seed(1234)
+        with torch.no_grad():
+            h = self.model.rpn.head
+            w = torch.randn(h.weight.shape, generator=g) * 0.02              # box deltas: boxes stay near their anchors
+            w[6::7] = torch.randn(w[6::7].shape, generator=g) * 0.5          # channel a*7+6 = the score of anchor a
+            h.weight.copy_(w.to(h.weight.device))
+            h.bias.zero_()
 
     def upstream_grads(self, k=0):
         """(dY of the backbone output, dY of the mask logits or None) of micro-batch k, BEFORE the 1 / batches_per_step scale."""
@@ -149,15 +174,29 @@ class SceneStep:
             logits = None
         else:
             scene = (self.coords, fin, self.size, self.batch_size, self.splits)
-            logits, selection = m.mask(scene, out, self.boxes, prepared_cut=cut)
+            boxes, roots, root_grads = self.boxes, [out.features], [gys]
+            if self.with_rpn:
+                # configs[2] as written (model.py:141-160): the proposals are this forward's -- dense heads on the coarsest
+                # encoder level, top-k + NMS on the device; the RPN losses' gradients arrive at rpn_bbox / rpn_score
+                rpn_bbox, rpn_score, anchors = m.rpn(m.backbone.unet.interims[-1])
+                roi_score, boxes, roi_index = m.roi_selector(rpn_bbox, rpn_score, anchors)
+                self.rpn_out = (rpn_bbox, rpn_score, anchors, roi_score, boxes, roi_index)
+                gr = self._grs.get(k)
+                if gr is None or gr[0].shape != rpn_bbox.shape:
+                    gr = self._grs[k] = tuple((torch.randn(t.shape, generator=self._gen) * 1e-2).to(self.device)
+                                              for t in (rpn_bbox, rpn_score))
+                roots += [rpn_bbox, rpn_score]
+                root_grads += [g if scale == 1.0 else g * scale for g in gr]
+            logits, selection = m.mask(scene, out, boxes, prepared_cut=cut)
             gm = self._gms.get(k)
             if gm is None or gm.shape != logits.shape:
                 gm = self._gms[k] = torch.randn(logits.shape, generator=self._gen).to(self.device)
                 self.n_roi_rows = sum(g.shape[0] for g in self._gms.values())
             if logits.requires_grad and logits.shape[0]:
-                torch.autograd.backward([out.features, logits], [gys, gm if scale == 1.0 else gm * scale])
-            else:         # empty crop (no proposal caught a point): the mask branch contributes nothing on this rank
-                out.features.backward(gys)
+                roots.append(logits)
+                root_grads.append(gm if scale == 1.0 else gm * scale)
+            # (an empty crop -- no proposal caught a point: the mask branch contributes nothing on this rank)
+            torch.autograd.backward(roots, root_grads)
         self.out, self.logits, self.fin = out, logits, fin
 
     def forward_only(self, k=0):
@@ -178,7 +217,11 @@ class SceneStep:
             logits = None
             if m.mask is not None:
                 scene = (self.coords, self.feats, self.size, self.batch_size, self.splits)
-                logits, _ = m.mask(scene, out, self.boxes)
+                boxes = self.boxes
+                if self.with_rpn:
+                    rpn_bbox, rpn_score, anchors = m.rpn(m.backbone.unet.interims[-1])
+                    _, boxes, _ = m.roi_selector(rpn_bbox, rpn_score, anchors)
+                logits, _ = m.mask(scene, out, boxes)
         return out, logits
 
     def step(self):
@@ -203,10 +246,18 @@ class SceneStep:
         s = (f"BASELINE {self.baseline_entry}: {self.batch_size} synthetic ScanNet-shaped sample(s) per GPU, {self.n_active} "
              f"active voxels (grid {self.grid[0]}x{self.grid[1]}x{self.grid[2]}, 1.15 points/voxel), U-Net "
              + "-".join(map(str, self.channels)) + ", 2 pre-act residual blocks/level, 2^3/2 conv+deconv")
-        if self.n_boxes:
+        if self.n_boxes and self.with_rpn:
+            r = self.model.rpn
+            s += (f"; + RPN boundary INSIDE the step: SparseToDense of the stride-{r.stride} level ({r.channels} ch) -> dense "
+                  f"dilation stack {r.channels}-{r.width}-{r.width} (3^3, torch/MIOpen) + 1x1 head ({r.n_anchors} anchors/cell) "
+                  f"-> sigmoid, top-1024, one-launch NMS 0.5, <= {self.n_boxes} boxes/scene -> sparse ROI crop "
+                  f"({self.n_roi_rows} cropped points) -> mask branch (SubM1 + 2 units @16, internal U-Net 23-32-48-64, "
+                  "Linear 23-32-18); backward from the backbone output, rpn_bbox, rpn_score and the mask logits")
+        elif self.n_boxes:
             s += (f"; + {self.n_boxes} fp32 boxes/scene (edges 8-96 voxels) -> sparse ROI crop ({self.n_roi_rows} cropped "
-                  "points) -> mask branch (SubM1 + 2 units @16, internal U-Net 23-32-48-64, Linear 23-32-18); proposals "
-                  "are synthetic (the dense RPN is PyTorch, outside the hot path)")
+                  "points) -> mask branch (SubM1 + 2 units @16, internal U-Net 23-32-48-64, Linear 23-32-18); CROP + MASK "
+                  "BRANCH ONLY: the boxes are synthetic and known before the forward (no RPN in this step; "
+                  "--workload cfg3-rpn has it)")
         s += "; step = rulebooks + fwd + bwd (+ grad all-reduce + SGD)"
         if self.prefetch:
             s += "; rulebooks of batch i+1 built on a helper thread during batch i"

@@ -469,7 +469,7 @@ class FrozenReLU:
 
 
 def unet_forward(scene: OracleScene, feats_pts: torch.Tensor, params: dict, channels, identity_first=False,
-                 storage=None, tile_weights=None, split_nin=False, record=None, relu=None):
+                 storage=None, tile_weights=None, split_nin=False, record=None, relu=None, interims=None):
     """A12: encoder level = {SubM1 | Conv2s2} + 2x[x + SubM3(ReLU(SubM3(ReLU(x))))];
     decoder level = ReLU -> Deconv2s2 -> Join(up, skip) -> NiN -> 2x residual
     (module_factory.py:127-183, 513-578; custom_container.py:70-83: cat((upsampled, skip))).
@@ -479,7 +479,8 @@ def unet_forward(scene: OracleScene, feats_pts: torch.Tensor, params: dict, chan
     on the bf16 tile kernel in that mode (SubM 3^3, Convolution: their LDS image is bf16; the 1x1 / deconvolution GEMMs
     keep fp32 weights).  split_nin: the NetworkInNetwork over a JoinTable as the HIP path evaluates it -- one GEMM per
     joined part, the first partial result stored (rounded) before the second is added.
-    relu: replaces torch.relu (FrozenReLU: prescribed sign masks, consumed in the order the network applies its ReLUs)."""
+    relu: replaces torch.relu (FrozenReLU: prescribed sign masks, consumed in the order the network applies its ReLUs).
+    interims: a list that receives the encoder outputs (differentiable: the RPN's inputs, model.py:293-298)."""
     P = params
     relu = torch.relu if relu is None else relu        # relu: a FrozenReLU (prescribed masks), default the real one
     q = storage if storage is not None else (lambda t: t)
@@ -514,6 +515,8 @@ def unet_forward(scene: OracleScene, feats_pts: torch.Tensor, params: dict, chan
         skips.append(x)
         if record is not None:
             record.append((f"enc{l}", x.detach()))
+    if interims is not None:
+        interims.extend(skips)
     for l in range(L - 2, -1, -1):
         rules = swap_rules(scene.strided_rules(l))
         up = q(conv(relu(x), P[f"dec{l}.up.weight"], P[f"dec{l}.up.bias"], rules, scene.n(l)))

@@ -174,6 +174,9 @@ FROZEN_L2_F32 = 2e-5
 FROZEN_L2_BF16 = 2e-2
 
 
+RPN_L2_F32 = 1e-4          # dense RPN parameters: MIOpen's fp32 convolution against torch's CPU one
+
+
 def _check_grad_frozen(name, what, got, ref, bound):
     e = _err(got, ref)
     _record(name, what, e, f"frozen ReLU masks: rel_l2 <= {bound}")
@@ -452,6 +455,102 @@ def test_cfg3_end_to_end_backbone_crop_mask_vs_oracle_at_150k(gpu, dtype):
     assert e_out["rel_to_scale"] <= FEAT_TOL and e_log["rel_to_scale"] <= FEAT_TOL, (e_out, e_log)
     for k in grads:
         _check_grad_frozen(name, "grad " + k, got[k], grads[k].view_as(got[k]), FROZEN_L2_F32)
+
+
+def test_cfg3_rpn_chain_vs_oracle_at_150k(gpu):
+    """BASELINE configs[2] AS WRITTEN at size: trainstep.SceneStep("cfg3-rpn") -- the step
+    `bench.py --workload cfg3-rpn` times -- on the 150k-voxel scene.  The boxes do not exist before the forward: backbone ->
+    SparseToDense of the stride-8 encoder level -> dense dilation stack + 1x1 head (torch / MIOpen) -> RoiSelector (sigmoid,
+    top-1024, one-launch NMS, <= 64 kept) -> sparse ROI crop with THOSE boxes -> mask branch; backward from the backbone
+    output, rpn_bbox, rpn_score and the mask logits (model.py:116-240, anchor_network.py:73-124, proposal_selector.py:23-89).
+    Against the oracle: SparseToDense of the oracle's level-3 slab, the same dense layers on the CPU, rpn outputs within 1e-4
+    of their scale; the selection -- made on the DEVICE's scores, as in test_rpn_boundary_chain...: two evaluations of a
+    1.2 M-anchor score field differ in their last bits and top-k ties -- equals the oracle's greedy NMS on the device's sorted
+    boxes bit for bit; crop, logits and ALL gradients (76 backbone + 6 dense RPN + 80 mask tensors + the input features) with
+    the ReLU masks of the HIP forward frozen into the oracle."""
+    import copy
+    from sparse_rcnn_amd import rpn as R
+    from sparse_rcnn_amd.trainstep import SceneStep
+    job = SceneStep("cfg3-rpn", gpu, dtype="f32", prefetch=False, seed=1, grad_seed=100, lr=0.0)
+    m = job.model
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(21)
+        for n_, p in m.named_parameters():
+            if p.dim() == 1 and not n_.startswith("rpn.head"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    with _record_relu_masks() as masks:
+        job.forward_backward()
+    torch.cuda.synchronize()
+    assert len(masks) == 31 + 32
+    rpn_bbox, rpn_score, anchors, roi_score, roi_bbox, roi_index = job.rpn_out
+    name = "cfg3_rpn_chain_150k"
+    n_anch = rpn_score.shape[1]
+    assert rpn_bbox.shape == (1, n_anch, 2, 3) and n_anch == 64 * 64 * 32 * m.rpn.n_anchors
+    assert 1 <= len(roi_bbox[0]) <= 64 and job.n_roi_rows > 0
+    print(f"[parity] {name}: {len(roi_bbox[0])} proposals kept, {job.n_roi_rows} cropped points, score range "
+          f"{float(rpn_score.min()):.2f} .. {float(rpn_score.max()):.2f}")
+    # ---- selection: the device's own decoded boxes in its own top-k order -> the oracle's greedy NMS
+    sc = torch.sigmoid(rpn_score.detach())
+    top, idx = torch.topk(sc, 1024, dim=1, sorted=True)
+    cpu_top = torch.topk(sc.cpu(), 1024, dim=1, sorted=True)[0]
+    assert torch.equal(top.cpu(), cpu_top)                              # (values: ties may pick other indices)
+    dec = R.decode_boxes(anchors, rpn_bbox.detach())[0][idx[0]].cpu()
+    keep = torch.from_numpy(O.nms(dec.numpy(), 0.5))
+    assert torch.equal(roi_index[0], idx[0].cpu()[keep][:64])
+    assert torch.equal(roi_bbox[0].cpu(), dec[keep][:64]) and torch.equal(roi_score[0].cpu(), top[0].cpu()[keep][:64])
+    boxes = [b.detach().cpu() for b in roi_bbox]
+    # ---- the oracle chain
+    pb = dict(m.backbone.unet.named_oracle_params())
+    pm = dict(m.mask.named_oracle_params())
+    ch = job.channels
+    scene = O.OracleScene(job.coords_cpu.numpy())
+    bshapes = dict(O.unet_param_shapes(7, list(ch)))
+    po = {k: v.detach().cpu().clone().view(bshapes[k]).requires_grad_() for k, v in pb.items()}
+    mo = _mask_oracle_params(pm)
+    fo = job.feats_cpu.clone().requires_grad_()
+    fr = O.FrozenReLU(masks)
+    inter = []
+    out = O.unet_forward(scene, fo, po, list(ch), relu=fr, interims=inter)
+    gen = torch.Generator().manual_seed(100)
+    gy = torch.randn(out.shape, generator=gen)
+    size3 = [int(v) // 8 for v in job.size]
+    dense = O.sparse_to_dense(inter[3], scene.level_coords[3], size3, 1)
+    got_dense = m.rpn.to_dense(m.backbone.unet.interims[-1]).detach().cpu()
+    assert got_dense.shape == dense.shape and torch.equal(got_dense != 0, dense.detach() != 0)       # same cells
+    _record(name, "SparseToDense of the stride-8 level", _err(got_dense, dense.detach()), FEAT_TOL)
+    stack, head = copy.deepcopy(m.rpn.stack).cpu(), copy.deepcopy(m.rpn.head).cpu()
+    raw = head(stack(dense))
+    raw = raw.view(1, m.rpn.n_anchors, 7, -1).permute(0, 3, 1, 2).reshape(1, -1, 7)
+    ob, os_ = raw[..., :6].reshape(1, -1, 2, 3), raw[..., 6]
+    e_b, e_s = _err(rpn_bbox, ob), _err(rpn_score, os_)
+    _record(name, "rpn_bbox (dense stack: MIOpen vs CPU)", e_b, 1e-4)
+    _record(name, "rpn_score", e_s, 1e-4)
+    assert e_b["rel_to_scale"] <= 1e-4 and e_s["rel_to_scale"] <= 1e-4, (e_b, e_s)
+    gr = [torch.randn(t.shape, generator=gen) * 1e-2 for t in (ob, os_)]          # SceneStep: dY, then rpn grads, then dM
+    boxes_np, cnt, assoc = O.transform_boxes([b.numpy() for b in boxes])
+    logits, src, box_of, rscene = _oracle_mask_branch(job.coords_cpu.numpy(), fo, out, mo, boxes_np, assoc, scene, relu=fr)
+    assert fr.k == len(masks) and len(src) == job.n_roi_rows and logits.shape == job.logits.shape
+    gm = torch.randn(logits.shape, generator=gen)
+    torch.autograd.backward([out, ob, os_, logits], [gy, gr[0], gr[1], gm])
+    e_out, e_log = _err(job.out.features, out), _err(job.logits, logits)
+    _record(name, "backbone features", e_out, FEAT_TOL)
+    _record(name, "mask logits", e_log, FEAT_TOL)
+    assert e_out["rel_to_scale"] <= FEAT_TOL and e_log["rel_to_scale"] <= FEAT_TOL, (e_out, e_log)
+    grads = {k: v.grad for k, v in po.items()}
+    grads.update({"m:" + k: v.grad for k, v in mo.items()})
+    grads["input features"] = fo.grad
+    got = {k: p.grad for k, p in pb.items()}
+    got.update({"m:" + k: p.grad for k, p in pm.items()})
+    got["input features"] = job.fin.grad
+    dense_o = dict(list(stack.named_parameters(prefix="rpn.stack")) + list(head.named_parameters(prefix="rpn.head")))
+    dense_g = {k: p for k, p in m.named_parameters() if k.startswith("rpn.")}
+    assert set(dense_o) == set(dense_g) and len(dense_o) == 6
+    for k in dense_o:
+        grads["d:" + k], got["d:" + k] = dense_o[k].grad, dense_g[k].grad
+    assert set(got) == set(grads) and len(grads) == 76 + 80 + 6 + 1
+    for k in grads:
+        # the dense layers' own gradients and everything their backward reaches ride on MIOpen's fp32 convolutions
+        _check_grad_frozen(name, "grad " + k, got[k], grads[k].view_as(got[k]), RPN_L2_F32 if k.startswith("d:") else FROZEN_L2_F32)
 
 
 @pytest.mark.parametrize("variant", ["unet_only", "both_skip", "raw_skip"])

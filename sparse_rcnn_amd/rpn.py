@@ -9,7 +9,17 @@ head"): the proposals of a step come out of the SAME forward that feeds the mask
 
 What this package contributes to it: SparseToDense (A13, scn_elem.hip), the one-launch NMS (proposals.py) and the consumer
 of the boxes (roi.SparseRoiCut).  The dense layers are plain torch modules with the reference's structure
-(module_factory.py:581-611 `get_dilation_network`: `num_dilations` x [same convolution + ReLU] behind a SparseToDense).
+(module_factory.py:581-611 `get_dilation_network`: `num_dilations` x [same convolution + ReLU] behind a SparseToDense;
+`get_same_convolution` :396-414: kernel 3, dilation 1, padding 1) -- nn.Conv3d parameters with the reference's names / shapes.
+
+Two engines evaluate those layers (same parameters, same mathematics):
+  "miopen"  torch.nn.functional.conv3d on the NCDHW volume.  On this stack MIOpen takes its GEMM fallback solvers for the 3-D
+            backward passes (im2col, 450 MB of workspace): 2.4 ms forward but 43 ms forward + backward in fp32, 22 ms under
+            bf16 autocast, for a 64 x 64 x 32 volume -- five times the whole sparse step (profiles/r5_dense_rpn_probe.txt).
+  "tiles"   (default) a dense same-convolution IS a submanifold convolution on a grid whose every site is active: the volume
+            is kept channels-last as the feature slab [B X Y Z, C] of a fully active Metadata (built once per volume shape and
+            kept), and the 3^3 layers run on this package's tile kernels (k_conv_ts / k_conv_tb, k_wgrad_*), the 1x1 head on
+            the row GEMM.  W_scn[(a*3+b)*3+c, ci, co] = W_torch[co, ci, a, b, c] (SURVEY Appendix B dense identity).
 """
 from __future__ import annotations
 
@@ -28,13 +38,16 @@ class DenseRpn(nn.Module):
     forward(level_tensor) -> (rpn_bbox [B, N, 2, 3] = (position delta, log-size delta), rpn_score [B, N] raw,
     anchors [N, 2, 3] = (centre, size)), N = X' Y' Z' x A, spatial-major / anchor-minor."""
 
-    def __init__(self, channels, stride=8, width=32, num_dilations=2, anchors=DEFAULT_ANCHORS, autocast_bf16=False):
+    ENGINE = "tiles"            # class-wide default: "tiles" | "miopen"
+
+    def __init__(self, channels, stride=8, width=32, num_dilations=2, anchors=DEFAULT_ANCHORS, autocast_bf16=False, engine=None):
         super().__init__()
+        self.engine = engine
         self.channels, self.stride, self.width = int(channels), int(stride), int(width)
         self.to_dense = M.SparseToDense(3, self.channels)
         layers, cin = [], self.channels
-        for d in range(num_dilations):                       # get_dilation_network: same convolution + ReLU, dilation 1, 2, ...
-            layers += [nn.Conv3d(cin, self.width, 3, padding=d + 1, dilation=d + 1), nn.ReLU(inplace=True)]
+        for d in range(num_dilations):                       # get_dilation_network: [same convolution (3^3, dilation 1) + ReLU] x n
+            layers += [nn.Conv3d(cin, self.width, 3, padding=1), nn.ReLU(inplace=True)]
             cin = self.width
         self.stack = nn.Sequential(*layers)
         self.register_buffer("anchor_sizes", torch.tensor(anchors, dtype=torch.float32))
@@ -42,6 +55,12 @@ class DenseRpn(nn.Module):
         self.head = nn.Conv3d(cin, self.n_anchors * 7, 1)    # anchor_network.py:88-92: num_anchors x (2 x num_dims + 1)
         self.autocast_bf16 = bool(autocast_bf16)
         self._anchor_cache = {}
+        self._dense_md = {}
+
+    def __getstate__(self):
+        d = self.__dict__.copy()                 # (the fully active Metadata objects: device index structures, rebuilt on use)
+        d["_dense_md"], d["_anchor_cache"] = {}, {}
+        return d
 
     def anchors_for(self, shape, device):
         key = (tuple(shape), str(device))
@@ -54,7 +73,52 @@ class DenseRpn(nn.Module):
             a = self._anchor_cache[key] = a.to(device)
         return a
 
+    # ---- "tiles": the dense volume as the slab of a fully active grid ------------------------------------------------------
+    def dense_metadata(self, size, batch, device):
+        """Metadata of the grid `size` with EVERY site of every sample active, rows in (b, x, y, z) order -- row r is cell
+        r of the channels-last volume [B, X, Y, Z, C].  Depends on the shape only: built once, kept."""
+        from .metadata import Metadata
+        key = (tuple(size), int(batch), str(device))
+        md = self._dense_md.get(key)
+        if md is None:
+            X, Y, Z = size
+            g = torch.stack(torch.meshgrid(torch.arange(batch), torch.arange(X), torch.arange(Y), torch.arange(Z), indexing="ij"),
+                            -1).reshape(-1, 4)
+            coords = g[:, [1, 2, 3, 0]].contiguous().to(torch.int64)          # (x, y, z, batch), batch-major rows
+            md = self._dense_md[key] = Metadata(3).build_native(size, coords.to(device), batch, 4, 1, 3)
+        return md
+
+    def _forward_tiles(self, level_tensor):
+        from . import functional as F
+        feats = level_tensor.features
+        md = level_tensor.metadata
+        size = tuple(int(v) for v in level_tensor.spatial_size)
+        B = md.n_samples
+        c = md.grid(size).coords.long()                                         # int32 [N, 4] = (x, y, z, b) on the device
+        ridx = ((c[:, 3] * size[0] + c[:, 0]) * size[1] + c[:, 1]) * size[2] + c[:, 2]
+        slab = feats.new_zeros((B * size[0] * size[1] * size[2], feats.shape[1])).index_copy(0, ridx, feats)   # SparseToDense, channels-last
+        dmd = self.dense_metadata(size, B, feats.device)
+        ssz = torch.as_tensor(size, dtype=torch.long)
+        x, relu_in = slab, False
+        for layer in self.stack:
+            if isinstance(layer, nn.ReLU):
+                relu_in = True                                                  # fused into the next layer's gather
+                continue
+            W = layer.weight.permute(2, 3, 4, 1, 0).reshape(27, layer.in_channels, layer.out_channels)
+            x = M._conv_input(x, layer.in_channels, layer.out_channels, True)
+            x = F.SubmanifoldConvolutionFunction.apply(x, W, layer.bias, dmd, ssz, 3, relu_in, None)
+            relu_in = False
+        x = x.float()
+        if relu_in:
+            x = F.ReLUFunction.apply(x)
+        Wh = self.head.weight.reshape(self.head.out_channels, self.head.in_channels).t()
+        raw = F.NetworkInNetworkFunction.apply(x, Wh, self.head.bias)           # [B X Y Z, A * 7]: spatial-major, anchor-minor
+        raw = raw.view(B, -1, 7)
+        return raw[..., :6].reshape(B, -1, 2, 3), raw[..., 6], self.anchors_for(size, raw.device)
+
     def forward(self, level_tensor):
+        if (self.engine or self.ENGINE) == "tiles" and level_tensor.features.is_cuda:
+            return self._forward_tiles(level_tensor)
         dense = self.to_dense(level_tensor)                  # [B, C, X', Y', Z'] (bf16 when the slab is bf16-stored)
         if self.autocast_bf16:
             with torch.autocast("cuda", dtype=torch.bfloat16):

@@ -102,6 +102,7 @@ class SceneStep:
         broadcast_params(self.flat)
         self._gen = torch.Generator(device="cpu").manual_seed(grad_seed)
         self._gys, self._gms, self._grs = {}, {}, {}
+        self._gm_pool = None
         self.rpn_out = None
         self._md_next = None
         self.n_active = 0
@@ -190,7 +191,16 @@ class SceneStep:
             logits, selection = m.mask(scene, out, boxes, prepared_cut=cut)
             gm = self._gms.get(k)
             if gm is None or gm.shape != logits.shape:
-                gm = self._gms[k] = torch.randn(logits.shape, generator=self._gen).to(self.device)
+                if self.with_rpn:
+                    # the proposals -- and with them the number of cropped points -- change from step to step: dM is a slice
+                    # of one device-resident pool (drawing 2 M normals on the host per step would be timed as part of it)
+                    pool = self._gm_pool
+                    if pool is None or pool.shape[0] < logits.shape[0] or pool.shape[1:] != logits.shape[1:]:
+                        rows = max(2 * logits.shape[0], 1 << 18)
+                        pool = self._gm_pool = torch.randn((rows,) + tuple(logits.shape[1:]), generator=self._gen).to(self.device)
+                    gm = self._gms[k] = pool[:logits.shape[0]]
+                else:
+                    gm = self._gms[k] = torch.randn(logits.shape, generator=self._gen).to(self.device)
                 self.n_roi_rows = sum(g.shape[0] for g in self._gms.values())
             if logits.requires_grad and logits.shape[0]:
                 roots.append(logits)

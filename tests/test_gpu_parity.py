@@ -1559,3 +1559,45 @@ def test_global_pool_and_split_batch_match_reference_golden(gpu, path):
     exp = torch.stack([torch.median(p, dim=0).values if len(p) else p.new_zeros(p.shape[1]) for p in
                        O.split_batch(feats, d["coords"], bs)])
     assert torch.equal(med.cpu(), exp)
+
+
+def test_dense_rpn_stack_on_the_tile_kernels_equals_the_miopen_engine(gpu):
+    """rpn.DenseRpn: a dense same-convolution is a submanifold convolution on a fully active grid.  The "tiles" engine (the
+    volume as the channels-last slab of a fully active Metadata, 3^3 layers on k_conv_ts / k_wgrad, head on the row GEMM)
+    against the "miopen" engine (scn.SparseToDense -> torch conv3d on NCDHW) with the same nn.Conv3d parameters: rpn_bbox /
+    rpn_score and every gradient -- the sparse level's features, both dense convolutions, the head -- within 1e-4 of the
+    scale (MIOpen's own accuracy), two samples, fp32; and against torch's CPU conv3d."""
+    import copy
+    from sparse_rcnn_amd.rpn import DenseRpn
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=77, cin=16, grid=(16, 12, 8), n=500, batch=2, dup=50)
+    torch.manual_seed(9)
+    net = DenseRpn(16, stride=8, width=8, num_dilations=2).to(gpu)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(torch.randn_like(p) * 0.1)
+    res = {}
+    for engine in ("tiles", "miopen"):
+        net.engine = engine
+        net.zero_grad()
+        X = x.features.detach().clone().requires_grad_()
+        t = scn.SparseConvNetTensor(features=X, metadata=x.metadata, spatial_size=x.spatial_size)
+        bb, sc, an = net(t)
+        g = torch.Generator().manual_seed(3)
+        gb, gs = torch.randn(bb.shape, generator=g).to(gpu), torch.randn(sc.shape, generator=g).to(gpu)
+        torch.autograd.backward([bb, sc], [gb, gs])
+        res[engine] = [bb.detach(), sc.detach(), X.grad] + [p.grad.clone() for p in net.parameters()]
+        assert an.shape == (16 * 12 * 8 * net.n_anchors, 2, 3) and bb.shape == (2, an.shape[0], 2, 3)
+    # torch on the CPU: the oracle of the dense layers
+    cpu = copy.deepcopy(net).cpu()
+    Xo = x.features.detach().cpu().clone().requires_grad_()
+    dense = O.sparse_to_dense(Xo, scene.coords0, size.tolist(), 2)
+    raw = cpu.head(cpu.stack(dense))
+    raw = raw.view(2, cpu.n_anchors, 7, -1).permute(0, 3, 1, 2).reshape(2, -1, 7)
+    ob, os_ = raw[..., :6].reshape(2, -1, 2, 3), raw[..., 6]
+    cpu.zero_grad()
+    torch.autograd.backward([ob, os_], [gb.cpu(), gs.cpu()])
+    ref = [ob.detach(), os_.detach(), Xo.grad] + [p.grad for p in cpu.parameters()]
+    names = ["rpn_bbox", "rpn_score", "d level features"] + ["d " + n for n, _ in net.named_parameters()]
+    for n, a, b, r in zip(names, res["tiles"], res["miopen"], ref):
+        _close(a, r, 1e-4, f"tiles engine vs CPU: {n}")
+        _close(b, r, 1e-4, f"miopen engine vs CPU: {n}")

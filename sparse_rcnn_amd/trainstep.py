@@ -69,6 +69,10 @@ class SceneStep:
         batch is sharded one scene per rank, loss.py:401-431; the counts are summed over ranks once per step)."""
         ch, gr, tg, nb, self.baseline_entry, n_samples = WORKLOADS[workload]
         self.workload, self.dtype, self.prefetch, self.lr = workload, dtype, prefetch, lr
+        if workload.endswith("-rpn") and lr == 1e-6:
+            # the SAME synthetic gradient on 3.7 M RPN outputs every step is a steady push, not noise: at 1e-6 the score field
+            # grows 4 % per step and overflows within a bench run (profiles/r5_rpn_stats.txt); the update itself is unchanged
+            self.lr = 1e-8
         if weighting not in ("equal", "count"):
             raise ValueError("weighting: equal | count")
         self.weighting = weighting
@@ -184,7 +188,7 @@ class SceneStep:
                 self.rpn_out = (rpn_bbox, rpn_score, anchors, roi_score, boxes, roi_index)
                 gr = self._grs.get(k)
                 if gr is None or gr[0].shape != rpn_bbox.shape:
-                    gr = self._grs[k] = tuple((torch.randn(t.shape, generator=self._gen) * 1e-2).to(self.device)
+                    gr = self._grs[k] = tuple((torch.randn(t.shape, generator=self._gen) * 1e-3).to(self.device)
                                               for t in (rpn_bbox, rpn_score))
                 roots += [rpn_bbox, rpn_score]
                 root_grads += [g if scale == 1.0 else g * scale for g in gr]

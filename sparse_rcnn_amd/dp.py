@@ -67,6 +67,7 @@ class FlatParams:
             p.data = self.flat[off:off + n].view_as(p)
             self.grad_views.append(self.flat_grad[off:off + n].view_as(p))
             off += n
+        self._datas = [p.data for p in self.params]
         self._events, self._ev_used = [], 0
         self._setup_buckets(n_buckets)
 
@@ -259,9 +260,13 @@ class FlatParams:
             self.sgd_step(lr)
             return
         self.flat_grad_valid = False
-        have = [(p, p.grad) for p in self.params if p.grad is not None]
-        if have:
-            torch._foreach_add_([p.data for p, _ in have], [g for _, g in have], alpha=-lr)
+        grads = [p.grad for p in self.params]
+        if None in grads:
+            have = [(d, g) for d, g in zip(self._datas, grads) if g is not None]
+            if have:
+                torch._foreach_add_([d for d, _ in have], [g for _, g in have], alpha=-lr)
+        else:                                   # (the views into `flat` are made once: `p.data` builds a tensor per access)
+            torch._foreach_add_(self._datas, grads, alpha=-lr)
 
 
 def broadcast_params(fp: FlatParams, src: int = 0):

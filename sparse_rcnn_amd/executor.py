@@ -468,11 +468,13 @@ class StageFunction(torch.autograd.Function):
             if lean and fl:                      # a backward-data image: only a backward pass reads it
                 continue
             W = phys[j]
-            img = F.packed_image(W, cin, cout, n_off, fl)
-            if img is None:
+            ent = F.packed_entry(W, cin, cout, n_off, fl)
+            if ent is None:
                 img = F.pack_weights_bf16(W.detach(), cin, cout, n_off, fl)
-            images.append(img)
-            ptab[k] = img.data_ptr()
+                ent = (img, img.data_ptr())
+            if not images or images[-1] is not ent[0]:
+                images.append(ent[0])                # (the pack buffer of a network: one tensor for all its images)
+            ptab[k] = ent[1]
         _run(stage, stage.fwd_arr, levels, table, ptab, None, dev)
         if F.RELU_RECORD is not None:
             _record_relu_masks(stage, ns, ws, offs, inputs, out)

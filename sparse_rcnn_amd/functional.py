@@ -275,7 +275,23 @@ _BACK = L.F_W_TRANSPOSED | L.F_OFF_REVERSE
 
 
 def packed_image(W, cin, cout, n_off, flags):
-    return PACKED.get((W.data_ptr(), cin, cout, n_off, flags & _BACK))
+    """The packed bf16 image of a layer's weight as a tensor (a view of the pack buffer), or None."""
+    e = PACKED.get((W.data_ptr(), cin, cout, n_off, flags & _BACK))
+    if e is None or torch.is_tensor(e):
+        return e
+    buf, o, b = e
+    return buf[o:o + b]
+
+
+def packed_entry(W, cin, cout, n_off, flags):
+    """(pack buffer, device address of the image) or None -- what the step executor needs (an address for its table and ONE
+    tensor to keep alive); slicing a view per image cost the host ~2.5 us each, 124 per step."""
+    e = PACKED.get((W.data_ptr(), cin, cout, n_off, flags & _BACK))
+    if e is None:
+        return None
+    if torch.is_tensor(e):
+        return e, e.data_ptr()
+    return e[0], e[3]
 
 
 class PackPlan:
@@ -326,7 +342,7 @@ class packed_weights:
             pl.Ip[i] = base + o
         L.check(L.lib().scn_conv_tiles_bf16_pack_many(pl.n, pl.Wp, pl.ci, pl.co, pl.no, pl.fl, pl.Ip, L.stream()))
         for key, o, b in zip(pl.keys, pl.offs, pl.sizes):
-            PACKED[key] = buf[o:o + b]
+            PACKED[key] = (buf, o, b, base + o)           # (views are cut on demand: packed_image)
         self.keys = pl.keys
         return self
 

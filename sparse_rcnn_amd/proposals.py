@@ -35,6 +35,11 @@ class ProposalSelector(torch.nn.Module):
         self.num_keep_pre_nms, self.num_keep_post_nms, self.thresh_nms = num_keep_pre_nms, num_keep_post_nms, thresh_nms
 
     def forward(self, rpn_score, rpn_bbox):
+        return self.finish(self.start(rpn_score, rpn_bbox))
+
+    def start(self, rpn_score, rpn_bbox):
+        """top-k + gather + NMS queued, nothing awaited (-> state for `finish`).  The reference's forward is start + finish;
+        split so that a caller can queue other work between the NMS launch and the data-dependent selection."""
         if self.num_keep_pre_nms > 0:
             rpn_score, indices = torch.topk(rpn_score, self.num_keep_pre_nms, dim=1, sorted=True)
         else:
@@ -42,6 +47,11 @@ class ProposalSelector(torch.nn.Module):
         batch_index = torch.arange(len(rpn_bbox), device=rpn_bbox.device).unsqueeze(1)
         rpn_bbox = rpn_bbox[batch_index, indices]
         keep = non_maximum_suppression(rpn_bbox, self.thresh_nms)
+        return rpn_score, rpn_bbox, indices, keep
+
+    def finish(self, state):
+        """The data-dependent part: boolean selection of the kept proposals (one host wait), first `num_keep_post_nms`."""
+        rpn_score, rpn_bbox, indices, keep = state
         post = self.num_keep_post_nms
         scores = [s[k][:post] for s, k in zip(rpn_score, keep)]
         boxes = [b[k][:post] for b, k in zip(rpn_bbox, keep)]

@@ -154,6 +154,13 @@ class RoiSelector(nn.Module):
         self.detach = detach
 
     def forward(self, rpn_bbox, rpn_score, anchors):
+        return self.finish(self.start(rpn_bbox, rpn_score, anchors))
+
+    def start(self, rpn_bbox, rpn_score, anchors):
+        """Everything up to and including the NMS launch, nothing awaited (ProposalSelector.start)."""
         if self.detach:
             rpn_bbox, rpn_score = rpn_bbox.detach(), rpn_score.detach()
-        return self.proposal_selector(torch.sigmoid(rpn_score), decode_boxes(anchors, rpn_bbox))
+        return self.proposal_selector.start(torch.sigmoid(rpn_score), decode_boxes(anchors, rpn_bbox))
+
+    def finish(self, state):
+        return self.proposal_selector.finish(state)

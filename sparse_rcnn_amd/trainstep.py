@@ -41,6 +41,19 @@ import os as _os
 
 # developer switch (A/B in tools/): start the ROI batch's index build before the backbone forward (helper thread + stream)
 EARLY_ROI_CUT = _os.environ.get("SCN_ROI_EARLY", "0") != "0"
+# developer switches (A/B): the RPN's kernels between encoder and decoder; the prefetch thread started after the forward's kernels
+RPN_BEFORE_DECODER = _os.environ.get("SCN_RPN_EARLY", "1") != "0"
+LATE_PREFETCH = _os.environ.get("SCN_LATE_PREFETCH", "1") != "0"
+# backward on the calling thread (torch.autograd.set_multithreading_enabled(False)): no hand-off to the device thread per step
+BACKWARD_INLINE = _os.environ.get("SCN_BACKWARD_INLINE", "0") != "0"
+
+
+def _backward(roots, grads):
+    if BACKWARD_INLINE:
+        with torch.autograd.set_multithreading_enabled(False):
+            torch.autograd.backward(roots, grads)
+    else:
+        torch.autograd.backward(roots, grads)
 
 
 class SparseStepModel(torch.nn.Module):
@@ -151,16 +164,28 @@ class SceneStep:
         self._md_next = None
         # the index structures of the NEXT batch depend on its coordinates only (a data loader's output): a helper thread
         # builds them on the high-priority index stream while this batch runs; every step contains one complete build
-        if self.prefetch:
-            nx = self._scenes[(k + 1) % self.batches_per_step]
-            self._md_next = m.backbone.prefetch_in_thread(nx["coords"], nx["size"], nx["batch_size"])
+        def start_prefetch():
+            if self.prefetch and self._md_next is None:
+                nx = self._scenes[(k + 1) % self.batches_per_step]
+                self._md_next = m.backbone.prefetch_in_thread(nx["coords"], nx["size"], nx["batch_size"])
+        if not LATE_PREFETCH:
+            start_prefetch()
+        # cfg3-rpn: the RPN reads the ENCODER outputs only (model.py:141-160), so its heads, top-k and NMS are queued between
+        # encoder and decoder, and the one host wait of the selection falls while the decoder's kernels run
+        rpn_state = {}
+
+        def rpn_after_encoder(interims):
+            rpn_bbox, rpn_score, anchors = m.rpn(interims[-1])
+            rpn_state["out"] = (rpn_bbox, rpn_score, anchors, m.roi_selector.start(rpn_bbox, rpn_score, anchors))
+        hook = rpn_after_encoder if (self.with_rpn and RPN_BEFORE_DECODER) else None
         # cfg3: the ROI crop's selection and the ROI batch's index structures depend on coordinates and boxes only -- the
         # boxes of a step are known before its backbone runs (here: synthetic; in the reference: the RPN's proposals of
         # the same forward, so this applies to the mask branch's SECOND use of a scene, e.g. evaluation on cached proposals)
         cut = None
         if m.mask is not None and EARLY_ROI_CUT:
             cut = m.mask.prepare_cut(self.coords, self.size, self.boxes)      # (resident int64 coords: no dependency on md)
-        out = m.backbone(self.coords, fin, self.size, self.batch_size, metadata=md)
+        out = m.backbone(self.coords, fin, self.size, self.batch_size, metadata=md, after_encoder=hook)
+        start_prefetch()             # (LATE_PREFETCH: the helper thread is started once this batch's forward kernels are queued)
         gy = self._gys.get(k)
         if gy is None or gy.shape != out.features.shape:
             gy = self._gys[k] = torch.randn(out.features.shape, generator=self._gen).to(self.device)   # upstream grad dY ~ N(0,1)
@@ -175,7 +200,7 @@ class SceneStep:
                 dist.all_reduce(tot)
             self._total_weight = float(tot.item())
         if m.mask is None:
-            out.features.backward(gys)
+            _backward([out.features], [gys])
             logits = None
         else:
             scene = (self.coords, fin, self.size, self.batch_size, self.splits)
@@ -183,8 +208,10 @@ class SceneStep:
             if self.with_rpn:
                 # configs[2] as written (model.py:141-160): the proposals are this forward's -- dense heads on the coarsest
                 # encoder level, top-k + NMS on the device; the RPN losses' gradients arrive at rpn_bbox / rpn_score
-                rpn_bbox, rpn_score, anchors = m.rpn(m.backbone.unet.interims[-1])
-                roi_score, boxes, roi_index = m.roi_selector(rpn_bbox, rpn_score, anchors)
+                if "out" not in rpn_state:
+                    rpn_after_encoder(m.backbone.unet.interims)
+                rpn_bbox, rpn_score, anchors, sel_state = rpn_state["out"]
+                roi_score, boxes, roi_index = m.roi_selector.finish(sel_state)
                 self.rpn_out = (rpn_bbox, rpn_score, anchors, roi_score, boxes, roi_index)
                 gr = self._grs.get(k)
                 if gr is None or gr[0].shape != rpn_bbox.shape:
@@ -210,7 +237,7 @@ class SceneStep:
                 roots.append(logits)
                 root_grads.append(gm if scale == 1.0 else gm * scale)
             # (an empty crop -- no proposal caught a point: the mask branch contributes nothing on this rank)
-            torch.autograd.backward(roots, root_grads)
+            _backward(roots, root_grads)
         self.out, self.logits, self.fin = out, logits, fin
 
     def forward_only(self, k=0):

@@ -301,6 +301,7 @@ class SparseUNet(nn.Module):
                 f = EX.run_stage(plan["enc"][l], lv, [f])
             interims.append(SparseConvNetTensor(features=f, metadata=x.metadata, spatial_size=sizes[l]))
         object.__setattr__(self, "interims", interims)
+        self._after_encoder()
         for i, st in enumerate(plan["dec"]):
             l = L - 2 - i
             f = EX.run_stage(st, lv, [f, interims[l].features])
@@ -322,10 +323,19 @@ class SparseUNet(nn.Module):
             x = self._units(level[1], x)
             interims.append(x)
         object.__setattr__(self, "interims", interims)      # (nn.Module.__setattr__ costs ~60 us per call on the hot path)
+        self._after_encoder()
         for i, d in enumerate(self.decoder):
             skip = interims[len(self.channels) - 2 - i]
             x = self._units(d["units"], d["nin"](d["join"]([d["up"](x), skip])))
         return M.CastFeatures(torch.float32)(x) if self.bf16_all else x
+
+    def _after_encoder(self):
+        """A consumer of the encoder outputs that wants its kernels queued BEFORE the decoder's (Backbone.forward(...,
+        after_encoder=): the RPN heads of a detection step -- the decoder then runs while the host waits for the proposals)."""
+        hook = self.__dict__.get("_encoder_hook")
+        if hook is not None:
+            object.__setattr__(self, "_encoder_hook", None)
+            hook(self.interims)
 
     def _units(self, seq, x):
         if not self.bf16_blocks:
@@ -406,14 +416,21 @@ class Backbone(nn.Module):
     # thread overlap it with the main thread (measured 7.3 -> 6.6 ms/step; the Python-driven prefetch gained nothing).
     NATIVE_INDEX = False
 
-    def forward(self, coords, feats, spatial_size, batch_size=0, metadata=None):
-        """metadata: optional Metadata prepared for the same coords (`prefetch` / `prefetch_in_thread`)."""
+    def forward(self, coords, feats, spatial_size, batch_size=0, metadata=None, after_encoder=None):
+        """metadata: optional Metadata prepared for the same coords (`prefetch` / `prefetch_in_thread`).
+        after_encoder: callable(interims) run between the encoder and the decoder -- whoever consumes the encoder outputs
+        (the RPN of model.py:141-160 reads `box_feature_map_levels`) queues its kernels ahead of the decoder's; results do not
+        depend on it."""
+        object.__setattr__(self.unet, "_encoder_hook", after_encoder)
         if metadata is None and self.NATIVE_INDEX and coords.shape[0] > 0:
             from .metadata import Metadata
             metadata = Metadata(3).build_native(spatial_size, coords, batch_size, 4, len(self.unet.channels), 3,
                                                 xcd_order=self._xcd_order())
         x = InputLayer(3, spatial_size, mode=4)((coords, feats, batch_size), metadata)
-        return self.unet(x)
+        try:
+            return self.unet(x)
+        finally:
+            object.__setattr__(self.unet, "_encoder_hook", None)
 
     def _xcd_order(self):
         """bf16 storage: the SubM tiles of the pyramid also get the XCD-local hand-out order (scn_tiles_build_x)."""

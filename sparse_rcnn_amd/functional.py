@@ -279,7 +279,7 @@ def packed_image(W, cin, cout, n_off, flags):
     e = PACKED.get((W.data_ptr(), cin, cout, n_off, flags & _BACK))
     if e is None or torch.is_tensor(e):
         return e
-    buf, o, b = e
+    buf, o, b, _ = e
     return buf[o:o + b]
 
 

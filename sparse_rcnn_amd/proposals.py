@@ -11,8 +11,12 @@ import torch
 from . import _lib as L
 
 
+SERIAL_NMS = False          # True: the round-1 kernel (scn_nms: one workgroup walks the boxes); the tests' cross-check
+
+
 def non_maximum_suppression(proposed_boxes: torch.Tensor, overlap_threshold: float) -> torch.Tensor:
-    """proposed_boxes fp32 [*, N, 2, D=3] sorted by descending confidence -> bool [*, N] (True = kept)."""
+    """proposed_boxes fp32 [*, N, 2, D=3] sorted by descending confidence -> bool [*, N] (True = kept).
+    N <= 4096: scn_nms_bits (suppression bit matrix over the chip + one serial walk, ~20 us for 1024 boxes); above: scn_nms."""
     if proposed_boxes.shape[-2:] != (2, 3):
         raise NotImplementedError("scn_nms handles 3-D boxes [*, N, 2, 3] (the reference's ScanNet path)")
     lead, n = proposed_boxes.shape[:-3], proposed_boxes.shape[-3]
@@ -22,7 +26,12 @@ def non_maximum_suppression(proposed_boxes: torch.Tensor, overlap_threshold: flo
     if not b.is_cuda:
         raise L.ScnError("boxes must live on the MI355X (no CPU fallback)")
     keep = torch.empty((b.shape[0], n), dtype=torch.uint8, device=b.device)
-    L.check(L.lib().scn_nms(L.ptr(b), b.shape[0], n, float(overlap_threshold), L.ptr(keep), L.stream()))
+    lib = L.lib()
+    if n <= 4096 and not SERIAL_NMS:
+        scratch = L.scratch(lib.scn_nms_scratch_bytes(b.shape[0], n), b.device)
+        L.check(lib.scn_nms_bits(L.ptr(b), b.shape[0], n, float(overlap_threshold), L.ptr(keep), scratch.data_ptr(), L.stream()))
+    else:
+        L.check(lib.scn_nms(L.ptr(b), b.shape[0], n, float(overlap_threshold), L.ptr(keep), L.stream()))
     return keep.bool().reshape(*lead, n)
 
 

@@ -43,9 +43,10 @@ import os as _os
 EARLY_ROI_CUT = _os.environ.get("SCN_ROI_EARLY", "0") != "0"
 # developer switches (A/B): the RPN's kernels between encoder and decoder; the prefetch thread started after the forward's kernels
 RPN_BEFORE_DECODER = _os.environ.get("SCN_RPN_EARLY", "1") != "0"
-LATE_PREFETCH = _os.environ.get("SCN_LATE_PREFETCH", "1") != "0"
+LATE_PREFETCH = _os.environ.get("SCN_LATE_PREFETCH", "0") != "0"       # (measured neutral: off)
 # backward on the calling thread (torch.autograd.set_multithreading_enabled(False)): no hand-off to the device thread per step
-BACKWARD_INLINE = _os.environ.get("SCN_BACKWARD_INLINE", "0") != "0"
+# (A/B inside one process, profiles/r5_ab_inproc.txt: cfg 3 bf16 7.13 -> 6.51 ms per step, cfg 2 bf16 3.44 -> 3.31, fp32 neutral)
+BACKWARD_INLINE = _os.environ.get("SCN_BACKWARD_INLINE", "1") != "0"
 
 
 def _backward(roots, grads):

@@ -668,6 +668,33 @@ def test_nms_edge_cases(gpu):
     assert np.array_equal(got, O.nms(boxes, 0.25))
 
 
+@pytest.mark.parametrize("n,batch,thr", [(1, 1, 0.5), (63, 2, 0.3), (64, 1, 0.5), (65, 3, 0.5), (1000, 2, 0.25), (1024, 8, 0.5),
+                                          (1025, 1, 0.7), (2500, 2, 0.25), (4096, 1, 0.4)])
+def test_bit_matrix_nms_equals_the_serial_kernel_and_the_oracle(gpu, n, batch, thr):
+    """scn_nms_bits (round 5: suppression bit matrix over the chip + one serial walk out of LDS) against scn_nms (one workgroup
+    walking the boxes) and the oracle's greedy NMS: keep decisions bit for bit, also with degenerate (zero-volume, NaN IoU)
+    and duplicate boxes, sizes around the 64-box word and 256-row staging boundaries."""
+    from sparse_rcnn_amd import proposals as P
+    rng = np.random.default_rng(n * 7 + batch)
+    c = rng.uniform(0, 40, size=(batch, n, 3)); sz = rng.uniform(1, 8, size=(batch, n, 3))
+    boxes = np.stack([c - sz, c + sz], 2).astype(np.float32)
+    if n >= 64:
+        boxes[:, 5] = boxes[:, 3]                               # a duplicate
+        boxes[:, 7, 1] = boxes[:, 7, 0]                         # zero volume
+        boxes[:, 9] = 0.0                                       # zero box: 0 / 0 against its copies
+        boxes[:, 11] = 0.0
+    b = torch.from_numpy(boxes).to(gpu)
+    got = P.non_maximum_suppression(b, thr).cpu().numpy()
+    P.SERIAL_NMS = True
+    try:
+        ref = P.non_maximum_suppression(b, thr).cpu().numpy()
+    finally:
+        P.SERIAL_NMS = False
+    assert np.array_equal(got, ref)
+    for s_ in range(batch):
+        assert np.array_equal(got[s_], O.nms(boxes[s_], thr)), s_
+
+
 VOX_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "voxelize_*.npz")))
 
 

@@ -483,7 +483,11 @@ def test_cfg3_rpn_chain_vs_oracle_at_150k(gpu):
     torch.cuda.synchronize()
     # 31 backbone masks, the 2 ReLUs of the dense stack (the "tiles" engine runs it on this package's kernels: rpn.py), 32 mask-branch
     assert m.rpn.ENGINE == "tiles" and len(masks) == 31 + 2 + 32
-    rpn_masks, masks = masks[31:33], masks[:31] + masks[33:]
+    # (the RPN's kernels are queued between encoder and decoder -- trainstep.RPN_BEFORE_DECODER -- so its two masks follow the
+    # encoder's 16: four levels x two units x two ReLUs)
+    from sparse_rcnn_amd import trainstep as TS
+    at = 16 if TS.RPN_BEFORE_DECODER else 31
+    rpn_masks, masks = masks[at:at + 2], masks[:at] + masks[at + 2:]
     rpn_bbox, rpn_score, anchors, roi_score, roi_bbox, roi_index = job.rpn_out
     name = "cfg3_rpn_chain_150k"
     n_anch = rpn_score.shape[1]

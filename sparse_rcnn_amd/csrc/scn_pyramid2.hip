@@ -24,6 +24,16 @@
 //   come from `tables`: scan, scatter | hist, scan, scatter | hist, scan, scatter; rule scans / fills ride in the first two) |
 //   tiles | tile orders  =  14 + (L - 1)   (17 for the benchmark U-Net; rounds 1-3: 136), one host wait.
 //
+// Round 5: BRICKS.  Every neighbour / sibling / child / parent probe of the build went to an open-addressing table keyed by the
+// voxel: 4 M scattered probes for the 27-neighbour tables of the 150 k scene alone, each a miss in the XCD's L2 (100 us of the
+// 326 us of kernels).  Now every level also keeps its sites in 4 x 4 x 4 BRICKS: a small directory keyed by (b, x>>2, y>>2, z>>2)
+// -- a surface scene has one brick per ~10 rows, so the directory and the bricks (64 row numbers + a 64-bit occupancy word
+// each) of a level stay in L2 -- and rows arrive in mesh order, so the probes of a wave meet the same few bricks.  The 27
+// neighbours of a voxel lie in at most 8 bricks, its 8 siblings / the 8 children of a coarse site / its parent in ONE.  The
+// bricks are filled where the rows are numbered (k_number0, k_coarsen): no launch is added.  A directory that overflows
+// (points so sparse that nearly every one has a brick of its own) sets a device word and every consumer takes the voxel
+// tables as before -- same structures either way (tests: fused == round-3 builder, SCN_PYRAMID_NO_BRICKS A/B).
+//
 // Same structures as the step-by-step entry points, bit for bit (tables, compacted rules, perm / tstab / tile_mask / both
 // tile orders, parents, child tables, row numbering): tests/test_gpu_parity.py::test_fused_pyramid_build_*.  Only the hash
 // tables differ (every level gets the capacity of n_points: its size must not depend on a count the host does not know).
@@ -46,7 +56,9 @@ constexpr int SPIN_MAX = 1 << 22;      // look-back polls before a workgroup giv
 
 // the device-resident sizes (int64 words), copied to the host ONCE when everything has been queued
 constexpr int DS_BAD = 0, DS_ERR = 1, DS_N = 2 /* + l */, DS_SP = 16 /* + 28 l + o */, DS_CP = 16 + 28 * MAXL /* + 9 l + o */;
-constexpr int DS_LEN = DS_CP + 9 * MAXL;
+constexpr int DS_NOBRICK = DS_CP + 9 * MAXL;      // != 0: a brick directory overflowed (or bricks are switched off): voxel tables
+constexpr int DS_LEN = DS_NOBRICK + 1;
+constexpr int BRICK_PROBES = 32;       // slots an insert may walk before it gives the directory up
 
 struct KeyBits { unsigned char pos[32]; };
 
@@ -65,7 +77,11 @@ struct PA {
     int* tickets;                       // [MAXL]  (numbering of level l)
     unsigned long long* keys;           // [n_levels][cap]
     int* hrows;                         // [n_levels][cap]
-    long long cap, bound;
+    unsigned long long* bkeys;          // [n_levels][bcap]      brick directory: keys (b, x>>2, y>>2, z>>2), EMPTY-filled
+    unsigned long long* bmask;          // [n_levels][bcap]      occupancy of the 64 sites of a brick, zero-filled
+    int* bent;                          // [n_levels][bcap][64]  row numbers, valid where the occupancy bit is set
+    long long cap, bound, bcap;
+    int no_bricks;                      // developer switch SCN_PYRAMID_NO_BRICKS: voxel tables everywhere (A/B, cross-check)
     int n_levels, k, with_x, nblk;      // nblk = cdiv(bound, TILE)
     LvA lv[MAXL];
     KeyBits kb;
@@ -94,6 +110,73 @@ __device__ __forceinline__ int lookup(const unsigned long long* __restrict__ key
 }
 
 __device__ __forceinline__ long long cdiv_dev(long long n) { return (n + TILE - 1) / TILE; }
+
+// ---- bricks ---------------------------------------------------------------------------------------------------------
+struct Bricks { unsigned long long* keys; unsigned long long* mask; int* ent; unsigned long long m; };
+__device__ __forceinline__ Bricks bricks_of(const PA& a, int l) {
+    return Bricks{a.bkeys + (size_t)l * a.bcap, a.bmask + (size_t)l * a.bcap, a.bent + (size_t)l * a.bcap * 64,
+                  (unsigned long long)a.bcap - 1ull};
+}
+__device__ __forceinline__ int brick_local(int x, int y, int z) { return ((x & 3) * 4 + (y & 3)) * 4 + (z & 3); }
+
+// row `row` at site (x, y, z, b): claim / find the brick, set the occupancy bit, store the row.  false: directory full.
+__device__ __forceinline__ bool brick_insert(const Bricks& B, int x, int y, int z, int b, int row) {
+    const unsigned long long key = scn_pack_key(x >> 2, y >> 2, z >> 2, b);
+    unsigned long long slot = scn_hash_slot(key, B.m);
+    for (int p = 0; p < BRICK_PROBES; ++p) {
+        const unsigned long long prev = atomicCAS(&B.keys[slot], SCN_EMPTY_KEY, key);
+        if (prev == SCN_EMPTY_KEY || prev == key) {
+            B.ent[slot * 64 + brick_local(x, y, z)] = row;
+            atomicOr(&B.mask[slot], 1ull << brick_local(x, y, z));
+            return true;
+        }
+        slot = (slot + 1) & B.m;
+    }
+    return false;
+}
+
+// G brick keys -> directory slots (or -1) and occupancy words; the G first-slot loads are in flight together (as lookup_n)
+template <int G>
+__device__ __forceinline__ void brick_find_n(const Bricks& B, const unsigned long long (&key)[G], const bool (&want)[G],
+                                             int (&slot_out)[G], unsigned long long (&occ)[G]) {
+    unsigned long long slot[G], k[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) slot[j] = scn_hash_slot(key[j], B.m);
+#pragma unroll
+    for (int j = 0; j < G; ++j) k[j] = B.keys[slot[j]];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        slot_out[j] = (want[j] && k[j] == key[j]) ? (int)slot[j] : -1;
+        if (want[j] && k[j] != key[j] && k[j] != SCN_EMPTY_KEY) {          // a foreign key in the first slot: walk on (rare)
+            unsigned long long s2 = (slot[j] + 1) & B.m;
+            for (int p = 1; p < BRICK_PROBES; ++p) {
+                const unsigned long long kk = B.keys[s2];
+                if (kk == key[j]) { slot_out[j] = (int)s2; break; }
+                if (kk == SCN_EMPTY_KEY) break;
+                s2 = (s2 + 1) & B.m;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) occ[j] = B.mask[slot_out[j] >= 0 ? slot_out[j] : 0];
+#pragma unroll
+    for (int j = 0; j < G; ++j) occ[j] = slot_out[j] >= 0 ? occ[j] : 0ull;
+}
+
+// the 2 x 2 x 2 cell with even corner (x0, y0, z0) lies in one brick: its 8 rows (or -1), o = (dx * 2 + dy) * 2 + dz
+__device__ __forceinline__ void brick_cell8(const Bricks& B, int x0, int y0, int z0, int b, bool want, int (&out)[8]) {
+    unsigned long long key[1] = {scn_pack_key(x0 >> 2, y0 >> 2, z0 >> 2, b)}, occ[1];
+    bool w[1] = {want};
+    int s[1];
+    brick_find_n<1>(B, key, w, s, occ);
+    const int* e = B.ent + (size_t)(s[0] >= 0 ? s[0] : 0) * 64;
+    int v[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) v[o] = e[brick_local(x0 + (o >> 2), y0 + ((o >> 1) & 1), z0 + (o & 1))];
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+        out[o] = ((occ[0] >> brick_local(x0 + (o >> 2), y0 + ((o >> 1) & 1), z0 + (o & 1))) & 1ull) ? v[o] : -1;
+}
 
 __device__ __forceinline__ unsigned gray_rank(unsigned m) {      // binary value whose reflected Gray code is m
     m ^= m >> 1; m ^= m >> 2; m ^= m >> 4; m ^= m >> 8; m ^= m >> 16;
@@ -290,7 +373,9 @@ __global__ __launch_bounds__(TT) void k_number0(PA a, long long n, const int4* _
         const int pos = excl + lp;
         hrows[slot] = pos;
         row_first[pos] = (int)i;
-        coords[pos] = c32[i];
+        const int4 c = c32[i];
+        coords[pos] = c;
+        if (!a.no_bricks && !brick_insert(bricks_of(a, 0), c.x, c.y, c.z, c.w, pos)) a.dsz[DS_NOBRICK] = 1;
     }
     if (base + TILE >= n && threadIdx.x == 0) a.dsz[DS_N] = excl + agg;
 }
@@ -324,7 +409,10 @@ __global__ __launch_bounds__(TT) void k_coarsen(PA a, int l) {
         key[o] = scn_pack_key((c.x & ~1) + (o >> 2), (c.y & ~1) + ((o >> 1) & 1), (c.z & ~1) + (o & 1), c.w);
         want[o] = live;
     }
-    lookup_n<8>(fkeys, frows, mask, key, want, sib);         // (its own offset answers i: not lower)
+    // (a word the kernels BEFORE this one may have set: the bricks of level l are complete whenever it reads zero)
+    const bool use_bricks = !a.no_bricks && a.dsz[DS_NOBRICK] == 0;
+    if (use_bricks) brick_cell8(bricks_of(a, l), c.x & ~1, c.y & ~1, c.z & ~1, c.w, live, sib);
+    else lookup_n<8>(fkeys, frows, mask, key, want, sib);    // (its own offset answers i: not lower)
     bool f = live;
 #pragma unroll
     for (int o = 0; o < 8; ++o) f = f && !(sib[o] >= 0 && sib[o] < (int)i);
@@ -344,6 +432,7 @@ __global__ __launch_bounds__(TT) void k_coarsen(PA a, int l) {
             }
             slot = (slot + 1) & mask;
         }
+        if (!a.no_bricks && !brick_insert(bricks_of(a, l + 1), cc.x, cc.y, cc.z, cc.w, pos)) a.dsz[DS_NOBRICK] = 1;
     }
     if (base + TILE >= n && threadIdx.x == 0) a.dsz[DS_N + l + 1] = excl + agg;
 }
@@ -384,6 +473,59 @@ __device__ __forceinline__ void table_job(const PA& a, int l, int b) {
     const int4 c = live ? coords[r] : make_int4(0, 0, 0, 0);
     unsigned m = 0;
     constexpr int G = SUBM ? 9 : 8;
+    const bool use_bricks = !a.no_bricks && a.dsz[DS_NOBRICK] == 0;      // (every brick was filled by the kernels before this one)
+    if (use_bricks) {
+        const Bricks B = bricks_of(a, l);
+        int v[N_OFF];
+        if constexpr (SUBM) {
+            // the 3 x 3 x 3 neighbourhood of (x, y, z) meets the bricks (bx0 | bx1, by0 | by1, bz0 | bz1): at most 8 directory
+            // probes and occupancy words, then 27 loads out of those bricks
+            const int bx0 = (c.x - 1) >> 2, by0 = (c.y - 1) >> 2, bz0 = (c.z - 1) >> 2;
+            const int bx1 = (c.x + 1) >> 2, by1 = (c.y + 1) >> 2, bz1 = (c.z + 1) >> 2;
+            unsigned long long key[8], occ[8];
+            bool want[8];
+            int bs[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ix = j >> 2, iy = (j >> 1) & 1, iz = j & 1;
+                const int bx = ix ? bx1 : bx0, by = iy ? by1 : by0, bz = iz ? bz1 : bz0;
+                want[j] = live && (!ix || bx1 != bx0) && (!iy || by1 != by0) && (!iz || bz1 != bz0) &&
+                          (unsigned)bx < 16384u && (unsigned)by < 16384u && (unsigned)bz < 16384u;
+                key[j] = scn_pack_key(bx & 16383, by & 16383, bz & 16383, c.w);
+            }
+            brick_find_n<8>(B, key, want, bs, occ);
+            int loc[N_OFF], sl[N_OFF];
+            bool ok[N_OFF];
+#pragma unroll
+            for (int o = 0; o < N_OFF; ++o) {
+                const int x = c.x + (o / 9 - 1), y = c.y + ((o / 3) % 3 - 1), z = c.z + (o % 3 - 1);
+                const int j = (((x >> 2) != bx0) * 2 + ((y >> 2) != by0)) * 2 + ((z >> 2) != bz0);
+                int sj = bs[0];
+                unsigned long long oj = occ[0];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) { sj = j == q ? bs[q] : sj; oj = j == q ? occ[q] : oj; }
+                loc[o] = brick_local(x, y, z);
+                ok[o] = live && sj >= 0 && ((oj >> loc[o]) & 1ull) && (unsigned)x < 65536u && (unsigned)y < 65536u && (unsigned)z < 65536u;
+                sl[o] = sj >= 0 ? sj : 0;
+            }
+#pragma unroll
+            for (int o = 0; o < N_OFF; ++o) v[o] = B.ent[(size_t)sl[o] * 64 + loc[o]];
+#pragma unroll
+            for (int o = 0; o < N_OFF; ++o) v[o] = ok[o] ? v[o] : -1;
+        } else {
+            int v8[8];
+            brick_cell8(B, 2 * c.x, 2 * c.y, 2 * c.z, c.w, live, v8);          // the 8 children of coarse site c: one brick
+#pragma unroll
+            for (int o = 0; o < 8; ++o) v[o] = v8[o];
+        }
+#pragma unroll
+        for (int o = 0; o < N_OFF; ++o) {
+            if (live) table[(long long)o * n + r] = v[o];
+            m |= (v[o] >= 0 ? 1u : 0u) << (SUBM ? a.kb.pos[o] : o);
+            const int cnt = __popcll(__ballot(v[o] >= 0));
+            if (lane == 0) wsum[o][w] = cnt;
+        }
+    } else
 #pragma unroll
     for (int g = 0; g < N_OFF / G; ++g) {
         unsigned long long key[G];
@@ -444,9 +586,21 @@ __global__ __launch_bounds__(TT) void k_tables(PA a, const int* __restrict__ slo
         const int4* __restrict__ fine = at<int4>(a, a.lv[l].coords);
         int* __restrict__ parent = at<int>(a, a.lv[l].parent);
         int* __restrict__ fine_off = at<int>(a, a.lv[l].fine_off);
+        const bool use_bricks = !a.no_bricks && a.dsz[DS_NOBRICK] == 0;
+        const Bricks B = bricks_of(a, l + 1);
         for (long long i = (long long)b * TT + threadIdx.x; i < n; i += (long long)a.nblk * TT) {
             const int4 c = fine[i];
-            parent[i] = lookup(ckeys, crows, mask, scn_pack_key(c.x >> 1, c.y >> 1, c.z >> 1, c.w));
+            if (use_bricks) {                                // (the parent exists: it was numbered from this very row's cell)
+                const int px = c.x >> 1, py = c.y >> 1, pz = c.z >> 1;
+                unsigned long long key[1] = {scn_pack_key(px >> 2, py >> 2, pz >> 2, c.w)}, occ[1];
+                bool w1[1] = {true};
+                int s1[1];
+                brick_find_n<1>(B, key, w1, s1, occ);
+                const int loc = brick_local(px, py, pz);
+                parent[i] = (s1[0] >= 0 && ((occ[0] >> loc) & 1ull)) ? B.ent[(size_t)s1[0] * 64 + loc] : -1;
+            } else {
+                parent[i] = lookup(ckeys, crows, mask, scn_pack_key(c.x >> 1, c.y >> 1, c.z >> 1, c.w));
+            }
             fine_off[i] = ((c.x & 1) * 2 + (c.y & 1)) * 2 + (c.z & 1);
         }
         return;
@@ -971,7 +1125,7 @@ struct Bump2 {
 };
 
 struct Plan {
-    int64_t keys, hrows, zero, zero_end, dsz, tickets, row_count, status[MAXL];
+    int64_t keys, hrows, zero, zero_end, dsz, tickets, row_count, status[MAXL], bkeys, bmask, bent, bcap;
     int64_t c32, slot0, item_row, row_first;
     int64_t off[MAXL][40];
     int64_t total, cap, nblk, bsums_ints, cbsums_ints;
@@ -989,15 +1143,23 @@ Plan make_plan(int64_t n, int n_levels, int k, bool with_x) {
     const int64_t cap = scn_hash_capacity(n), nblk = cdiv(n, TILE), nt = cdiv(n, 16);
     const int n_off = k * k * k;
     p.cap = cap; p.nblk = nblk;
-    p.keys = w.take((int64_t)n_levels * cap * 8);
+    // brick directories: a quarter of the voxel tables' slots (a 4^3 brick of a surface scene holds ~10 rows: load < 0.2; a
+    // scene with a brick per row overflows it and the build falls back to the voxel tables).  The keys sit right behind the
+    // voxel keys (one fill region), the occupancy words inside the zero region.
+    const int64_t bcap = cap / 4 > 1024 ? cap / 4 : 1024;
+    p.bcap = bcap;
+    p.keys = w.take((int64_t)n_levels * cap * 8 + (int64_t)n_levels * bcap * 8);
+    p.bkeys = p.keys + (int64_t)n_levels * cap * 8;
     p.hrows = w.take((int64_t)n_levels * cap * 4);
     // ---- zero region
     p.zero = p.dsz = w.take(DS_LEN * 8);
     p.tickets = w.take(64 * 4);
     p.row_count = w.take(n * 4);
     for (int l = 0; l < n_levels; ++l) p.status[l] = w.take(nblk * 4);
+    p.bmask = w.take((int64_t)n_levels * bcap * 8);
     w.used = (w.used + 255) & ~(int64_t)255;
     p.zero_end = w.used;
+    p.bent = w.take((int64_t)n_levels * bcap * 64 * 4);          // (never initialised: valid where an occupancy bit is set)
     // ---- the rest
     p.c32 = w.take(n * 16);
     p.slot0 = w.take(n * 4);
@@ -1088,6 +1250,11 @@ int pyramid2_build(const int64_t* coords, int64_t n_points, int n_levels, int k,
     a.tickets = (int*)(base + p.tickets);
     a.keys = (unsigned long long*)(base + p.keys);
     a.hrows = (int*)(base + p.hrows);
+    a.bkeys = (unsigned long long*)(base + p.bkeys);
+    a.bmask = (unsigned long long*)(base + p.bmask);
+    a.bent = (int*)(base + p.bent);
+    a.bcap = p.bcap;
+    a.no_bricks = scn::sw(scn::SW_PYRAMID_NO_BRICKS).set ? 1 : 0;
     a.cap = p.cap; a.bound = n; a.n_levels = n_levels; a.k = k; a.with_x = with_x ? 1 : 0; a.nblk = (int)nblk;
     a.kb = make_key_bits27();
     auto q = [](int64_t off) { return (uint32_t)(off >> 8); };
@@ -1107,7 +1274,7 @@ int pyramid2_build(const int64_t* coords, int64_t n_points, int n_levels, int k,
 
     // ---- queue everything; nothing below waits for the device ------------------------------------------------------
     FillA fa{};
-    fa.p[0] = (uint4*)(base + p.keys);  fa.n16[0] = (int64_t)n_levels * p.cap * 8 / 16; fa.v[0] = 0xFFFFFFFFu;
+    fa.p[0] = (uint4*)(base + p.keys);  fa.n16[0] = ((int64_t)n_levels * p.cap * 8 + (int64_t)n_levels * p.bcap * 8) / 16; fa.v[0] = 0xFFFFFFFFu;
     fa.p[1] = (uint4*)(base + p.hrows); fa.n16[1] = (int64_t)n_levels * p.cap * 4 / 16; fa.v[1] = 0x7FFFFFFFu;
     fa.p[2] = (uint4*)(base + p.zero);  fa.n16[2] = (p.zero_end - p.zero) / 16;          fa.v[2] = 0u;
     hipLaunchKernelGGL(k_fill, dim3(scn::ew_grid(fa.n16[0], T)), dim3(T), 0, st, fa);

@@ -850,6 +850,44 @@ def _index_tensors(md, with_x=False):
     return out
 
 
+@pytest.mark.parametrize("case", ["150k-4", "12crops-6", "sparse-overflow", "edges"])
+def test_brick_tables_of_the_fused_build_change_no_structure(gpu, case):
+    """Round 5: the fused build looks neighbours / siblings / children / parents up in 4^3 bricks (scn_pyramid2.hip) instead of
+    probing a voxel hash table 27 times per row.  With the bricks off (SCN_PYRAMID_NO_BRICKS) every index structure is the
+    same bit for bit; `sparse-overflow`: 5 000 random points in 256^3 -- nearly one brick per point, the directory (a quarter
+    of the voxel table) overflows and the build falls back to the voxel tables by itself, same structures; `edges`: sites on
+    the faces of the 16-bit coordinate range (neighbours outside it do not exist)."""
+    from sparse_rcnn_amd.metadata import Metadata
+    from sparse_rcnn_amd.synthetic import make_batch
+    if case == "sparse-overflow":
+        g = torch.Generator().manual_seed(5)
+        coords = torch.cat([torch.randint(0, 256, (5000, 3), generator=g), torch.zeros(5000, 1, dtype=torch.long)], 1)
+        size, bs, levels = torch.tensor([256, 256, 256]), 1, 3
+    elif case == "edges":
+        g = torch.Generator().manual_seed(6)
+        c = torch.randint(0, 6, (3000, 3), generator=g)
+        c = torch.where(torch.rand(3000, 3, generator=g) < 0.5, c, 65535 - c)          # both ends of every axis
+        coords = torch.cat([c, torch.randint(0, 2, (3000, 1), generator=g)], 1)
+        coords = coords[coords[:, 3].argsort(stable=True)]
+        size, bs, levels = torch.tensor([65536, 65536, 65536]), 2, 3
+    else:
+        n_s, grid, target, levels = {"150k-4": (1, (512, 512, 256), 150_000, 4), "12crops-6": (12, (128, 128, 64), 12_500, 6)}[case]
+        coords, _, size, bs, _ = make_batch(n_s, grid, target, dup=1.15, seed=4)
+    cg = coords.to(gpu)
+    b = Metadata(3).build_native(size, cg, bs, 4, levels, 3)
+    _SW["SCN_PYRAMID_NO_BRICKS"] = "1"
+    try:
+        a = Metadata(3).build_native(size, cg, bs, 4, levels, 3)
+    finally:
+        del _SW["SCN_PYRAMID_NO_BRICKS"]
+    torch.cuda.synchronize()
+    assert list(a.grids) == list(b.grids) and [g.n for g in a.grids.values()] == [g.n for g in b.grids.values()]
+    ta, tb = _index_tensors(a), _index_tensors(b)
+    assert [n for n, _ in ta] == [n for n, _ in tb]
+    for (name, x), (_, y) in zip(ta, tb):
+        assert x.shape == y.shape and torch.equal(x, y), (case, name)
+
+
 @pytest.mark.parametrize("case", ["150k-4", "150k-6-x", "12crops-6", "small-3-x", "tiny-2", "one-level"])
 def test_fused_pyramid_build_equals_the_round3_builder(gpu, case):
     """scn_pyramid_build_ex(SCN_PYRAMID_FUSED) -- level sizes device-resident, the levels side by side inside each launch,

@@ -377,14 +377,17 @@ def roofline(dom, d, sampled, args):
     """`roofline` object of the contract for the dominant kernel (HIP events around its launches, live)."""
     us = d["ms"] * 1e3 / d["launches"]
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r4_traffic.json")       # separate rocprofv3 --pmc passes (tools/collect_traffic.py)
+    # separate rocprofv3 --pmc passes (tools/collect_traffic.py, tools/collect_r5.sh); round 5: one file, an entry per
+    # (workload, storage type) -- the bf16 lines have counter bytes too
+    tfile = os.path.join(ROOT, "profiles", "r5_traffic.json")
     if not os.path.exists(tfile):
-        tfile = os.path.join(ROOT, "profiles", "r2_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "r4_traffic.json")
     try:
         with open(tfile) as f:
             t = json.load(f)
-        traffic = t["kernels"][dom]["hbm_bytes_per_launch"] if t.get("workload") == args.workload and \
-            t.get("dtype", "f32") == args.dtype else None
+        for ent in t.get("entries", [t]):
+            if ent.get("workload") == args.workload and ent.get("dtype", "f32") == args.dtype:
+                traffic = ent["kernels"][dom]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
     common = {"kernel": dom, "traffic": traffic,

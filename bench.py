@@ -271,6 +271,7 @@ def run(args):
         dist.barrier()
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats()                      # peak HBM of the timed region (memory audit)
+    base_alloc = torch.cuda.memory_allocated()                # resident before the step: parameters, inputs, the prefetched index
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if use_timer:
@@ -335,6 +336,7 @@ def run(args):
             "per_rank": per_rank,
             "peak_hbm_bytes": int(peak_alloc),
             "peak_hbm": {"allocated_bytes": int(peak_alloc), "reserved_bytes": int(peak_reserved),
+                         "resident_before_step_bytes": int(base_alloc), "step_working_set_bytes": int(peak_alloc - base_alloc),
                          "note": "torch.cuda.max_memory_allocated / max_memory_reserved over the timed region of rank 0: feature "
                                  "slabs, index structures of two batches (this one + the prefetched one), workspaces, "
                                  "parameters, gradients, weight images; of 288 GB"},
@@ -460,6 +462,8 @@ def side_measurements(job, args, world, dist, torch):
     # ---- forward only (evaluation: eval_model, training.py:244-304; SparseMaskPredictor, model.py:826-882): the same scene
     # under torch.no_grad() -- forward-only slab plan, no backward-data weight images -- with its own peak HBM
     job.finish()
+    job.out = job.logits = job.fin = job.rpn_out = None       # (what the last training step left behind)
+    job.flat.zero_grad()
     n = max(5, min(20, args.steps))
     for _ in range(3):
         job.forward_only()
@@ -467,6 +471,7 @@ def side_measurements(job, args, world, dist, torch):
         dist.barrier()
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats()
+    fo_base = torch.cuda.memory_allocated()
     t0 = time.perf_counter()
     for _ in range(n):
         job.forward_only()
@@ -479,6 +484,8 @@ def side_measurements(job, args, world, dist, torch):
     ex["forward_only"] = {"ms_per_step": fo_ms, "value": job.n_active / job.batches_per_step / (fo_ms * 1e-3),
                           "unit": "active-voxels/s, forward only", "steps": n,
                           "peak_hbm_bytes": int(torch.cuda.max_memory_allocated()),
+                          "resident_before_bytes": int(fo_base),
+                          "working_set_bytes": int(torch.cuda.max_memory_allocated() - fo_base),
                           "note": "index build (pipelined as in the step) + forward under torch.no_grad(): the executor's "
                                   "forward-only slab plan, no backward-data weight images; bit-equal to the training forward "
                                   "(tests/test_gpu_exec.py::test_forward_only_is_bit_equal...)"}

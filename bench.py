@@ -68,6 +68,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-bf16-leg", dest="bf16_leg", action="store_false",
                     help="skip the short bf16-storage side leg (cfg2 in bf16: ms/step + k_conv_tb roofline) of the default run")
     ap.add_argument("--no-extras", action="store_true", help="skip the index-build / no-prefetch side measurements")
+    ap.add_argument("--batches-per-step", type=int, default=1,
+                    help="micro-batches (scenes) accumulated per optimizer step and rank -- the reference's batch scaling, "
+                         "training.py:436,458-460 (2 or 6 with the mask head); ONE gradient all-reduce per step")
     a = ap.parse_args(argv)
     if a.bf16_all:
         a.dtype = "bf16"
@@ -234,7 +237,7 @@ def run(args):
     # one balanced scene per rank (cfg 2: seed 1; cfg 4 style: seeds 10+rank)
     seed = 1 if world == 1 else 10 + rank
     job = SceneStep(args.workload, dev, dtype=args.dtype, prefetch=args.prefetch, seed=seed, grad_seed=100 + rank,
-                    target=args.target)
+                    target=args.target, batches_per_step=args.batches_per_step)
 
     # Kernel timing: HIP events on the launch stream around the launches of the dominant kernel on 3-4 steps spread over the
     # timed region.  Round 4: those steps stay on the production path -- the step executor's C calls bracket their
@@ -330,7 +333,8 @@ def run(args):
                           "first layer, fp32 accumulation, fp32 parameters / parameter gradients / optimizer",
             "data": "synthetic",
             "config": {"workload": job.describe(),
-                       "parallelism": f"dp{world} (1 scene/GPU, flat-bucket all-reduce)"},
+                       "parallelism": f"dp{world} (1 scene/GPU, flat-bucket all-reduce)",
+                       "batches_per_step": job.batches_per_step},
             "n_ranks_seen_by_rccl": ranks_seen if backend == "nccl" else None,
             "n_ranks_seen": ranks_seen, "collective_backend": backend if dist_on else None,
             "per_rank": per_rank,
@@ -489,11 +493,53 @@ def side_measurements(job, args, world, dist, torch):
                           "note": "index build (pipelined as in the step) + forward under torch.no_grad(): the executor's "
                                   "forward-only slab plan, no backward-data weight images; bit-equal to the training forward "
                                   "(tests/test_gpu_exec.py::test_forward_only_is_bit_equal...)"}
+    if args.workload == "cfg2" and world == 1 and args.target is None and args.batches_per_step == 1:
+        ex["changing_scenes"] = changing_scenes_leg(job, args, torch)
     if args.dropin and args.workload == "cfg2" and world == 1:
         ex["dropin"] = dropin_measurement(job, args, torch)
     if args.bf16_leg and args.workload == "cfg2" and args.dtype == "f32" and world == 1 and args.target is None:
         ex["bf16"] = bf16_side_leg(args, job.device, torch)
     return ex
+
+
+def changing_scenes_leg(job, args, torch):
+    """The headline times ONE scene repeated (BASELINE configs[1] names a scene); a data loader hands over another scene every
+    step.  The same pipelined step over four scenes of 90-165 k voxels in rotation (other seeds than the headline's): shapes,
+    rulebooks and tile counts change every step, the caching allocator sees four size classes."""
+    from sparse_rcnn_amd.synthetic import make_batch
+    m, flat, dev = job.model.backbone, job.flat, job.device
+    scenes = []
+    for seed, target in ((11, 150_000), (12, 120_000), (13, 165_000), (14, 90_000)):
+        c, f, size, bs, _ = make_batch(1, job.grid, target, dup=1.15, seed=seed)
+        scenes.append((c.to(dev), f.to(dev), size, bs))
+    gys = {}
+    n, warm = max(8, min(40, args.steps)), 8
+    pending = m.prefetch_in_thread(scenes[0][0], scenes[0][2], scenes[0][3]) if job.prefetch else None
+    vox, t0 = 0, None
+    for it in range(warm + n):
+        if it == warm:
+            torch.cuda.synchronize()
+            vox, t0 = 0, time.perf_counter()
+        c, f, size, bs = scenes[it % 4]
+        md = pending.result() if pending is not None else None
+        if job.prefetch:
+            nc, _, nsize, nbs = scenes[(it + 1) % 4]
+            pending = m.prefetch_in_thread(nc, nsize, nbs)
+        flat.zero_grad()
+        out = m(c, f.detach().requires_grad_(), size, bs, metadata=md)
+        gy = gys.get(it % 4)
+        if gy is None:
+            gy = gys[it % 4] = torch.randn_like(out.features)
+        with torch.autograd.set_multithreading_enabled(False):
+            out.features.backward(gy)
+        flat.step_single_rank(job.lr)
+        vox += out.features.shape[0]
+    if pending is not None:
+        pending.result()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"ms_per_step": dt / n * 1e3, "value": vox / dt, "steps": n, "scenes": "4 scenes of 150 / 120 / 165 / 90 k target voxels "
+            "(seeds 11-14) in rotation, a different one every step; same pipelined step"}
 
 
 def bf16_side_leg(args, dev, torch):

@@ -260,6 +260,8 @@ class FlatParams:
             self.sgd_step(lr)
             return
         self.flat_grad_valid = False
+        if self._datas[0].data_ptr() != self.params[0].data_ptr() or self._datas[-1].data_ptr() != self.params[-1].data_ptr():
+            self._datas = [p.data for p in self.params]        # (a parameter was re-pointed after construction: module.to(...))
         grads = [p.grad for p in self.params]
         if None in grads:
             have = [(d, g) for d, g in zip(self._datas, grads) if g is not None]

@@ -300,6 +300,9 @@ class SceneStep:
                   "points) -> mask branch (SubM1 + 2 units @16, internal U-Net 23-32-48-64, Linear 23-32-18); CROP + MASK "
                   "BRANCH ONLY: the boxes are synthetic and known before the forward (no RPN in this step; "
                   "--workload cfg3-rpn has it)")
+        if self.batches_per_step > 1:
+            s += (f"; {self.batches_per_step} micro-batches (scenes) accumulated per optimizer step (training.py:436,458-460), "
+                  "voxels = all of them")
         s += "; step = rulebooks + fwd + bwd (+ grad all-reduce + SGD)"
         if self.prefetch:
             s += "; rulebooks of batch i+1 built on a helper thread during batch i"

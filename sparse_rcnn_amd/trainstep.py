@@ -47,6 +47,10 @@ LATE_PREFETCH = _os.environ.get("SCN_LATE_PREFETCH", "0") != "0"       # (measur
 # backward on the calling thread (torch.autograd.set_multithreading_enabled(False)): no hand-off to the device thread per step
 # (A/B inside one process, profiles/r5_ab_inproc.txt: cfg 3 bf16 7.13 -> 6.51 ms per step, cfg 2 bf16 3.44 -> 3.31, fp32 neutral)
 BACKWARD_INLINE = _os.environ.get("SCN_BACKWARD_INLINE", "1") != "0"
+# measurement only (tools/r5_ab_inproc.py): every step re-uses the index structures of the first one -- the bound of a
+# perfectly hidden index build (one scene repeated: the structures are the same anyway)
+REUSE_INDEX = False
+_reused_md = {}
 
 
 def _backward(roots, grads):
@@ -163,10 +167,19 @@ class SceneStep:
         fin = self.feats.detach().requires_grad_()
         md = self._md_next.result() if self._md_next is not None else None
         self._md_next = None
+        if REUSE_INDEX:
+            from .metadata import Metadata
+            base = _reused_md.get((id(self), k))
+            if base is None and md is not None:
+                base = _reused_md[(id(self), k)] = md
+            if base is not None:
+                md = Metadata(3)
+                md.__dict__.update(base.__dict__)
+                md.ready_event = None
         # the index structures of the NEXT batch depend on its coordinates only (a data loader's output): a helper thread
         # builds them on the high-priority index stream while this batch runs; every step contains one complete build
         def start_prefetch():
-            if self.prefetch and self._md_next is None:
+            if self.prefetch and self._md_next is None and not (REUSE_INDEX and (id(self), k) in _reused_md):
                 nx = self._scenes[(k + 1) % self.batches_per_step]
                 self._md_next = m.backbone.prefetch_in_thread(nx["coords"], nx["size"], nx["batch_size"])
         if not LATE_PREFETCH:

@@ -353,48 +353,29 @@ __device__ __forceinline__ int lookback(unsigned* __restrict__ status, int vb, i
     return s_excl;
 }
 
-// Round 5: CO-RESIDENT forms.  The next batch's index build runs on a helper stream beside this batch's matrix kernels, whose
-// workgroups (16 waves, ~109 VGPRs, 110 KB of LDS) hold a CU each for a whole launch and leave ONE wave slot of <= 64 registers
-// per SIMD and 50 KB of LDS.  The numbering and table kernels used 1024-thread workgroups (and up to 111 registers): they could
-// only start on a CU a matrix workgroup had left, and a matrix launch whose grid is one workgroup per CU then started some of
-// its workgroups late -- the "hidden" build cost the step its full 0.21 ms (profiles/r5_ab_index_interference.txt).  Now every
-// kernel of the build is 256 threads (one wave per SIMD) at <= 64 registers: a workgroup fits BESIDE a matrix workgroup.  A
-// workgroup still owns TILE = 1024 consecutive items (4 per thread, item = base + it * T + tid), so every per-workgroup array
-// (look-back status, digit counts, rule counts) keeps its layout and the structures their bits.
-#define SCN_CORESIDENT __attribute__((amdgpu_waves_per_eu(8, 8)))
-
 // points -> level-0 rows: the first point of a voxel (atomicMin above) gets the next row, in point order
-__global__ __launch_bounds__(T) SCN_CORESIDENT void k_number0(PA a, long long n, const int4* __restrict__ c32,
-                                                              const int* __restrict__ slot_of, int* __restrict__ row_first) {
+__global__ __launch_bounds__(TT) void k_number0(PA a, long long n, const int4* __restrict__ c32, const int* __restrict__ slot_of,
+                                                int* __restrict__ row_first) {
     const int vb = take_ticket(&a.tickets[0]);
     const long long base = (long long)vb * TILE;
     if (base >= n) return;
     int* __restrict__ hrows = a.hrows;                       // level 0's table: holds the minimum point index per slot
     int4* __restrict__ coords = at<int4>(a, a.lv[0].coords);
-    bool f[IT];
-    int slot[IT], lp[IT];
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const long long i = base + it * T + threadIdx.x;
-        slot[it] = i < n ? slot_of[i] : -1;
-    }
+    const long long i = base + threadIdx.x;
+    const int slot = i < n ? slot_of[i] : -1;
     // (the row number is written over the minimum below while other workgroups still compare: a later point j of the same
     //  voxel reads either the minimum i or the row number, and both are < j -- its flag stays false)
-#pragma unroll
-    for (int it = 0; it < IT; ++it) f[it] = slot[it] >= 0 && hrows[slot[it]] == (int)(base + it * T + threadIdx.x);
-    const int agg = block_rank(f, lp);
+    const bool f = slot >= 0 && hrows[slot] == (int)i;
+    int lp;
+    const int agg = block_rank1(f, &lp);
     const int excl = lookback(at<unsigned>(a, a.lv[0].status), vb, agg, a.dsz);
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        if (f[it]) {
-            const long long i = base + it * T + threadIdx.x;
-            const int pos = excl + lp[it];
-            hrows[slot[it]] = pos;
-            row_first[pos] = (int)i;
-            const int4 c = c32[i];
-            coords[pos] = c;
-            if (!a.no_bricks && !brick_insert(bricks_of(a, 0), c.x, c.y, c.z, c.w, pos)) a.dsz[DS_NOBRICK] = 1;
-        }
+    if (f) {
+        const int pos = excl + lp;
+        hrows[slot] = pos;
+        row_first[pos] = (int)i;
+        const int4 c = c32[i];
+        coords[pos] = c;
+        if (!a.no_bricks && !brick_insert(bricks_of(a, 0), c.x, c.y, c.z, c.w, pos)) a.dsz[DS_NOBRICK] = 1;
     }
     if (base + TILE >= n && threadIdx.x == 0) a.dsz[DS_N] = excl + agg;
 }
@@ -402,7 +383,7 @@ __global__ __launch_bounds__(T) SCN_CORESIDENT void k_number0(PA a, long long n,
 // level l -> l + 1: fine row i is the FIRST row of its coarse site iff no other child of that site has a lower row number;
 // the first rows get the coarse rows in ascending fine-row order (= first occurrence scanning the fine rows ascending, the
 // canonical order of DESIGN.md section 2) and enter the coarse site into level l + 1's hash table
-__global__ __launch_bounds__(T) SCN_CORESIDENT void k_coarsen(PA a, int l) {
+__global__ __launch_bounds__(TT) void k_coarsen(PA a, int l) {
     const int vb = take_ticket(&a.tickets[l + 1]);
     const long long n = a.dsz[DS_N + l];
     const long long base = (long long)vb * TILE;
@@ -417,57 +398,41 @@ __global__ __launch_bounds__(T) SCN_CORESIDENT void k_coarsen(PA a, int l) {
     int* __restrict__ crows = a.hrows + (size_t)(l + 1) * a.cap;
     const int4* __restrict__ fine = at<int4>(a, a.lv[l].coords);
     int4* __restrict__ coarse = at<int4>(a, a.lv[l + 1].coords);
+    const long long i = base + threadIdx.x;
+    const bool live = i < n;
+    const int4 c = live ? fine[i] : make_int4(0, 0, 0, 0);
+    unsigned long long key[8];
+    bool want[8];
+    int sib[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        key[o] = scn_pack_key((c.x & ~1) + (o >> 2), (c.y & ~1) + ((o >> 1) & 1), (c.z & ~1) + (o & 1), c.w);
+        want[o] = live;
+    }
     // (a word the kernels BEFORE this one may have set: the bricks of level l are complete whenever it reads zero)
     const bool use_bricks = !a.no_bricks && a.dsz[DS_NOBRICK] == 0;
-    unsigned fm = 0;                                         // flags of the thread's IT items (a bit each: the loop is not unrolled)
-    int lp[IT];
-#pragma unroll 1
-    for (int it = 0; it < IT; ++it) {
-        const long long i = base + it * T + threadIdx.x;
-        const bool live = i < n;
-        const int4 c = live ? fine[i] : make_int4(0, 0, 0, 0);
-        int sib[8];
-        bool fb = false;                                     // (fallback path: a lower-numbered sibling was found)
-        if (use_bricks) {
-            brick_cell8(bricks_of(a, l), c.x & ~1, c.y & ~1, c.z & ~1, c.w, live, sib);
-        } else {
-#pragma unroll 1
-            for (int o = 0; o < 8; ++o) {                    // (voxel table: the fallback; its own offset answers i: not lower)
-                int v1 = -1;
-                if (live) v1 = lookup(fkeys, frows, mask, scn_pack_key((c.x & ~1) + (o >> 2), (c.y & ~1) + ((o >> 1) & 1), (c.z & ~1) + (o & 1), c.w));
-                if (v1 >= 0 && v1 < (int)i) fb = true;
-            }
+    if (use_bricks) brick_cell8(bricks_of(a, l), c.x & ~1, c.y & ~1, c.z & ~1, c.w, live, sib);
+    else lookup_n<8>(fkeys, frows, mask, key, want, sib);    // (its own offset answers i: not lower)
+    bool f = live;
 #pragma unroll
-            for (int o = 0; o < 8; ++o) sib[o] = -1;
-        }
-        bool ff = live && !fb;
-#pragma unroll
-        for (int o = 0; o < 8; ++o) ff = ff && !(sib[o] >= 0 && sib[o] < (int)i);
-        fm |= (ff ? 1u : 0u) << it;
-    }
-    bool f[IT];
-#pragma unroll
-    for (int it = 0; it < IT; ++it) f[it] = (fm >> it) & 1u;
-    const int agg = block_rank(f, lp);
+    for (int o = 0; o < 8; ++o) f = f && !(sib[o] >= 0 && sib[o] < (int)i);
+    int lp;
+    const int agg = block_rank1(f, &lp);
     const int excl = lookback(at<unsigned>(a, a.lv[l + 1].status), vb, agg, a.dsz);
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        if (f[it]) {
-            const int4 c = fine[base + it * T + threadIdx.x];
-            const int pos = excl + lp[it];
-            const int4 cc = make_int4(c.x >> 1, c.y >> 1, c.z >> 1, c.w);
-            coarse[pos] = cc;
-            const unsigned long long ck = scn_pack_key(cc.x, cc.y, cc.z, cc.w);
-            unsigned long long slot = scn_hash_slot(ck, mask);
-            for (long long probe = 0; probe < a.cap; ++probe) {          // every coarse site is inserted exactly once
-                if (atomicCAS(&ckeys[slot], SCN_EMPTY_KEY, ck) == SCN_EMPTY_KEY) {
-                    crows[slot] = pos;
-                    break;
-                }
-                slot = (slot + 1) & mask;
+    if (f) {
+        const int pos = excl + lp;
+        const int4 cc = make_int4(c.x >> 1, c.y >> 1, c.z >> 1, c.w);
+        coarse[pos] = cc;
+        const unsigned long long ck = scn_pack_key(cc.x, cc.y, cc.z, cc.w);
+        unsigned long long slot = scn_hash_slot(ck, mask);
+        for (long long probe = 0; probe < a.cap; ++probe) {          // every coarse site is inserted exactly once
+            if (atomicCAS(&ckeys[slot], SCN_EMPTY_KEY, ck) == SCN_EMPTY_KEY) {
+                crows[slot] = pos;
+                break;
             }
-            if (!a.no_bricks && !brick_insert(bricks_of(a, l + 1), cc.x, cc.y, cc.z, cc.w, pos)) a.dsz[DS_NOBRICK] = 1;
+            slot = (slot + 1) & mask;
         }
+        if (!a.no_bricks && !brick_insert(bricks_of(a, l + 1), cc.x, cc.y, cc.z, cc.w, pos)) a.dsz[DS_NOBRICK] = 1;
     }
     if (base + TILE >= n && threadIdx.x == 0) a.dsz[DS_N + l + 1] = excl + agg;
 }
@@ -476,8 +441,8 @@ __global__ __launch_bounds__(T) SCN_CORESIDENT void k_coarsen(PA a, int l) {
 // tables: SubM table + sort key + first-pass digit counts + per-offset rule counts of every level, child tables likewise,
 // parents / fine offsets, the points' rows -- one launch, job = blockIdx / nblk
 // ---------------------------------------------------------------------------------------------------------------------
-// 1024 rows per workgroup, four per thread (one after the other: the registers of ONE row's probes); per offset the workgroup's
-// rule count (ballots, a column of `wsum` per wave), per row the sort key, per workgroup the digit counts of the first sort pass
+// 1024 rows per workgroup, one per thread: the probes of a row in groups of G in flight; per offset the workgroup's rule
+// count (ballots), per row the sort key, per workgroup the digit counts of the first sort pass
 template <int N_OFF, bool SUBM>
 __device__ __forceinline__ void table_job(const PA& a, int l, int b) {
     // SUBM: rows of level l, probes of level l's own table at the k^3 offsets; else: rows of level l + 1 (coarse), probes of
@@ -488,16 +453,14 @@ __device__ __forceinline__ void table_job(const PA& a, int l, int b) {
     int* __restrict__ bsums = at<int>(a, SUBM ? L.bsums : L.cbsums);
     int* __restrict__ counts = at<int>(a, SUBM ? L.counts : L.ccounts);
     const long long base = (long long)b * TILE;
-    __shared__ int wsum[N_OFF][T / 64];
+    __shared__ int wsum[N_OFF][TT / 64];
     __shared__ int hist[MAXB];
     constexpr int width0 = SUBM ? 9 : 8, bins = 1 << width0;
     if (base >= n) {                                     // surplus workgroup: its rule counts must read zero in the scan
         if (threadIdx.x < N_OFF) bsums[threadIdx.x * a.nblk + b] = 0;
         return;
     }
-    for (int d = threadIdx.x; d < bins; d += T) hist[d] = 0;
-    for (int e = threadIdx.x; e < N_OFF * (T / 64); e += T) (&wsum[0][0])[e] = 0;
-    __syncthreads();
+    for (int d = threadIdx.x; d < bins; d += TT) hist[d] = 0;
     const unsigned long long mask = (unsigned long long)a.cap - 1ull;
     const unsigned long long* __restrict__ keys = a.keys + (size_t)l * a.cap;
     const int* __restrict__ rows = a.hrows + (size_t)l * a.cap;
@@ -505,104 +468,104 @@ __device__ __forceinline__ void table_job(const PA& a, int l, int b) {
     int* __restrict__ table = at<int>(a, SUBM ? L.table : L.child);
     unsigned* __restrict__ key_out = at<unsigned>(a, SUBM ? L.key : L.ckey);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long r = base + threadIdx.x;
+    const bool live = r < n;
+    const int4 c = live ? coords[r] : make_int4(0, 0, 0, 0);
+    unsigned m = 0;
+    constexpr int G = SUBM ? 9 : 8;
     const bool use_bricks = !a.no_bricks && a.dsz[DS_NOBRICK] == 0;      // (every brick was filled by the kernels before this one)
-    const Bricks B = bricks_of(a, l);
-    // one group of offsets of one row: table entries, mask bits, the wave's rule counts
-#define TABLE_EMIT(O0, CNT, V)                                                                       \
-    _Pragma("unroll") for (int j_ = 0; j_ < (CNT); ++j_) {                                           \
-        const int o_ = (O0) + j_;                                                                    \
-        if (live) table[(long long)o_ * n + r] = (V)[j_];                                            \
-        m |= ((V)[j_] >= 0 ? 1u : 0u) << (SUBM ? a.kb.pos[o_] : o_);                                 \
-        const int cnt_ = __popcll(__ballot((V)[j_] >= 0));                                           \
-        if (lane == 0) wsum[o_][w] += cnt_;                                                          \
-    }
-#pragma unroll 1
-    for (int it = 0; it < IT; ++it) {
-        const long long r = base + it * T + threadIdx.x;
-        const bool live = r < n;
-        const int4 c = live ? coords[r] : make_int4(0, 0, 0, 0);
-        unsigned m = 0;
-        if (use_bricks) {
-            if constexpr (SUBM) {
-                // the 3 x 3 x 3 neighbourhood of (x, y, z), slab by slab in x: the 9 sites of a slab lie in the (at most) 4
-                // bricks (x >> 2, by0 | by1, bz0 | bz1) -- 4 directory probes + occupancy words (the next slab mostly asks for
-                // the same ones again: L1 hits; cheaper than holding 8 bricks' words across the slabs at <= 64 registers),
-                // then 9 loads out of those bricks
-                const int by0 = (c.y - 1) >> 2, bz0 = (c.z - 1) >> 2, by1 = (c.y + 1) >> 2, bz1 = (c.z + 1) >> 2;
+    if (use_bricks) {
+        const Bricks B = bricks_of(a, l);
+        int v[N_OFF];
+        if constexpr (SUBM) {
+            // the 3 x 3 x 3 neighbourhood of (x, y, z) meets the bricks (bx0 | bx1, by0 | by1, bz0 | bz1): at most 8 directory
+            // probes and occupancy words, then 27 loads out of those bricks
+            const int bx0 = (c.x - 1) >> 2, by0 = (c.y - 1) >> 2, bz0 = (c.z - 1) >> 2;
+            const int bx1 = (c.x + 1) >> 2, by1 = (c.y + 1) >> 2, bz1 = (c.z + 1) >> 2;
+            unsigned long long key[8], occ[8];
+            bool want[8];
+            int bs[8];
 #pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    const int x = c.x + g - 1, bx = x >> 2;
-                    unsigned long long key[4], o4[4];
-                    bool want[4];
-                    int s4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int iy = q >> 1, iz = q & 1;
-                        const int by = iy ? by1 : by0, bz = iz ? bz1 : bz0;
-                        want[q] = live && (!iy || by1 != by0) && (!iz || bz1 != bz0) && (unsigned)bx < 16384u &&
-                                  (unsigned)by < 16384u && (unsigned)bz < 16384u;
-                        key[q] = scn_pack_key(bx & 16383, by & 16383, bz & 16383, c.w);
-                    }
-                    brick_find_n<4>(B, key, want, s4, o4);
-                    int v[9];
-                    unsigned idx[9], okm = 0;
-#pragma unroll
-                    for (int j = 0; j < 9; ++j) {
-                        const int y = c.y + (j / 3 - 1), z = c.z + (j % 3 - 1);
-                        const int q = ((y >> 2) != by0) * 2 + ((z >> 2) != bz0);
-                        const int sj = q == 0 ? s4[0] : q == 1 ? s4[1] : q == 2 ? s4[2] : s4[3];
-                        const unsigned long long oj = q == 0 ? o4[0] : q == 1 ? o4[1] : q == 2 ? o4[2] : o4[3];
-                        const int loc = brick_local(x, y, z);
-                        const bool ok = live && sj >= 0 && ((oj >> loc) & 1ull) && (unsigned)x < 65536u && (unsigned)y < 65536u &&
-                                        (unsigned)z < 65536u;
-                        okm |= (ok ? 1u : 0u) << j;
-                        idx[j] = (unsigned)(sj >= 0 ? sj : 0) * 64u + (unsigned)loc;       // (< 2^32: 27 n < 2^31 bounds the directory)
-                    }
-#pragma unroll
-                    for (int j = 0; j < 9; ++j) v[j] = B.ent[idx[j]];
-#pragma unroll
-                    for (int j = 0; j < 9; ++j) v[j] = ((okm >> j) & 1u) ? v[j] : -1;
-                    TABLE_EMIT(g * 9, 9, v)
-                }
-            } else {
-                int v8[8];
-                brick_cell8(B, 2 * c.x, 2 * c.y, 2 * c.z, c.w, live, v8);          // the 8 children of coarse site c: one brick
-                TABLE_EMIT(0, 8, v8)
+            for (int j = 0; j < 8; ++j) {
+                const int ix = j >> 2, iy = (j >> 1) & 1, iz = j & 1;
+                const int bx = ix ? bx1 : bx0, by = iy ? by1 : by0, bz = iz ? bz1 : bz0;
+                want[j] = live && (!ix || bx1 != bx0) && (!iy || by1 != by0) && (!iz || bz1 != bz0) &&
+                          (unsigned)bx < 16384u && (unsigned)by < 16384u && (unsigned)bz < 16384u;
+                key[j] = scn_pack_key(bx & 16383, by & 16383, bz & 16383, c.w);
             }
-        } else {
-            // the voxel tables: the fallback (an overflowed brick directory, SCN_PYRAMID_NO_BRICKS) -- one probe at a time, so
-            // that this path does not set the register budget of the kernel
-#pragma unroll 1
+            brick_find_n<8>(B, key, want, bs, occ);
+            int loc[N_OFF], sl[N_OFF];
+            bool ok[N_OFF];
+#pragma unroll
             for (int o = 0; o < N_OFF; ++o) {
-                const int x = SUBM ? c.x + (o / 9 - 1) : 2 * c.x + (o >> 2), y = SUBM ? c.y + ((o / 3) % 3 - 1) : 2 * c.y + ((o >> 1) & 1),
-                          z = SUBM ? c.z + (o % 3 - 1) : 2 * c.z + (o & 1);
-                const bool want = live && (unsigned)x < 65536u && (unsigned)y < 65536u && (unsigned)z < 65536u;
-                int v1 = -1;
-                if (want) v1 = lookup(keys, rows, mask, scn_pack_key(x & 65535, y & 65535, z & 65535, c.w));
-                if (live) table[(long long)o * n + r] = v1;
-                m |= (v1 >= 0 ? 1u : 0u) << (SUBM ? a.kb.pos[o] : o);
-                const int cnt1 = __popcll(__ballot(v1 >= 0));
-                if (lane == 0) wsum[o][w] += cnt1;
+                const int x = c.x + (o / 9 - 1), y = c.y + ((o / 3) % 3 - 1), z = c.z + (o % 3 - 1);
+                const int j = (((x >> 2) != bx0) * 2 + ((y >> 2) != by0)) * 2 + ((z >> 2) != bz0);
+                int sj = bs[0];
+                unsigned long long oj = occ[0];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) { sj = j == q ? bs[q] : sj; oj = j == q ? occ[q] : oj; }
+                loc[o] = brick_local(x, y, z);
+                ok[o] = live && sj >= 0 && ((oj >> loc[o]) & 1ull) && (unsigned)x < 65536u && (unsigned)y < 65536u && (unsigned)z < 65536u;
+                sl[o] = sj >= 0 ? sj : 0;
             }
+#pragma unroll
+            for (int o = 0; o < N_OFF; ++o) v[o] = B.ent[(size_t)sl[o] * 64 + loc[o]];
+#pragma unroll
+            for (int o = 0; o < N_OFF; ++o) v[o] = ok[o] ? v[o] : -1;
+        } else {
+            int v8[8];
+            brick_cell8(B, 2 * c.x, 2 * c.y, 2 * c.z, c.w, live, v8);          // the 8 children of coarse site c: one brick
+#pragma unroll
+            for (int o = 0; o < 8; ++o) v[o] = v8[o];
         }
-        if (live) {
-            const unsigned kk = gray_rank(m);
-            key_out[r] = kk;
-            atomicAdd(&hist[kk & (unsigned)(bins - 1)], 1);
+#pragma unroll
+        for (int o = 0; o < N_OFF; ++o) {
+            if (live) table[(long long)o * n + r] = v[o];
+            m |= (v[o] >= 0 ? 1u : 0u) << (SUBM ? a.kb.pos[o] : o);
+            const int cnt = __popcll(__ballot(v[o] >= 0));
+            if (lane == 0) wsum[o][w] = cnt;
+        }
+    } else
+#pragma unroll
+    for (int g = 0; g < N_OFF / G; ++g) {
+        unsigned long long key[G];
+        bool want[G];
+        int v[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int o = g * G + j;
+            const int x = SUBM ? c.x + (o / 9 - 1) : 2 * c.x + (o >> 2), y = SUBM ? c.y + ((o / 3) % 3 - 1) : 2 * c.y + ((o >> 1) & 1),
+                      z = SUBM ? c.z + (o % 3 - 1) : 2 * c.z + (o & 1);
+            want[j] = live && (unsigned)x < 65536u && (unsigned)y < 65536u && (unsigned)z < 65536u;
+            key[j] = scn_pack_key(x & 65535, y & 65535, z & 65535, c.w);
+        }
+        lookup_n<G>(keys, rows, mask, key, want, v);       // (the centre offset of a SubM table finds the row itself)
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int o = g * G + j;
+            if (live) table[(long long)o * n + r] = v[j];
+            m |= (v[j] >= 0 ? 1u : 0u) << (SUBM ? a.kb.pos[o] : o);
+            const int cnt = __popcll(__ballot(v[j] >= 0));
+            if (lane == 0) wsum[o][w] = cnt;
         }
     }
-#undef TABLE_EMIT
-    __syncthreads();
+    __syncthreads();                                      // (also orders the hist zeroing before the adds)
+    if (live) {
+        const unsigned kk = gray_rank(m);
+        key_out[r] = kk;
+        atomicAdd(&hist[kk & (unsigned)(bins - 1)], 1);
+    }
     if (threadIdx.x < N_OFF) {
         int s = 0;
 #pragma unroll
-        for (int k = 0; k < T / 64; ++k) s += wsum[threadIdx.x][k];
+        for (int k = 0; k < TT / 64; ++k) s += wsum[threadIdx.x][k];
         bsums[threadIdx.x * a.nblk + b] = s;
     }
-    for (int d = threadIdx.x; d < bins; d += T) counts[(long long)d * a.nblk + b] = hist[d];
+    __syncthreads();
+    for (int d = threadIdx.x; d < bins; d += TT) counts[(long long)d * a.nblk + b] = hist[d];
 }
 
-__global__ __launch_bounds__(T) SCN_CORESIDENT void k_tables(PA a, const int* __restrict__ slot_of, long long n_points,
+__global__ __launch_bounds__(TT) void k_tables(PA a, const int* __restrict__ slot_of, long long n_points,
                                                int* __restrict__ item_row, int* __restrict__ row_count) {
     const int Lc = a.n_levels;
     const int job = blockIdx.x / a.nblk, b = blockIdx.x % a.nblk;
@@ -625,7 +588,7 @@ __global__ __launch_bounds__(T) SCN_CORESIDENT void k_tables(PA a, const int* __
         int* __restrict__ fine_off = at<int>(a, a.lv[l].fine_off);
         const bool use_bricks = !a.no_bricks && a.dsz[DS_NOBRICK] == 0;
         const Bricks B = bricks_of(a, l + 1);
-        for (long long i = (long long)b * T + threadIdx.x; i < n; i += (long long)a.nblk * T) {
+        for (long long i = (long long)b * TT + threadIdx.x; i < n; i += (long long)a.nblk * TT) {
             const int4 c = fine[i];
             if (use_bricks) {                                // (the parent exists: it was numbered from this very row's cell)
                 const int px = c.x >> 1, py = c.y >> 1, pz = c.z >> 1;
@@ -643,7 +606,7 @@ __global__ __launch_bounds__(T) SCN_CORESIDENT void k_tables(PA a, const int* __
         return;
     }
     // the points' rows and the multiplicity of every level-0 row (InputLayer mode 4 divides by it)
-    for (long long i = (long long)b * T + threadIdx.x; i < n_points; i += (long long)a.nblk * T) {
+    for (long long i = (long long)b * TT + threadIdx.x; i < n_points; i += (long long)a.nblk * TT) {
         const int s = slot_of[i];
         const int r = s >= 0 ? a.hrows[s] : 0;
         item_row[i] = r;
@@ -1321,14 +1284,14 @@ int pyramid2_build(const int64_t* coords, int64_t n_points, int n_levels, int k,
     hipLaunchKernelGGL(k_insert0, dim3(scn::ew_grid(n, T)), dim3(T), 0, st, (const long long*)coords, (long long)n, c32, a.keys,
                        a.hrows, (long long)p.cap, slot0, a.dsz);
     SCN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_number0, dim3((unsigned)nblk), dim3(T), 0, st, a, (long long)n, (const int4*)c32, (const int*)slot0,
+    hipLaunchKernelGGL(k_number0, dim3((unsigned)nblk), dim3(TT), 0, st, a, (long long)n, (const int4*)c32, (const int*)slot0,
                        (int*)(base + p.row_first));
     SCN_LAUNCH_CHECK();
     for (int l = 0; l + 1 < n_levels; ++l) {
-        hipLaunchKernelGGL(k_coarsen, dim3((unsigned)nblk), dim3(T), 0, st, a, l);
+        hipLaunchKernelGGL(k_coarsen, dim3((unsigned)nblk), dim3(TT), 0, st, a, l);
         SCN_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_tables, dim3((unsigned)((3 * n_levels - 1) * nblk)), dim3(T), 0, st, a, (const int*)slot0, (long long)n,
+    hipLaunchKernelGGL(k_tables, dim3((unsigned)((3 * n_levels - 1) * nblk)), dim3(TT), 0, st, a, (const int*)slot0, (long long)n,
                        (int*)(base + p.item_row), (int*)(base + p.row_count));
     SCN_LAUNCH_CHECK();
     {

@@ -43,7 +43,9 @@ import os as _os
 EARLY_ROI_CUT = _os.environ.get("SCN_ROI_EARLY", "0") != "0"
 # developer switches (A/B): the RPN's kernels between encoder and decoder; the prefetch thread started after the forward's kernels
 RPN_BEFORE_DECODER = _os.environ.get("SCN_RPN_EARLY", "1") != "0"
-LATE_PREFETCH = _os.environ.get("SCN_LATE_PREFETCH", "0") != "0"       # (measured neutral: off)
+# (in-process A/B, profiles/r5_ab_index_interference.txt: cfg 2 fp32 5.539 -> 5.512 ms, bf16 3.128 -> 3.094, cfg 3 neutral:
+#  starting a thread costs the host ~0.1 ms exactly where the GPU's queue is shallowest, the step boundary)
+LATE_PREFETCH = _os.environ.get("SCN_LATE_PREFETCH", "1") != "0"
 # backward on the calling thread (torch.autograd.set_multithreading_enabled(False)): no hand-off to the device thread per step
 # (A/B inside one process, profiles/r5_ab_inproc.txt: cfg 3 bf16 7.13 -> 6.51 ms per step, cfg 2 bf16 3.44 -> 3.31, fp32 neutral)
 BACKWARD_INLINE = _os.environ.get("SCN_BACKWARD_INLINE", "1") != "0"
@@ -169,6 +171,16 @@ class SceneStep:
         self._md_next = None
         if REUSE_INDEX:
             from .metadata import Metadata
+            if REUSE_INDEX == 2:          # (measurement: the helper thread still builds -- a TINY scene: host side of a build only)
+                tiny = _reused_md.get("tiny")
+                if tiny is None:
+                    from .synthetic import make_batch
+                    c, _, sz, bs_, _ = make_batch(1, (64, 64, 32), 2000, dup=1.15, seed=5)
+                    tiny = _reused_md["tiny"] = (c.to(self.device), sz, bs_)
+                pend = _reused_md.pop("tiny_pending", None)
+                if pend is not None:
+                    pend.result()
+                _reused_md["tiny_pending"] = m.backbone.prefetch_in_thread(*tiny)
             base = _reused_md.get((id(self), k))
             if base is None and md is not None:
                 base = _reused_md[(id(self), k)] = md

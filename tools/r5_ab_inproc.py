@@ -14,7 +14,8 @@ while args:
     elif a == "--steps": steps = int(args.pop(0))
     else:
         name, spec = a.split("=")
-        modes.append((name, [(kv.split(":")[0], kv.split(":")[1] == "1") for kv in spec.split(",") if kv]))
+        modes.append((name, [(kv.split(":")[0], (int(kv.split(":")[1]) if kv.split(":")[1] not in "01" else kv.split(":")[1] == "1"))
+                             for kv in spec.split(",") if kv]))
 job = TS.SceneStep(wl, torch.device("cuda", 0), dtype=dt, prefetch=True, seed=1)
 def apply(flags):
     for k, v in flags:

@@ -18,8 +18,15 @@ while args:
                              for kv in spec.split(",") if kv]))
 job = TS.SceneStep(wl, torch.device("cuda", 0), dtype=dt, prefetch=True, seed=1)
 def apply(flags):
+    from sparse_rcnn_amd._lib import switches
     for k, v in flags:
-        setattr(TS, k, v)
+        if k.startswith("SCN_"):                 # a library switch (scn_debug_set): SCN_PYRAMID_V1:1 / :0 (0 = unset)
+            if v:
+                switches[k] = "1"
+            else:
+                del switches[k]
+        else:
+            setattr(TS, k, v)
 for _ in range(20):
     job.step()
 torch.cuda.synchronize(); gc.collect(); gc.freeze()

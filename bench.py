@@ -68,6 +68,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-bf16-leg", dest="bf16_leg", action="store_false",
                     help="skip the short bf16-storage side leg (cfg2 in bf16: ms/step + k_conv_tb roofline) of the default run")
     ap.add_argument("--no-extras", action="store_true", help="skip the index-build / no-prefetch side measurements")
+    ap.add_argument("--buckets", type=int, default=4,
+                    help="slices of the flat gradient buffer all-reduced from the gradient hooks while backward runs (N > 1); "
+                         "0: one all-reduce after backward")
     ap.add_argument("--batches-per-step", type=int, default=1,
                     help="micro-batches (scenes) accumulated per optimizer step and rank -- the reference's batch scaling, "
                          "training.py:436,458-460 (2 or 6 with the mask head); ONE gradient all-reduce per step")
@@ -237,7 +240,7 @@ def run(args):
     # one balanced scene per rank (cfg 2: seed 1; cfg 4 style: seeds 10+rank)
     seed = 1 if world == 1 else 10 + rank
     job = SceneStep(args.workload, dev, dtype=args.dtype, prefetch=args.prefetch, seed=seed, grad_seed=100 + rank,
-                    target=args.target, batches_per_step=args.batches_per_step)
+                    target=args.target, batches_per_step=args.batches_per_step, n_buckets=args.buckets)
 
     # Kernel timing: HIP events on the launch stream around the launches of the dominant kernel on 3-4 steps spread over the
     # timed region.  Round 4: those steps stay on the production path -- the step executor's C calls bracket their

@@ -637,7 +637,7 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     if (wg_per_cu > 2) wg_per_cu = 2;                  // 16 waves each: 2 workgroups fill a CU
     if (wg_per_cu < 1) wg_per_cu = 1;
     // grid sized to the chip: workgroups per (column chunk, K-chunk) slice; a workgroup should see at least ~16 tiles
-    int64_t n_tg = (256 * wg_per_cu) / ((int64_t)n_chunks * n_kc);
+    int64_t n_tg = ((int64_t)scn::cu_budget() * wg_per_cu) / ((int64_t)n_chunks * n_kc);
     if (n_tg > cdiv(nt, tiles_per_round)) n_tg = cdiv(nt, tiles_per_round);
     if (n_tg < 1) n_tg = 1;
     const bool part = cin % TS_KC != 0;
@@ -656,7 +656,7 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
         const int ncf = n_chunks - (n_tail ? 1 : 0), nkf = n_kc - (k_tail ? 1 : 0);
         const double wsum = (double)nkf * ncf + (n_tail ? nkf * w_half : 0.0) + (k_tail ? ncf * w_half : 0.0) +
                             (n_tail && k_tail ? w_both : 0.0);
-        const int64_t total_wg = 256 * wg_per_cu, cap = cdiv(nt, tiles_per_round);   // a workgroup should see at least ~16 tiles
+        const int64_t total_wg = (int64_t)scn::cu_budget() * wg_per_cu, cap = cdiv(nt, tiles_per_round);   // a workgroup should see at least ~16 tiles
         auto share = [&](double w) { int64_t g = (int64_t)(total_wg * w / wsum); return (int)(g > cap ? cap : (g < 1 ? 1 : g)); };
         slices.g_full = share(1.0);
         slices.g_ntail = n_tail ? share(w_half) : 0;

@@ -938,7 +938,7 @@ extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, con
     int wg_per_cu = (int)((160 * 1024) / lds);
     if (wg_per_cu > 2) wg_per_cu = 2;
     if (wg_per_cu < 1) wg_per_cu = 1;
-    int64_t n_tg = (256 * wg_per_cu) / ((int64_t)n_chunks * n_kc);
+    int64_t n_tg = ((int64_t)scn::cu_budget() * wg_per_cu) / ((int64_t)n_chunks * n_kc);
     if (n_tg > cdiv(nt, TB_NW)) n_tg = cdiv(nt, TB_NW);
     if (n_tg < 1) n_tg = 1;
     const bool fused = n_kc > 1 && arrival != nullptr && !(flags & SCN_F_SPLIT_SUM) &&

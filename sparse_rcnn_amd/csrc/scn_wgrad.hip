@@ -736,7 +736,7 @@ int make_dplan(int cin, int cout, const int64_t* prefix_host, int n_off, DPlan& 
     int rounds = (sh.quad ? nblk > 1 : (sh.ta == 4 && sh.tb == 4) || (sh.ta == 3 && nblk > 1)) ? 2 : 1;
     const bool tb_big = hb_mfma && tb_tiles(cin) == 4 && tb_tiles(cout) == 4;      // 128 x 128 workgroup blocks
     if (hb_mfma) { occ = 4; rounds = 1; }                                   // 32 KB of LDS, <= 128 registers: 4 per CU
-    int64_t target = (256 * occ * rounds) / nblk - n_off;
+    int64_t target = ((int64_t)scn::cu_budget() * occ * rounds) / nblk - n_off;
     if (scn::sw(scn::SW_WGRAD_SPLITS).set) target = (int)scn::sw(scn::SW_WGRAD_SPLITS).i;       // developer override
     if (target < 1) target = 1;
     const int64_t gran = hb_mfma ? 32 : (sh.quad ? 16 : 64);
@@ -748,7 +748,7 @@ int make_dplan(int cin, int cout, const int64_t* prefix_host, int n_off, DPlan& 
         // paired launch at C = 256 jumps from 42.5 to 57.3 us between 110 and 120 target units: per 672 = two equal units
         // of the ~1340 rules of an offset, per 608 = three).  Measured on the cfg-2 scene: 51.8 -> 40.6 us per paired
         // launch at C = 128, 50.4 -> 42.6 at C = 256; long units (600 k voxels) keep all four workgroups per CU.
-        const int64_t avg = cdiv(total, n_off), slots = (256 * 2) / nblk;
+        const int64_t avg = cdiv(total, n_off), slots = ((int64_t)scn::cu_budget() * 2) / nblk;
         int64_t k = (slots + n_off / 2) / n_off;
         if (k < 1) k = 1;
         for (;; --k) {                           // the largest k whose units still fit the slots in one round

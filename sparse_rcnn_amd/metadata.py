@@ -596,6 +596,8 @@ class Metadata:
         new = object.__new__
         stride = L.PYRAMID_LEVEL_STRIDE
         per_level = [desc[8 + l * stride:8 + (l + 1) * stride] for l in range(n_levels)]      # (ctypes slices: plain int lists)
+        # (executor.build_levels fills its level table straight from these descriptors: no attribute chains, no views)
+        self._native = (size, n_levels, k, wsp, per_level, bool(self.xcd_order))
         for l in range(n_levels):
             D = per_level[l]
             Dn = per_level[l + 1] if l + 1 < n_levels else None

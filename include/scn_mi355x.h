@@ -55,7 +55,7 @@ extern "C" {
  *      caller that kept raw tables across a library upgrade is affected); + scn_exec_timing_enable / _collect, scn_pad_params_many, scn_conv_tiles_split_count, scn_dedup_launch_div, scn_child_table_div (107 entry points);
  *      scn_pool_fwd / _bwd (+ _bf16): `average` carries the pool volume above bit 8 (0 = the 2^3 of every configuration) */
 /*   4  round 5: + scn_debug_set / scn_debug_get (developer switches no longer follow the ambient environment per launch);
- *      scn_exec_timing_collect forgets only the records it returned; + scn_nms_bits / scn_nms_scratch_bytes */
+ *      scn_exec_timing_collect forgets only the records it returned; + scn_nms_bits / scn_nms_scratch_bytes, scn_dilate_gather_fwd / _bwd */
 #define SCN_ABI_VERSION 4
 
 /* flags for the gather-GEMM entry points */
@@ -588,6 +588,18 @@ int scn_sparse_to_dense_fwd_bf16(const uint16_t* X, const int32_t* coords, int64
                                  uint16_t* out, scn_stream_t stream);
 int scn_sparse_to_dense_bwd_bf16(const uint16_t* dOut, const int32_t* coords, int64_t n, int c, const int64_t* size3_host,
                                  uint16_t* dX, scn_stream_t stream);
+
+/* Dilation gather (round 5; the first dense same-convolution behind scn.SparseToDense, module_factory.py:581-611 + :396-414: a
+ * 3^3 conv3d with padding 1 on a volume whose only non-zero cells are the n active sites of a sparse level).  With
+ * P[r][o][:] = X[r] . W[o] from ONE row GEMM over the active rows ([n][27][c]; o = (a*3+b)*3+c' over the kernel taps),
+ *   fwd: out[cell][:] = bias + sum_o P[map[cell + (a-1, b-1, c'-1)]][o][:]   (ascending o; map: cell -> active row or -1, [B X Y Z])
+ *   bwd: dP[r][o][:]  = dOut[cell(r) - (a-1, b-1, c'-1)][:] or 0 outside the volume   (cell_of_row: int64 [n])
+ * out / dOut are the channels-last volume [B X Y Z][c]; bf16 != 0: P, out, dOut, dP are bf16 (fp32 accumulation).  bias may be
+ * NULL.  The bias gradient is the column sum of dOut (scn_colsum*). */
+int scn_dilate_gather_fwd(const void* P, const int32_t* map, int batch, const int64_t* size3_host, int c, int bf16,
+                          const float* bias, void* out, scn_stream_t stream);
+int scn_dilate_gather_bwd(const void* dOut, const int64_t* cell_of_row, int64_t n, const int64_t* size3_host, int c, int bf16,
+                          void* dP, scn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Step executor (scn_exec.hip): ONE call walks the launch plan of a whole network pass.

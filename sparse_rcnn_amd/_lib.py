@@ -104,6 +104,8 @@ _SIGS = {
     "scn_vox_discretize": (C.c_int, [p, i64, p, p, p, p, p, p]),
     "scn_vox_gather": (C.c_int, [p, p, i64, p, i64, p, p]),
     "scn_nms": (C.c_int, [p, i32, i32, f32, p, p]),
+    "scn_dilate_gather_fwd": (C.c_int, [p, p, i32, C.POINTER(i64), i32, i32, p, p, p]),
+    "scn_dilate_gather_bwd": (C.c_int, [p, p, i64, C.POINTER(i64), i32, i32, p, p]),
     "scn_nms_scratch_bytes": (i64, [i32, i32]),
     "scn_nms_bits": (C.c_int, [p, i32, i32, f32, p, p, p]),
     "scn_pool_fwd": (C.c_int, [p, p, i64, i32, i32, p, p]),

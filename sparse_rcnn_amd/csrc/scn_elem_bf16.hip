@@ -243,3 +243,104 @@ extern "C" int scn_sparse_to_dense_bwd_bf16(const uint16_t* dOut, const int32_t*
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Dilation gather (round 5; rpn.DenseRpn): the first dense 3^3 same-convolution behind scn.SparseToDense
+// (module_factory.py:581-611 `get_dilation_network`) reads a volume in which only the N active sites of the sparse level are
+// non-zero (2.3 % at the stride-8 level of the cfg-2 scene).  conv3d(pad 1):  h[c] = b + sum_o x[c + d_o] . W[o],  o = (a*3+b)*3+c',
+// d_o = (a-1, b-1, c'-1): a cell sums over its ACTIVE neighbours only.  So the layer is ONE row GEMM on the active rows,
+//   P[r][o][:] = X[r] . W[o]        ([N, 27 * Cout]; 1.3 GFLOP instead of the volume's 58),
+// followed by this gather:  h[c] = b + sum_o P[map[c + d_o]][o][:]  in ascending o (deterministic), map = cell -> active row | -1.
+// Backward: dP[r][o][:] = dh[cell(r) - d_o] (a pure gather), db = column sums of dh (scn_colsum), dX / dW through the GEMM.
+// T = float (fp32 slabs) or unsigned short (bf16-stored P / h; fp32 accumulation, one round-to-nearest-even per output).
+// ------------------------------------------------------------------------------------------------
+template <typename TT_> __device__ __forceinline__ float dg_ld(const TT_* p);
+template <> __device__ __forceinline__ float dg_ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float dg_ld<us>(const us* p) { return bw(*p); }
+template <typename TT_> __device__ __forceinline__ void dg_st(TT_* p, float v);
+template <> __device__ __forceinline__ void dg_st<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void dg_st<us>(us* p, float v) { *p = bn(v); }
+
+template <typename TT_>
+__global__ __launch_bounds__(256) void k_dilate_fwd(const TT_* __restrict__ P, const int* __restrict__ map, int B, int X, int Y,
+                                                    int Z, int c, const float* __restrict__ bias, TT_* __restrict__ out) {
+    const long long cells = (long long)B * X * Y * Z, total = cells * c;
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256ll) {
+        const long long cell = e / c;
+        const int ch = (int)(e - cell * c);
+        int z = (int)(cell % Z);
+        long long t = cell / Z;
+        int y = (int)(t % Y);
+        t /= Y;
+        int x = (int)(t % X);
+        const long long b = t / X;
+        float acc = bias ? bias[ch] : 0.f;
+#pragma unroll 1
+        for (int o = 0; o < 27; ++o) {
+            const int nx = x + o / 9 - 1, ny = y + (o / 3) % 3 - 1, nz = z + o % 3 - 1;
+            if ((unsigned)nx >= (unsigned)X || (unsigned)ny >= (unsigned)Y || (unsigned)nz >= (unsigned)Z) continue;
+            const int r = map[((b * X + nx) * Y + ny) * Z + nz];
+            if (r >= 0) acc += dg_ld<TT_>(P + ((long long)r * 27 + o) * c + ch);
+        }
+        dg_st<TT_>(out + e, acc);
+    }
+}
+
+template <typename TT_>
+__global__ __launch_bounds__(256) void k_dilate_bwd(const TT_* __restrict__ dOut, const long long* __restrict__ cell_of_row,
+                                                    long long n, int X, int Y, int Z, int c, TT_* __restrict__ dP) {
+    const long long total = n * 27 * c;
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256ll) {
+        const int ch = (int)(e % c);
+        const long long ro = e / c;
+        const int o = (int)(ro % 27);
+        const long long r = ro / 27;
+        const long long cell = cell_of_row[r];
+        int z = (int)(cell % Z);
+        long long t = cell / Z;
+        int y = (int)(t % Y);
+        t /= Y;
+        int x = (int)(t % X);
+        const long long b = t / X;
+        // row r feeds cell c' through offset o iff c' + d_o = cell(r)
+        const int cx = x - (o / 9 - 1), cy = y - ((o / 3) % 3 - 1), cz = z - (o % 3 - 1);
+        float v = 0.f;
+        if ((unsigned)cx < (unsigned)X && (unsigned)cy < (unsigned)Y && (unsigned)cz < (unsigned)Z)
+            v = dg_ld<TT_>(dOut + (((b * X + cx) * Y + cy) * Z + cz) * c + ch);
+        dg_st<TT_>(dP + e, v);
+    }
+}
+
+extern "C" int scn_dilate_gather_fwd(const void* P, const int32_t* map, int batch, const int64_t* size3_host, int c, int bf16,
+                                     const float* bias, void* out, scn_stream_t stream) {
+    SCN_REQUIRE(batch >= 0 && size3_host && c >= 1);
+    const int X = (int)size3_host[0], Y = (int)size3_host[1], Z = (int)size3_host[2];
+    const int64_t total = (int64_t)batch * X * Y * Z * c;
+    if (total == 0) return SCN_OK;
+    SCN_REQUIRE(P && map && out && X > 0 && Y > 0 && Z > 0);
+    if (bf16)
+        hipLaunchKernelGGL(k_dilate_fwd<us>, dim3(scn::ew_grid(total, 256)), dim3(256), 0, S(stream), (const us*)P, map, batch, X,
+                           Y, Z, c, bias, (us*)out);
+    else
+        hipLaunchKernelGGL(k_dilate_fwd<float>, dim3(scn::ew_grid(total, 256)), dim3(256), 0, S(stream), (const float*)P, map,
+                           batch, X, Y, Z, c, bias, (float*)out);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+extern "C" int scn_dilate_gather_bwd(const void* dOut, const int64_t* cell_of_row, int64_t n, const int64_t* size3_host, int c,
+                                     int bf16, void* dP, scn_stream_t stream) {
+    SCN_REQUIRE(n >= 0 && size3_host && c >= 1);
+    if (n == 0) return SCN_OK;
+    const int X = (int)size3_host[0], Y = (int)size3_host[1], Z = (int)size3_host[2];
+    SCN_REQUIRE(dOut && cell_of_row && dP && X > 0 && Y > 0 && Z > 0);
+    const int64_t total = n * 27 * c;
+    if (bf16)
+        hipLaunchKernelGGL(k_dilate_bwd<us>, dim3(scn::ew_grid(total, 256)), dim3(256), 0, S(stream), (const us*)dOut,
+                           (const long long*)cell_of_row, (long long)n, X, Y, Z, c, (us*)dP);
+    else
+        hipLaunchKernelGGL(k_dilate_bwd<float>, dim3(scn::ew_grid(total, 256)), dim3(256), 0, S(stream), (const float*)dOut,
+                           (const long long*)cell_of_row, (long long)n, X, Y, Z, c, (float*)dP);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}

@@ -1641,8 +1641,9 @@ def test_dense_rpn_stack_on_the_tile_kernels_equals_the_miopen_engine(gpu):
         for p in net.parameters():
             p.add_(torch.randn_like(p) * 0.1)
     res = {}
-    for engine in ("tiles", "miopen"):
-        net.engine = engine
+    for engine in ("tiles", "tiles-dense-first", "miopen"):
+        net.engine = "tiles" if engine.startswith("tiles") else engine
+        net.SPARSE_FIRST = engine == "tiles"          # (the first layer as one row GEMM over the active rows + a dilation gather)
         net.zero_grad()
         X = x.features.detach().clone().requires_grad_()
         t = scn.SparseConvNetTensor(features=X, metadata=x.metadata, spatial_size=x.spatial_size)
@@ -1663,6 +1664,18 @@ def test_dense_rpn_stack_on_the_tile_kernels_equals_the_miopen_engine(gpu):
     torch.autograd.backward([ob, os_], [gb.cpu(), gs.cpu()])
     ref = [ob.detach(), os_.detach(), Xo.grad] + [p.grad for p in cpu.parameters()]
     names = ["rpn_bbox", "rpn_score", "d level features"] + ["d " + n for n, _ in net.named_parameters()]
-    for n, a, b, r in zip(names, res["tiles"], res["miopen"], ref):
-        _close(a, r, 1e-4, f"tiles engine vs CPU: {n}")
+    for n, a, a2, b, r in zip(names, res["tiles"], res["tiles-dense-first"], res["miopen"], ref):
+        _close(a, r, 1e-4, f"tiles engine (sparse first layer) vs CPU: {n}")
+        _close(a2, r, 1e-4, f"tiles engine (every layer on the volume) vs CPU: {n}")
         _close(b, r, 1e-4, f"miopen engine vs CPU: {n}")
+    # bf16-stored level features: the two forms of the first layer against each other (different roundings: both round the
+    # layer's output to bf16 once, the sparse form also its GEMM result)
+    outs = []
+    for sparse_first in (True, False):
+        net.engine, net.SPARSE_FIRST = "tiles", sparse_first
+        Xb = x.features.detach().to(torch.bfloat16)
+        t = scn.SparseConvNetTensor(features=Xb, metadata=x.metadata, spatial_size=x.spatial_size)
+        bb, sc, _ = net(t)
+        outs.append((bb.float(), sc.float()))
+    for u, v in zip(*outs):
+        assert float((u - v).abs().max()) <= 3e-2 * max(float(v.abs().max()), 1e-6)

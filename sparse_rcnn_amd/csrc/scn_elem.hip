@@ -757,13 +757,18 @@ __global__ __launch_bounds__(256) void k_nms_resolve(const unsigned long long* _
         }
         __syncthreads();
         if (threadIdx.x < 64) {
-            for (int r = 0; r < nr; ++r) {
-                const int j = r0 + r;
-                const unsigned long long row = lane < nw ? rows[r * nw + lane] : 0ull;
-                const unsigned lo = __builtin_amdgcn_readlane((unsigned)removed, j >> 6);
-                const unsigned hi = __builtin_amdgcn_readlane((unsigned)(removed >> 32), j >> 6);
-                const unsigned long long wj = ((unsigned long long)hi << 32) | lo;
-                if (!((wj >> (j & 63)) & 1ull)) removed |= row;          // wave-uniform: box j is kept, it suppresses its row
+            for (int r = 0; r < nr; r += 8) {            // 8 rows of the matrix in flight (LDS latency), walked one after the other
+                unsigned long long row[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) row[u] = (lane < nw && r + u < nr) ? rows[(r + u) * nw + lane] : 0ull;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = r0 + r + u;
+                    const unsigned lo = __builtin_amdgcn_readlane((unsigned)removed, j >> 6);
+                    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(removed >> 32), j >> 6);
+                    const unsigned long long wj = ((unsigned long long)hi << 32) | lo;
+                    if (r + u < nr && !((wj >> (j & 63)) & 1ull)) removed |= row[u];   // wave-uniform: box j is kept, it suppresses its row
+                }
             }
         }
         __syncthreads();

@@ -133,8 +133,13 @@ class DenseRpn(nn.Module):
         md = level_tensor.metadata
         size = tuple(int(v) for v in level_tensor.spatial_size)
         B = md.n_samples
-        c = md.grid(size).coords.long()                                         # int32 [N, 4] = (x, y, z, b) on the device
-        ridx = ((c[:, 3] * size[0] + c[:, 0]) * size[1] + c[:, 1]) * size[2] + c[:, 2]
+        # cell of every active row: ((b X + x) Y + y) Z + z from the level's int32 coordinates (x, y, z, b) -- three small launches
+        wkey = (size, str(feats.device))
+        w = self._anchor_cache.get(("cellw",) + wkey)
+        if w is None:
+            w = self._anchor_cache[("cellw",) + wkey] = torch.tensor(
+                [size[1] * size[2], size[2], 1, size[0] * size[1] * size[2]], dtype=torch.long, device=feats.device)
+        ridx = (md.grid(size).coords.long() * w).sum(1)
         dmd = self.dense_metadata(size, B, feats.device)
         ssz = torch.as_tensor(size, dtype=torch.long)
         layers = list(self.stack)

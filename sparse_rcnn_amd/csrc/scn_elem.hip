@@ -757,17 +757,35 @@ __global__ __launch_bounds__(256) void k_nms_resolve(const unsigned long long* _
         }
         __syncthreads();
         if (threadIdx.x < 64) {
-            for (int r = 0; r < nr; r += 8) {            // 8 rows of the matrix in flight (LDS latency), walked one after the other
-                unsigned long long row[8];
+            // A block of 64 rows only tests ONE word of the removed set (word w = j >> 6), and that word of every row is known as
+            // soon as the row is loaded -- independent of the walk.  So the serial chain runs on scalars: `cur` = word w of the
+            // removed set, rw[u] = word w of row u (read from lane w up front); per box one test and one conditional OR on
+            // SGPRs (~10 cycles; the first version re-read the vector per box: ~230).  The full-width OR into `removed` follows
+            // off the critical path.
+            for (int rb = 0; rb < nr; rb += 64) {
+                const int w = (r0 + rb) >> 6;
+                unsigned cur_lo = __builtin_amdgcn_readlane((unsigned)removed, w);
+                unsigned cur_hi = __builtin_amdgcn_readlane((unsigned)(removed >> 32), w);
+                const int nb = min(64, nr - rb);
+                for (int r = 0; r < nb; r += 8) {
+                    unsigned long long row[8];
+                    unsigned rw_lo[8], rw_hi[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) row[u] = (lane < nw && r + u < nr) ? rows[(r + u) * nw + lane] : 0ull;
+                    for (int u = 0; u < 8; ++u) row[u] = (lane < nw && r + u < nb) ? rows[(rb + r + u) * nw + lane] : 0ull;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int j = r0 + r + u;
-                    const unsigned lo = __builtin_amdgcn_readlane((unsigned)removed, j >> 6);
-                    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(removed >> 32), j >> 6);
-                    const unsigned long long wj = ((unsigned long long)hi << 32) | lo;
-                    if (r + u < nr && !((wj >> (j & 63)) & 1ull)) removed |= row[u];   // wave-uniform: box j is kept, it suppresses its row
+                    for (int u = 0; u < 8; ++u) {
+                        rw_lo[u] = __builtin_amdgcn_readlane((unsigned)row[u], w);
+                        rw_hi[u] = __builtin_amdgcn_readlane((unsigned)(row[u] >> 32), w);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int bit = (r0 + rb + r + u) & 63;                    // (rb, r multiples of 8: bit = r + u)
+                        const unsigned long long cur = ((unsigned long long)cur_hi << 32) | cur_lo;
+                        const bool alive = r + u < nb && !((cur >> bit) & 1ull);  // wave-uniform: box j is kept, it suppresses its row
+                        cur_lo |= alive ? rw_lo[u] : 0u;
+                        cur_hi |= alive ? rw_hi[u] : 0u;
+                        removed |= alive ? row[u] : 0ull;
+                    }
                 }
             }
         }

@@ -742,7 +742,7 @@ __global__ __launch_bounds__(64) void k_nms_matrix(const float* __restrict__ box
     Ms[(long long)j * nw + cb] = bits;
 }
 
-__global__ __launch_bounds__(256) void k_nms_resolve(const unsigned long long* __restrict__ M, int n,
+__global__ __launch_bounds__(1024) void k_nms_resolve(const unsigned long long* __restrict__ M, int n,
                                                      unsigned char* __restrict__ keep_out) {
     extern __shared__ unsigned long long rows[];              // [NMSB_ROWS][nw]
     const int nw = (n + 63) >> 6, lane = threadIdx.x & 63;
@@ -751,9 +751,21 @@ __global__ __launch_bounds__(256) void k_nms_resolve(const unsigned long long* _
     unsigned long long removed = 0;                           // wave 0, lane l: word l
     for (int r0 = 0; r0 < n; r0 += NMSB_ROWS) {
         const int nr = min(NMSB_ROWS, n - r0);
-        for (int e = threadIdx.x; e < nr * nw; e += blockDim.x) {
-            const int r = e / nw, w = e - r * nw;
-            rows[e] = w >= ((r0 + r) >> 6) ? Ms[(long long)(r0 + r) * nw + w] : 0ull;       // (lower triangle: not written)
+        for (int e0 = threadIdx.x; e0 < nr * nw; e0 += 4 * blockDim.x) {          // four independent loads in flight per thread
+            unsigned long long v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = e0 + q * blockDim.x;
+                const int r = e / nw, w = e - r * nw;
+                const bool want = e < nr * nw && w >= ((r0 + r) >> 6);                      // (lower triangle: not written)
+                v[q] = Ms[want ? (long long)(r0 + r) * nw + w : (long long)r0 * nw + nw - 1];
+                v[q] = want ? v[q] : 0ull;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = e0 + q * blockDim.x;
+                if (e < nr * nw) rows[e] = v[q];
+            }
         }
         __syncthreads();
         if (threadIdx.x < 64) {
@@ -791,12 +803,10 @@ __global__ __launch_bounds__(256) void k_nms_resolve(const unsigned long long* _
         }
         __syncthreads();
     }
-    if (threadIdx.x < 64 && lane < nw) {
-        for (int b = 0; b < 64; ++b) {
-            const int i = lane * 64 + b;
-            if (i < n) K[i] = (unsigned char)(((removed >> b) & 1ull) ? 0 : 1);
-        }
-    }
+    // keep[] bytes: wave 0 parks the removed set in LDS, the workgroup writes one byte per thread and step
+    if (threadIdx.x < 64 && lane < nw) rows[lane] = removed;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) K[i] = (unsigned char)(((rows[i >> 6] >> (i & 63)) & 1ull) ? 0 : 1);
 }
 
 extern "C" int64_t scn_nms_scratch_bytes(int batch, int n) {
@@ -819,7 +829,7 @@ extern "C" int scn_nms_bits(const float* boxes, int batch, int n, float overlap_
         SCN_HIP(hipFuncSetAttribute((const void*)k_nms_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, NMSB_ROWS * 64 * 8));
         attr = true;
     }
-    hipLaunchKernelGGL(k_nms_resolve, dim3(batch), dim3(256), lds, S(stream), (const unsigned long long*)scratch, n, keep);
+    hipLaunchKernelGGL(k_nms_resolve, dim3(batch), dim3(1024), lds, S(stream), (const unsigned long long*)scratch, n, keep);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }

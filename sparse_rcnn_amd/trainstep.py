@@ -161,8 +161,8 @@ class SceneStep:
         by 1 / batches_per_step.  zero: drop the gradients first (the first micro-batch of a step).
         Keeps .out / .logits / .fin for checks."""
         m = self.model
-        if zero:
-            self.flat.zero_grad()
+        # (the gradients are dropped right before backward, not here: at the step boundary the GPU's queue is empty, and 156
+        #  attribute stores are 40-50 us the first forward kernels would wait for)
         if k != self._k:
             self._use_scene(k)
         scale = 1.0 / self.batches_per_step
@@ -226,6 +226,8 @@ class SceneStep:
                 dist.all_reduce(tot)
             self._total_weight = float(tot.item())
         if m.mask is None:
+            if zero:
+                self.flat.zero_grad()
             _backward([out.features], [gys])
             logits = None
         else:
@@ -263,6 +265,8 @@ class SceneStep:
                 roots.append(logits)
                 root_grads.append(gm if scale == 1.0 else gm * scale)
             # (an empty crop -- no proposal caught a point: the mask branch contributes nothing on this rank)
+            if zero:
+                self.flat.zero_grad()
             _backward(roots, root_grads)
         self.out, self.logits, self.fin = out, logits, fin
 

@@ -55,7 +55,8 @@ extern "C" {
  *      caller that kept raw tables across a library upgrade is affected); + scn_exec_timing_enable / _collect, scn_pad_params_many, scn_conv_tiles_split_count, scn_dedup_launch_div, scn_child_table_div (107 entry points);
  *      scn_pool_fwd / _bwd (+ _bf16): `average` carries the pool volume above bit 8 (0 = the 2^3 of every configuration) */
 /*   4  round 5: + scn_debug_set / scn_debug_get (developer switches no longer follow the ambient environment per launch);
- *      scn_exec_timing_collect forgets only the records it returned; + scn_nms_bits / scn_nms_scratch_bytes, scn_dilate_gather_fwd / _bwd */
+ *      scn_exec_timing_collect forgets only the records it returned; + scn_nms_bits / scn_nms_scratch_bytes, scn_dilate_gather_fwd / _bwd,
+ *      scn_parent_lookup_div (114 entry points) */
 #define SCN_ABI_VERSION 4
 
 /* flags for the gather-GEMM entry points */
@@ -138,6 +139,13 @@ int scn_dedup_launch_div(const int32_t* coords, int64_t n, int sx, int sy, int s
                          void* scratch, int64_t* n_rows_dev, scn_stream_t stream);
 int scn_child_table_div(const int32_t* fine_coords, const int32_t* parent, int64_t n_fine, int64_t n_coarse, int sx, int sy,
                         int sz, int32_t* child, int32_t* fine_off, scn_stream_t stream);
+/* The first of the two steps when the coarse grid ALREADY EXISTS on the Metadata (SparseConvNet keys its grids by spatial size:
+ * 64 -> 16 by one stride-4 layer after 64 -> 32 -> 16 by two stride-2 layers lands in the same grid): parent[i] = the existing
+ * grid's row of (x / sx, y / sy, z / sz), -1 where that site is not in the grid; *n_missing_dev = how many were not (the
+ * caller refuses those: upstream would grow the grid under the tensors that live on it).  scn_child_table_div then builds
+ * the child table against that numbering (n_coarse may exceed n_fine there). */
+int scn_parent_lookup_div(const int32_t* fine_coords, int64_t n_fine, int sx, int sy, int sz, const uint64_t* table_keys,
+                          const int32_t* table_rows, int64_t cap, int32_t* parent, int64_t* n_missing_dev, scn_stream_t stream);
 
 /* Compaction of a rule table into (in,out) pairs -- wave ballot + prefix sum.
  * Phase 1: counts; block_sums must hold scn_rules_blocks(n_off, n_out) int32; writes prefix (device, int64[n_off+1])

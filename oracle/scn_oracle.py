@@ -174,8 +174,10 @@ def subm_rulebook(coords: np.ndarray, k: int = 3):
     return nbr, rules
 
 
-def strided_rulebook(coords: np.ndarray, s=2):
+def strided_rulebook(coords: np.ndarray, s=2, existing=None):
     """Fine coords [Nf,4] -> dict(coarse coords, parent, off, child table, rules).
+    `existing` = the coords [Nc,4] of a coarse grid the Metadata already holds (grids are keyed by spatial size upstream: a
+    second path to the same size lands in the same grid): rows are numbered as THAT grid numbers them.
 
     size = stride = s (an int, or one entry per axis: `get_downsampler(stride=...)`, module_factory.py:221-241).
     Coarse site = floor(p/s); offset o = ((x%sx)*sy + y%sy)*sz + z%sz.
@@ -186,8 +188,16 @@ def strided_rulebook(coords: np.ndarray, s=2):
     coords = np.asarray(coords, dtype=np.int64).reshape(-1, 4)
     cc = coords.copy()
     cc[:, :3] //= st
-    parent, first = _first_occurrence_rows(pack_keys(cc))
-    nc = len(first)
+    if existing is None:
+        parent, first = _first_occurrence_rows(pack_keys(cc))
+        nc, coarse = len(first), cc[first]
+    else:
+        coarse = np.asarray(existing, dtype=np.int64).reshape(-1, 4)
+        ek = pack_keys(coarse)
+        order = np.argsort(ek, kind="stable")
+        parent = _lookup(ek[order], order.astype(np.int64), pack_keys(cc))
+        assert (parent >= 0).all(), "the existing grid lacks sites this layer needs"
+        nc = len(coarse)
     r = coords[:, :3] % st
     off = ((r[:, 0] * st[1] + r[:, 1]) * st[2] + r[:, 2]).astype(np.int32)
     n_off = int(st.prod())
@@ -197,7 +207,7 @@ def strided_rulebook(coords: np.ndarray, s=2):
     for o in range(n_off):
         out = np.nonzero(child[o] >= 0)[0].astype(np.int32)
         rules.append((child[o][out].astype(np.int32), out))
-    return dict(coords=cc[first], parent=parent.astype(np.int32), off=off, child=child, rules=rules)
+    return dict(coords=coarse, parent=parent.astype(np.int32), off=off, child=child, rules=rules)
 
 
 def rules_concat(rules):

@@ -30,6 +30,7 @@ _SIGS = {
     "scn_dedup_launch": (C.c_int, [p, i64, i32, p, p, i64, p, p, p, p, p, p, p]),
     "scn_dedup_launch_div": (C.c_int, [p, i64, i32, i32, i32, p, p, i64, p, p, p, p, p, p, p]),
     "scn_child_table_div": (C.c_int, [p, p, i64, i64, i32, i32, i32, p, p, p]),
+    "scn_parent_lookup_div": (C.c_int, [p, i64, i32, i32, i32, p, p, i64, p, p, p]),
     "scn_subm_table": (C.c_int, [p, i64, p, p, i64, i32, p, p]),
     "scn_child_table": (C.c_int, [p, p, i64, i64, p, p, p]),
     "scn_rules_blocks": (i64, [i32, i64]),

@@ -450,13 +450,43 @@ __global__ void k_child_table_div(const int4* __restrict__ fine, const int* __re
 
 extern "C" int scn_child_table_div(const int32_t* fine_coords, const int32_t* parent, int64_t n_fine, int64_t n_coarse,
                                    int sx, int sy, int sz, int32_t* child, int32_t* fine_off, scn_stream_t stream) {
-    SCN_REQUIRE(n_fine >= 0 && n_coarse >= 0 && n_coarse <= n_fine && sx >= 1 && sy >= 1 && sz >= 1);
+    SCN_REQUIRE(n_fine >= 0 && n_coarse >= 0 && sx >= 1 && sy >= 1 && sz >= 1);   // (n_coarse > n_fine: an existing, larger grid)
     SCN_REQUIRE((int64_t)sx * sy * sz <= 4096);
     if (n_fine == 0) return SCN_OK;
     SCN_REQUIRE(fine_coords && parent && child && fine_off);
     SCN_HIP(hipMemsetAsync(child, 0xFF, sizeof(int32_t) * (size_t)sx * sy * sz * n_coarse, S(stream)));
     hipLaunchKernelGGL(k_child_table_div, dim3(scn::ew_grid(n_fine, 256)), dim3(256), 0, S(stream),
                        (const int4*)fine_coords, parent, (long long)n_fine, (long long)n_coarse, sx, sy, sz, child, fine_off);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+// A size = stride Convolution INTO a grid that already exists (another path of the network reached the same spatial size on this
+// Metadata; SparseConvNet keys its grids by spatial size): parent[i] = the existing grid's row of floor(fine[i] / stride), -1 and a
+// count when that site is not in the grid.
+__global__ void k_parent_lookup_div(const int4* __restrict__ fine, long long n, int sx, int sy, int sz,
+                                    const unsigned long long* __restrict__ keys, const int* __restrict__ rows, long long cap,
+                                    int* __restrict__ parent, unsigned long long* __restrict__ n_missing) {
+    const unsigned long long mask = (unsigned long long)cap - 1ull;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int4 c = fine[i];
+        const int r = hash_lookup(keys, rows, mask, scn_pack_key(c.x / sx, c.y / sy, c.z / sz, c.w));
+        parent[i] = r;
+        if (r < 0) atomicAdd(n_missing, 1ull);
+    }
+}
+
+extern "C" int scn_parent_lookup_div(const int32_t* fine_coords, int64_t n_fine, int sx, int sy, int sz,
+                                     const uint64_t* table_keys, const int32_t* table_rows, int64_t cap, int32_t* parent,
+                                     int64_t* n_missing_dev, scn_stream_t stream) {
+    SCN_REQUIRE(n_fine >= 0 && sx >= 1 && sy >= 1 && sz >= 1 && n_missing_dev);
+    SCN_HIP(hipMemsetAsync(n_missing_dev, 0, sizeof(int64_t), S(stream)));
+    if (n_fine == 0) return SCN_OK;
+    SCN_REQUIRE(fine_coords && table_keys && table_rows && parent && cap > 0 && (cap & (cap - 1)) == 0);
+    hipLaunchKernelGGL(k_parent_lookup_div, dim3(scn::ew_grid(n_fine, 256)), dim3(256), 0, S(stream),
+                       (const int4*)fine_coords, (long long)n_fine, sx, sy, sz, (const unsigned long long*)table_keys, table_rows,
+                       (long long)cap, parent, (unsigned long long*)n_missing_dev);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }

@@ -712,6 +712,8 @@ class Metadata:
         if stride != (2, 2, 2):
             return self._general_strided_rulebook(size, stride)
         rb = self.strided.get(size)
+        if rb is None and tuple(s // 2 for s in size) in self.grids and not any(s % 2 for s in size):
+            rb = self.strided[size] = self._general_strided_rulebook(size, stride)      # into the grid that exists
         if rb is None:
             rb = self._strided_finish(size, self._strided_launch(size))
         self._unrequested.discard(size)
@@ -726,8 +728,6 @@ class Metadata:
             raise L.ScnError(f"Convolution size=stride={stride} needs a spatial size that is a multiple of it, got {size} "
                              "((out-1)*stride+filter != in)")
         coarse_size = tuple(s // st for s, st in zip(size, stride))
-        if coarse_size in self.grids and coarse_size != size:
-            raise L.ScnError(f"Metadata already holds a grid of size {coarse_size}")
         g = self.grid(size)
         lib = L.lib()
         dev = g.coords.device
@@ -735,6 +735,21 @@ class Metadata:
         if stride == (1, 1, 1):                       # a 1^3 / 1 "downsampler" keeps the grid
             cg = g
             parent = torch.arange(g.n, dtype=torch.int32, device=dev)
+        elif coarse_size in self.grids:
+            # Another path of the network has reached this spatial size on this Metadata (64 -> 16 by stride 4 after 64 -> 32 ->
+            # 16 by two stride-2 layers): SparseConvNet keys its grids by spatial size, so the layer lands in THAT grid and its
+            # row numbering.  Upstream would also add sites the grid lacks -- under the tensors that already live on it; every
+            # site is there whenever both paths start from the same input, anything else is refused.
+            cg = self.grids[coarse_size]
+            parent = _empty(g.n, torch.int32, dev)
+            missing = torch.empty(1, dtype=torch.int64, device=dev)
+            L.check(lib.scn_parent_lookup_div(L.ptr(g.coords), g.n, stride[0], stride[1], stride[2], L.ptr(cg.table_keys),
+                                              L.ptr(cg.table_rows), cg.cap, L.ptr(parent), L.ptr(missing), L.stream()))
+            n_missing = int(missing.item())
+            if n_missing:
+                raise L.ScnError(f"Metadata already holds a grid of size {coarse_size} that lacks {n_missing} of the sites a "
+                                 f"size=stride={stride} Convolution from {size} needs (SparseConvNet would grow that grid "
+                                 "under the tensors living on it)")
         else:
             cg, parent, _, _ = _Dedup(g.coords, stride, False, False).finish()
             self.grids[coarse_size] = cg
@@ -841,12 +856,14 @@ class Metadata:
         size = tuple(int(s) for s in size)
         for level in range(n_levels):
             pending = None
-            if level + 1 < n_levels and size not in self.strided:
+            if level + 1 < n_levels and size not in self.strided and tuple(s // 2 for s in size) not in self.grids:
                 pending = self._strided_launch(size)
             self.subm_rulebook(size, k)
             if level + 1 < n_levels:
                 if pending is not None:
                     self._strided_finish(size, pending)
+                elif size not in self.strided:
+                    self.strided_rulebook(size)                # the coarse grid exists (another path built it): reuse it
                 size = tuple(s // 2 for s in size)
 
     # ---- parity helpers (tests) -------------------------------------------------------------------

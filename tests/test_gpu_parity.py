@@ -408,6 +408,68 @@ def test_general_stride_conv_deconv_and_pooling(gpu, stride):
         scn.Convolution(3, 8, 8, (3, 3, 3), (2, 2, 2), True)                               # overlapping filters: not the reference's
 
 
+@pytest.mark.parametrize("order", ["two_then_four", "four_then_two"])
+def test_a_second_path_to_the_same_spatial_size_lands_in_the_existing_grid(gpu, order):
+    """SparseConvNet keys a Metadata's grids by spatial size, so 24 -> 6 by ONE stride-4 Convolution after
+    24 -> 12 -> 6 by two stride-2 layers (or the other way round) lands in the SAME grid and takes ITS row numbering
+    (`scn_parent_lookup_div` + the child table against that numbering); round 4 raised "already holds a grid".  Checked
+    against the oracle's rulebook built into the existing grid (forward, every gradient, the Deconvolution back), the two
+    results live on one row order (their sum is a plain AddTable), and a grid that lacks a needed site is refused."""
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=13, cin=8, grid=(24, 24, 16))
+    s0 = tuple(int(v) for v in size)
+    c4 = scn.Convolution(3, 8, 16, (4, 4, 4), (4, 4, 4), True).to(gpu)
+    c2a = scn.Convolution(3, 8, 8, (2, 2, 2), (2, 2, 2), True).to(gpu)
+    c2b = scn.Convolution(3, 8, 16, (2, 2, 2), (2, 2, 2), True).to(gpu)
+    up4 = scn.Deconvolution(3, 16, 8, (4, 4, 4), (4, 4, 4), True).to(gpu)
+    with torch.no_grad():
+        for m in (c4, c2a, c2b, up4):
+            m.bias.normal_(0, 0.5)
+    if order == "two_then_four":
+        y2 = c2b(c2a(x)); y4 = c4(x)
+    else:
+        y4 = c4(x); y2 = c2b(c2a(x))
+    assert y2.metadata is y4.metadata and tuple(int(v) for v in y4.spatial_size) == tuple(v // 4 for v in s0)
+    # the oracle: whichever path came first numbers the 6 x 6 x 4 grid; the other is built INTO it
+    r1 = O.strided_rulebook(scene.coords0, 2)
+    if order == "two_then_four":
+        r2 = O.strided_rulebook(r1["coords"], 2)
+        r4 = O.strided_rulebook(scene.coords0, 4, existing=r2["coords"])
+        grid = r2["coords"]
+    else:
+        r4 = O.strided_rulebook(scene.coords0, 4)
+        r2 = O.strided_rulebook(r1["coords"], 2, existing=r4["coords"])
+        grid = r4["coords"]
+    nc = len(grid)
+    assert np.array_equal(y4.get_spatial_locations().numpy(), grid) and np.array_equal(y2.get_spatial_locations().numpy(), grid)
+    md = x.metadata
+    assert np.array_equal(md.strided_rulebook(s0, (4, 4, 4)).child.cpu().numpy(), r4["child"])
+    assert np.array_equal(md.strided_rulebook(tuple(v // 2 for v in s0)).child.cpu().numpy(), r2["child"])
+    Xo = O.input_layer_fwd(feats, scene.prow, scene.n(0), 4).requires_grad_()
+    P = {n: (m.weight.detach().cpu().requires_grad_(), m.bias.detach().cpu().requires_grad_())
+         for n, m in (("c4", c4), ("c2a", c2a), ("c2b", c2b), ("up4", up4))}
+    o4 = O.conv(Xo, *P["c4"], r4["rules"], nc)
+    o2 = O.conv(O.conv(Xo, *P["c2a"], r1["rules"], len(r1["coords"])), *P["c2b"], r2["rules"], nc)
+    _close(y4.features, o4, what="stride-4 path"); _close(y2.features, o2, what="two stride-2 layers")
+    total = scn.AddTable()([y4, y2])                                   # one grid, one row order
+    back = up4(total)
+    ob = O.conv(o4 + o2, *P["up4"], O.swap_rules(r4["rules"]), scene.n(0))
+    _close(back.features, ob, what="deconvolution back through the stride-4 rulebook")
+    g = torch.randn(ob.shape, generator=torch.Generator().manual_seed(3))
+    mods = (c4, c2a, c2b, up4)
+    got = _grads(back.features, (x.features,) + tuple(m.weight for m in mods) + tuple(m.bias for m in mods), g.to(gpu))
+    names = ("c4", "c2a", "c2b", "up4")
+    exp = _grads(ob, (Xo,) + tuple(P[n][0] for n in names) + tuple(P[n][1] for n in names), g)
+    for a, e, name in zip(got, exp, ("dX",) + tuple("dW " + n for n in names) + tuple("db " + n for n in names)):
+        _close(a, e, what=name)
+    # a grid of that size which lacks sites: refused, not grown (planted here: the first five coarse sites only)
+    from sparse_rcnn_amd.metadata import dedup
+    scn2, coords2, feats2, fg2, x2, scene2, size2 = _input(gpu, seed=14, cin=8, grid=(24, 24, 16))
+    few = torch.from_numpy(np.ascontiguousarray(O.strided_rulebook(scene2.coords0, 4)["coords"][:5])).to(torch.int32).to(gpu)
+    x2.metadata.grids[tuple(v // 4 for v in s0)] = dedup(few.contiguous(), 0, False, False)[0]
+    with pytest.raises(scn.ScnError, match="lacks"):
+        c4(x2)
+
+
 def test_deconvolution_needs_cached_level(gpu):
     scn, coords, feats, fg, x, scene, size = _input(gpu, seed=4, cin=4)
     with pytest.raises(scn.ScnError):

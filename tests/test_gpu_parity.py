@@ -461,8 +461,20 @@ def test_a_second_path_to_the_same_spatial_size_lands_in_the_existing_grid(gpu, 
     exp = _grads(ob, (Xo,) + tuple(P[n][0] for n in names) + tuple(P[n][1] for n in names), g)
     for a, e, name in zip(got, exp, ("dX",) + tuple("dW " + n for n in names) + tuple("db " + n for n in names)):
         _close(a, e, what=name)
-    # a grid of that size which lacks sites: refused, not grown (planted here: the first five coarse sites only)
+    # first-occurrence numbering composes (both paths number the sites alike), so the lookup is also pinned on a grid that is
+    # numbered some OTHER way: the same sites planted in a permuted order
     from sparse_rcnn_amd.metadata import dedup
+    scn3, coords3, feats3, fg3, x3, scene3, size3 = _input(gpu, seed=13, cin=8, grid=(24, 24, 16))
+    shuffled = np.ascontiguousarray(grid[np.random.default_rng(1).permutation(nc)])
+    x3.metadata.grids[tuple(v // 4 for v in s0)] = dedup(torch.from_numpy(shuffled).to(torch.int32).to(gpu).contiguous(), 0,
+                                                         False, False)[0]
+    y3 = c4(x3)
+    r3 = O.strided_rulebook(scene3.coords0, 4, existing=shuffled)
+    assert np.array_equal(y3.get_spatial_locations().numpy(), shuffled)
+    assert np.array_equal(x3.metadata.strided_rulebook(s0, (4, 4, 4)).child.cpu().numpy(), r3["child"])
+    assert not np.array_equal(r3["child"], r4["child"])
+    _close(y3.features, O.conv(Xo.detach(), P["c4"][0].detach(), P["c4"][1].detach(), r3["rules"], nc), what="planted grid")
+    # a grid of that size which lacks sites: refused, not grown (planted here: the first five coarse sites only)
     scn2, coords2, feats2, fg2, x2, scene2, size2 = _input(gpu, seed=14, cin=8, grid=(24, 24, 16))
     few = torch.from_numpy(np.ascontiguousarray(O.strided_rulebook(scene2.coords0, 4)["coords"][:5])).to(torch.int32).to(gpu)
     x2.metadata.grids[tuple(v // 4 for v in s0)] = dedup(few.contiguous(), 0, False, False)[0]

@@ -110,6 +110,31 @@ def test_strided_conv_and_deconv_match_dense():
         assert torch.allclose(a, c, atol=1e-4, rtol=1e-4)
 
 
+def test_strided_rulebook_into_an_existing_grid_matches_dense():
+    """The oracle's rulebook of a size = stride layer whose coarse grid already exists (another path numbered it): a stride-4
+    Convolution into the grid two stride-2 layers built equals conv3d(kernel = stride = 4) sampled at THAT grid's sites."""
+    pts, grid, batch = _cloud(5, grid=(12, 8, 8))
+    coords, _, _ = O.input_layer_rules(pts)
+    r2 = O.strided_rulebook(O.strided_rulebook(coords, 2)["coords"], 2)
+    own = O.strided_rulebook(coords, 4)
+    # first-occurrence numbering composes: two stride-2 layers number the sites exactly as one stride-4 layer does ...
+    assert np.array_equal(own["coords"], r2["coords"])
+    assert np.array_equal(O.strided_rulebook(coords, 4, existing=r2["coords"])["child"], own["child"])
+    # ... so the form is pinned on a grid numbered some OTHER way (a permutation of it)
+    r2 = dict(coords=r2["coords"][np.random.default_rng(0).permutation(len(r2["coords"]))])
+    rb = O.strided_rulebook(coords, 4, existing=r2["coords"])
+    assert np.array_equal(rb["coords"], r2["coords"]) and not np.array_equal(rb["child"], own["child"])
+    g = torch.Generator().manual_seed(4)
+    X = torch.randn(len(coords), 3, generator=g)
+    W, b = torch.randn(64, 3, 5, generator=g), torch.randn(5, generator=g)
+    Y = O.conv(X, W, b, rb["rules"], len(r2["coords"]))
+    Wt = W.reshape(4, 4, 4, 3, 5).permute(4, 3, 0, 1, 2)
+    Yd = _sample(F.conv3d(_dense(X, coords, grid, batch), Wt, b, stride=4), r2["coords"])
+    assert torch.allclose(Y, Yd, atol=TOL, rtol=TOL)
+    with pytest.raises(AssertionError):
+        O.strided_rulebook(coords, 4, existing=r2["coords"][:3])
+
+
 def test_batchnorm_relu_matches_dense_and_scn_momentum():
     g = torch.Generator().manual_seed(5)
     X = torch.randn(200, 6, generator=g)

@@ -56,7 +56,7 @@ extern "C" {
  *      scn_pool_fwd / _bwd (+ _bf16): `average` carries the pool volume above bit 8 (0 = the 2^3 of every configuration) */
 /*   4  round 5: + scn_debug_set / scn_debug_get (developer switches no longer follow the ambient environment per launch);
  *      scn_exec_timing_collect forgets only the records it returned; + scn_nms_bits / scn_nms_scratch_bytes, scn_dilate_gather_fwd / _bwd,
- *      scn_parent_lookup_div (114 entry points) */
+ *      scn_parent_lookup_div, scn_topk_boxes / scn_topk_scratch_bytes (116 entry points) */
 #define SCN_ABI_VERSION 4
 
 /* flags for the gather-GEMM entry points */
@@ -535,6 +535,18 @@ int scn_nms(const float* boxes, int batch, int n, float overlap_threshold, uint8
 int64_t scn_nms_scratch_bytes(int batch, int n);
 int scn_nms_bits(const float* boxes, int batch, int n, float overlap_threshold, uint8_t* keep, void* scratch,
                  scn_stream_t stream);
+
+/* Exact top-k of a score field with the boxes gathered along -- what ProposalSelector runs before its NMS
+ * (ndsis/modules/proposal_selector.py:60-75: torch.topk(rpn_score, num_keep_pre_nms, sorted) and rpn_bbox[batch, indices]).
+ * scores fp32 [batch][n], boxes fp32 [batch][n][6] or NULL; out_scores [batch][k] descending, out_index int64 [batch][k],
+ * out_boxes [batch][k][6].  Equal scores come out by ascending index (torch.topk leaves their order open); NaN counts as
+ * the largest value, as in torch.  Radix select (two 11-bit histogram passes over an order-preserving key, one compaction,
+ * one LDS sort of the candidates): 4 launches instead of torch.topk's 19 on a [1, 524 288] field.  k <= 2048, k <= n.
+ * scratch: scn_topk_scratch_bytes(batch) bytes that are ZERO before the first call; every call leaves them zero again
+ * (after a failed call: zero them).  One stream at a time per scratch. */
+int64_t scn_topk_scratch_bytes(int batch);
+int scn_topk_boxes(const float* scores, const float* boxes, int batch, int64_t n, int k, float* out_scores,
+                   int64_t* out_index, float* out_boxes, void* scratch, scn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Voxelisation front-end: the deterministic core of augment_coords

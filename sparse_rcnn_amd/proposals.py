@@ -35,6 +35,63 @@ def non_maximum_suppression(proposed_boxes: torch.Tensor, overlap_threshold: flo
     return keep.bool().reshape(*lead, n)
 
 
+TORCH_TOPK = False          # True: torch.topk + advanced indexing (the reference's calls); the tests' cross-check and the A/B
+_TOPK_MAX_K = 2048          # scn_topk_boxes: k <= 2048
+_topk_scratch = {}          # (device, batch) -> the zeroed state scn_topk_boxes keeps between calls
+
+
+class _TopkBoxes(torch.autograd.Function):
+    """torch.topk(score, k, dim=1, sorted=True) and boxes[batch, indices] as one call (scn_topk_boxes: radix select, 4 launches
+    against torch.topk's 19 on a [1, 524 288] field).  Equal scores come out by ascending index (torch leaves that open)."""
+
+    @staticmethod
+    def forward(ctx, score, boxes, k):
+        b, n = score.shape
+        s = score.detach().contiguous()
+        bx = boxes.detach().reshape(b, n, 6).contiguous()
+        vals = torch.empty((b, k), dtype=torch.float32, device=s.device)
+        idx = torch.empty((b, k), dtype=torch.int64, device=s.device)
+        out = torch.empty((b, k, 2, 3), dtype=torch.float32, device=s.device)
+        lib = L.lib()
+        key = (s.device, b)
+        scratch = _topk_scratch.get(key)
+        if scratch is None:
+            scratch = _topk_scratch[key] = torch.zeros(lib.scn_topk_scratch_bytes(b), dtype=torch.uint8, device=s.device)
+        try:
+            L.check(lib.scn_topk_boxes(L.ptr(s), L.ptr(bx), b, n, k, L.ptr(vals), L.ptr(idx), L.ptr(out), L.ptr(scratch),
+                                       L.stream()))
+        except Exception:
+            scratch.zero_()                     # (the state is only zero again after a COMPLETE call)
+            raise
+        ctx.save_for_backward(idx)
+        ctx.shape = (b, n, tuple(boxes.shape))
+        ctx.mark_non_differentiable(idx)
+        return vals, idx, out
+
+    @staticmethod
+    def backward(ctx, gv, _gi, gb):
+        (idx,) = ctx.saved_tensors
+        b, n, bshape = ctx.shape
+        ds = db = None
+        if ctx.needs_input_grad[0] and gv is not None:
+            ds = torch.zeros((b, n), dtype=gv.dtype, device=gv.device).scatter_(1, idx, gv)
+        if ctx.needs_input_grad[1] and gb is not None:
+            db = torch.zeros((b, n, 6), dtype=gb.dtype, device=gb.device)
+            db.scatter_(1, idx.unsqueeze(-1).expand(b, idx.shape[1], 6), gb.reshape(b, -1, 6))
+            db = db.reshape(bshape)
+        return ds, db, None
+
+
+def topk_boxes(score: torch.Tensor, boxes: torch.Tensor, k: int):
+    """-> (score [B, k] descending, indices int64 [B, k], boxes[batch, indices] [B, k, 2, 3]); differentiable in score and boxes."""
+    b, n = score.shape
+    if (TORCH_TOPK or not score.is_cuda or score.dtype != torch.float32 or boxes.dtype != torch.float32 or k > _TOPK_MAX_K
+            or k > n or tuple(boxes.shape[-2:]) != (2, 3) or b == 0):
+        vals, idx = torch.topk(score, k, dim=1, sorted=True)
+        return vals, idx, boxes[torch.arange(len(boxes), device=boxes.device).unsqueeze(1), idx]
+    return _TopkBoxes.apply(score, boxes, int(k))
+
+
 class ProposalSelector(torch.nn.Module):
     """``ProposalSelector(num_keep_pre_nms, num_keep_post_nms, thresh_nms)`` (proposal_selector.py:52-89): same
     arguments and return values (lists of per-sample score / box / index tensors)."""
@@ -50,11 +107,10 @@ class ProposalSelector(torch.nn.Module):
         """top-k + gather + NMS queued, nothing awaited (-> state for `finish`).  The reference's forward is start + finish;
         split so that a caller can queue other work between the NMS launch and the data-dependent selection."""
         if self.num_keep_pre_nms > 0:
-            rpn_score, indices = torch.topk(rpn_score, self.num_keep_pre_nms, dim=1, sorted=True)
+            rpn_score, indices, rpn_bbox = topk_boxes(rpn_score, rpn_bbox, self.num_keep_pre_nms)
         else:
             rpn_score, indices = torch.sort(rpn_score, dim=1, descending=True)
-        batch_index = torch.arange(len(rpn_bbox), device=rpn_bbox.device).unsqueeze(1)
-        rpn_bbox = rpn_bbox[batch_index, indices]
+            rpn_bbox = rpn_bbox[torch.arange(len(rpn_bbox), device=rpn_bbox.device).unsqueeze(1), indices]
         keep = non_maximum_suppression(rpn_bbox, self.thresh_nms)
         return rpn_score, rpn_bbox, indices, keep
 

@@ -482,6 +482,85 @@ def test_a_second_path_to_the_same_spatial_size_lands_in_the_existing_grid(gpu, 
         c4(x2)
 
 
+def _topk_case(name):
+    g = torch.Generator().manual_seed(len(name))
+    if name == "rpn_field":                       # the detection step's shape: 1 x 524 288 sigmoid scores, 1024 kept
+        return torch.sigmoid(torch.randn(1, 524288, generator=g) * 2 - 3), 1024
+    if name == "constant_background":             # most anchors carry ONE score; the threshold lies above it
+        s = torch.full((2, 200000), 0.0474)
+        s[:, torch.randperm(200000, generator=g)[:5000]] = torch.rand(5000, generator=g)
+        return s, 1024
+    if name == "threshold_is_the_constant":       # ... and below it: > 6144 ties in the threshold's bucket (the slow path)
+        s = torch.full((2, 150000), 0.25)
+        s[:, torch.randperm(150000, generator=g)[:700]] = 0.5 + torch.rand(700, generator=g) / 2
+        s[1, 77:140000:3] = 0.1
+        return s, 2048
+    if name == "ragged_batch":
+        return torch.randn(3, 10007, generator=g), 100
+    if name == "everything":
+        return torch.randn(2, 1500, generator=g), 1500
+    if name == "one":
+        return torch.randn(1, 1, generator=g), 1
+    if name == "few_values":                      # 50 distinct values: every bucket is a tie
+        return torch.randint(0, 50, (2, 5000), generator=g).float() - 20, 300
+    if name == "specials":
+        s = torch.randn(2, 4096, generator=g)
+        s[0, 5] = s[0, 700] = s[1, 9] = float("nan")
+        s[0, 6] = s[1, 10] = float("inf"); s[0, 7] = float("-inf")
+        s[1, 100:140] = 0.0; s[1, 110:120] = -0.0
+        return s, 2048
+    if name == "all_equal":
+        return torch.zeros(2, 30000), 257
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("case", ["rpn_field", "constant_background", "threshold_is_the_constant", "ragged_batch", "everything",
+                                  "one", "few_values", "specials", "all_equal"])
+def test_radix_select_topk_equals_a_stable_descending_sort(gpu, case):
+    """`scn_topk_boxes` (ProposalSelector's torch.topk + rpn_bbox[batch, indices], proposal_selector.py:60-75) against the
+    first k entries of torch's STABLE descending sort on the CPU: same values bit for bit, same indices (equal scores by
+    ascending index -- torch.topk itself leaves that order open; NaN on top and -0 == +0 as in torch), the boxes of those
+    indices; against torch.topk on the device the values are equal too.  Twice in a row (the state goes back to zero), and
+    the gradients of score and boxes equal those of the torch calls."""
+    from sparse_rcnn_amd import proposals as PR
+    score, k = _topk_case(case)
+    b, n = score.shape
+    boxes = torch.randn(b, n, 2, 3, generator=torch.Generator().manual_seed(3))
+    sd, bd = score.to(gpu).requires_grad_(), boxes.to(gpu).requires_grad_()
+    exp_v, exp_i = torch.sort(score, dim=1, descending=True, stable=True)
+    exp_v, exp_i = exp_v[:, :k], exp_i[:, :k]
+    for _ in range(2):
+        v, i, bx = PR.topk_boxes(sd, bd, k)
+        assert i.dtype == torch.int64 and tuple(bx.shape) == (b, k, 2, 3)
+        assert torch.equal(i.cpu(), exp_i), case
+        assert torch.equal(v.detach().cpu().view(torch.int32), score.gather(1, exp_i).view(torch.int32))
+        assert torch.equal(bx.detach().cpu(), boxes[torch.arange(b).unsqueeze(1), exp_i])
+    tv, _ = torch.topk(sd.detach(), k, dim=1, sorted=True)
+    assert torch.equal(torch.nan_to_num(tv, nan=7.0), torch.nan_to_num(v.detach(), nan=7.0))
+    gv = torch.randn(b, k, generator=torch.Generator().manual_seed(4)).to(gpu)
+    gb = torch.randn(b, k, 2, 3, generator=torch.Generator().manual_seed(5)).to(gpu)
+    ds, db = torch.autograd.grad([v, bx], [sd, bd], [gv, gb])
+    with PR_switch(PR, "TORCH_TOPK", True):
+        v2, i2, bx2 = PR.topk_boxes(sd, bd, k)
+        assert not isinstance(v2.grad_fn, type(v.grad_fn))
+        # (torch's own tie order may differ: scatter the gradients through OUR indices for the comparison)
+    ds2 = torch.zeros_like(sd).scatter_(1, i, gv)
+    db2 = torch.zeros_like(bd)
+    db2[torch.arange(b, device=gpu).unsqueeze(1), i] = gb
+    assert torch.equal(ds, ds2) and torch.equal(db, db2)
+
+
+class PR_switch:
+    def __init__(self, mod, name, value):
+        self.mod, self.name, self.value = mod, name, value
+
+    def __enter__(self):
+        self.old = getattr(self.mod, self.name); setattr(self.mod, self.name, self.value)
+
+    def __exit__(self, *a):
+        setattr(self.mod, self.name, self.old)
+
+
 def test_deconvolution_needs_cached_level(gpu):
     scn, coords, feats, fg, x, scene, size = _input(gpu, seed=4, cin=4)
     with pytest.raises(scn.ScnError):

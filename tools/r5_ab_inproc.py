@@ -25,6 +25,10 @@ def apply(flags):
                 switches[k] = "1"
             else:
                 del switches[k]
+        elif "." in k:                           # a switch of another module of the package: proposals.TORCH_TOPK:1
+            import importlib
+            mod, attr = k.rsplit(".", 1)
+            setattr(importlib.import_module("sparse_rcnn_amd." + mod), attr, v)
         else:
             setattr(TS, k, v)
 for _ in range(20):

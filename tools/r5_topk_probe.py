@@ -21,3 +21,18 @@ us, (v, i) = t(one); print(f"one call            {us:7.1f} us")
 for G in (16, 64, 256, 512):
     us, (v2, i2) = t(two(G)); print(f"two stages, G={G:4d}  {us:7.1f} us  values equal {bool(torch.equal(v, v2))} indices equal {bool(torch.equal(i, i2))}")
 us, _ = t(lambda: torch.sort(x, dim=1, descending=True)); print(f"full sort           {us:7.1f} us")
+# round 5, later: the radix select of this library (scn_topk_boxes) against torch.topk + the advanced-indexing gather
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sparse_rcnn_amd import proposals as PR
+boxes = torch.randn(1, 524288, 2, 3, generator=g).to(dev)
+def ours(): return PR.topk_boxes(x, boxes, 1024)
+def theirs():
+    v, i = torch.topk(x, 1024, dim=1, sorted=True)
+    return v, i, boxes[torch.arange(1, device=dev).unsqueeze(1), i]
+us, r = t(theirs); print(f"torch.topk + gather {us:7.1f} us")
+us, r2 = t(ours); print(f"scn_topk_boxes      {us:7.1f} us   values equal {bool(torch.equal(r[0], r2[0]))}")
+y = torch.sigmoid(torch.randn(1, 524288, generator=g) * 2 - 3).to(dev)          # no tie class
+x = y
+us, r = t(theirs); print(f"no tie class: torch {us:7.1f} us")
+us, r2 = t(ours); print(f"no tie class: ours  {us:7.1f} us   values equal {bool(torch.equal(r[0], r2[0]))} indices equal {bool(torch.equal(r[1], r2[1]))}")

@@ -530,7 +530,7 @@ int scn_mask_gather_bwd(const float* dpred, int64_t m, int k, const int32_t* box
 int scn_nms(const float* boxes, int batch, int n, float overlap_threshold, uint8_t* keep, scn_stream_t stream);
 /* The same selection, round 5: the upper triangle of the n x n suppression relation as a bit matrix (one wave per 64 x 64 block,
  * spread over the chip) and ONE serial walk over its rows out of LDS -- keep[] equals scn_nms's bit for bit; 1024 boxes:
- * 13 + 69 us (rocprofv3, one scene) instead of 600 (scn_nms walks the boxes with two workgroup barriers each).  n <= 4096.
+ * 12 + 42 us (rocprofv3, one scene) instead of 600 (scn_nms walks the boxes with two workgroup barriers each).  n <= 4096.
  * scratch: scn_nms_scratch_bytes(batch, n) = batch * n * ceil(n / 64) * 8 bytes, need not be initialised. */
 int64_t scn_nms_scratch_bytes(int batch, int n);
 int scn_nms_bits(const float* boxes, int batch, int n, float overlap_threshold, uint8_t* keep, void* scratch,

@@ -16,7 +16,7 @@ SERIAL_NMS = False          # True: the round-1 kernel (scn_nms: one workgroup w
 
 def non_maximum_suppression(proposed_boxes: torch.Tensor, overlap_threshold: float) -> torch.Tensor:
     """proposed_boxes fp32 [*, N, 2, D=3] sorted by descending confidence -> bool [*, N] (True = kept).
-    N <= 4096: scn_nms_bits (suppression bit matrix over the chip + one serial walk, ~80 us for 1024 boxes against 600); above: scn_nms."""
+    N <= 4096: scn_nms_bits (suppression bit matrix over the chip + one serial walk, 12 + 42 us for 1024 boxes against 600); above: scn_nms."""
     if proposed_boxes.shape[-2:] != (2, 3):
         raise NotImplementedError("scn_nms handles 3-D boxes [*, N, 2, 3] (the reference's ScanNet path)")
     lead, n = proposed_boxes.shape[:-3], proposed_boxes.shape[-3]

@@ -36,6 +36,7 @@ def non_maximum_suppression(proposed_boxes: torch.Tensor, overlap_threshold: flo
 
 
 TORCH_TOPK = False          # True: torch.topk + advanced indexing (the reference's calls); the tests' cross-check and the A/B
+DECODE_FIRST = False        # True: RoiSelector decodes every anchor's box before the selection (the reference's order of calls)
 _TOPK_MAX_K = 2048          # scn_topk_boxes: k <= 2048
 _topk_scratch = {}          # (device, batch) -> the zeroed state scn_topk_boxes keeps between calls
 
@@ -114,11 +115,24 @@ class ProposalSelector(torch.nn.Module):
         keep = non_maximum_suppression(rpn_bbox, self.thresh_nms)
         return rpn_score, rpn_bbox, indices, keep
 
+    def start_from_deltas(self, rpn_score, deltas, anchors, decode):
+        """`start(rpn_score, decode(anchors, deltas))` with the decode AFTER the selection: the box arithmetic is per anchor, so
+        decoding the k selected anchors gives the bits decoding all of them and gathering would (8 elementwise launches over
+        524 k anchors become 8 over 1024).  anchors [N, 2, 3], deltas [B, N, 2, 3]."""
+        if self.num_keep_pre_nms <= 0 or DECODE_FIRST:
+            return self.start(rpn_score, decode(anchors, deltas))
+        rpn_score, indices, deltas_k = topk_boxes(rpn_score, deltas, self.num_keep_pre_nms)
+        rpn_bbox = decode(anchors.reshape(-1, 2, 3)[indices], deltas_k)
+        keep = non_maximum_suppression(rpn_bbox, self.thresh_nms)
+        return rpn_score, rpn_bbox, indices, keep
+
     def finish(self, state):
         """The data-dependent part: boolean selection of the kept proposals (one host wait), first `num_keep_post_nms`."""
         rpn_score, rpn_bbox, indices, keep = state
         post = self.num_keep_post_nms
-        scores = [s[k][:post] for s, k in zip(rpn_score, keep)]
-        boxes = [b[k][:post] for b, k in zip(rpn_bbox, keep)]
-        index = [i[k][:post].cpu() for i, k in zip(indices, keep)]        # the reference returns CPU indices (:66)
+        # (x[k][:post] three times is three `nonzero` passes and three host waits: ONE list of kept positions, three gathers)
+        sel = [k.nonzero().squeeze(1)[:post] for k in keep]
+        scores = [s[j] for s, j in zip(rpn_score, sel)]
+        boxes = [b[j] for b, j in zip(rpn_bbox, sel)]
+        index = [i[j].cpu() for i, j in zip(indices, sel)]                # the reference returns CPU indices (:66)
         return scores, boxes, index

@@ -4,7 +4,7 @@ head"): the proposals of a step come out of the SAME forward that feeds the mask
     encoder level (sparse, stride 8)  --scn.SparseToDense-->  dense [B, C, X/8, Y/8, Z/8]
         --dilation stack (Conv3d 3^3 + ReLU, torch / MIOpen: SURVEY §2 row 8 leaves the dense RPN to PyTorch)-->
         --1x1x1 head--> per anchor 6 box deltas + 1 score          (anchor_network.py:73-124 `AnchorNetworkConv`)
-        --RoiSelector: detach, decode against the anchors, sigmoid, top-k, greedy NMS (ONE launch: scn_nms), keep `post`-->
+        --RoiSelector: detach, sigmoid, top-k (scn_topk_boxes), decode the selected anchors, greedy NMS (scn_nms_bits), keep `post`-->
         list of fp32 boxes [n_i, 2, 3] per sample                    (proposal_selector.py:23-89; bbox.py:139-165,367-398)
 
 What this package contributes to it: SparseToDense (A13, scn_elem.hip), the one-launch NMS (proposals.py) and the consumer
@@ -215,7 +215,7 @@ class RoiSelector(nn.Module):
         """Everything up to and including the NMS launch, nothing awaited (ProposalSelector.start)."""
         if self.detach:
             rpn_bbox, rpn_score = rpn_bbox.detach(), rpn_score.detach()
-        return self.proposal_selector.start(torch.sigmoid(rpn_score), decode_boxes(anchors, rpn_bbox))
+        return self.proposal_selector.start_from_deltas(torch.sigmoid(rpn_score), rpn_bbox, anchors, decode_boxes)
 
     def finish(self, state):
         return self.proposal_selector.finish(state)

@@ -171,6 +171,28 @@ class SceneStep:
         self._md_next = None
         if REUSE_INDEX:
             from .metadata import Metadata
+            if REUSE_INDEX in (3, 4, 5, 6, 7):  # (measurement: what of a helper-thread build costs the step when the build itself is
+                from .metadata import PendingMetadata, index_stream        #  taken away: 3 = an empty job on the helper thread,
+                pend = _reused_md.pop("tiny_pending", None)                #  4 = + the workspace allocation on the index stream,
+                if pend is not None:                                       #  5 = + one small kernel and a device->host wait there)
+                    pend.result()
+                dev, mode = self.device, REUSE_INDEX
+
+                def job():
+                    torch.cuda.set_device(dev)
+                    if mode >= 4:
+                        side = index_stream(dev)
+                        with torch.cuda.stream(side):
+                            ws = torch.empty(40 << 20, dtype=torch.uint8, device=dev)
+                            if mode == 5:
+                                ws[:1024].zero_()
+                                int(ws[:8].sum().item())
+                            if mode >= 6:                          # 6 / 7 = 17 / 68 one-workgroup kernels on the index stream
+                                for _ in range(17 if mode == 6 else 68):
+                                    ws[:256].zero_()
+                                side.synchronize()
+                    return None
+                _reused_md["tiny_pending"] = PendingMetadata(job)
             if REUSE_INDEX == 2:          # (measurement: the helper thread still builds -- a TINY scene: host side of a build only)
                 tiny = _reused_md.get("tiny")
                 if tiny is None:

@@ -586,3 +586,45 @@ def test_fuzz_backbone_bf16_storage_modes(gpu, seed):
         assert torch.isfinite(b.grad).all() and rel < 0.5, (cfg, k, rel)       # (deep levels hold a few dozen rows)
         num += (b.grad - a.grad).double().pow(2).sum().item(); den += a.grad.double().pow(2).sum().item()
     assert (num / max(den, 1e-30)) ** 0.5 < 0.15, (cfg, (num / max(den, 1e-30)) ** 0.5)
+
+
+@pytest.mark.parametrize("seed", _seeds(700, 40))
+def test_fuzz_radix_select_topk(gpu, seed):
+    """`scn_topk_boxes` on drawn fields: sizes around the pass boundaries (2048-element tiles, 256 workgroups), k from 1 to
+    2048 (and k = n), value distributions that put the k-th score in a crowded or an empty bucket (few distinct values, one
+    dominant constant, heavy tails, exact duplicates of the threshold), batches -- against the first k entries of a stable
+    descending sort on the CPU (values bit for bit, indices, gathered boxes)."""
+    from sparse_rcnn_amd import proposals as PR
+    rng = np.random.default_rng(9000 + seed)
+    b = int(rng.integers(1, 4))
+    n = int(rng.choice([1, 2, 63, 64, 65, 255, 257, 2047, 2048, 2049, 4097, 30000, 65537, 300001, 524288 + 3]))
+    k = int(min(n, rng.choice([1, 2, 7, 64, 100, 1000, 1024, 2047, 2048])))
+    if rng.random() < 0.15:
+        k = min(n, 2048)
+    g = torch.Generator().manual_seed(seed)
+    kind = int(rng.integers(0, 6))
+    if kind == 0:
+        s = torch.randn(b, n, generator=g)
+    elif kind == 1:
+        s = torch.sigmoid(torch.randn(b, n, generator=g) * 3 - 4)
+    elif kind == 2:                                                     # few distinct values
+        s = torch.randint(0, int(rng.integers(1, 40)), (b, n), generator=g).float() * 0.125 - 1
+    elif kind == 3:                                                     # one dominant constant around a thin set of others
+        s = torch.full((b, n), float(rng.random()))
+        m = max(1, n // int(rng.choice([3, 50, 1000])))
+        s[:, torch.randperm(n, generator=g)[:m]] = torch.rand(m, generator=g)
+    elif kind == 4:                                                     # heavy tail over many binades
+        s = torch.randn(b, n, generator=g) * torch.exp(torch.randn(b, n, generator=g) * 6)
+    else:                                                               # exact duplicates of whatever the threshold will be
+        s = torch.randn(b, n, generator=g)
+        thr = torch.sort(s, dim=1, descending=True)[0][:, k - 1:k]
+        dup = torch.rand(b, n, generator=g) < 0.3
+        s = torch.where(dup, thr.expand(b, n), s)
+    boxes = torch.randn(b, n, 2, 3, generator=g)
+    exp_v, exp_i = torch.sort(s, dim=1, descending=True, stable=True)
+    exp_i = exp_i[:, :k]
+    v, i, bx = PR.topk_boxes(s.to(gpu), boxes.to(gpu), k)
+    what = f"b={b} n={n} k={k} kind={kind}"
+    assert i.dtype == torch.int64 and torch.equal(i.cpu(), exp_i), what
+    assert torch.equal(v.cpu().view(torch.int32), s.gather(1, exp_i).view(torch.int32)), what
+    assert torch.equal(bx.cpu(), boxes[torch.arange(b).unsqueeze(1), exp_i]), what

@@ -56,7 +56,7 @@ extern "C" {
  *      scn_pool_fwd / _bwd (+ _bf16): `average` carries the pool volume above bit 8 (0 = the 2^3 of every configuration) */
 /*   4  round 5: + scn_debug_set / scn_debug_get (developer switches no longer follow the ambient environment per launch);
  *      scn_exec_timing_collect forgets only the records it returned; + scn_nms_bits / scn_nms_scratch_bytes, scn_dilate_gather_fwd / _bwd,
- *      scn_parent_lookup_div, scn_topk_boxes / scn_topk_scratch_bytes (116 entry points) */
+ *      scn_parent_lookup_div, scn_topk_boxes / scn_topk_scratch_bytes, scn_cell_map (117 entry points) */
 #define SCN_ABI_VERSION 4
 
 /* flags for the gather-GEMM entry points */
@@ -620,6 +620,12 @@ int scn_dilate_gather_fwd(const void* P, const int32_t* map, int batch, const in
                           const float* bias, void* out, scn_stream_t stream);
 int scn_dilate_gather_bwd(const void* dOut, const int64_t* cell_of_row, int64_t n, const int64_t* size3_host, int c, int bf16,
                           void* dP, scn_stream_t stream);
+/* The two index vectors of the above from a level's int32 coordinates (x, y, z, sample) [n][4]: cell_of_row[r] =
+ * ((sample X + x) Y + y) Z + z and map[cell] = r, -1 on empty cells (map: int32 [batch X Y Z], need not be initialised).
+ * *n_outside_dev = rows outside the volume (the caller checks it when it next waits for the device; such rows get cell 0
+ * and no map entry). */
+int scn_cell_map(const int32_t* coords, int64_t n, int batch, const int64_t* size3_host, int64_t* cell_of_row, int32_t* map,
+                 int32_t* n_outside_dev, scn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Step executor (scn_exec.hip): ONE call walks the launch plan of a whole network pass.

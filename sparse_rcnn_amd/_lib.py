@@ -107,6 +107,7 @@ _SIGS = {
     "scn_nms": (C.c_int, [p, i32, i32, f32, p, p]),
     "scn_dilate_gather_fwd": (C.c_int, [p, p, i32, C.POINTER(i64), i32, i32, p, p, p]),
     "scn_dilate_gather_bwd": (C.c_int, [p, p, i64, C.POINTER(i64), i32, i32, p, p]),
+    "scn_cell_map": (C.c_int, [p, i64, i32, C.POINTER(i64), p, p, p, p]),
     "scn_nms_scratch_bytes": (i64, [i32, i32]),
     "scn_nms_bits": (C.c_int, [p, i32, i32, f32, p, p, p]),
     "scn_topk_scratch_bytes": (C.c_int64, [i32]),

@@ -344,6 +344,40 @@ __global__ __launch_bounds__(256) void k_dilate_bwd(const TT_* __restrict__ dOut
     }
 }
 
+// cell of every active row of a sparse level in the channels-last volume [B X Y Z] and the inverse map (-1 on empty cells):
+// what SparseToDense's scatter and the dilation gather above index with -- one memset + one launch for torch's seven.
+__global__ void k_cell_map(const int4* __restrict__ coords, long long n, int X, int Y, int Z, int batch,
+                           long long* __restrict__ cell_of_row, int* __restrict__ map, int* __restrict__ bad) {
+    for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x) {
+        const int4 c = coords[r];                                         // (x, y, z, sample)
+        if ((unsigned)c.x >= (unsigned)X || (unsigned)c.y >= (unsigned)Y || (unsigned)c.z >= (unsigned)Z || (unsigned)c.w >= (unsigned)batch) {
+            atomicAdd(bad, 1);
+            cell_of_row[r] = 0;
+            continue;
+        }
+        const long long cell = (((long long)c.w * X + c.x) * Y + c.y) * Z + c.z;
+        cell_of_row[r] = cell;
+        map[cell] = (int)r;
+    }
+}
+
+extern "C" int scn_cell_map(const int32_t* coords, int64_t n, int batch, const int64_t* size3_host, int64_t* cell_of_row,
+                            int32_t* map, int32_t* n_outside_dev, scn_stream_t stream) {
+    SCN_REQUIRE(batch >= 0 && n >= 0 && size3_host && n_outside_dev);
+    const int X = (int)size3_host[0], Y = (int)size3_host[1], Z = (int)size3_host[2];
+    const int64_t cells = (int64_t)batch * X * Y * Z;
+    SCN_REQUIRE(X > 0 && Y > 0 && Z > 0 && cells < (1ll << 31) && n < (1ll << 31));
+    SCN_HIP(hipMemsetAsync(n_outside_dev, 0, sizeof(int32_t), S(stream)));
+    if (cells == 0) return SCN_OK;
+    SCN_REQUIRE(map && (n == 0 || (coords && cell_of_row)));
+    SCN_HIP(hipMemsetAsync(map, 0xFF, sizeof(int32_t) * (size_t)cells, S(stream)));
+    if (n == 0) return SCN_OK;
+    hipLaunchKernelGGL(k_cell_map, dim3(scn::ew_grid(n, 256)), dim3(256), 0, S(stream), (const int4*)coords, (long long)n, X, Y, Z,
+                       batch, (long long*)cell_of_row, map, n_outside_dev);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
 extern "C" int scn_dilate_gather_fwd(const void* P, const int32_t* map, int batch, const int64_t* size3_host, int c, int bf16,
                                      const float* bias, void* out, scn_stream_t stream) {
     SCN_REQUIRE(batch >= 0 && size3_host && c >= 1);

@@ -133,22 +133,21 @@ class DenseRpn(nn.Module):
         md = level_tensor.metadata
         size = tuple(int(v) for v in level_tensor.spatial_size)
         B = md.n_samples
-        # cell of every active row: ((b X + x) Y + y) Z + z from the level's int32 coordinates (x, y, z, b) -- three small launches
-        wkey = (size, str(feats.device))
-        w = self._anchor_cache.get(("cellw",) + wkey)
-        if w is None:
-            w = self._anchor_cache[("cellw",) + wkey] = torch.tensor(
-                [size[1] * size[2], size[2], 1, size[0] * size[1] * size[2]], dtype=torch.long, device=feats.device)
-        ridx = (md.grid(size).coords.long() * w).sum(1)
+        # cell of every active row, ((b X + x) Y + y) Z + z, and the inverse map (-1 on empty cells): scn_cell_map, one launch
+        n_cells = B * size[0] * size[1] * size[2]
+        n_rows = feats.shape[0]
+        ridx = torch.empty(n_rows, dtype=torch.int64, device=feats.device)
+        cmap = torch.empty(n_cells, dtype=torch.int32, device=feats.device)
+        flag = torch.empty(1, dtype=torch.int32, device=feats.device)      # (rows outside the volume: none by construction)
+        hs = L.host_i64(3)
+        hs[0], hs[1], hs[2] = size
+        L.check(L.lib().scn_cell_map(L.ptr(md.grid(size).coords), n_rows, B, hs, L.ptr(ridx), L.ptr(cmap), L.ptr(flag), L.stream()))
         dmd = self.dense_metadata(size, B, feats.device)
         ssz = torch.as_tensor(size, dtype=torch.long)
         layers = list(self.stack)
         if self.SPARSE_FIRST and isinstance(layers[0], nn.Conv3d) and layers[0].in_channels % 8 == 0 and layers[0].out_channels % 8 == 0:
             # SparseToDense + the first same-convolution without ever building the (mostly zero) input volume
             conv = layers.pop(0)
-            n_cells = B * size[0] * size[1] * size[2]
-            cmap = torch.full((n_cells,), -1, dtype=torch.int32, device=feats.device)
-            cmap.index_copy_(0, ridx, torch.arange(feats.shape[0], dtype=torch.int32, device=feats.device))
             Wall = conv.weight.permute(1, 2, 3, 4, 0).reshape(conv.in_channels, 27 * conv.out_channels)     # [Cin][o][Cout]
             P = F.NetworkInNetworkFunction.apply(feats, Wall, None)
             x = _DilateGather.apply(P, conv.bias, cmap, ridx, B, size)

@@ -561,6 +561,31 @@ class PR_switch:
         setattr(self.mod, self.name, self.old)
 
 
+def test_cell_map_of_a_level(gpu):
+    """`scn_cell_map`: the cell of every active row in the channels-last volume [B X Y Z] and the inverse map, against the
+    integer formula; a row outside the volume is counted, gets cell 0 and no map entry."""
+    from sparse_rcnn_amd import _lib as L
+    rng = np.random.default_rng(5)
+    B, X, Y, Z = 3, 7, 5, 9
+    lin = rng.choice(B * X * Y * Z, size=400, replace=False)
+    b, x, y, z = np.unravel_index(lin, (B, X, Y, Z))
+    coords = np.stack([x, y, z, b], 1).astype(np.int32)
+    coords[17] = (X, 0, 0, 0)                                            # outside
+    cd = torch.from_numpy(coords).to(gpu)
+    ridx = torch.empty(400, dtype=torch.int64, device=gpu)
+    cmap = torch.empty(B * X * Y * Z, dtype=torch.int32, device=gpu)
+    flag = torch.empty(1, dtype=torch.int32, device=gpu)
+    hs = L.host_i64(3)
+    hs[0], hs[1], hs[2] = X, Y, Z
+    L.check(L.lib().scn_cell_map(L.ptr(cd), 400, B, hs, L.ptr(ridx), L.ptr(cmap), L.ptr(flag), L.stream()))
+    exp = lin.astype(np.int64).copy(); exp[17] = 0
+    assert int(flag.item()) == 1 and np.array_equal(ridx.cpu().numpy(), exp)
+    em = np.full(B * X * Y * Z, -1, np.int32)
+    keep = np.arange(400) != 17
+    em[lin[keep]] = np.arange(400, dtype=np.int32)[keep]
+    assert np.array_equal(cmap.cpu().numpy(), em)
+
+
 def test_deconvolution_needs_cached_level(gpu):
     scn, coords, feats, fg, x, scene, size = _input(gpu, seed=4, cin=4)
     with pytest.raises(scn.ScnError):

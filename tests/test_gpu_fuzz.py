@@ -271,7 +271,13 @@ def test_fuzz_unet(gpu, seed):
     params = O.init_unet_params(7, channels, seed=seed)
     net = Backbone(7, channels).to(gpu)
     net.unet.load_oracle_params(params)
-    out = net(coords, feats.to(gpu), torch.tensor(grid), batch)
+    from sparse_rcnn_amd import functional as F
+    F.RELU_RECORD = []                       # the sign mask of every slab a ReLU is applied to, in call order (as test_gpu_atsize)
+    try:
+        out = net(coords, feats.to(gpu), torch.tensor(grid), batch)
+        masks = F.RELU_RECORD
+    finally:
+        F.RELU_RECORD = None
     scene = O.OracleScene(coords.numpy())
     po = {k: v.clone().requires_grad_() for k, v in params.items()}
     exp = O.unet_forward(scene, feats, po, channels)
@@ -279,17 +285,30 @@ def test_fuzz_unet(gpu, seed):
     g = torch.randn(exp.shape, generator=torch.Generator().manual_seed(seed + 1))
     out.features.backward(g.to(gpu))
     exp.backward(g)
+    # (1) the oracle with the ReLU masks the HIP forward took (O.FrozenReLU): both sides differentiate the same piecewise-linear
+    # function, what is left is summation order -- every parameter gradient within 2e-5 relative L2 (test_gpu_atsize's bound)
+    pf = {k: v.clone().requires_grad_() for k, v in params.items()}
+    fr = O.FrozenReLU(masks)
+    O.unet_forward(scene, feats, pf, channels, relu=fr).backward(g)
+    assert fr.k == len(masks), (fr.k, len(masks), cfg)
+    for k, p in net.unet.named_oracle_params().items():
+        a, e = p.grad.detach().cpu().double(), pf[k].grad.view_as(p).double()
+        l2 = ((a - e).norm() / e.norm().clamp_min(1e-12)).item()
+        assert l2 <= 2e-5, f"grad {k} {cfg}: relative L2 {l2:.2e} with the device's ReLU masks"
+    # (2) the oracle with its OWN ReLU decisions:
     # Gradients of a deep ReLU network are only piecewise continuous: among ~10^6 activations a few lie within fp32
     # rounding of zero, and the two sides may then take different ReLU masks -- the fp64 oracle's own gradient moves by
     # 2e-2 (relative to max |grad|) in one weight slice when its input is scaled by 1 - 5e-7.  Such a flip changes one
     # output channel of one layer (by ~1/rows) and spreads, decaying, towards the input: observed relative L2 errors of
-    # the affected parameters are 2e-4 .. 1e-3, against 1e-6 without a flip and >= 1e-1 for one wrong channel.  So:
-    # strict on the forward pass (above) and on single layers and blocks (the tests above, which skip cases with a
-    # ReLU input within rounding of zero); here the relative L2 error of every parameter's gradient below 2e-2.
+    # the affected parameters are 2e-4 .. 1e-3, against 1e-6 without a flip and >= 1e-1 for one wrong channel -- on the
+    # 10^5-row scenes; the drawn scenes here have a few hundred rows per level, where ONE flipped row moves a weight slice by
+    # ~1 / rows (round 5: seed 70275 of an extended sweep, 2.3e-2 on `enc1.res1.conv0.weight` with its own masks, 1e-6 with
+    # the shared ones).  So: strict with shared masks (above), on the forward pass and on single layers and blocks; here the
+    # relative L2 error of every parameter's gradient below 5e-2 (one wrong channel of a layer is >= 1e-1).
     for k, p in net.unet.named_oracle_params().items():
         a, e = p.grad.detach().cpu().double(), po[k].grad.view_as(p).double()
         l2 = ((a - e).norm() / e.norm().clamp_min(1e-12)).item()
-        assert l2 <= 2e-2, f"grad {k} {cfg}: relative L2 {l2:.2e}"
+        assert l2 <= 5e-2, f"grad {k} {cfg}: relative L2 {l2:.2e}"
 
 
 @pytest.mark.parametrize("seed", _seeds(700, 12))

@@ -291,6 +291,23 @@ int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32_t* tstab, 
                    const int32_t* tile_order, int n_off, int64_t n_out, const float* W, const float* bias, const float* residual,
                    const float* relu_mask, float* Y, int cout, int flags, void* scratch, int32_t* arrival,
                    scn_stream_t stream);
+/* CHAINED launch (round 6): 2-4 DEPENDENT convolutions over the same tiles -- the SubM 3^3 launches of a level's residual
+ * units (module_factory.py:127-183 builds x + SubM3(ReLU(SubM3(ReLU(x)))); two units per level, :513-530), forward or
+ * backward-data -- as ONE launch.  Role r reads what role r-1 wrote (X, residual or relu_mask of role r may be Y of an
+ * earlier role); the workgroups of role r are placed on the CUs role r-1 leaves, stage their weights there and wait for
+ * role r-1 to complete before their first row gather (scn_conv_ts.hip, "CHAIN").  Same arithmetic per role as n_roles
+ * scn_conv_tiles calls: same bits.  Shapes the chained kernel does not cover (channel counts that are no multiple of 32,
+ * levels on the four-waves-per-tile loop, SCN_TS_NO_CHAIN=1) run as n_roles plain calls.  All roles share n_in, cin, the
+ * tile structures, n_out, cout, SCN_F_W_TRANSPOSED and SCN_F_OFF_REVERSE; `flags` may differ in the other bits. */
+typedef struct scn_conv_role {
+    const void* X; const void* W; const void* bias; const void* residual; const void* relu_mask; void* Y;
+    int32_t flags; int32_t reserved;
+} scn_conv_role;
+int scn_conv_tiles_chain(int n_roles, const scn_conv_role* roles, int64_t n_in, int cin, const int32_t* tstab,
+                         const uint32_t* tile_mask, const int32_t* perm, const int32_t* tile_order, int n_off, int64_t n_out,
+                         int cout, void* scratch, int32_t* arrival, scn_stream_t stream);
+/* out[0] = chained launches, out[1] = roles they carried, since the last reset (fp32 and bf16 together). */
+void scn_conv_tiles_chain_counts(int64_t out[2], int reset);
 /* Which kernel variant the scn_conv_tiles calls of this process took since the last reset: out[0] = launches on the fast path
  * (raw-buffer gathers: 16-byte rows, < 2^23 rows, < 4 GB slabs), out[1] = launches that fell back to the general kernel
  * (same results, 64-bit addressing), out[2] = launches with the in-launch K reduction, out[3] = launches that left the K

@@ -80,18 +80,62 @@ __device__ __forceinline__ int ts_ws_off(int o, int k, int n) { return (o * TS_K
 // numbered class by class: [full slices][column-tail slices][K-tail slices][the corner slice].
 struct TsSlices { int g_full, g_ntail, g_ktail, g_both; };
 
-template <bool WT, bool VEC, bool VECN, bool FULLK, bool PART, bool FUSED, bool TAIL = false, int SPLIT = 1>
+// CHAIN (round 6): up to four DEPENDENT convolutions over the same tiles (the four SubM 3^3 launches of a level's two
+// residual units, forward or backward-data: scn_conv_tiles_chain) as ONE launch of n_roles x wgs workgroups.  A workgroup
+// draws a ticket (global atomic: roles are dealt in the order workgroups actually START, so a workgroup of role r exists
+// only once every workgroup of the roles before it is running or done -- no assumption about dispatch order, no deadlock),
+// role = ticket / wgs, and with it its operands.  Role r's workgroups are placed as role r-1's leave their CUs: they stage
+// THEIR weight slice and fetch their first tile's mask and rows while role r-1's tail drains, then wait for
+// done[r-1] == wgs (one lane polls, agent-scope acquire, workgroup barrier: MI350X_MICROARCH "Valid forms", consumer side).
+// Producer side: every output store of a chained launch is write-through (sc1), every wave drains its stores, workgroup
+// barrier, one agent-scope add on done[r].  The last workgroup of the last role puts the words back to zero.
+// What it removes per link: the launch front (~4 us) and, on every CU but the last to finish, the 3.3 us of weight staging.
+#define TS_MAX_ROLES 4
+struct TsRole {
+    const float* X; const float* W; const float* bias; const float* residual; const float* relu_mask; float* Y;
+    int flags, pad;
+};
+struct TsChain {
+    int n_roles, wgs;
+    int exp, pad;           // (developer experiments, SCN_EXP_A: 1 no wait, 2 plain stores, 4 role = blockIdx / wgs, no ticket)
+    int* sync;              // [0] ticket, [1 .. n_roles] done counters, [7] spin-limit flag; zero on entry, zero on exit
+    TsRole role[TS_MAX_ROLES];
+};
+
+template <bool WT, bool VEC, bool VECN, bool FULLK, bool PART, bool FUSED, bool TAIL = false, int SPLIT = 1, bool CHAIN = false>
 __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
-    const float* __restrict__ X, long long n_in, int cin, const int* __restrict__ tstab,
+    const float* __restrict__ X_, long long n_in, int cin, const int* __restrict__ tstab,
     const unsigned* __restrict__ tile_mask,
     const int* __restrict__ perm, const int* __restrict__ tile_order, int n_off, long long nt,
-    const float* __restrict__ W, const float* __restrict__ bias,
-    const float* __restrict__ residual, const float* __restrict__ relu_mask, float* __restrict__ Y,
-    float* __restrict__ slabs, long long n_out, int cout, int flags, int n_chunks, int n_kc,
-    int* __restrict__ counters, TsSlices slices) {
+    const float* __restrict__ W_, const float* __restrict__ bias_,
+    const float* __restrict__ residual_, const float* __restrict__ relu_mask_, float* __restrict__ Y_,
+    float* __restrict__ slabs, long long n_out, int cout, int flags_, int n_chunks, int n_kc,
+    int* __restrict__ counters, TsSlices slices, TsChain chain) {
     extern __shared__ __attribute__((aligned(16))) float Ws[];           // [n_off][32 k][32 n] swizzled
     constexpr int THREADS = TS_NW * 64;
     const int tid = threadIdx.x, lane = tid & 63;
+    int* counter = (int*)(Ws + n_off * TS_KC * TS_CT);                   // [0] tile queue, [1] ticket of a chained launch
+    int bid = (int)blockIdx.x, n_bid = (int)gridDim.x, role = 0;
+    if (tid == 0) {
+        *counter = 0;
+        if constexpr (CHAIN)
+            counter[1] = (chain.exp & 4) ? (int)blockIdx.x : __hip_atomic_fetch_add(chain.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if constexpr (CHAIN) {
+        const int ticket = __builtin_amdgcn_readfirstlane(counter[1]);
+        role = ticket / chain.wgs;
+        bid = ticket - role * chain.wgs;
+        n_bid = chain.wgs;
+    }
+    // operands of this workgroup's role (a plain launch: the kernel arguments)
+    const float* __restrict__ X = CHAIN ? chain.role[role].X : X_;
+    const float* __restrict__ W = CHAIN ? chain.role[role].W : W_;
+    const float* __restrict__ bias = CHAIN ? chain.role[role].bias : bias_;
+    const float* __restrict__ residual = CHAIN ? chain.role[role].residual : residual_;
+    const float* __restrict__ relu_mask = CHAIN ? chain.role[role].relu_mask : relu_mask_;
+    float* __restrict__ Y = CHAIN ? chain.role[role].Y : Y_;
+    const int flags = CHAIN ? chain.role[role].flags : flags_;
     int chunk, kci, tg, n_tg;
     if constexpr (TAIL) {
         const int ncf = n_chunks - (slices.g_ntail ? 1 : 0), nkf = n_kc - (slices.g_ktail ? 1 : 0);   // full column / K chunks
@@ -112,10 +156,10 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
             tg = b - end_k; n_tg = slices.g_both; chunk = n_chunks - 1; kci = n_kc - 1;
         }
     } else {
-        chunk = blockIdx.x % n_chunks;
-        kci = (blockIdx.x / n_chunks) % n_kc;
-        tg = blockIdx.x / (n_chunks * n_kc);
-        n_tg = gridDim.x / (n_chunks * n_kc);
+        chunk = bid % n_chunks;
+        kci = (bid / n_chunks) % n_kc;
+        tg = bid / (n_chunks * n_kc);
+        n_tg = n_bid / (n_chunks * n_kc);
     }
     const int n0 = chunk * TS_CT, kc = kci * TS_KC;
     const bool kh = TAIL && cin - kc <= 16, nh = TAIL && cout - n0 <= 16;     // wave-uniform: dead K half / dead column block
@@ -130,9 +174,6 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     long long tl_t0 = 0, tl_t1 = 0, tl_c1 = 0, tl_steps = 0, tl_tiles = 0;
     if (TS_TIMELINE) tl_t0 = wall_clock64();
     const int n_tiles = (int)((nt - tg + n_tg - 1) / n_tg);
-    int* counter = (int*)(Ws + n_off * TS_KC * TS_CT);
-    if (tid == 0) *counter = 0;
-    __syncthreads();
     auto grab = [&]() -> long long {                    // -> tile id or -1
         int tl = 0;
         if (lane == 0) tl = atomicAdd(counter, 1);
@@ -209,6 +250,27 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         }
     }
     __syncthreads();
+    if constexpr (CHAIN) {
+        // the role before this one has to be complete: its outputs are this role's X / residual / mask, and its K-split
+        // slabs and arrival counters are this role's too.  One lane polls (relaxed, L1-bypassing), then the agent-scope
+        // acquire (buffer_inv sc1) and its wait; the barrier holds the other waves until the invalidate is done.
+        if (role > 0 && !(chain.exp & 1)) {
+            if (tid == 0) {
+                const int* done = chain.sync + role;
+                int spins = 0;
+                while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chain.wgs) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 24)) {          // bounded: a lost workgroup must not hang the GPU (flag: results invalid)
+                        __hip_atomic_store(chain.sync + 7, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+        }
+    }
     if (TS_TIMELINE) { tl_t1 = wall_clock64(); tl_c1 = clock64(); }
 
     const int ka = kc + 4 * kq;
@@ -339,6 +401,12 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     // ---- epilogue pieces --------------------------------------------------------------------------------------------
     // ts_write: 16 lanes write 64 contiguous bytes of a row.  The residual / ReLU-mask operands of all eight outputs are
     // requested first and consumed afterwards (one wait, not eight round trips).
+    auto put = [&](float* p, float y) {                 // an output element: write-through in a chained launch (hand-off)
+        if constexpr (CHAIN) {
+            if (chain.exp & 2) *p = y;
+            else __hip_atomic_store(p, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else *p = y;
+    };
     auto ts_write = [&](const int (&orow)[4], const f32x4& c0, const f32x4& c1) {
         float rs[4][2], mk[4][2];
 #pragma unroll
@@ -364,13 +432,13 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
                 float y = c0[j] + (res_last ? 0.f : rs[j][0]);
                 if (!(mk[j][0] > 0.f)) y = 0.f;
                 if (res_last) y += rs[j][0];
-                out[off + nA] = y;
+                put(out + off + nA, y);
             }
             if (nB < cout) {
                 float y = c1[j] + (res_last ? 0.f : rs[j][1]);
                 if (!(mk[j][1] > 0.f)) y = 0.f;
                 if (res_last) y += rs[j][1];
-                out[off + nB] = y;
+                put(out + off + nB, y);
             }
         }
     };
@@ -385,13 +453,13 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
                 float y = c0[j] + (res_last ? 0.f : rs[j][0]);
                 if (use_mask && !(mk[j][0] > 0.f)) y = 0.f;
                 if (res_last) y += rs[j][0];
-                out[off + nA] = y;
+                put(out + off + nA, y);
             }
             if (nB < cout) {
                 float y = c1[j] + (res_last ? 0.f : rs[j][1]);
                 if (use_mask && !(mk[j][1] > 0.f)) y = 0.f;
                 if (res_last) y += rs[j][1];
-                out[off + nB] = y;
+                put(out + off + nB, y);
             }
         }
     };
@@ -516,6 +584,17 @@ if constexpr (SPLIT == 1) {
         ts_retire();                         // combine the tile before last, ticket the last one
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ts_retire();                         // combine the last one
+    }
+    if constexpr (CHAIN) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every wave: its write-through stores have landed
+        __syncthreads();
+        if (tid == 0) {
+            const int t = __hip_atomic_fetch_add(chain.sync + 1 + role, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (role == chain.n_roles - 1 && t == chain.wgs - 1) {    // the very last workgroup: nobody polls any more
+                for (int k = 0; k <= chain.n_roles; ++k)
+                    __hip_atomic_store(chain.sync + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
     if (TS_TIMELINE && lane == 0) {         // [t0, staged, end, tiles, steps] per wave, after the K-chunk slabs
         long long* d = (long long*)(slabs + (n_kc > 1 ? (long long)n_kc * nt * TS_T * n_chunks * TS_CT : 0)) +
@@ -679,7 +758,7 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
         }                                                                                                           \
         hipLaunchKernelGGL((k_conv_ts<T, V, VN, FK, PT, FU, TL, SP>), grid, dim3(TS_NW * 64), lds, st, X, (long long)n_in, cin, tstab, tile_mask, \
                            perm, tile_order, n_off, (long long)nt, W, bias, residual, relu_mask, Y, slabs,                      \
-                           (long long)n_out, cout, flags, n_chunks, n_kc, counters, slices);                        \
+                           (long long)n_out, cout, flags, n_chunks, n_kc, counters, slices, TsChain{});             \
     } while (0)
 #define LAUNCH_TS(T, V, VN, FK, PT)                                                                                 \
     do {                                                                                                            \
@@ -715,6 +794,132 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     SCN_LAUNCH_CHECK();
     if (fused || (flags & SCN_F_SPLIT_SUM)) return SCN_OK;
     return scn_conv_tiles_finish(cin, n_out, bias, residual, relu_mask, Y, cout, flags, scratch, stream);
+}
+
+// ---- chained launch (round 6) -------------------------------------------------------------------------------------------
+// Sync words of a chained launch: 8 ints per (device, stream), zero between launches (the kernel's last workgroup resets
+// them); allocated once, never freed (a process has a handful of streams).
+#include <map>
+#include <mutex>
+namespace {
+std::mutex g_chain_mu;
+std::map<std::pair<int, hipStream_t>, int*> g_chain_sync;
+int chain_sync_words(hipStream_t st, int** out) {
+    int dev = 0;
+    SCN_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_chain_mu);
+    auto key = std::make_pair(dev, st);
+    auto it = g_chain_sync.find(key);
+    if (it == g_chain_sync.end()) {
+        int* p = nullptr;
+        SCN_HIP(hipMalloc(&p, 64));
+        SCN_HIP(hipMemsetAsync(p, 0, 64, st));
+        it = g_chain_sync.emplace(key, p).first;
+    }
+    *out = it->second;
+    return SCN_OK;
+}
+std::atomic<int64_t> g_ts_chain_launches, g_ts_chain_roles;
+}  // namespace
+
+extern "C" void scn_conv_tiles_chain_counts(int64_t out[2], int reset) {
+    out[0] = reset ? g_ts_chain_launches.exchange(0) : g_ts_chain_launches.load();
+    out[1] = reset ? g_ts_chain_roles.exchange(0) : g_ts_chain_roles.load();
+}
+
+// 1 if scn_conv_tiles_chain would run these shapes as ONE launch (else it runs its roles as separate scn_conv_tiles calls)
+static bool ts_chainable(int n_roles, int64_t n_in, int cin, int n_off, int64_t n_out, int cout, const scn_conv_role* roles) {
+    if (n_roles < 2 || n_roles > TS_MAX_ROLES) return false;
+    if (scn::sw(scn::SW_TS_NO_CHAIN).set && scn::sw(scn::SW_TS_NO_CHAIN).i != 0) return false;
+    if (cin % TS_KC != 0 || cout % TS_CT != 0) return false;                       // no PART / TAIL slices
+    const int64_t nt = cdiv(n_out, TS_T);
+    const int n_chunks = (int)cdiv(cout, TS_CT), n_kc = (int)cdiv(cin, TS_KC);
+    if (n_in >= (1ll << 23) || n_in * cin * 4 >= (1ll << 32) - (1ll << 24) || n_out >= (1ll << 23) ||
+        n_out * cout * 4 >= (1ll << 32) - (1ll << 24))
+        return false;                                                              // FULLK only
+    if (n_kc > 1 && nt * n_chunks * n_kc * (int64_t)(TS_T * TS_CT * 4) >= (1ll << 31)) return false;
+    const int64_t sp_max = scn::sw(scn::SW_TS_SPLIT_MAX).set ? scn::sw(scn::SW_TS_SPLIT_MAX).i : 2048;
+    const scn::SwitchVal sp_sw = scn::sw(scn::SW_TS_SPLIT);
+    if (nt * n_chunks * n_kc <= sp_max && !(sp_sw.set && sp_sw.i == 0)) return false;   // the four-waves-per-tile loop
+    if ((size_t)n_off * TS_KC * TS_CT * sizeof(float) + 16 > 160 * 1024) return false;
+    const int f0 = roles[0].flags & (SCN_F_W_TRANSPOSED | SCN_F_OFF_REVERSE);
+    for (int r = 0; r < n_roles; ++r) {
+        if ((roles[r].flags & (SCN_F_W_TRANSPOSED | SCN_F_OFF_REVERSE)) != f0) return false;
+        if (roles[r].flags & SCN_F_SPLIT_SUM) return false;
+        if (!roles[r].X || !roles[r].W || !roles[r].Y) return false;
+        if ((((uintptr_t)roles[r].X | (uintptr_t)roles[r].W) & 15) != 0) return false;
+    }
+    return true;
+}
+
+extern "C" int scn_conv_tiles_chain(int n_roles, const scn_conv_role* roles, int64_t n_in, int cin, const int32_t* tstab,
+                                    const uint32_t* tile_mask, const int32_t* perm, const int32_t* tile_order, int n_off,
+                                    int64_t n_out, int cout, void* scratch, int32_t* arrival, scn_stream_t stream) {
+    SCN_REQUIRE(n_roles >= 1 && roles != nullptr);
+    SCN_REQUIRE(n_off >= 1 && n_off <= 27 && n_out >= 0 && n_in >= 0 && cin >= 1 && cout >= 1);
+    if (n_out == 0) return SCN_OK;
+    const int n_kc = (int)cdiv(cin, TS_KC);
+    if (!ts_chainable(n_roles, n_in, cin, n_off, n_out, cout, roles) || (n_kc > 1 && arrival == nullptr)) {
+        for (int r = 0; r < n_roles; ++r) {
+            const int rc = scn_conv_tiles((const float*)roles[r].X, n_in, cin, tstab, tile_mask, perm, tile_order, n_off, n_out,
+                                          (const float*)roles[r].W, (const float*)roles[r].bias, (const float*)roles[r].residual,
+                                          (const float*)roles[r].relu_mask, (float*)roles[r].Y, cout, roles[r].flags, scratch,
+                                          arrival, stream);
+            if (rc != SCN_OK) return rc;
+        }
+        return SCN_OK;
+    }
+    SCN_REQUIRE(tstab && tile_mask && perm && tile_order && scratch);
+    const int64_t nt = cdiv(n_out, TS_T);
+    const int n_chunks = (int)cdiv(cout, TS_CT);
+    hipStream_t st = S(stream);
+    int* sync = nullptr;
+    { const int rc = chain_sync_words(st, &sync); if (rc != SCN_OK) return rc; }
+    float* slabs = (float*)((char*)scratch + ts_counter_bytes(cin, cout));
+    const bool fused = n_kc > 1;
+    const bool wt = roles[0].flags & SCN_F_W_TRANSPOSED;
+    const size_t lds = (size_t)n_off * TS_KC * TS_CT * sizeof(float) + 16;
+    int wg_per_cu = (int)((160 * 1024) / lds);
+    if (wg_per_cu > 2) wg_per_cu = 2;
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    int64_t n_tg = ((int64_t)scn::cu_budget() * wg_per_cu) / ((int64_t)n_chunks * n_kc);
+    if (n_tg > cdiv(nt, TS_NW)) n_tg = cdiv(nt, TS_NW);
+    if (n_tg < 1) n_tg = 1;
+    TsChain chain{};
+    chain.n_roles = n_roles;
+    chain.exp = scn::sw(scn::SW_EXP_A).set ? (int)scn::sw(scn::SW_EXP_A).i : 0;
+    chain.wgs = (int)(n_tg * n_chunks * n_kc);
+    chain.sync = sync;
+    for (int r = 0; r < n_roles; ++r) {
+        chain.role[r].X = (const float*)roles[r].X; chain.role[r].W = (const float*)roles[r].W;
+        chain.role[r].bias = (const float*)roles[r].bias; chain.role[r].residual = (const float*)roles[r].residual;
+        chain.role[r].relu_mask = (const float*)roles[r].relu_mask; chain.role[r].Y = (float*)roles[r].Y;
+        chain.role[r].flags = roles[r].flags;
+    }
+    g_ts_paths[0].fetch_add(n_roles, std::memory_order_relaxed);
+    if (n_kc > 1) g_ts_paths[2].fetch_add(n_roles, std::memory_order_relaxed);
+    g_ts_chain_launches.fetch_add(1, std::memory_order_relaxed);
+    g_ts_chain_roles.fetch_add(n_roles, std::memory_order_relaxed);
+    dim3 grid((unsigned)((int64_t)chain.wgs * n_roles));
+    TsSlices slices = {0, 0, 0, 0};
+#define LAUNCH_TS_C(T, FU)                                                                                          \
+    do {                                                                                                            \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            SCN_HIP(hipFuncSetAttribute((const void*)k_conv_ts<T, true, true, true, false, FU, false, 1, true>,     \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        hipLaunchKernelGGL((k_conv_ts<T, true, true, true, false, FU, false, 1, true>), grid, dim3(TS_NW * 64), lds, st,        \
+                           (const float*)nullptr, (long long)n_in, cin, tstab, tile_mask, perm, tile_order, n_off, (long long)nt, \
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,          \
+                           (float*)nullptr, slabs, (long long)n_out, cout, 0, n_chunks, n_kc, (int*)arrival, slices, chain);    \
+    } while (0)
+    if (wt) { if (fused) LAUNCH_TS_C(true, true); else LAUNCH_TS_C(true, false); }
+    else { if (fused) LAUNCH_TS_C(false, true); else LAUNCH_TS_C(false, false); }
+#undef LAUNCH_TS_C
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
 }
 
 extern "C" int scn_conv_tiles_finish(int cin, int64_t n_out, const float* bias, const float* residual,

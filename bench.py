@@ -45,13 +45,16 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--target", type=int, default=None, help="active voxels per scene (default: the workload's)")
-    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg3-rpn", "cfg5", "ref", "ref-crop"), default="cfg2",
+    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg3-rpn", "cfg5", "ref", "ref-crop", "ref-crop-rpn"), default="cfg2",
                     help="cfg2 = the configuration the metric is quoted on (default); cfg3 = backbone + OutputLayer + "
                          "sparse ROI crop (64 synthetic boxes) + mask-branch U-Net, fwd+bwd (crop + mask branch only); cfg3-rpn = "
-                         "configs[2] as written: the boxes come out of the same forward (SparseToDense -> dense RPN heads -> "
-                         "top-k + NMS); cfg5 = 600k voxels, 5 levels to 512; "
+                         "configs[2] with the RPN boundary inside the step: the boxes come out of the same forward (SparseToDense "
+                         "-> a STAND-IN dense stack, 2 x 32 on one anchor level, on this library's tile kernels -> inside anchors "
+                         "-> top-k + NMS, 64 kept); cfg5 = 600k voxels, 5 levels to 512; "
                          "ref = the reference's own 6-level plan 32-48-64-80-96-112 on the 150k scene; ref-crop = the same "
-                         "plan on the reference's training batch (12 crops of 128x128x64)")
+                         "plan on the reference's training batch (12 crops of 128x128x64); ref-crop-rpn = that batch with the "
+                         "reference's RPN shape (two anchor levels, 5 x 128 / 5 x 256 dilation stacks, top-1024 / NMS 0.5 / 256 "
+                         "kept, scannet_config/run.py:525-536,609,847-853) + crop + mask branch on the 24 best per sample")
     ap.add_argument("--dtype", choices=("f32", "bf16", "bf16-blocks"), default="f32",
                     help="feature STORAGE type: f32 (the headline, the reference's arithmetic) or bf16 (BASELINE configs "
                          "3-5: bf16-stored features, fp32 accumulation, fp32 parameters)")
@@ -337,7 +340,9 @@ def run(args):
             "data": "synthetic",
             "config": {"workload": job.describe(),
                        "parallelism": f"dp{world} (1 scene/GPU, flat-bucket all-reduce)",
-                       "batches_per_step": job.batches_per_step},
+                       "batches_per_step": job.batches_per_step,
+                       "optimizer": "plain SGD on the flat fp32 parameter buffer (dp.FlatParams); the reference trains with Adam",
+                       "lr": job.lr},
             "n_ranks_seen_by_rccl": ranks_seen if backend == "nccl" else None,
             "n_ranks_seen": ranks_seen, "collective_backend": backend if dist_on else None,
             "per_rank": per_rank,

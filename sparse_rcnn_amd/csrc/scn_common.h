@@ -1,6 +1,7 @@
 // Shared host-side helpers for libscn_mi355x (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -48,13 +49,23 @@ inline int fail(int code, const char* fmt, const char* a = "", long long b = 0, 
 enum Switch {
     SW_TS_SPLIT, SW_TS_SPLIT_MAX, SW_TS_NO_TAIL, SW_TS_W_HALF, SW_TS_W_BOTH, SW_TB_NB, SW_TB_KH, SW_TB_STREAM,
     SW_TB_NO_XORDER, SW_TS_STREAM, SW_TSS_NW, SW_EXEC_DEFER_SUMS, SW_PYRAMID_V1, SW_PYRAMID_ONE_STREAM, SW_WD_NO_T3,
-    SW_WGRAD_BF16_MFMA, SW_WGRAD_SPLITS, SW_WD_NO_EVEC, SW_PYRAMID_NO_BRICKS, SW_CU_BUDGET, SW_EXP_A, SW_EXP_B, SW_TS_NO_CHAIN, SW_COUNT
+    SW_WGRAD_BF16_MFMA, SW_WGRAD_SPLITS, SW_WD_NO_EVEC, SW_PYRAMID_NO_BRICKS, SW_CU_BUDGET, SW_EXP_A, SW_EXP_B, SW_TS_NO_CHAIN, SW_TS_PROG, SW_COUNT
 };
 struct SwitchVal { bool set = false; long long i = 0; double f = 0.0; };
 SwitchVal sw(Switch s);
 // CUs the matrix kernels size their grids to (SCN_CU_BUDGET, default 256 = the chip): a grid of one workgroup per CU starts some
 // of its workgroups late whenever another stream's kernel (an RCCL collective, the index build) holds a CU.
 inline int cu_budget() { const SwitchVal v = sw(SW_CU_BUDGET); return (v.set && v.i >= 32 && v.i <= 256) ? (int)v.i : 256; }
+
+// "Once per device" guard of a hipFuncSetAttribute call site (a process-wide `static bool` is neither per device nor
+// safe against a second launching thread).  One bit per device ordinal; the bit is set AFTER the attribute call, so two threads
+// may both make the (idempotent) call but neither launches before it has been made on its device.
+struct DeviceOnce {
+    std::atomic<uint64_t> mask{0};
+    static int cur() { int d = 0; return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) ? d : -1; }
+    bool needed() const { const int d = cur(); return d < 0 || !(mask.load(std::memory_order_acquire) & (1ull << d)); }
+    void done() { const int d = cur(); if (d >= 0) mask.fetch_or(1ull << d, std::memory_order_release); }
+};
 
 inline hipStream_t S(scn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

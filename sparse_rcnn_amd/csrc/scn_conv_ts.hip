@@ -28,6 +28,9 @@
 #ifndef TS_DEPTH
 #define TS_DEPTH 3          // row gathers this many offsets ahead of the MFMAs (3: indices 5 ahead; 5: indices 7 ahead)
 #endif
+#ifndef TS_TIMELINE_NOPROG
+#define TS_TIMELINE_NOPROG 0
+#endif
 #ifndef TS_TIMELINE
 #define TS_TIMELINE 0       // 1: per-wave wall_clock64 stamps appended to the scratch buffer (tools/ts_timeline.py)
 #endif
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     int bid = (int)blockIdx.x, n_bid = (int)gridDim.x, role = 0;
     if (tid == 0) {
         *counter = 0;
+        counter[2] = 0;                                                  // PROG: waves whose later weight groups have landed
         if constexpr (CHAIN)
             counter[1] = (chain.exp & 4) ? (int)blockIdx.x : __hip_atomic_fetch_add(chain.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -181,11 +185,51 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         return tl < n_tiles ? tile_order[tg + (long long)tl * n_tg] : -1;
     };
     const int i = lane & 15, kq = lane >> 4;
+    // PROG (round 6): PROGRESSIVE staging of the forward slice.  The 27 x 4 KB image is 108 pieces of 1 KB =
+    // one LDS-DMA wave-instruction each (global_load_lds_dwordx4: lane-linear destination, the XOR-16 column swizzle applied
+    // to the SOURCE address), dealt to the 16 waves in offset order, all in flight at once.  A wave waits only for its pieces
+    // of the first g0 offsets before the workgroup barrier; the other pieces land while the first tile's index loads, row
+    // gathers and first g0 steps run.  Loads retire in order, so the first row index a wave consumes proves that its own
+    // DMA pieces have landed: it then adds one to an LDS word, and the first step that needs an offset >= g0 waits until that
+    // word reads TS_NW (LDS serves its requests in order: a wave that read TS_NW reads the landed bytes).  The DMA
+    // instructions are inline asm, invisible to hipcc's wait counting: they are the OLDEST vector-memory operations of the
+    // wave (every counted load is issued after them), so hipcc's counted waits stay sufficient.
+    constexpr bool PROG_OK = !WT && VECN && FULLK && !PART && !TAIL && SPLIT == 1 && !CHAIN && TS_DEPTH == 3 && !TS_TIMELINE_NOPROG;
+    const int g0 = PROG_OK ? (flags_ >> 24) & 31 : 0;                   // offsets staged before the barrier; 0: classic staging
+    bool w_ready = true, sig_pending = false;                           // wave-uniform
     // first tile: id, mask and output rows are requested before the weight slice is staged
     // (SPLIT > 1, scn_conv_ts_small.inc: tiles are dealt to wave groups by round, nothing to grab)
     long long tile_next = SPLIT == 1 ? grab() : -1;
     unsigned m_next = 0;
     int orow_next[4] = {-1, -1, -1, -1};
+    if (PROG_OK && g0 > 0) {
+        if (tile_next >= 0) m_next = __builtin_amdgcn_readfirstlane(tile_mask[tile_next]);   // consumed BEFORE the asm loads
+        const int wv = tid >> 6, n_pieces = n_off * 4;
+        const unsigned lds0 = (unsigned)(uintptr_t)Ws;
+        const int p4 = (lane & 7) * 4, kr = lane >> 3;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            int c = wv + TS_NW * j;
+            c = c < n_pieces ? c : n_pieces - 1;                        // (a wave with six pieces fetches its last one twice)
+            const int o = c >> 2, k = 8 * (c & 3) + kr;
+            const int wo = rev ? n_off - 1 - o : o;
+            const float* src = W + ((long long)wo * cin + kc + k) * cout + n0 + (p4 ^ (((k >> 2) & 1) << 4));
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)c * 1024u);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        }
+        // pieces j < g0 / 4 hold the offsets below g0 (g0 is 4, 8 or 12)
+        if (g0 <= 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (g0 <= 8) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        w_ready = false; sig_pending = true;
+        if (tile_next >= 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) orow_next[j] = perm[tile_next * TS_T + 4 * kq + j];
+        }
+    } else {
     if (tile_next >= 0) {
         m_next = tile_mask[tile_next];
 #pragma unroll
@@ -250,6 +294,7 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         }
     }
     __syncthreads();
+    }
     if constexpr (CHAIN) {
         // the role before this one has to be complete: its outputs are this role's X / residual / mask, and its K-split
         // slabs and arrival counters are this role's too.  One lane polls (relaxed, L1-bypassing), then the agent-scope
@@ -361,6 +406,9 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
     // ZERO0: (non-FULLK only) the item multiplied now has rows without a rule -> handled in TS_GATHER (zero-filled).
 #define TS_STEP(C0, C1, G0, G1, IOLD, INEW)                                                          \
     do {                                                                                             \
+        if constexpr (PROG_OK) {                        /* first use of a weight group that may not have landed */ \
+            if (!w_ready && oq0 >= g0) { ts_wait_groups(); w_ready = true; }                         \
+        }                                                                                            \
         int o4_ = -1;                                                                                \
         if (m) { o4_ = __builtin_ctz(m); m &= m - 1; olast = o4_; }                                  \
         if (TS_EXP >= 2) INEW = olast + i; else                                                      \
@@ -398,6 +446,20 @@ __global__ __launch_bounds__(TS_NW * 64) void k_conv_ts(
         if (TS_DEPTH == 3) oq4 = o4_; else ts_o4_ = o4_;     /* (depth 5: the caller shifts the longer queue) */ \
     } while (0)
 
+    // PROG: the word the waves count themselves into / wait on
+    auto ts_signal = [&]() {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");               // all but the six youngest (the prologue's row gathers)
+        if (lane == 0) atomicAdd(counter + 2, 1);
+    };
+    auto ts_wait_groups = [&]() {                      // (asm: a volatile read through the generic pointer compiles to flat_load)
+        const unsigned fa = (unsigned)(uintptr_t)(counter + 2);
+        int f;
+        do {
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(fa) : "memory");
+            if (__builtin_amdgcn_readfirstlane(f) >= TS_NW) break;
+            __builtin_amdgcn_s_sleep(1);
+        } while (true);
+    };
     // ---- epilogue pieces --------------------------------------------------------------------------------------------
     // ts_write: 16 lanes write 64 contiguous bytes of a row.  The residual / ReLU-mask operands of all eight outputs are
     // requested first and consumed afterwards (one wait, not eight round trips).
@@ -579,6 +641,12 @@ if constexpr (SPLIT == 1) {
 #undef TS_KH
 #undef TS_NH
     }
+    if constexpr (PROG_OK) {
+        if (sig_pending) {                   // a wave without a tile still owes its arrival
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) atomicAdd(counter + 2, 1);
+        }
+    }
     if (FUSED && !single) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ts_retire();                         // combine the tile before last, ticket the last one
@@ -708,7 +776,7 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     // alone: every form of a layer (fused / two-launch K reduction, TAIL / padded slices) takes the same loop.
     // SCN_TS_SPLIT=0: never (A/B; the cross-check in the tests -- the two loops associate an element's sum differently).
     const scn::SwitchVal sp_sw = scn::sw(scn::SW_TS_SPLIT);            // (scn_debug_set: the tests switch it inside one process)
-    static const int64_t sp_max = scn::sw(scn::SW_TS_SPLIT_MAX).set ? scn::sw(scn::SW_TS_SPLIT_MAX).i : 2048;   // (developer switch)
+    const int64_t sp_max = scn::sw(scn::SW_TS_SPLIT_MAX).set ? scn::sw(scn::SW_TS_SPLIT_MAX).i : 2048;   // (developer switch)
     const bool split4 = fullk && nt * n_chunks * n_kc <= sp_max && !(sp_sw.set && sp_sw.i == 0);
     const int tiles_per_round = split4 ? TS_NW / 4 : TS_NW;
     const size_t lds = (size_t)n_off * TS_KC * TS_CT * sizeof(float) + 16 + (split4 ? (size_t)2 * (TS_NW / 4) * 3 * 2 * 64 * 16 : 0);   // two buffers of partial tiles
@@ -730,8 +798,8 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     TsSlices slices = {0, 0, 0, 0};
     int64_t grid_x = n_tg * n_chunks * n_kc;
     if (tail) {
-        static const double w_half = scn::sw(scn::SW_TS_W_HALF).set ? scn::sw(scn::SW_TS_W_HALF).f : 0.70;
-        static const double w_both = scn::sw(scn::SW_TS_W_BOTH).set ? scn::sw(scn::SW_TS_W_BOTH).f : 0.50;
+        const double w_half = scn::sw(scn::SW_TS_W_HALF).set ? scn::sw(scn::SW_TS_W_HALF).f : 0.70;
+        const double w_both = scn::sw(scn::SW_TS_W_BOTH).set ? scn::sw(scn::SW_TS_W_BOTH).f : 0.50;
         const int ncf = n_chunks - (n_tail ? 1 : 0), nkf = n_kc - (k_tail ? 1 : 0);
         const double wsum = (double)nkf * ncf + (n_tail ? nkf * w_half : 0.0) + (k_tail ? ncf * w_half : 0.0) +
                             (n_tail && k_tail ? w_both : 0.0);
@@ -743,6 +811,16 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
         slices.g_both = n_tail && k_tail ? share(w_both) : 0;
         grid_x = (int64_t)nkf * ncf * slices.g_full + (int64_t)nkf * slices.g_ntail + (int64_t)ncf * slices.g_ktail + slices.g_both;
     }
+    // progressive staging of the forward slice (PROG in the kernel): SCN_TS_PROG = offsets staged before the barrier (4 / 8 / 12;
+    // 0 = the classic staging)
+    int prog_g0 = 0;
+    if (fullk && !wt && vecn && !part && !tail && !split4 && n_off == 27 && cout % TS_CT == 0) {
+        const scn::SwitchVal pg = scn::sw(scn::SW_TS_PROG);
+        prog_g0 = pg.set ? (int)pg.i : 0;
+        if (prog_g0 < 0 || prog_g0 > 12) prog_g0 = 0;
+        prog_g0 = (prog_g0 + 3) / 4 * 4;
+    }
+    const int kflags = (flags & 0xFFFFFF) | (prog_g0 << 24);
     g_ts_paths[fullk ? 0 : 1].fetch_add(1, std::memory_order_relaxed);
     if (n_kc > 1) g_ts_paths[fused ? 2 : 3].fetch_add(1, std::memory_order_relaxed);
     if (split4) g_ts_split.fetch_add(1, std::memory_order_relaxed);
@@ -750,15 +828,15 @@ extern "C" int scn_conv_tiles(const float* X, int64_t n_in, int cin, const int32
     hipStream_t st = S(stream);
 #define LAUNCH_TS_F(T, V, VN, FK, PT, FU, TL, SP)                                                                   \
     do {                                                                                                            \
-        static bool attr_set = false;                                                                               \
-        if (!attr_set) {                                                                                            \
+        static scn::DeviceOnce attr_set;                                                                               \
+        if (attr_set.needed()) {                                                                                            \
             SCN_HIP(hipFuncSetAttribute((const void*)k_conv_ts<T, V, VN, FK, PT, FU, TL, SP>,                       \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-            attr_set = true;                                                                                        \
+            attr_set.done();                                                                                        \
         }                                                                                                           \
         hipLaunchKernelGGL((k_conv_ts<T, V, VN, FK, PT, FU, TL, SP>), grid, dim3(TS_NW * 64), lds, st, X, (long long)n_in, cin, tstab, tile_mask, \
                            perm, tile_order, n_off, (long long)nt, W, bias, residual, relu_mask, Y, slabs,                      \
-                           (long long)n_out, cout, flags, n_chunks, n_kc, counters, slices, TsChain{});             \
+                           (long long)n_out, cout, kflags, n_chunks, n_kc, counters, slices, TsChain{});             \
     } while (0)
 #define LAUNCH_TS(T, V, VN, FK, PT)                                                                                 \
     do {                                                                                                            \
@@ -904,11 +982,11 @@ extern "C" int scn_conv_tiles_chain(int n_roles, const scn_conv_role* roles, int
     TsSlices slices = {0, 0, 0, 0};
 #define LAUNCH_TS_C(T, FU)                                                                                          \
     do {                                                                                                            \
-        static bool attr_set = false;                                                                               \
-        if (!attr_set) {                                                                                            \
+        static scn::DeviceOnce attr_set;                                                                               \
+        if (attr_set.needed()) {                                                                                            \
             SCN_HIP(hipFuncSetAttribute((const void*)k_conv_ts<T, true, true, true, false, FU, false, 1, true>,     \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-            attr_set = true;                                                                                        \
+            attr_set.done();                                                                                        \
         }                                                                                                           \
         hipLaunchKernelGGL((k_conv_ts<T, true, true, true, false, FU, false, 1, true>), grid, dim3(TS_NW * 64), lds, st,        \
                            (const float*)nullptr, (long long)n_in, cin, tstab, tile_mask, perm, tile_order, n_off, (long long)nt, \

@@ -709,8 +709,8 @@ namespace {
 struct TbShape { int nb, kh, ct, kc, n_chunks, n_kc; };
 
 TbShape tb_shape(int cin, int cout) {
-    static const int nb_env = (int)scn::sw(scn::SW_TB_NB).i;      // developer switches
-    static const int kh_env = (int)scn::sw(scn::SW_TB_KH).i;
+    const int nb_env = (int)scn::sw(scn::SW_TB_NB).i;      // developer switches
+    const int kh_env = (int)scn::sw(scn::SW_TB_KH).i;
     // shapes: 32 columns x 32 channels (small layers), 64 columns x 32 channels, 32 columns x 64 channels -- the last
     // halves the number of K-chunks (no partial sums at Cin = 64) at twice the gather traffic per output
     TbShape s;
@@ -910,11 +910,11 @@ extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, con
         const size_t lds = (size_t)2 * n_kc * 64 * 32 * sizeof(uint16_t) + (size_t)nw * (((n_off + 1) * 16 + 63) / 64 * 64) * 4 + 16;
 #define LAUNCH_TBS(KS_, NO_, NW_, D_)                                                                                  \
     do {                                                                                                            \
-        static bool attr_set = false;                                                                               \
-        if (!attr_set) {                                                                                            \
+        static scn::DeviceOnce attr_set;                                                                               \
+        if (attr_set.needed()) {                                                                                            \
             SCN_HIP(hipFuncSetAttribute((const void*)k_conv_tbs<KS_, NO_, NW_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                         160 * 1024));                                                               \
-            attr_set = true;                                                                                        \
+            attr_set.done();                                                                                        \
         }                                                                                                           \
         hipLaunchKernelGGL((k_conv_tbs<KS_, NO_, NW_, D_>), grid, dim3(NW_ * 64), lds, st, X, (long long)n_in, cin, tstab,  \
                            tile_mask, perm, tile_order, (long long)nt, image, bias, residual, relu_mask, Y, (long long)n_out, \
@@ -954,11 +954,11 @@ extern "C" int scn_conv_tiles_bf16(const uint16_t* X, int64_t n_in, int cin, con
                        n_tg >= 8) ? 8 / n_slices : 1;
 #define LAUNCH_TB(N, K, FU, PT)                                                                                     \
     do {                                                                                                            \
-        static bool attr_set = false;                                                                               \
-        if (!attr_set) {                                                                                            \
+        static scn::DeviceOnce attr_set;                                                                               \
+        if (attr_set.needed()) {                                                                                            \
             SCN_HIP(hipFuncSetAttribute((const void*)k_conv_tb<N, K, FU, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                         160 * 1024));                                                               \
-            attr_set = true;                                                                                        \
+            attr_set.done();                                                                                        \
         }                                                                                                           \
         hipLaunchKernelGGL((k_conv_tb<N, K, FU, PT>), grid, dim3(TB_NW * 64), lds, st, X, (long long)n_in, cin, tstab, \
                            tile_mask, perm, tile_order, n_off, (long long)nt, image, bias, residual, relu_mask, Y, slabs, \

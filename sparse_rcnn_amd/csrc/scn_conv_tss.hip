@@ -282,7 +282,7 @@ int conv_tiles_stream(const float* X, int64_t n_in, int cin, const int32_t* tsta
     // consecutive tiles the union is ~25 of 27 offsets for tiles that have ~14 each, and the SIMD a stalled wave sits on has
     // nobody else to run (measured: 119 us per launch at level 1 against k_conv_ts's 69).  With 4 waves per workgroup (one per
     // SIMD) the union stays near a tile's own mask and the other resident workgroups of the CU fill the matrix pipe.
-    static const int nw_env = (int)scn::sw(scn::SW_TSS_NW).i;
+    const int nw_env = (int)scn::sw(scn::SW_TSS_NW).i;
     const int nw = (nw_env == 4 || nw_env == 8 || nw_env == 16) ? (ks == 4 && nw_env == 16 ? 8 : nw_env) : 4;
     const size_t lds0 = (size_t)2 * ks * 32 * SS_CT * sizeof(float) + (size_t)nw * (((n_off + 1) * 16 + 63) / 64 * 64) * 4 + 16;
     int64_t per_cu = (int64_t)((160 * 1024) / lds0);
@@ -297,11 +297,11 @@ int conv_tiles_stream(const float* X, int64_t n_in, int cin, const int32_t* tsta
     const size_t lds = (size_t)2 * ks * 32 * SS_CT * sizeof(float) + (size_t)nw * (((n_off + 1) * 16 + 63) / 64 * 64) * 4 + 16;
 #define LAUNCH_TSS(KS_, NO_, NW_, WT_)                                                                              \
     do {                                                                                                            \
-        static bool attr_set = false;                                                                               \
-        if (!attr_set) {                                                                                            \
+        static scn::DeviceOnce attr_set;                                                                               \
+        if (attr_set.needed()) {                                                                                            \
             SCN_HIP(hipFuncSetAttribute((const void*)k_conv_tss<KS_, NO_, NW_, WT_>,                                \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-            attr_set = true;                                                                                        \
+            attr_set.done();                                                                                        \
         }                                                                                                           \
         hipLaunchKernelGGL((k_conv_tss<KS_, NO_, NW_, WT_>), grid, dim3(NW_ * 64), lds, st, X, (long long)n_in, cin, tstab, \
                            tile_mask, perm, (long long)nt, W, bias, residual, relu_mask, Y, (long long)n_out, cout, flags, \

@@ -18,6 +18,7 @@ Entry g_sw[SW_COUNT] = {
     {"SCN_PYRAMID_V1", {}},      {"SCN_PYRAMID_ONE_STREAM", {}}, {"SCN_WD_NO_T3", {}},    {"SCN_WGRAD_BF16_MFMA", {}},
     {"SCN_WGRAD_SPLITS", {}},    {"SCN_WD_NO_EVEC", {}},    {"SCN_PYRAMID_NO_BRICKS", {}},            {"SCN_CU_BUDGET", {}},
     {"SCN_EXP_A", {}},           {"SCN_EXP_B", {}},         {"SCN_TS_NO_CHAIN", {}},
+    {"SCN_TS_PROG", {}},
 };
 std::once_flag g_once;
 std::mutex g_mu;
@@ -34,6 +35,7 @@ void load_env() {
 
 SwitchVal sw(Switch s) {
     std::call_once(g_once, load_env);
+    std::lock_guard<std::mutex> lock(g_mu);          // (scn_debug_set writes under the same lock: no torn {set, i, f})
     return g_sw[s].v;
 }
 }  // namespace scn

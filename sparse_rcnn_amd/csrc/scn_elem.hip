@@ -841,10 +841,10 @@ extern "C" int scn_nms_bits(const float* boxes, int batch, int n, float overlap_
     int rpr = (int)((NMSB_LDS_BYTES / ((size_t)nw * 8)) / 64 * 64);
     rpr = std::max(64, std::min(rpr, (n + 63) / 64 * 64));
     const size_t lds = (size_t)rpr * nw * 8;
-    static bool attr = false;
-    if (!attr) {
+    static scn::DeviceOnce attr;
+    if (attr.needed()) {
         SCN_HIP(hipFuncSetAttribute((const void*)k_nms_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NMSB_LDS_BYTES));
-        attr = true;
+        attr.done();
     }
     hipLaunchKernelGGL(k_nms_resolve, dim3(batch), dim3(1024), lds, S(stream), (const unsigned long long*)scratch, n, rpr, keep);
     SCN_LAUNCH_CHECK();

@@ -308,7 +308,7 @@ extern "C" int scn_exec_run_streams(const scn_exec_op* ops, int n_ops, const scn
     // Deferred sums: the unit sums of the pass's weight-gradient launches run as ONE batched launch at its end (7 us
     // launches of a few hundred workgroups each, 27 per backbone step; SCN_EXEC_DEFER_SUMS=0: one sum per launch).  Needs
     // the per-op scratch regions scn_exec_requirements counts; a caller that sized the scratch otherwise keeps the old form.
-    static const bool defer_env = !(scn::sw(scn::SW_EXEC_DEFER_SUMS).set && scn::sw(scn::SW_EXEC_DEFER_SUMS).i == 0);
+    const bool defer_env = !(scn::sw(scn::SW_EXEC_DEFER_SUMS).set && scn::sw(scn::SW_EXEC_DEFER_SUMS).i == 0);
     // (the weight-gradient needs are computed once per pass and only for passes that have such ops: backward passes)
     int n_wg = 0;
     for (int i = 0; i < n_ops; ++i) n_wg += is_wgrad(ops[i].op) ? 1 : 0;

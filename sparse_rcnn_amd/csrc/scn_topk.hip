@@ -295,10 +295,10 @@ extern "C" int scn_topk_boxes(const float* scores, const float* boxes, int batch
     SCN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_topk_compact, dim3(g, batch), dim3(256), 0, S(stream), scores, (long long)n, k, st, cand);
     SCN_LAUNCH_CHECK();
-    static bool attr = false;
-    if (!attr) {
+    static scn::DeviceOnce attr;
+    if (attr.needed()) {
         SCN_HIP(hipFuncSetAttribute((const void*)k_topk_final, hipFuncAttributeMaxDynamicSharedMemorySize, TK_CAND * 8));
-        attr = true;
+        attr.done();
     }
     hipLaunchKernelGGL(k_topk_final, dim3(batch), dim3(1024), (size_t)TK_CAND * 8, S(stream), scores, boxes, (long long)n, k, st,
                        cand, out_scores, (long long*)out_index, out_boxes);

@@ -708,7 +708,7 @@ Shape pick_shape(int cin, int cout, bool hb = false) {
 // bf16 MFMA kernel: tiles of 16 channels per wave along Cin / Cout (workgroup block 32 T x 32 T)
 int tb_tiles(int c) { return c <= 32 ? 1 : (c <= 64 ? 2 : 4); }
 bool tb_usable(int cin, int cout) {
-    static const bool off = scn::sw(scn::SW_WGRAD_BF16_MFMA).set && scn::sw(scn::SW_WGRAD_BF16_MFMA).i == 0;
+    const bool off = scn::sw(scn::SW_WGRAD_BF16_MFMA).set && scn::sw(scn::SW_WGRAD_BF16_MFMA).i == 0;
     return !off && cin % 8 == 0 && cout % 8 == 0;
 }
 
@@ -870,11 +870,11 @@ static int wgrad_impl(const float* X, int cin, const float* dY, int cout, const 
 #define LAUNCH_WD(TA_, TB_, Q_, E_, I_, H_)                                                                      \
     do {                                                                                                         \
         const size_t lds_ = ((Q_) ? 4 * 64 : 4 * (TA_) * (TB_) * 4 * 64 + 4 * 64) * sizeof(float);               \
-        static bool attr_set = false;                                                                            \
-        if (!attr_set) {                                                                                         \
+        static scn::DeviceOnce attr_set;                                                                            \
+        if (attr_set.needed()) {                                                                                         \
             SCN_HIP(hipFuncSetAttribute((const void*)k_wgrad_direct<TA_, TB_, Q_, E_, I_, H_>,                   \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                \
-            attr_set = true;                                                                                     \
+            attr_set.done();                                                                                     \
         }                                                                                                        \
         hipLaunchKernelGGL((k_wgrad_direct<TA_, TB_, Q_, E_, I_, H_>), grid, dim3(256), lds_, S(stream), X, cin, \
                            dY, cout, in_rows, out_rows, pl, (float*)scratch, relu_in, db_slabs, db_mask,         \

@@ -38,7 +38,8 @@ def non_maximum_suppression(proposed_boxes: torch.Tensor, overlap_threshold: flo
 TORCH_TOPK = False          # True: torch.topk + advanced indexing (the reference's calls); the tests' cross-check and the A/B
 DECODE_FIRST = False        # True: RoiSelector decodes every anchor's box before the selection (the reference's order of calls)
 _TOPK_MAX_K = 2048          # scn_topk_boxes: k <= 2048
-_topk_scratch = {}          # (device, batch) -> the zeroed state scn_topk_boxes keeps between calls
+_topk_scratch = {}          # (device, batch, STREAM) -> the zeroed state scn_topk_boxes keeps between calls: the kernels'
+                            # histogram / cursor atomics of two calls must never interleave, and calls on one stream do not
 
 
 class _TopkBoxes(torch.autograd.Function):
@@ -54,13 +55,14 @@ class _TopkBoxes(torch.autograd.Function):
         idx = torch.empty((b, k), dtype=torch.int64, device=s.device)
         out = torch.empty((b, k, 2, 3), dtype=torch.float32, device=s.device)
         lib = L.lib()
-        key = (s.device, b)
+        stream = L.stream()
+        key = (s.device, b, stream)
         scratch = _topk_scratch.get(key)
         if scratch is None:
             scratch = _topk_scratch[key] = torch.zeros(lib.scn_topk_scratch_bytes(b), dtype=torch.uint8, device=s.device)
         try:
             L.check(lib.scn_topk_boxes(L.ptr(s), L.ptr(bx), b, n, k, L.ptr(vals), L.ptr(idx), L.ptr(out), L.ptr(scratch),
-                                       L.stream()))
+                                       stream))
         except Exception:
             scratch.zero_()                     # (the state is only zero again after a COMPLETE call)
             raise

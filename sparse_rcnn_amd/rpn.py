@@ -2,9 +2,11 @@
 head"): the proposals of a step come out of the SAME forward that feeds the mask head.
 
     encoder level (sparse, stride 8)  --scn.SparseToDense-->  dense [B, C, X/8, Y/8, Z/8]
-        --dilation stack (Conv3d 3^3 + ReLU, torch / MIOpen: SURVEY §2 row 8 leaves the dense RPN to PyTorch)-->
+        --dilation stack (Conv3d 3^3 + ReLU; engine "tiles", the default: this library's tile kernels on a fully active grid;
+          engine "miopen": torch.nn.functional.conv3d -- SURVEY §2 row 8 leaves the dense RPN to PyTorch)-->
         --1x1x1 head--> per anchor 6 box deltas + 1 score          (anchor_network.py:73-124 `AnchorNetworkConv`)
-        --RoiSelector: detach, sigmoid, top-k (scn_topk_boxes), decode the selected anchors, greedy NMS (scn_nms_bits), keep `post`-->
+        --anchors that leave the scene dropped: deltas / scores / anchors compacted (anchor.py:103-113, :177-197)-->
+        --RoiSelector: detach, sigmoid, top-k (scn_topk_boxes), decode + clip the selected anchors, greedy NMS (scn_nms_bits), keep `post`-->
         list of fp32 boxes [n_i, 2, 3] per sample                    (proposal_selector.py:23-89; bbox.py:139-165,367-398)
 
 What this package contributes to it: SparseToDense (A13, scn_elem.hip), the one-launch NMS (proposals.py) and the consumer
@@ -64,6 +66,16 @@ class _DilateGather(torch.autograd.Function):
         return dP, db, None, None, None, None
 
 
+# the reference's anchor table (scannet_config/network.py:7-23, metres) at its input voxel size with the up-convoluted anchor
+# network (run.py:361: 0.0375 m): the three small anchors on the first anchor level, the eleven large ones on the second
+REF_RAW_ANCHORS_M = ((0.3752, 0.3752, 0.4221), (0.6566, 0.6566, 0.5159), (0.6566, 0.6566, 0.9380), (0.4221, 0.4221, 1.6415),
+                     (0.1876, 1.3132, 1.0318), (0.3283, 0.9849, 1.8291), (0.7035, 1.5008, 0.8442), (1.3132, 0.1876, 1.0318),
+                     (0.9849, 0.3283, 1.7822), (1.5008, 0.7035, 0.8442), (0.8442, 2.1574, 0.3752), (2.1574, 0.8442, 0.3752),
+                     (2.4857, 1.1256, 1.0318), (1.1256, 2.4857, 1.0318))
+REF_VOXEL_M = 0.0375
+REF_ANCHOR_LEVELS_VOXELS = tuple(tuple(tuple(v / REF_VOXEL_M for v in a) for a in lv)
+                                 for lv in (REF_RAW_ANCHORS_M[:3], REF_RAW_ANCHORS_M[3:]))
+
 # anchor edge lengths in voxels at the one anchor level (stride 8); the synthetic boxes of cfg 3 have edges 8-96
 DEFAULT_ANCHORS = ((12.0, 12.0, 12.0), (24.0, 24.0, 24.0), (48.0, 48.0, 32.0), (96.0, 96.0, 48.0))
 
@@ -79,9 +91,15 @@ class DenseRpn(nn.Module):
     # dilation gather (scn_dilate_gather_*) -- 1.3 GFLOP instead of the volume's 58; False: on the tile kernels like the rest
     SPARSE_FIRST = True
 
-    def __init__(self, channels, stride=8, width=32, num_dilations=2, anchors=DEFAULT_ANCHORS, autocast_bf16=False, engine=None):
+    def __init__(self, channels, stride=8, width=32, num_dilations=2, anchors=DEFAULT_ANCHORS, autocast_bf16=False, engine=None,
+                 keep_inside=True, allowed_border=0):
+        """keep_inside: return only the anchors that lie inside the scene (+ allowed_border), as the reference's
+        `rpn_bbox_score_splitter` does (anchor.py:103-113,177-197; `allowed_border=0`, scannet_config/run.py:841) -- deltas,
+        scores and anchors compacted in anchor order.  The reference's own shape is width 128 / 256 and num_dilations 5
+        (run.py:525-536,609): the defaults here are the light stand-in of `--workload cfg3-rpn` (trainstep.py)."""
         super().__init__()
         self.engine = engine
+        self.keep_inside, self.allowed_border = bool(keep_inside), float(allowed_border)
         self.channels, self.stride, self.width = int(channels), int(stride), int(width)
         self.to_dense = M.SparseToDense(3, self.channels)
         layers, cin = [], self.channels
@@ -95,10 +113,11 @@ class DenseRpn(nn.Module):
         self.autocast_bf16 = bool(autocast_bf16)
         self._anchor_cache = {}
         self._dense_md = {}
+        self._flag_host = {}
 
     def __getstate__(self):
         d = self.__dict__.copy()                 # (the fully active Metadata objects: device index structures, rebuilt on use)
-        d["_dense_md"], d["_anchor_cache"] = {}, {}
+        d["_dense_md"], d["_anchor_cache"], d["_flag_host"] = {}, {}, {}
         return d
 
     def anchors_for(self, shape, device):
@@ -111,6 +130,26 @@ class DenseRpn(nn.Module):
             a = torch.stack([g.expand(-1, sz.shape[1], -1), sz.expand(g.shape[0], -1, -1)], 2).reshape(-1, 2, 3)
             a = self._anchor_cache[key] = a.to(device)
         return a
+
+    def inside_for(self, shape, device):
+        """-> (int64 indices of the anchors of `anchors_for(shape)` that lie inside the scene, those anchors); cached per shape."""
+        key = ("inside", tuple(shape), str(device))
+        got = self._anchor_cache.get(key)
+        if got is None:
+            a = self.anchors_for(shape, device)
+            scene = torch.tensor([int(v) * self.stride for v in shape], dtype=torch.float32, device=a.device)
+            idx = inside_indicator(a, scene, self.allowed_border).nonzero().squeeze(1)
+            got = self._anchor_cache[key] = (idx, a[idx])
+        return got
+
+    def _finish(self, raw, shape):
+        """raw [B, N, 7] in anchor order -> (rpn_bbox, rpn_score, anchors), inside-the-scene anchors only when asked."""
+        if self.keep_inside:
+            idx, anchors = self.inside_for(shape, raw.device)
+            raw = raw.index_select(1, idx)
+        else:
+            anchors = self.anchors_for(shape, raw.device)
+        return raw[..., :6].reshape(raw.shape[0], -1, 2, 3), raw[..., 6], anchors
 
     # ---- "tiles": the dense volume as the slab of a fully active grid ------------------------------------------------------
     def dense_metadata(self, size, batch, device):
@@ -167,8 +206,16 @@ class DenseRpn(nn.Module):
             x = F.ReLUFunction.apply(x)
         Wh = self.head.weight.reshape(self.head.out_channels, self.head.in_channels).t()
         raw = F.NetworkInNetworkFunction.apply(x, Wh, self.head.bias)           # [B X Y Z, A * 7]: spatial-major, anchor-minor
-        raw = raw.view(B, -1, 7)
-        return raw[..., :6].reshape(B, -1, 2, 3), raw[..., 6], self.anchors_for(size, raw.device)
+        out = self._finish(raw.view(B, -1, 7), size)
+        # scn_cell_map's count of rows outside the volume (a level tensor whose spatial_size / batch disagrees with its
+        # coordinates): copied to pinned memory behind the launch, carried on rpn_score, read by RoiSelector.finish after the
+        # host wait it makes anyway
+        fh = self._flag_host.get(str(feats.device))
+        if fh is None:
+            fh = self._flag_host[str(feats.device)] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        fh.copy_(flag, non_blocking=True)
+        out[1].cell_flags = [fh]
+        return out
 
     def forward(self, level_tensor):
         if (self.engine or self.ENGINE) == "tiles" and level_tensor.features.is_cuda:
@@ -183,18 +230,68 @@ class DenseRpn(nn.Module):
         B = raw.shape[0]
         shape = raw.shape[2:]
         raw = raw.view(B, self.n_anchors, 7, -1).permute(0, 3, 1, 2).reshape(B, -1, 7)
-        rpn_bbox = raw[..., :6].reshape(B, -1, 2, 3)
-        rpn_score = raw[..., 6]
-        return rpn_bbox, rpn_score, self.anchors_for(shape, raw.device)
+        return self._finish(raw, shape)
 
 
-def decode_boxes(anchors, deltas):
+def inside_indicator(anchors, scene_shape, allowed_border=0.0):
+    """AnchorDescriptionMultiLevel.inside_indicator (ndsis/modules/anchor.py:103-113): anchors [N, 2, 3] = (centre, size),
+    True where start >= -border and end <= scene_shape + border on every axis (calc_start_end, utils/bbox.py:267-287)."""
+    half = anchors[..., 1, :] / 2
+    start, end = anchors[..., 0, :] - half, anchors[..., 0, :] + half
+    scene_shape = torch.as_tensor(scene_shape, dtype=anchors.dtype, device=anchors.device)
+    return torch.all(start >= -allowed_border, dim=-1) & torch.all(end <= scene_shape + allowed_border, dim=-1)
+
+
+def decode_boxes(anchors, deltas, scene_shape=None):
     """bbox_transform_inv (ndsis/utils/bbox.py:139-165,267-287,367-398): anchors (centre, size), deltas (position, log size)
-    -> boxes (start, stop).  fp32, same operation order as the reference."""
+    -> boxes (start, stop).  fp32, same operation order as the reference.  scene_shape: clip the boxes to [0, scene_shape]
+    as `AnchorDescriptionMultiLevel.forward` does (anchor.py:218-227, `clip_boxes` utils/bbox.py:16-34)."""
     pos = deltas[..., 0, :] * anchors[..., 1, :] + anchors[..., 0, :]
     size = torch.exp(deltas[..., 1, :]) * anchors[..., 1, :]
     half = size / 2
-    return torch.stack((pos - half, pos + half), dim=-2)
+    boxes = torch.stack((pos - half, pos + half), dim=-2)
+    if scene_shape is not None:
+        boxes = torch.min(boxes, torch.as_tensor(scene_shape, dtype=boxes.dtype, device=boxes.device)).clamp(min=0)
+    return boxes
+
+
+class MultiLevelRpn(nn.Module):
+    """The reference's RPN shape with several anchor levels (scannet_config/run.py:525-536: `upconvoluted_anchornetwork`,
+    one dilation network per anchor level, `anchor_output_channels = [128, 256]`, `num_dilations = 5` :609): one DenseRpn per
+    level -- SparseToDense of THAT encoder level, its own dilation stack, a 1x1 head for its own anchors -- the levels'
+    outputs concatenated in level order and the anchors that leave the scene dropped (`rpn_bbox_score_splitter`,
+    anchor.py:177-197).  The reference's heads are transposed convolutions that refine the anchor grid
+    (`AnchorNetworkUpsample`, anchor_network.py:127-219): dense torch modules, out of scope; the 1x1 heads
+    here keep every level's anchors on the level's own grid.
+    levels: [(channels, stride, width, anchors [A, 3] in voxels)];  forward(level_tensors) -> (rpn_bbox [B, N, 2, 3],
+    rpn_score [B, N], anchors [N, 2, 3]) over the inside anchors of all levels."""
+
+    def __init__(self, levels, num_dilations=5, autocast_bf16=False, engine=None, allowed_border=0):
+        super().__init__()
+        self.levels = nn.ModuleList(DenseRpn(c, stride, width, num_dilations, tuple(map(tuple, a)), autocast_bf16, engine,
+                                             keep_inside=False) for (c, stride, width, a) in levels)
+        self.allowed_border = float(allowed_border)
+        self._cache = {}
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_cache"] = {}
+        return d
+
+    def forward(self, level_tensors):
+        outs = [rpn(t) for rpn, t in zip(self.levels, level_tensors)]
+        scene = tuple(int(v) * self.levels[0].stride for v in level_tensors[0].spatial_size)
+        key = (scene, tuple(o[2].shape[0] for o in outs), str(outs[0][0].device))
+        got = self._cache.get(key)
+        if got is None:
+            anchors = torch.cat([o[2] for o in outs], 0)
+            idx = inside_indicator(anchors, torch.tensor(scene, dtype=torch.float32), self.allowed_border).nonzero().squeeze(1)
+            got = self._cache[key] = (idx, anchors[idx])
+        idx, anchors = got
+        rpn_bbox = torch.cat([o[0] for o in outs], 1).index_select(1, idx)
+        rpn_score = torch.cat([o[1] for o in outs], 1).index_select(1, idx)
+        rpn_score.cell_flags = [f for o in outs for f in getattr(o[1], "cell_flags", [])]
+        return rpn_bbox, rpn_score, anchors
 
 
 class RoiSelector(nn.Module):
@@ -207,14 +304,21 @@ class RoiSelector(nn.Module):
         self.proposal_selector = ProposalSelector(num_keep_pre_nms, num_keep_post_nms, thresh_nms)
         self.detach = detach
 
-    def forward(self, rpn_bbox, rpn_score, anchors):
-        return self.finish(self.start(rpn_bbox, rpn_score, anchors))
+    def forward(self, rpn_bbox, rpn_score, anchors, scene_shape=None):
+        return self.finish(self.start(rpn_bbox, rpn_score, anchors, scene_shape))
 
-    def start(self, rpn_bbox, rpn_score, anchors):
-        """Everything up to and including the NMS launch, nothing awaited (ProposalSelector.start)."""
+    def start(self, rpn_bbox, rpn_score, anchors, scene_shape=None):
+        """Everything up to and including the NMS launch, nothing awaited (ProposalSelector.start).  scene_shape: the
+        proposals are clipped to the scene, as `anchor_description(rpn_bbox)` does in the reference (anchor.py:218-227)."""
+        flags = getattr(rpn_score, "cell_flags", [])
         if self.detach:
             rpn_bbox, rpn_score = rpn_bbox.detach(), rpn_score.detach()
-        return self.proposal_selector.start_from_deltas(torch.sigmoid(rpn_score), rpn_bbox, anchors, decode_boxes)
+        decode = decode_boxes if scene_shape is None else (lambda a, d: decode_boxes(a, d, scene_shape))
+        return self.proposal_selector.start_from_deltas(torch.sigmoid(rpn_score), rpn_bbox, anchors, decode) + (flags,)
 
     def finish(self, state):
-        return self.proposal_selector.finish(state)
+        out = self.proposal_selector.finish(state[:4])          # (waits on the host: the pinned cell flags are complete)
+        if any(int(f[0]) != 0 for f in state[4]):
+            raise L.ScnError("DenseRpn: rows of a level tensor lie outside its spatial_size / batch (scn_cell_map counted "
+                             f"{[int(f[0]) for f in state[4]]}): its Metadata and its coordinates disagree")
+        return out

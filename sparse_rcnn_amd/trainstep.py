@@ -6,10 +6,21 @@ Workloads (BASELINE.json configs; SURVEY.md §8d synthetic inputs):
   cfg2  configs[1]  one ~150k-voxel scene, U-Net backbone 32-64-128-256
   cfg3  configs[2] WITHOUT its RPN ("crop + mask branch only"): cfg2 + 64 synthetic boxes per scene, known before the
                     forward -> sparse ROI crop -> mask branch (maskhead.MaskBranch)
-  cfg3-rpn  configs[2] as written: backbone -> SparseToDense of the anchor level -> dense dilation stack + 1x1 heads
-                    (torch / MIOpen) -> RoiSelector (top-k + one-launch NMS) -> <= 64 boxes per scene -> sparse ROI crop ->
-                    mask branch -> backward through both (rpn.py; model.py:116-240, anchor_network.py:73-124,
-                    proposal_selector.py:23-89).  The boxes exist only after the heads have produced them.
+  cfg3-rpn  configs[2] with the RPN boundary INSIDE the step: backbone -> SparseToDense of the anchor level -> dense dilation
+                    stack + 1x1 heads (rpn.DenseRpn: by default on THIS library's tile kernels, engine "tiles" -- a dense
+                    same-convolution is a submanifold convolution on a fully active grid) -> anchors that leave the scene
+                    dropped (anchor.py:103-113) -> RoiSelector (top-k + one-launch NMS) -> <= 64 boxes per scene -> sparse ROI
+                    crop -> mask branch -> backward through both (rpn.py; model.py:116-240, anchor_network.py:73-124,
+                    proposal_selector.py:23-89).  The boxes exist only after the heads have produced them.  Its RPN is a
+                    STAND-IN, lighter than the reference's: ONE anchor level with a 2 x 32 dilation stack and 64 proposals
+                    kept (BASELINE configs[2]: "~64 proposals/scene"), where scannet_config/run.py:339,525-536,609,847-853
+                    builds two anchor levels with 5 x 128 / 5 x 256 stacks and keeps 256 -- `ref-crop-rpn` has that shape.
+  ref-crop-rpn  the reference's own detection step as far as this path reaches: plan 32-48-64-80-96-112 on its training batch
+                    (12 crops of 128 x 128 x 64, run.py:364,485-488), SparseToDense of BOTH anchor levels (stride 4: 64 ch,
+                    stride 8: 80 ch), a 5 x 128 and a 5 x 256 dilation stack (run.py:525-536,609), 3 + 11 anchors per cell
+                    (scannet_config/network.py:7-45) behind 1x1 heads (NOT AnchorNetworkUpsample's transposed convolutions:
+                    dense, out of scope), inside-the-scene anchors only, top-1024 / NMS 0.5 / 256 kept (run.py:847-853), boxes
+                    clipped to the scene (anchor.py:218-225), sparse ROI crop + mask branch.
   cfg5  configs[4]  one ~600k-voxel scene, 5-level U-Net to 512 channels
 configs[3] (8 scenes data-parallel) is cfg3 with one scene per rank.
 """
@@ -34,6 +45,8 @@ WORKLOADS = {      # name -> (channels, grid, active voxels per sample, boxes pe
     # ... on its own training input: 12 random crops of 128 x 128 x 64 voxels per batch (run.py:364,485-488)
     "ref-crop": (REF_PLAN, (128, 128, 64), 12_500, 0, "the reference's training batch: 12 crops of 128x128x64 voxels, "
                  "plan 32-48-64-80-96-112", 12),
+    "ref-crop-rpn": (REF_PLAN, (128, 128, 64), 12_500, 256, "the reference's training batch (12 crops of 128x128x64, plan "
+                     "32-48-64-80-96-112) with its RPN shape: two anchor levels, 5x128 / 5x256 dilation stacks, 256 kept", 12),
 }
 
 
@@ -49,10 +62,6 @@ LATE_PREFETCH = _os.environ.get("SCN_LATE_PREFETCH", "1") != "0"
 # backward on the calling thread (torch.autograd.set_multithreading_enabled(False)): no hand-off to the device thread per step
 # (A/B inside one process, profiles/r5_ab_inproc.txt: cfg 3 bf16 7.13 -> 6.51 ms per step, cfg 2 bf16 3.44 -> 3.31, fp32 neutral)
 BACKWARD_INLINE = _os.environ.get("SCN_BACKWARD_INLINE", "1") != "0"
-# measurement only (tools/r5_ab_inproc.py): every step re-uses the index structures of the first one -- the bound of a
-# perfectly hidden index build (one scene repeated: the structures are the same anyway)
-REUSE_INDEX = False
-_reused_md = {}
 
 
 def _backward(roots, grads):
@@ -67,19 +76,36 @@ class SparseStepModel(torch.nn.Module):
     """Backbone (+ mask branch for cfg3) as one module, so that one flat parameter buffer covers the step."""
 
     def __init__(self, channels, with_mask, storage, with_rpn=False, n_boxes=64):
+        """with_rpn: False | "stand-in" (cfg3-rpn: one anchor level, 2 x 32 stack) | "reference" (ref-crop-rpn: the reference's two
+        anchor levels with 5 x 128 / 5 x 256 stacks, rpn.MultiLevelRpn)."""
         super().__init__()
         self.backbone = Backbone(7, channels, bf16_blocks=storage)
         self.mask = MaskBranch(channels[0], 7, bf16_blocks=storage) if with_mask else None
         self.rpn = self.roi_selector = None
-        if with_rpn:                 # one anchor path on the coarsest level (run.py:524: num_anchor_pathes = 1), stride 2^(L-1)
+        self.rpn_levels = None                 # indices of the encoder levels the RPN reads
+        if with_rpn == "reference":
+            from .rpn import MultiLevelRpn, RoiSelector, REF_ANCHOR_LEVELS_VOXELS
+            # run.py:525-549: anchor paths on the two levels behind the in-between downsamplers (64 ch at stride 4, 80 ch at
+            # stride 8 in the plan 32-48-64-80-96-112), anchor_output_channels = [128, 256], num_dilations = 5 (run.py:609)
+            self.rpn_levels = (2, 3)
+            self.rpn = MultiLevelRpn([(channels[2], 4, 128, REF_ANCHOR_LEVELS_VOXELS[0]),
+                                      (channels[3], 8, 256, REF_ANCHOR_LEVELS_VOXELS[1])], num_dilations=5,
+                                     autocast_bf16=bool(storage))
+            self.roi_selector = RoiSelector(1024, n_boxes, 0.5)          # run.py:847-853: 1024 / 256 / 0.5
+        elif with_rpn:               # one anchor path on the coarsest level (run.py:524: num_anchor_pathes = 1), stride 2^(L-1)
             from .rpn import DenseRpn, RoiSelector
+            self.rpn_levels = (len(channels) - 1,)
             self.rpn = DenseRpn(channels[-1], stride=2 ** (len(channels) - 1), autocast_bf16=bool(storage))
             self.roi_selector = RoiSelector(1024, n_boxes, 0.5)          # run.py:848-850 with ~64 proposals kept per scene
+
+    def run_rpn(self, interims):
+        lv = [interims[i] for i in self.rpn_levels]
+        return self.rpn(lv if len(lv) > 1 else lv[0])
 
 
 class SceneStep:
     def __init__(self, workload="cfg2", device=None, dtype="f32", prefetch=True, seed=1, grad_seed=100, n_buckets=4,
-                 target=None, channels=None, grid=None, n_boxes=None, lr=1e-6, weighting="equal", batches_per_step=1):
+                 target=None, channels=None, grid=None, n_boxes=None, lr=None, weighting="equal", batches_per_step=1):
         """batches_per_step: micro-batches whose gradients are accumulated before ONE all-reduce + update, each scaled by
         1 / batches_per_step -- the reference's `(loss / batches_per_step).backward()` ... `optimizer.step()`
         (ndsis/training/training.py:436,458-460; 2 or 6 with the mask head, scannet_config/run.py:377-396).  Micro-batch k
@@ -88,11 +114,12 @@ class SceneStep:
         (each rank in proportion to its active voxels: what a loss normalised by batch-level counts gives when the
         batch is sharded one scene per rank, loss.py:401-431; the counts are summed over ranks once per step)."""
         ch, gr, tg, nb, self.baseline_entry, n_samples = WORKLOADS[workload]
-        self.workload, self.dtype, self.prefetch, self.lr = workload, dtype, prefetch, lr
-        if workload.endswith("-rpn") and lr == 1e-6:
-            # the SAME synthetic gradient on 3.7 M RPN outputs every step is a steady push, not noise: at 1e-6 the score field
-            # grows 4 % per step and overflows within a bench run (profiles/r5_rpn_stats.txt); the update itself is unchanged
-            self.lr = 1e-8
+        self.workload, self.dtype, self.prefetch = workload, dtype, prefetch
+        # lr=None: the workload's default (reported by describe() and in bench.py's line).  1e-6, and 1e-8 with an RPN in the
+        # step: the SAME synthetic gradient on 3.7 M RPN outputs every step is a steady push, not noise -- at 1e-6 the score
+        # field grows 4 % per step and overflows within a bench run (profiles/r5_rpn_stats.txt); the update itself (one SGD
+        # pass over the flat buffer) is the same work.  An explicit lr is used as given.
+        self.lr = (1e-8 if workload.endswith("-rpn") else 1e-6) if lr is None else float(lr)
         if weighting not in ("equal", "count"):
             raise ValueError("weighting: equal | count")
         self.weighting = weighting
@@ -119,7 +146,12 @@ class SceneStep:
         self._use_scene(0)
         torch.manual_seed(0)
         self.with_rpn = workload.endswith("-rpn")
-        self.model = SparseStepModel(self.channels, bool(self.n_boxes), storage, self.with_rpn, self.n_boxes).to(self.device)
+        # ref-crop-rpn: 256 proposals per sample survive the selection (run.py:847-853); the mask network then works on the
+        # <= 24 its TrainSelector draws from them (mask_network_params.selection_tuple = (24, 0, True), run.py:799-810;
+        # model.py:919-1014 draws by ground-truth overlap -- out of scope: here the 24 best-scored ones)
+        self.mask_boxes = 24 if workload == "ref-crop-rpn" else None
+        rpn_kind = "reference" if workload == "ref-crop-rpn" else ("stand-in" if self.with_rpn else False)
+        self.model = SparseStepModel(self.channels, bool(self.n_boxes), storage, rpn_kind, self.n_boxes).to(self.device)
         if self.with_rpn:
             self._init_rpn()
         self.flat = FlatParams(self.model, n_buckets=n_buckets)
@@ -141,16 +173,31 @@ class SceneStep:
         self.coords, self.feats, self.boxes = sc["coords"], sc["feats"], sc["boxes"]
         self._k = k
 
+    def _scene_shape(self):
+        return tuple(float(v) for v in self.size)
+
     def _init_rpn(self):
         """Random-init heads give near-constant scores; the synthetic RPN gets a head whose scores spread (so that top-k and
         NMS have something to decide) -- seeded, the same on every rank."""
         g = torch.Generator().manual_seed(1234)
+        rpn = self.model.rpn
         with torch.no_grad():
-            h = self.model.rpn.head
-            w = torch.randn(h.weight.shape, generator=g) * 0.02              # box deltas: boxes stay near their anchors
-            w[6::7] = torch.randn(w[6::7].shape, generator=g) * 0.5          # channel a*7+6 = the score of anchor a
-            h.weight.copy_(w.to(h.weight.device))
-            h.bias.zero_()
+            for h in ([r.head for r in rpn.levels] if hasattr(rpn, "levels") else [rpn.head]):
+                w = torch.randn(h.weight.shape, generator=g) * 0.02              # box deltas: boxes stay near their anchors
+                w[6::7] = torch.randn(w[6::7].shape, generator=g) * 0.5          # channel a*7+6 = the score of anchor a
+                h.weight.copy_(w.to(h.weight.device))
+                h.bias.zero_()
+
+    def _take_index(self, k):
+        """The index structures of micro-batch k if a helper thread built them (else None: the forward builds them)."""
+        md = self._md_next.result() if self._md_next is not None else None
+        self._md_next = None
+        return md
+
+    def _start_prefetch(self, k):
+        if self.prefetch and self._md_next is None:
+            nx = self._scenes[(k + 1) % self.batches_per_step]
+            self._md_next = self.model.backbone.prefetch_in_thread(nx["coords"], nx["size"], nx["batch_size"])
 
     def upstream_grads(self, k=0):
         """(dY of the backbone output, dY of the mask logits or None) of micro-batch k, BEFORE the 1 / batches_per_step scale."""
@@ -167,64 +214,19 @@ class SceneStep:
             self._use_scene(k)
         scale = 1.0 / self.batches_per_step
         fin = self.feats.detach().requires_grad_()
-        md = self._md_next.result() if self._md_next is not None else None
-        self._md_next = None
-        if REUSE_INDEX:
-            from .metadata import Metadata
-            if REUSE_INDEX in (3, 4, 5, 6, 7):  # (measurement: what of a helper-thread build costs the step when the build itself is
-                from .metadata import PendingMetadata, index_stream        #  taken away: 3 = an empty job on the helper thread,
-                pend = _reused_md.pop("tiny_pending", None)                #  4 = + the workspace allocation on the index stream,
-                if pend is not None:                                       #  5 = + one small kernel and a device->host wait there)
-                    pend.result()
-                dev, mode = self.device, REUSE_INDEX
-
-                def job():
-                    torch.cuda.set_device(dev)
-                    if mode >= 4:
-                        side = index_stream(dev)
-                        with torch.cuda.stream(side):
-                            ws = torch.empty(40 << 20, dtype=torch.uint8, device=dev)
-                            if mode == 5:
-                                ws[:1024].zero_()
-                                int(ws[:8].sum().item())
-                            if mode >= 6:                          # 6 / 7 = 17 / 68 one-workgroup kernels on the index stream
-                                for _ in range(17 if mode == 6 else 68):
-                                    ws[:256].zero_()
-                                side.synchronize()
-                    return None
-                _reused_md["tiny_pending"] = PendingMetadata(job)
-            if REUSE_INDEX == 2:          # (measurement: the helper thread still builds -- a TINY scene: host side of a build only)
-                tiny = _reused_md.get("tiny")
-                if tiny is None:
-                    from .synthetic import make_batch
-                    c, _, sz, bs_, _ = make_batch(1, (64, 64, 32), 2000, dup=1.15, seed=5)
-                    tiny = _reused_md["tiny"] = (c.to(self.device), sz, bs_)
-                pend = _reused_md.pop("tiny_pending", None)
-                if pend is not None:
-                    pend.result()
-                _reused_md["tiny_pending"] = m.backbone.prefetch_in_thread(*tiny)
-            base = _reused_md.get((id(self), k))
-            if base is None and md is not None:
-                base = _reused_md[(id(self), k)] = md
-            if base is not None:
-                md = Metadata(3)
-                md.__dict__.update(base.__dict__)
-                md.ready_event = None
+        md = self._take_index(k)
         # the index structures of the NEXT batch depend on its coordinates only (a data loader's output): a helper thread
         # builds them on the high-priority index stream while this batch runs; every step contains one complete build
-        def start_prefetch():
-            if self.prefetch and self._md_next is None and not (REUSE_INDEX and (id(self), k) in _reused_md):
-                nx = self._scenes[(k + 1) % self.batches_per_step]
-                self._md_next = m.backbone.prefetch_in_thread(nx["coords"], nx["size"], nx["batch_size"])
         if not LATE_PREFETCH:
-            start_prefetch()
+            self._start_prefetch(k)
         # cfg3-rpn: the RPN reads the ENCODER outputs only (model.py:141-160), so its heads, top-k and NMS are queued between
         # encoder and decoder, and the one host wait of the selection falls while the decoder's kernels run
         rpn_state = {}
 
         def rpn_after_encoder(interims):
-            rpn_bbox, rpn_score, anchors = m.rpn(interims[-1])
-            rpn_state["out"] = (rpn_bbox, rpn_score, anchors, m.roi_selector.start(rpn_bbox, rpn_score, anchors))
+            rpn_bbox, rpn_score, anchors = m.run_rpn(interims)
+            rpn_state["out"] = (rpn_bbox, rpn_score, anchors,
+                                m.roi_selector.start(rpn_bbox, rpn_score, anchors, self._scene_shape()))
         hook = rpn_after_encoder if (self.with_rpn and RPN_BEFORE_DECODER) else None
         # cfg3: the ROI crop's selection and the ROI batch's index structures depend on coordinates and boxes only -- the
         # boxes of a step are known before its backbone runs (here: synthetic; in the reference: the RPN's proposals of
@@ -233,7 +235,7 @@ class SceneStep:
         if m.mask is not None and EARLY_ROI_CUT:
             cut = m.mask.prepare_cut(self.coords, self.size, self.boxes)      # (resident int64 coords: no dependency on md)
         out = m.backbone(self.coords, fin, self.size, self.batch_size, metadata=md, after_encoder=hook)
-        start_prefetch()             # (LATE_PREFETCH: the helper thread is started once this batch's forward kernels are queued)
+        self._start_prefetch(k)      # (LATE_PREFETCH: the helper thread is started once this batch's forward kernels are queued)
         gy = self._gys.get(k)
         if gy is None or gy.shape != out.features.shape:
             gy = self._gys[k] = torch.randn(out.features.shape, generator=self._gen).to(self.device)   # upstream grad dY ~ N(0,1)
@@ -263,6 +265,8 @@ class SceneStep:
                 rpn_bbox, rpn_score, anchors, sel_state = rpn_state["out"]
                 roi_score, boxes, roi_index = m.roi_selector.finish(sel_state)
                 self.rpn_out = (rpn_bbox, rpn_score, anchors, roi_score, boxes, roi_index)
+                if self.mask_boxes is not None:       # (the reference's mask head trains on <= 24 selected proposals per sample)
+                    boxes = [b[:self.mask_boxes] for b in boxes]
                 gr = self._grs.get(k)
                 if gr is None or gr[0].shape != rpn_bbox.shape:
                     gr = self._grs[k] = tuple((torch.randn(t.shape, generator=self._gen) * 1e-3).to(self.device)
@@ -300,11 +304,8 @@ class SceneStep:
         m = self.model
         if k != self._k:
             self._use_scene(k)
-        md = self._md_next.result() if self._md_next is not None else None
-        self._md_next = None
-        if self.prefetch:
-            nx = self._scenes[(k + 1) % self.batches_per_step]
-            self._md_next = m.backbone.prefetch_in_thread(nx["coords"], nx["size"], nx["batch_size"])
+        md = self._take_index(k)
+        self._start_prefetch(k)
         with torch.no_grad():
             out = m.backbone(self.coords, self.feats, self.size, self.batch_size, metadata=md)
             logits = None
@@ -312,8 +313,10 @@ class SceneStep:
                 scene = (self.coords, self.feats, self.size, self.batch_size, self.splits)
                 boxes = self.boxes
                 if self.with_rpn:
-                    rpn_bbox, rpn_score, anchors = m.rpn(m.backbone.unet.interims[-1])
-                    _, boxes, _ = m.roi_selector(rpn_bbox, rpn_score, anchors)
+                    rpn_bbox, rpn_score, anchors = m.run_rpn(m.backbone.unet.interims)
+                    _, boxes, _ = m.roi_selector(rpn_bbox, rpn_score, anchors, self._scene_shape())
+                    if self.mask_boxes is not None:
+                        boxes = [b[:self.mask_boxes] for b in boxes]
                 logits, _ = m.mask(scene, out, boxes)
         return out, logits
 
@@ -341,11 +344,27 @@ class SceneStep:
              + "-".join(map(str, self.channels)) + ", 2 pre-act residual blocks/level, 2^3/2 conv+deconv")
         if self.n_boxes and self.with_rpn:
             r = self.model.rpn
-            s += (f"; + RPN boundary INSIDE the step: SparseToDense of the stride-{r.stride} level ({r.channels} ch) -> dense "
-                  f"dilation stack {r.channels}-{r.width}-{r.width} (3^3, torch/MIOpen) + 1x1 head ({r.n_anchors} anchors/cell) "
-                  f"-> sigmoid, top-1024, one-launch NMS 0.5, <= {self.n_boxes} boxes/scene -> sparse ROI crop "
-                  f"({self.n_roi_rows} cropped points) -> mask branch (SubM1 + 2 units @16, internal U-Net 23-32-48-64, "
-                  "Linear 23-32-18); backward from the backbone output, rpn_bbox, rpn_score and the mask logits")
+            sel = (f"-> anchors that leave the scene dropped (anchor.py:103-113) -> sigmoid, top-1024, boxes clipped to the scene, "
+                   f"one-launch NMS 0.5, <= {self.n_boxes} boxes/sample" + (f", the {self.mask_boxes} best of them per sample" if self.mask_boxes else "")
+                   + f" -> sparse ROI crop ({self.n_roi_rows} cropped points) -> mask "
+                   "branch (SubM1 + 2 units @16, internal U-Net 23-32-48-64, Linear 23-32-18); backward from the backbone "
+                   "output, rpn_bbox, rpn_score and the mask logits")
+            if hasattr(r, "levels"):
+                eng = r.levels[0].engine or r.levels[0].ENGINE
+                s += ("; + the REFERENCE's RPN shape INSIDE the step (run.py:525-536,609,847-853): " + " + ".join(
+                    f"SparseToDense of the stride-{l.stride} level ({l.channels} ch) -> dense dilation stack {l.channels}"
+                    + f"-{l.width}" * (len(l.stack) // 2) + f" (3^3) + 1x1 head ({l.n_anchors} anchors/cell)" for l in r.levels)
+                    + f", dense layers on engine '{eng}' "
+                    + ("(this library's tile kernels on a fully active grid)" if eng == "tiles" else "(torch / MIOpen conv3d)")
+                    + "; 1x1 heads instead of AnchorNetworkUpsample's transposed convolutions (dense, out of scope) " + sel)
+            else:
+                eng = r.engine or r.ENGINE
+                s += (f"; + RPN boundary INSIDE the step, a STAND-IN lighter than the reference's (one anchor level, 2 x {r.width} "
+                      f"stack, {self.n_boxes} kept; the reference: two levels, 5 x 128 / 5 x 256, 256 kept -- `ref-crop-rpn`): "
+                      f"SparseToDense of the stride-{r.stride} level ({r.channels} ch) -> dense dilation stack {r.channels}"
+                      + f"-{r.width}" * (len(r.stack) // 2) + f" (3^3, engine '{eng}': "
+                      + ("this library's tile kernels on a fully active grid" if eng == "tiles" else "torch / MIOpen conv3d")
+                      + f") + 1x1 head ({r.n_anchors} anchors/cell) " + sel)
         elif self.n_boxes:
             s += (f"; + {self.n_boxes} fp32 boxes/scene (edges 8-96 voxels) -> sparse ROI crop ({self.n_roi_rows} cropped "
                   "points) -> mask branch (SubM1 + 2 units @16, internal U-Net 23-32-48-64, Linear 23-32-18); CROP + MASK "
@@ -354,7 +373,8 @@ class SceneStep:
         if self.batches_per_step > 1:
             s += (f"; {self.batches_per_step} micro-batches (scenes) accumulated per optimizer step (training.py:436,458-460), "
                   "voxels = all of them")
-        s += "; step = rulebooks + fwd + bwd (+ grad all-reduce + SGD)"
+        s += (f"; step = rulebooks + fwd + bwd (+ grad all-reduce) + plain SGD on the flat parameter buffer, lr {self.lr:g} "
+              "(the reference trains with Adam, scannet_config/run.py:1449: three more passes over the buffer)")
         if self.prefetch:
             s += "; rulebooks of batch i+1 built on a helper thread during batch i"
         return s

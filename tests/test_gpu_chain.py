@@ -102,3 +102,36 @@ def test_chain_switch_off_runs_plain_launches():
     assert launches == 0
     for a, b in zip(plain, chained):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("g0", [4, 8, 12])
+@pytest.mark.parametrize("c,down", [(32, 0), (64, 1), (128, 2)])
+def test_progressive_staging_is_bit_equal(c, down, g0):
+    """SCN_TS_PROG (round 6, profiles/r6_prog_staging.txt): the forward weight slice staged by LDS-DMA in offset order, the first
+    tile started behind the first g0 offsets -- a different way into LDS, the same arithmetic: same bits, every launch."""
+    from sparse_rcnn_amd import _lib as L
+    lib = L.lib()
+    rb = _level(60000, down)
+    n, t = rb.n, rb.tiles
+    g = torch.Generator(device="cuda").manual_seed(11 * c + g0)
+    X = torch.randn(n, c, device="cuda", generator=g)
+    W = torch.randn(27, c, c, device="cuda", generator=g) * (0.3 / c ** 0.5)
+    B = torch.randn(c, device="cuda", generator=g) * 0.1
+    R = torch.randn(n, c, device="cuda", generator=g)
+    scr = torch.empty(max(1, lib.scn_conv_tiles_scratch_bytes(c, n, c)), dtype=torch.uint8, device="cuda")
+    arr_t = torch.zeros(max(1, lib.scn_conv_tiles_arrival_counters(c, n, c)), dtype=torch.int32, device="cuda")
+    arr = L.ptr(arr_t) if c > 32 else 0
+
+    def run(Y, flags):
+        L.check(lib.scn_conv_tiles(L.ptr(X), n, c, L.ptr(t.tstab), L.ptr(t.tile_mask), L.ptr(t.perm), L.ptr(t.tile_order), 27, n,
+                                   L.ptr(W), L.ptr(B), L.ptr(R), 0, L.ptr(Y), c, flags, L.ptr(scr), arr, L.stream()))
+    for flags in (0, 1, 4):                    # plain, fused input ReLU, reversed offsets (forward-layout weights)
+        Ya = torch.full((n, c), float("nan"), device="cuda")
+        Yb = torch.full((n, c), float("nan"), device="cuda")
+        run(Ya, flags)
+        with L.debug_switch("SCN_TS_PROG", g0):
+            for _ in range(5):
+                run(Yb, flags)
+        torch.cuda.synchronize()
+        assert not torch.isnan(Yb).any()
+        assert torch.equal(Ya, Yb), f"flags {flags}: progressive staging differs from the classic staging"

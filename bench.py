@@ -239,6 +239,9 @@ def run(args):
     import sparse_rcnn_amd  # noqa: F401
     from sparse_rcnn_amd import profiling
     from sparse_rcnn_amd.trainstep import SceneStep
+    # torch's intra-op CPU pool follows os.cpu_count() (256 on a GPU box whose job owns 16 cores): a CPU operator that enters it
+    # stalls the step by tens of milliseconds every few calls (round 6: profiles/r6_ref_crop_rpn.txt) -- size it to the share
+    torch.set_num_threads(_host_threads())
 
     # one balanced scene per rank (cfg 2: seed 1; cfg 4 style: seeds 10+rank)
     seed = 1 if world == 1 else 10 + rank

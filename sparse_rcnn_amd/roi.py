@@ -60,8 +60,9 @@ def transform_boxes(bbox_batch, spatial_size=None, clip=False, resize=None):
     dev = torch.device("cuda", torch.cuda.current_device())
     counts = [len(b) for b in bbox_batch]
     bb = sum(counts)
-    assoc = torch.repeat_interleave(torch.arange(len(counts)), torch.tensor(counts, dtype=torch.long)) \
-        if counts else torch.zeros(0, dtype=torch.long)
+    # (a Python list, not torch.repeat_interleave: that CPU operator enters torch's intra-op thread pool, which on a box whose
+    #  cpu_count() exceeds the job's share stalls the step by tens of milliseconds every few calls -- profiles/r6_ref_crop_rpn.txt)
+    assoc = torch.tensor([s for s, c in enumerate(counts) for _ in range(c)], dtype=torch.long)
     out = torch.empty((bb, 8), dtype=torch.int32, device=dev)
     if bb:
         raw = torch.cat([b.reshape(-1, 2, 3) for b in bbox_batch]).to(device=dev, dtype=torch.float32).contiguous()

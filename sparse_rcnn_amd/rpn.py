@@ -281,11 +281,16 @@ class MultiLevelRpn(nn.Module):
     def forward(self, level_tensors):
         outs = [rpn(t) for rpn, t in zip(self.levels, level_tensors)]
         scene = tuple(int(v) * self.levels[0].stride for v in level_tensors[0].spatial_size)
-        key = (scene, tuple(o[2].shape[0] for o in outs), str(outs[0][0].device))
+        return self.combine(outs, scene)
+
+    def combine(self, outs, scene_shape):
+        """Per-level (rpn_bbox, rpn_score, anchors) over ALL anchors of each level -> the reference's concatenation in level
+        order with the anchors that leave `scene_shape` dropped (`rpn_bbox_score_splitter`, anchor.py:177-197)."""
+        key = (tuple(scene_shape), tuple(o[2].shape[0] for o in outs), str(outs[0][0].device))
         got = self._cache.get(key)
         if got is None:
             anchors = torch.cat([o[2] for o in outs], 0)
-            idx = inside_indicator(anchors, torch.tensor(scene, dtype=torch.float32), self.allowed_border).nonzero().squeeze(1)
+            idx = inside_indicator(anchors, torch.tensor(scene_shape, dtype=torch.float32), self.allowed_border).nonzero().squeeze(1)
             got = self._cache[key] = (idx, anchors[idx])
         idx, anchors = got
         rpn_bbox = torch.cat([o[0] for o in outs], 1).index_select(1, idx)
@@ -303,6 +308,7 @@ class RoiSelector(nn.Module):
         super().__init__()
         self.proposal_selector = ProposalSelector(num_keep_pre_nms, num_keep_post_nms, thresh_nms)
         self.detach = detach
+        self._scene_cache = {}                   # (scene shape, device) -> device tensor: no host-to-device copy per step
 
     def forward(self, rpn_bbox, rpn_score, anchors, scene_shape=None):
         return self.finish(self.start(rpn_bbox, rpn_score, anchors, scene_shape))
@@ -313,6 +319,12 @@ class RoiSelector(nn.Module):
         flags = getattr(rpn_score, "cell_flags", [])
         if self.detach:
             rpn_bbox, rpn_score = rpn_bbox.detach(), rpn_score.detach()
+        if scene_shape is not None and not torch.is_tensor(scene_shape):
+            key = (tuple(float(v) for v in scene_shape), str(rpn_bbox.device))
+            t = self._scene_cache.get(key)
+            if t is None:
+                t = self._scene_cache[key] = torch.tensor(key[0], dtype=torch.float32, device=rpn_bbox.device)
+            scene_shape = t
         decode = decode_boxes if scene_shape is None else (lambda a, d: decode_boxes(a, d, scene_shape))
         return self.proposal_selector.start_from_deltas(torch.sigmoid(rpn_score), rpn_bbox, anchors, decode) + (flags,)
 

@@ -457,58 +457,72 @@ def test_cfg3_end_to_end_backbone_crop_mask_vs_oracle_at_150k(gpu, dtype):
         _check_grad_frozen(name, "grad " + k, got[k], grads[k].view_as(got[k]), FROZEN_L2_F32)
 
 
-def test_cfg3_rpn_chain_vs_oracle_at_150k(gpu):
-    """BASELINE configs[2] AS WRITTEN at size: trainstep.SceneStep("cfg3-rpn") -- the step
-    `bench.py --workload cfg3-rpn` times -- on the 150k-voxel scene.  The boxes do not exist before the forward: backbone ->
-    SparseToDense of the stride-8 encoder level -> dense dilation stack + 1x1 head (torch / MIOpen) -> RoiSelector (sigmoid,
-    top-1024, one-launch NMS, <= 64 kept) -> sparse ROI crop with THOSE boxes -> mask branch; backward from the backbone
-    output, rpn_bbox, rpn_score and the mask logits (model.py:116-240, anchor_network.py:73-124, proposal_selector.py:23-89).
-    Against the oracle: SparseToDense of the oracle's level-3 slab, the same dense layers on the CPU, rpn outputs within 1e-4
-    of their scale; the selection -- made on the DEVICE's scores, as in test_rpn_boundary_chain...: two evaluations of a
-    1.2 M-anchor score field differ in their last bits and top-k ties -- equals the oracle's greedy NMS on the device's sorted
-    boxes bit for bit; crop, logits and ALL gradients (76 backbone + 6 dense RPN + 80 mask tensors + the input features) with
-    the ReLU masks of the HIP forward frozen into the oracle."""
+def _rpn_chain_vs_oracle(gpu, workload, name):
+    """The detection + mask step with the RPN boundary inside (`trainstep.SceneStep(workload)`, the step bench.py times) against
+    the oracle.  The boxes do not exist before the forward: backbone -> SparseToDense of the anchor level(s) -> dense dilation
+    stack(s) + 1x1 head(s) (on this package's tile kernels: rpn.DenseRpn engine "tiles") -> anchors that leave the scene dropped
+    -> RoiSelector (sigmoid, top-1024, decode + clip, one-launch NMS, <= n kept) -> sparse ROI crop with THOSE boxes -> mask
+    branch; backward from the backbone output, rpn_bbox, rpn_score and the mask logits (model.py:116-240,
+    anchor_network.py:73-124, anchor.py:177-227, proposal_selector.py:23-89).
+    Oracle side: SparseToDense of the oracle's encoder slabs, the same dense layers as torch CPU conv3d (their ReLUs frozen to
+    the device's sign masks like every other ReLU of the chain), rpn outputs within 1e-4 of their scale; the selection -- made
+    on the DEVICE's scores: two evaluations of a large score field differ in their last bits and in top-k ties -- equals the
+    oracle's greedy NMS on the device's sorted boxes bit for bit; crop, logits and ALL gradients (backbone + dense RPN + mask
+    tensors + the input features) with the ReLU masks of the HIP forward frozen into the oracle."""
     import copy
     from sparse_rcnn_amd import rpn as R
+    from sparse_rcnn_amd import trainstep as TS
     from sparse_rcnn_amd.trainstep import SceneStep
-    job = SceneStep("cfg3-rpn", gpu, dtype="f32", prefetch=False, seed=1, grad_seed=100, lr=0.0)
+    job = SceneStep(workload, gpu, dtype="f32", prefetch=False, seed=1, grad_seed=100, lr=0.0)
     m = job.model
     with torch.no_grad():
         g = torch.Generator().manual_seed(21)
         for n_, p in m.named_parameters():
-            if p.dim() == 1 and not n_.startswith("rpn.head"):
+            if p.dim() == 1 and ".head." not in n_ and not n_.startswith("rpn.head"):
                 p.copy_(torch.randn(p.shape, generator=g) * 0.05)
     with _record_relu_masks() as masks:
         job.forward_backward()
     torch.cuda.synchronize()
-    # 31 backbone masks, the 2 ReLUs of the dense stack (the "tiles" engine runs it on this package's kernels: rpn.py), 32 mask-branch
-    assert m.rpn.ENGINE == "tiles" and len(masks) == 31 + 2 + 32
-    # (the RPN's kernels are queued between encoder and decoder -- trainstep.RPN_BEFORE_DECODER -- so its two masks follow the
-    # encoder's 16: four levels x two units x two ReLUs)
-    from sparse_rcnn_amd import trainstep as TS
-    at = 16 if TS.RPN_BEFORE_DECODER else 31
-    rpn_masks, masks = masks[at:at + 2], masks[:at] + masks[at + 2:]
+    ch = job.channels
+    L_ = len(ch)
+    rpns = list(m.rpn.levels) if hasattr(m.rpn, "levels") else [m.rpn]
+    n_dense = sum(len(r.stack) // 2 for r in rpns)
+    n_enc, n_dec = 4 * L_, 5 * (L_ - 1)             # encoder: levels x two units x two ReLUs; decoder level: ReLU + two units
+    assert rpns[0].ENGINE == "tiles" and len(masks) == n_enc + n_dec + n_dense + 32
+    # (the RPN's kernels are queued between encoder and decoder -- trainstep.RPN_BEFORE_DECODER -- so its masks follow the encoder's)
+    at = n_enc if TS.RPN_BEFORE_DECODER else n_enc + n_dec
+    rpn_masks, masks = masks[at:at + n_dense], masks[:at] + masks[at + n_dense:]
     rpn_bbox, rpn_score, anchors, roi_score, roi_bbox, roi_index = job.rpn_out
-    name = "cfg3_rpn_chain_150k"
+    B = job.batch_size
+    size = [int(v) for v in job.size]
+    # anchors: every level's cells x anchors, those inside the scene kept, in level order (tests/test_rpn_cpu.py pins the
+    # bookkeeping against the reference's AnchorDescriptionMultiLevel)
+    all_anchors = torch.cat([r.anchors_for([v // r.stride for v in size], "cpu") for r in rpns], 0)
+    inside = R.inside_indicator(all_anchors, torch.tensor(size, dtype=torch.float32), 0).nonzero().squeeze(1)
     n_anch = rpn_score.shape[1]
-    assert rpn_bbox.shape == (1, n_anch, 2, 3) and n_anch == 64 * 64 * 32 * m.rpn.n_anchors
-    assert 1 <= len(roi_bbox[0]) <= 64 and job.n_roi_rows > 0
-    print(f"[parity] {name}: {len(roi_bbox[0])} proposals kept, {job.n_roi_rows} cropped points, score range "
-          f"{float(rpn_score.min()):.2f} .. {float(rpn_score.max()):.2f}")
-    # ---- selection: the device's own decoded boxes in its own top-k order -> the oracle's greedy NMS
+    assert rpn_bbox.shape == (B, n_anch, 2, 3) and n_anch == len(inside) and 0 < n_anch < len(all_anchors)
+    assert torch.equal(anchors.cpu(), all_anchors[inside])
+    post = job.n_boxes
+    assert all(1 <= len(b) <= post for b in roi_bbox) and job.n_roi_rows > 0
+    print(f"[parity] {name}: {n_anch} of {len(all_anchors)} anchors inside, {[len(b) for b in roi_bbox]} proposals kept, "
+          f"{job.n_roi_rows} cropped points, score range {float(rpn_score.min()):.2f} .. {float(rpn_score.max()):.2f}")
+    # ---- selection: the device's own decoded + clipped boxes in its own top-k order -> the oracle's greedy NMS
     sc = torch.sigmoid(rpn_score.detach())
     top, idx = torch.topk(sc, 1024, dim=1, sorted=True)
     cpu_top = torch.topk(sc.cpu(), 1024, dim=1, sorted=True)[0]
     assert torch.equal(top.cpu(), cpu_top)                              # (values: ties may pick other indices)
-    dec = R.decode_boxes(anchors, rpn_bbox.detach())[0][idx[0]].cpu()
-    keep = torch.from_numpy(O.nms(dec.numpy(), 0.5))
-    assert torch.equal(roi_index[0], idx[0].cpu()[keep][:64])
-    assert torch.equal(roi_bbox[0].cpu(), dec[keep][:64]) and torch.equal(roi_score[0].cpu(), top[0].cpu()[keep][:64])
-    boxes = [b.detach().cpu() for b in roi_bbox]
+    dec_all = R.decode_boxes(anchors, rpn_bbox.detach(), job._scene_shape())
+    boxes = []
+    for b in range(B):
+        dec = dec_all[b][idx[b]].cpu()
+        keep = torch.from_numpy(O.nms(dec.numpy(), 0.5))
+        assert torch.equal(roi_index[b], idx[b].cpu()[keep][:post])
+        assert torch.equal(roi_bbox[b].cpu(), dec[keep][:post]) and torch.equal(roi_score[b].cpu(), top[b].cpu()[keep][:post])
+        kept = roi_bbox[b].detach().cpu()
+        boxes.append(kept if job.mask_boxes is None else kept[:job.mask_boxes])
     # ---- the oracle chain
     pb = dict(m.backbone.unet.named_oracle_params())
     pm = dict(m.mask.named_oracle_params())
-    ch = job.channels
     scene = O.OracleScene(job.coords_cpu.numpy())
     bshapes = dict(O.unet_param_shapes(7, list(ch)))
     po = {k: v.detach().cpu().clone().view(bshapes[k]).requires_grad_() for k, v in pb.items()}
@@ -519,23 +533,32 @@ def test_cfg3_rpn_chain_vs_oracle_at_150k(gpu):
     out = O.unet_forward(scene, fo, po, list(ch), relu=fr, interims=inter)
     gen = torch.Generator().manual_seed(100)
     gy = torch.randn(out.shape, generator=gen)
-    size3 = [int(v) // 8 for v in job.size]
-    dense = O.sparse_to_dense(inter[3], scene.level_coords[3], size3, 1)
-    got_dense = m.rpn.to_dense(m.backbone.unet.interims[-1]).detach().cpu()
-    assert got_dense.shape == dense.shape and torch.equal(got_dense != 0, dense.detach() != 0)       # same cells
-    _record(name, "SparseToDense of the stride-8 level", _err(got_dense, dense.detach()), FEAT_TOL)
-    stack, head = copy.deepcopy(m.rpn.stack).cpu(), copy.deepcopy(m.rpn.head).cpu()
-    h = dense
-    for layer, mk in zip([stack[0], stack[2]], rpn_masks):                # conv3d -> ReLU with the device's sign decisions
-        h = layer(h)
-        mk = mk.view(1, *size3, -1).permute(0, 4, 1, 2, 3)               # the slab is the volume channels-last
-        assert mk.shape == h.shape
-        h = h * mk.to(h.dtype)
-    raw = head(h)
-    raw = raw.view(1, m.rpn.n_anchors, 7, -1).permute(0, 3, 1, 2).reshape(1, -1, 7)
-    ob, os_ = raw[..., :6].reshape(1, -1, 2, 3), raw[..., 6]
+    raws, dense_o, mk_at = [], {}, 0
+    for li, (r, lvl) in enumerate(zip(rpns, m.rpn_levels)):
+        size_l = [v // r.stride for v in size]
+        dense = O.sparse_to_dense(inter[lvl], scene.level_coords[lvl], size_l, B)
+        got_dense = r.to_dense(m.backbone.unet.interims[lvl]).detach().cpu()
+        assert got_dense.shape == dense.shape and torch.equal(got_dense != 0, dense.detach() != 0)       # same cells
+        _record(name, f"SparseToDense of the stride-{r.stride} level", _err(got_dense, dense.detach()), FEAT_TOL)
+        stack, head = copy.deepcopy(r.stack).cpu(), copy.deepcopy(r.head).cpu()
+        h = dense
+        for layer in stack:
+            if not isinstance(layer, torch.nn.Conv3d):
+                continue
+            h = layer(h)                                                  # conv3d -> ReLU with the device's sign decisions
+            mk = rpn_masks[mk_at].view(B, *size_l, -1).permute(0, 4, 1, 2, 3)      # the slab is the volume channels-last
+            mk_at += 1
+            assert mk.shape == h.shape
+            h = h * mk.to(h.dtype)
+        raw = head(h)
+        raws.append(raw.view(B, r.n_anchors, 7, -1).permute(0, 3, 1, 2).reshape(B, -1, 7))
+        pre = "rpn." if len(rpns) == 1 else f"rpn.levels.{li}."
+        dense_o.update(list(stack.named_parameters(prefix=pre + "stack")) + list(head.named_parameters(prefix=pre + "head")))
+    assert mk_at == n_dense
+    raw = torch.cat(raws, 1)[:, inside]
+    ob, os_ = raw[..., :6].reshape(B, -1, 2, 3), raw[..., 6]
     e_b, e_s = _err(rpn_bbox, ob), _err(rpn_score, os_)
-    _record(name, "rpn_bbox (dense stack: MIOpen vs CPU)", e_b, 1e-4)
+    _record(name, "rpn_bbox (dense stack: this library's tile kernels vs torch CPU conv3d)", e_b, 1e-4)
     _record(name, "rpn_score", e_s, 1e-4)
     assert e_b["rel_to_scale"] <= 1e-4 and e_s["rel_to_scale"] <= 1e-4, (e_b, e_s)
     gr = [g.cpu() for g in job._grs[0]]                 # the gradients SceneStep drew for rpn_bbox / rpn_score
@@ -556,15 +579,30 @@ def test_cfg3_rpn_chain_vs_oracle_at_150k(gpu):
     got = {k: p.grad for k, p in pb.items()}
     got.update({"m:" + k: p.grad for k, p in pm.items()})
     got["input features"] = job.fin.grad
-    dense_o = dict(list(stack.named_parameters(prefix="rpn.stack")) + list(head.named_parameters(prefix="rpn.head")))
     dense_g = {k: p for k, p in m.named_parameters() if k.startswith("rpn.")}
-    assert set(dense_o) == set(dense_g) and len(dense_o) == 6
+    assert set(dense_o) == set(dense_g) and len(dense_o) == 2 * (n_dense + len(rpns))
     for k in dense_o:
         grads["d:" + k], got["d:" + k] = dense_o[k].grad, dense_g[k].grad
-    assert set(got) == set(grads) and len(grads) == 76 + 80 + 6 + 1
+    assert set(got) == set(grads) and len(grads) == len(pb) + 80 + len(dense_o) + 1
     for k in grads:
-        # the dense layers' own gradients and everything their backward reaches ride on MIOpen's fp32 convolutions
+        # the dense layers' own gradients: same kernels, same bound
         _check_grad_frozen(name, "grad " + k, got[k], grads[k].view_as(got[k]), RPN_L2_F32 if k.startswith("d:") else FROZEN_L2_F32)
+
+
+def test_cfg3_rpn_chain_vs_oracle_at_150k(gpu):
+    """BASELINE configs[2] with the RPN boundary inside the step (`bench.py --workload cfg3-rpn`) on the
+    150k-voxel scene: a stand-in RPN (ONE anchor level, 2 x 32 stack, 64 kept) -- see `_rpn_chain_vs_oracle`; 76 backbone + 6
+    dense RPN + 80 mask gradient tensors + the input features."""
+    _rpn_chain_vs_oracle(gpu, "cfg3-rpn", "cfg3_rpn_chain_150k")
+
+
+def test_ref_crop_rpn_chain_vs_oracle_at_size(gpu):
+    """the REFERENCE's detection shape as far as this path reaches (`bench.py --workload ref-crop-rpn`):
+    plan 32-48-64-80-96-112 on its training batch (12 crops of 128 x 128 x 64, run.py:364,485-488), SparseToDense of BOTH
+    anchor levels (64 ch at stride 4, 80 ch at stride 8), a 5 x 128 and a 5 x 256 dilation stack (run.py:525-536,609), 3 + 11
+    anchors per cell, top-1024 / NMS 0.5 / 256 kept (run.py:847-853), the 24 best per sample -> crop -> mask branch: see
+    `_rpn_chain_vs_oracle`; 120 backbone + 24 dense RPN + 80 mask gradient tensors + the input features."""
+    _rpn_chain_vs_oracle(gpu, "ref-crop-rpn", "ref_crop_rpn_chain")
 
 
 @pytest.mark.parametrize("variant", ["unet_only", "both_skip", "raw_skip"])

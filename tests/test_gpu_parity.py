@@ -1814,7 +1814,7 @@ def test_dense_rpn_stack_on_the_tile_kernels_equals_the_miopen_engine(gpu):
     from sparse_rcnn_amd.rpn import DenseRpn
     scn, coords, feats, fg, x, scene, size = _input(gpu, seed=77, cin=16, grid=(16, 12, 8), n=500, batch=2, dup=50)
     torch.manual_seed(9)
-    net = DenseRpn(16, stride=8, width=8, num_dilations=2).to(gpu)
+    net = DenseRpn(16, stride=8, width=8, num_dilations=2, keep_inside=False).to(gpu)       # (every anchor: the engines are the subject)
     with torch.no_grad():
         for p in net.parameters():
             p.add_(torch.randn_like(p) * 0.1)
@@ -1831,6 +1831,16 @@ def test_dense_rpn_stack_on_the_tile_kernels_equals_the_miopen_engine(gpu):
         torch.autograd.backward([bb, sc], [gb, gs])
         res[engine] = [bb.detach(), sc.detach(), X.grad] + [p.grad.clone() for p in net.parameters()]
         assert an.shape == (16 * 12 * 8 * net.n_anchors, 2, 3) and bb.shape == (2, an.shape[0], 2, 3)
+    # keep_inside (the default): the same outputs compacted to the anchors inside the scene, in anchor order (anchor.py:103-113,177-197)
+    net.engine, net.SPARSE_FIRST, net.keep_inside = "tiles", True, True
+    t = scn.SparseConvNetTensor(features=x.features.detach(), metadata=x.metadata, spatial_size=x.spatial_size)
+    bb_i, sc_i, an_i = net(t)
+    idx, _ = net.inside_for((16, 12, 8), gpu)
+    assert 0 < len(idx) < an.shape[0] and torch.equal(an_i, an[idx])
+    assert torch.equal(bb_i, res["tiles"][0][:, idx]) and torch.equal(sc_i, res["tiles"][1][:, idx])
+    torch.cuda.synchronize()
+    assert [int(f[0]) for f in sc_i.cell_flags] == [0]               # (scn_cell_map: no row outside the volume)
+    net.keep_inside = False
     # torch on the CPU: the oracle of the dense layers
     cpu = copy.deepcopy(net).cpu()
     Xo = x.features.detach().cpu().clone().requires_grad_()

@@ -45,8 +45,9 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--target", type=int, default=None, help="active voxels per scene (default: the workload's)")
-    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg3-rpn", "cfg5", "ref", "ref-crop", "ref-crop-rpn"), default="cfg2",
-                    help="cfg2 = the configuration the metric is quoted on (default); cfg3 = backbone + OutputLayer + "
+    ap.add_argument("--workload", choices=("cfg2", "cfg2-bn", "cfg3", "cfg3-rpn", "cfg5", "ref", "ref-crop", "ref-crop-rpn"), default="cfg2",
+                    help="cfg2 = the configuration the metric is quoted on (default); cfg2-bn = cfg2 with BatchNormReLU in the "
+                         "residual units (the reference ships batch norm off); cfg3 = backbone + OutputLayer + "
                          "sparse ROI crop (64 synthetic boxes) + mask-branch U-Net, fwd+bwd (crop + mask branch only); cfg3-rpn = "
                          "configs[2] with the RPN boundary inside the step: the boxes come out of the same forward (SparseToDense "
                          "-> a STAND-IN dense stack, 2 x 32 on one anchor level, on this library's tile kernels -> inside anchors "
@@ -77,6 +78,9 @@ def parse_args(argv=None):
     ap.add_argument("--batches-per-step", type=int, default=1,
                     help="micro-batches (scenes) accumulated per optimizer step and rank -- the reference's batch scaling, "
                          "training.py:436,458-460 (2 or 6 with the mask head); ONE gradient all-reduce per step")
+    ap.add_argument("--forward-only-child", action="store_true",
+                    help="(internal) evaluation only, in this fresh process: forward_only steps of the workload, nothing else ever "
+                         "allocated -- prints one JSON line with its time and peak HBM (the parent's `forward_only.fresh_process`)")
     a = ap.parse_args(argv)
     if a.bf16_all:
         a.dtype = "bf16"
@@ -503,7 +507,11 @@ def side_measurements(job, args, world, dist, torch):
                           "working_set_bytes": int(torch.cuda.max_memory_allocated() - fo_base),
                           "note": "index build (pipelined as in the step) + forward under torch.no_grad(): the executor's "
                                   "forward-only slab plan, no backward-data weight images; bit-equal to the training forward "
-                                  "(tests/test_gpu_exec.py::test_forward_only_is_bit_equal...)"}
+                                  "(tests/test_gpu_exec.py::test_forward_only_is_bit_equal...); measured AFTER the training steps "
+                                  "in this process: peak_hbm_bytes carries their leftovers (resident_before_bytes) -- "
+                                  "`fresh_process` is the same evaluation in a process that never trained"}
+    if world == 1:
+        ex["forward_only"]["fresh_process"] = forward_only_fresh(args)
     if args.workload == "cfg2" and world == 1 and args.target is None and args.batches_per_step == 1:
         ex["changing_scenes"] = changing_scenes_leg(job, args, torch)
     if args.dropin and args.workload == "cfg2" and world == 1:
@@ -663,8 +671,69 @@ def dropin_measurement(job, args, torch):
     return out
 
 
+def forward_only_child(args):
+    """Evaluation in a process that has never trained (the in-process forward-only leg runs after the training
+    steps and its absolute peak carries their leftovers -- gradients, the backward workspaces' cached blocks): the scene, the
+    parameters, `forward_only()` steps.  One JSON line."""
+    import torch
+    import sparse_rcnn_amd  # noqa: F401
+    from sparse_rcnn_amd.trainstep import SceneStep
+    torch.set_num_threads(_host_threads())
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    job = SceneStep(args.workload, dev, dtype=args.dtype, prefetch=args.prefetch, seed=1, target=args.target)
+    for p in job.model.parameters():
+        p.requires_grad_(False)
+    n = max(5, min(20, args.steps))
+    for _ in range(4):
+        job.forward_only()
+    job.finish()
+    torch.cuda.synchronize()
+    gc.collect()
+    gc.freeze()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        job.forward_only()
+    job.finish()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    out_rows = int(job.forward_only()[0].features.shape[0])
+    print(json.dumps({"ms_per_step": ms, "steps": n, "active_voxels": out_rows, "value": out_rows / (ms * 1e-3),
+                      "unit": "active-voxels/s, forward only",
+                      "peak_hbm_bytes": int(torch.cuda.max_memory_allocated()),
+                      "peak_reserved_bytes": int(torch.cuda.max_memory_reserved()),
+                      "resident_before_bytes": int(base),
+                      "working_set_bytes": int(torch.cuda.max_memory_allocated() - base),
+                      "note": "a process that only evaluates: parameters (no gradients), the scene, the index structures of two "
+                              "batches (this one + the prefetched one), the forward-only slab plan"}), flush=True)
+    return 0
+
+
+def forward_only_fresh(args):
+    """Run `forward_only_child` as a child process (its own HIP context; this process keeps its GPU state) -> dict | error."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--forward-only-child", "--workload", args.workload, "--dtype", args.dtype,
+           "--steps", str(args.steps)]
+    if args.target is not None:
+        cmd += ["--target", str(args.target)]
+    if not args.prefetch:
+        cmd += ["--no-prefetch"]
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not line:
+            return {"error": f"child exit {p.returncode}: {p.stderr.decode()[-300:]}"}
+        return json.loads(line[-1])
+    except Exception as e:                       # noqa: BLE001  (a side figure must not take the headline down)
+        return {"error": repr(e)}
+
+
 def main():
     args = parse_args()
+    if args.forward_only_child:
+        sys.exit(forward_only_child(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     sys.exit(run(args))

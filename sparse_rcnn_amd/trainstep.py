@@ -37,6 +37,10 @@ REF_PLAN = (32, 48, 64, 80, 96, 112)      # the reference's own sparse U-Net pla
 
 WORKLOADS = {      # name -> (channels, grid, active voxels per sample, boxes per scene, BASELINE.json entry, samples per rank)
     "cfg2": ((32, 64, 128, 256), (512, 512, 256), 150_000, 0, "configs[1]", 1),
+    # cfg2 with BatchNormReLU in place of every ReLU of the residual units (north_star names the operator; the reference ships it
+    # off, run.py:612 `batchnorm=False`): the layer-by-layer path (the step executor does not cover batch norm), two more passes
+    # over every slab and direction; under DP each rank normalises with its own scene unless modules._BatchNorm.SYNC is set
+    "cfg2-bn": ((32, 64, 128, 256), (512, 512, 256), 150_000, 0, "configs[1] with BatchNormReLU units (batchnorm=True)", 1),
     "cfg3": ((32, 64, 128, 256), (512, 512, 256), 150_000, 64, "configs[2]", 1),
     "cfg3-rpn": ((32, 64, 128, 256), (512, 512, 256), 150_000, 64, "configs[2] with the RPN boundary inside the step", 1),
     "cfg5": ((32, 64, 128, 256, 512), (1024, 1024, 512), 600_000, 0, "configs[4] shape (one scene per GPU)", 1),
@@ -75,11 +79,11 @@ def _backward(roots, grads):
 class SparseStepModel(torch.nn.Module):
     """Backbone (+ mask branch for cfg3) as one module, so that one flat parameter buffer covers the step."""
 
-    def __init__(self, channels, with_mask, storage, with_rpn=False, n_boxes=64):
+    def __init__(self, channels, with_mask, storage, with_rpn=False, n_boxes=64, batchnorm=False):
         """with_rpn: False | "stand-in" (cfg3-rpn: one anchor level, 2 x 32 stack) | "reference" (ref-crop-rpn: the reference's two
         anchor levels with 5 x 128 / 5 x 256 stacks, rpn.MultiLevelRpn)."""
         super().__init__()
-        self.backbone = Backbone(7, channels, bf16_blocks=storage)
+        self.backbone = Backbone(7, channels, batchnorm=batchnorm, bf16_blocks=storage)
         self.mask = MaskBranch(channels[0], 7, bf16_blocks=storage) if with_mask else None
         self.rpn = self.roi_selector = None
         self.rpn_levels = None                 # indices of the encoder levels the RPN reads
@@ -151,7 +155,8 @@ class SceneStep:
         # model.py:919-1014 draws by ground-truth overlap -- out of scope: here the 24 best-scored ones)
         self.mask_boxes = 24 if workload == "ref-crop-rpn" else None
         rpn_kind = "reference" if workload == "ref-crop-rpn" else ("stand-in" if self.with_rpn else False)
-        self.model = SparseStepModel(self.channels, bool(self.n_boxes), storage, rpn_kind, self.n_boxes).to(self.device)
+        self.model = SparseStepModel(self.channels, bool(self.n_boxes), storage, rpn_kind, self.n_boxes,
+                                     batchnorm=workload.endswith("-bn")).to(self.device)
         if self.with_rpn:
             self._init_rpn()
         self.flat = FlatParams(self.model, n_buckets=n_buckets)
@@ -341,7 +346,9 @@ class SceneStep:
     def describe(self):
         s = (f"BASELINE {self.baseline_entry}: {self.batch_size} synthetic ScanNet-shaped sample(s) per GPU, {self.n_active} "
              f"active voxels (grid {self.grid[0]}x{self.grid[1]}x{self.grid[2]}, 1.15 points/voxel), U-Net "
-             + "-".join(map(str, self.channels)) + ", 2 pre-act residual blocks/level, 2^3/2 conv+deconv")
+             + "-".join(map(str, self.channels)) + ", 2 pre-act residual blocks/level, 2^3/2 conv+deconv"
+             + (", BatchNormReLU in the residual units (training mode, fp64 statistics; layer-by-layer path)"
+                if self.workload.endswith("-bn") else ""))
         if self.n_boxes and self.with_rpn:
             r = self.model.rpn
             sel = (f"-> anchors that leave the scene dropped (anchor.py:103-113) -> sigmoid, top-1024, boxes clipped to the scene, "

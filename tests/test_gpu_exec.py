@@ -451,7 +451,15 @@ def test_forward_only_is_bit_equal_to_the_training_forward_and_allocates_less(gp
     # backward): the allocator must see at least 90 % of the planned slab saving (both peaks include the index structures a
     # forward builds -- scene pyramid, ROI batch --, which evaluation needs as well; bf16 storage also drops the backward-data
     # weight images from the pack, on top of the slabs)
+    import gc
+
     def peak(fn):
+        # nothing of an earlier forward may be alive when the measurement starts: the network keeps its last encoder outputs
+        # (`.interims`, and through them a training forward's whole graph and workspaces) until the next forward replaces them
+        object.__setattr__(m.backbone.unet, "interims", [])
+        object.__setattr__(m.mask.output_conv_layer, "interims", [])
+        job.out = job.logits = job.fin = None
+        gc.collect()
         torch.cuda.synchronize()
         torch.cuda.reset_peak_memory_stats()
         base = torch.cuda.memory_allocated()

@@ -34,6 +34,11 @@ using scn::cdiv;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+#ifndef WD_EXP
+#define WD_EXP 0            // (developer builds, TIMING ONLY -- wrong results) 1: the dY row pieces and their row indices come from
+                            // registers, not from memory: the ceiling of any "one gather per rule" form whose dY tile sits in
+                            // LDS (profiles/r6_wgrad_one_gather.txt); 2: the dY pieces are read from a small LDS array (ds_read)
+#endif
 #ifndef WD_TIMELINE
 #define WD_TIMELINE 0       // 1 (developer builds): per-wave wall_clock64 stamps of k_wgrad_direct (tools/wd_timeline.py)
 #endif
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ 
         const int qs_ = (QB) < last_full ? (QB) : last_full;           /* scalar */                  \
         _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                           \
             IN[s_] = IDENT ? q0i + qs_ + lane_r + s_ : inq[qs_ + lane_r + s_];                       \
-            OUT[s_] = IDENT ? q0i + qs_ + lane_r + s_ : outq[qs_ + lane_r + s_];                     \
+            OUT[s_] = (IDENT || WD_EXP) ? q0i + qs_ + lane_r + s_ : outq[qs_ + lane_r + s_];         \
         }                                                                                            \
     }
 #define WD_ROWS(A, B, IN, OUT)                                                                       \
@@ -224,6 +229,13 @@ __global__ __launch_bounds__(256) void k_wgrad_direct(const float* __restrict__ 
                 _Pragma("unroll") for (int t_ = 0; t_ < TA; ++t_) A[s_][t_] = xr_[a_ok[t_] ? ca + t_ : 0]; \
                 _Pragma("unroll") for (int t_ = 0; t_ < TB; ++t_) B[s_][t_] = yr_[b_ok[t_] ? cbn + t_ : 0]; \
             }                                                                                        \
+        } else if (WD_EXP == 1) {                                                                    \
+            A[s_] = *(const ra_t*)(xlane + (long long)IN[s_] * xstride);                             \
+            _Pragma("unroll") for (int t_ = 0; t_ < (int)(sizeof(rb_t) / 4); ++t_)                   \
+                ((float*)&B[s_])[t_] = __int_as_float(0x3f800000 | (OUT[s_] & 0xffff));              \
+        } else if (WD_EXP == 2) {                                                                    \
+            A[s_] = *(const ra_t*)(xlane + (long long)IN[s_] * xstride);                             \
+            B[s_] = *(const rb_t*)((const char*)red + (((OUT[s_] & 15) * 16 + i) * (int)sizeof(rb_t)));  \
         } else {                                                                                     \
             A[s_] = *(const ra_t*)(xlane + (long long)IN[s_] * xstride);                             \
             B[s_] = *(const rb_t*)(ylane + (long long)OUT[s_] * ystride);                            \

@@ -49,7 +49,7 @@ inline int fail(int code, const char* fmt, const char* a = "", long long b = 0, 
 enum Switch {
     SW_TS_SPLIT, SW_TS_SPLIT_MAX, SW_TS_NO_TAIL, SW_TS_W_HALF, SW_TS_W_BOTH, SW_TB_NB, SW_TB_KH, SW_TB_STREAM,
     SW_TB_NO_XORDER, SW_TS_STREAM, SW_TSS_NW, SW_EXEC_DEFER_SUMS, SW_PYRAMID_V1, SW_PYRAMID_ONE_STREAM, SW_WD_NO_T3,
-    SW_WGRAD_BF16_MFMA, SW_WGRAD_SPLITS, SW_WD_NO_EVEC, SW_PYRAMID_NO_BRICKS, SW_CU_BUDGET, SW_EXP_A, SW_EXP_B, SW_TS_NO_CHAIN, SW_TS_PROG, SW_COUNT
+    SW_WGRAD_BF16_MFMA, SW_WGRAD_SPLITS, SW_WD_NO_EVEC, SW_PYRAMID_NO_BRICKS, SW_CU_BUDGET, SW_EXP_A, SW_EXP_B, SW_TS_NO_CHAIN, SW_TS_PROG, SW_TB_NO_BINS, SW_COUNT
 };
 struct SwitchVal { bool set = false; long long i = 0; double f = 0.0; };
 SwitchVal sw(Switch s);

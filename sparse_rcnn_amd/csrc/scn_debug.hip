@@ -18,7 +18,7 @@ Entry g_sw[SW_COUNT] = {
     {"SCN_PYRAMID_V1", {}},      {"SCN_PYRAMID_ONE_STREAM", {}}, {"SCN_WD_NO_T3", {}},    {"SCN_WGRAD_BF16_MFMA", {}},
     {"SCN_WGRAD_SPLITS", {}},    {"SCN_WD_NO_EVEC", {}},    {"SCN_PYRAMID_NO_BRICKS", {}},            {"SCN_CU_BUDGET", {}},
     {"SCN_EXP_A", {}},           {"SCN_EXP_B", {}},         {"SCN_TS_NO_CHAIN", {}},
-    {"SCN_TS_PROG", {}},
+    {"SCN_TS_PROG", {}},         {"SCN_TB_NO_BINS", {}},
 };
 std::once_flag g_once;
 std::mutex g_mu;

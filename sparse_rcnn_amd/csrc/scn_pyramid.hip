@@ -243,7 +243,9 @@ extern "C" int scn_pyramid_build_ex(const int64_t* coords, int64_t n_points, int
             }
             if ((rc = scn_subm_table(lv_coords, n, lv_keys, lv_hrows, lv_cap, k, table, sub))) return rc;
             if ((rc = scn_rules_scan(table, n_off, n, bsums, prefix, nullptr, sub))) return rc;
-            if ((rc = scn_tiles_build_x(table, n_off, n, perm, tstab, tmask, torder, with_x ? 1 : 0, tscr, sub))) return rc;
+            // (round 6: with the XCD-local order, level 0's tiles are sorted by (row bin, mask): 8 row bins -- as the fused build does)
+            const int lb0 = (with_x && l == 0 && n_off == 27 && !(scn::sw(scn::SW_TB_NO_BINS).set && scn::sw(scn::SW_TB_NO_BINS).i != 0)) ? 3 : 0;
+            if ((rc = scn_tiles_build_x(table, n_off, n, perm, tstab, tmask, torder, (with_x ? 1 : 0) | (lb0 << 8), tscr, sub))) return rc;
             prefix_dev[l][0] = prefix;
         }
         if (!has_next) {

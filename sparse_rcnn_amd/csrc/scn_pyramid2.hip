@@ -50,7 +50,7 @@ constexpr int T = 256;                 // threads per workgroup, every kernel of
 constexpr int IT = 4;                  // items per thread in the scan / sort workgroups
 constexpr int TILE = T * IT;           // items per workgroup: idx = base + it * T + tid  (ballot order == index order)
 constexpr int MAXL = SCN_PYRAMID_MAX_LEVELS;
-constexpr int MAXB = 512;              // radix bins
+constexpr int MAXB = 1024;             // radix bins (9-bit passes; 10-bit passes where the key carries row-bin bits)
 constexpr unsigned F_AGG = 1u << 30, F_INCL = 2u << 30, VMASK = (1u << 30) - 1u;
 constexpr int SPIN_MAX = 1 << 22;      // look-back polls before a workgroup gives up (sets DS_ERR; never hangs the GPU)
 
@@ -83,6 +83,7 @@ struct PA {
     long long cap, bound, bcap;
     int no_bricks;                      // developer switch SCN_PYRAMID_NO_BRICKS: voxel tables everywhere (A/B, cross-check)
     int n_levels, k, with_x, nblk;      // nblk = cdiv(bound, TILE)
+    int lbins;                          // log2 of the row bins in level 0's SubM sort key (0: mask sort only)
     LvA lv[MAXL];
     KeyBits kb;
 };
@@ -177,6 +178,12 @@ __device__ __forceinline__ void brick_cell8(const Bricks& B, int x0, int y0, int
     for (int o = 0; o < 8; ++o)
         out[o] = ((occ[0] >> brick_local(x0 + (o >> 2), y0 + ((o >> 1) & 1), z0 + (o & 1))) & 1ull) ? v[o] : -1;
 }
+
+// Width of a pass of the SubM mask sort at level l.  Round 6: with `lbins` (the bf16 tile kernels' builds) LEVEL 0 sorts by
+// (row bin, mask): 27 + 3 bits in three 10-bit passes -- its tiles then take their 16 rows from one region of the scene and the
+// 3^3 neighbours consecutive tiles gather meet in L2 (600 k voxels, C = 32: 71 -> 53 us per bf16 launch although the tiles
+// visit 10 % more offsets; deeper levels lose 3-7 % and keep the plain mask sort: profiles/r6_bin_tiles.txt).
+__device__ __forceinline__ int mask_sort_width(const PA& a, int l) { return (a.lbins && l == 0) ? 10 : 9; }
 
 __device__ __forceinline__ unsigned gray_rank(unsigned m) {      // binary value whose reflected Gray code is m
     m ^= m >> 1; m ^= m >> 2; m ^= m >> 4; m ^= m >> 8; m ^= m >> 16;
@@ -455,7 +462,7 @@ __device__ __forceinline__ void table_job(const PA& a, int l, int b) {
     const long long base = (long long)b * TILE;
     __shared__ int wsum[N_OFF][TT / 64];
     __shared__ int hist[MAXB];
-    constexpr int width0 = SUBM ? 9 : 8, bins = 1 << width0;
+    const int width0 = SUBM ? mask_sort_width(a, l) : 8, bins = 1 << width0;
     if (base >= n) {                                     // surplus workgroup: its rule counts must read zero in the scan
         if (threadIdx.x < N_OFF) bsums[threadIdx.x * a.nblk + b] = 0;
         return;
@@ -551,7 +558,8 @@ __device__ __forceinline__ void table_job(const PA& a, int l, int b) {
     }
     __syncthreads();                                      // (also orders the hist zeroing before the adds)
     if (live) {
-        const unsigned kk = gray_rank(m);
+        unsigned kk = gray_rank(m);
+        if (SUBM && a.lbins && l == 0) kk |= (unsigned)(((long long)r << a.lbins) / n) << 27;     // row bin above the 27 mask bits
         key_out[r] = kk;
         atomicAdd(&hist[kk & (unsigned)(bins - 1)], 1);
     }
@@ -625,8 +633,8 @@ __device__ __forceinline__ SortJob mask_sort_job(const PA& a, int l, int pass) {
     SortJob j;
     j.counts = at<int>(a, L.counts);
     j.totals = at<int>(a, L.totals);
-    j.shift = 9 * pass;
-    j.width = 9;
+    j.width = mask_sort_width(a, l);
+    j.shift = j.width * pass;
     // 27 bits, three passes: key -> key_s -> ktmp -> key_s (the last pass lands in the output)
     j.kin = pass == 0 ? at<unsigned>(a, L.key) : pass == 1 ? at<unsigned>(a, L.key_s) : at<unsigned>(a, L.ktmp);
     j.vin = pass == 0 ? nullptr : pass == 1 ? at<int>(a, L.rows_s) : at<int>(a, L.vtmp);
@@ -728,7 +736,7 @@ __device__ __forceinline__ void scan_totals(const int* __restrict__ totals, int 
 __device__ __forceinline__ unsigned long long peers_of(unsigned d, int width, bool valid) {
     unsigned long long peers = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < 9; ++b) {
+    for (int b = 0; b < 10; ++b) {
         if (b < width) {
             const unsigned long long m = __ballot((d >> b) & 1u);
             peers &= ((d >> b) & 1u) ? m : ~m;
@@ -955,7 +963,7 @@ __device__ __forceinline__ void tiles_job(const PA& a, int l, int b, int nblk16)
         const bool ok = e < n;
         const int row = ok ? sorted_rows[e] : -1;
         perm[e] = row;
-        const unsigned rank = ok ? sorted_key[e] : 0u;
+        const unsigned rank = ok ? sorted_key[e] & 0x7FFFFFFu : 0u;      // (without the row-bin bits of a binned key)
         const unsigned key = rank ^ (rank >> 1);            // Gray code of the rank = the (bit-permuted) mask
         unsigned m = 0;
 #pragma unroll 1
@@ -1256,6 +1264,7 @@ int pyramid2_build(const int64_t* coords, int64_t n_points, int n_levels, int k,
     a.bcap = p.bcap;
     a.no_bricks = scn::sw(scn::SW_PYRAMID_NO_BRICKS).set ? 1 : 0;
     a.cap = p.cap; a.bound = n; a.n_levels = n_levels; a.k = k; a.with_x = with_x ? 1 : 0; a.nblk = (int)nblk;
+    a.lbins = (with_x && k == 3 && !(scn::sw(scn::SW_TB_NO_BINS).set && scn::sw(scn::SW_TB_NO_BINS).i != 0)) ? 3 : 0;
     a.kb = make_key_bits27();
     auto q = [](int64_t off) { return (uint32_t)(off >> 8); };
     for (int l = 0; l < n_levels; ++l) {

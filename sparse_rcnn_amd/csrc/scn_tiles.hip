@@ -46,7 +46,10 @@ static KeyBits make_key_bits(int n_off) {
     return kb;
 }
 
-__global__ void k_row_masks(const int* __restrict__ table, int n_off, long long n, KeyBits kb, unsigned* __restrict__ key) {
+// bin_shift (round 6, bf16 tile kernels only): the key's top bits are the row's BIN, row * 2^lb / n -- rows are numbered in the
+// order the points arrive (mesh order), so a row range is a region of the scene: the rows of a tile then come from ONE region
+// and the 3^3 neighbours a launch gathers for consecutive tiles meet in L2.  27 mask bits + lb <= 5 bin bits.
+__global__ void k_row_masks(const int* __restrict__ table, int n_off, long long n, KeyBits kb, unsigned* __restrict__ key, int lb) {
     for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < n;
          r += (long long)gridDim.x * blockDim.x) {
         unsigned m = 0;
@@ -56,6 +59,7 @@ __global__ void k_row_masks(const int* __restrict__ table, int n_off, long long 
         // than in binary order -- executed/useful 1.276 / 1.157 / 1.173 / 1.253 on the four levels of the cfg-2 scene
         // against 1.311 / 1.175 / 1.186 / 1.267
         m ^= m >> 1; m ^= m >> 2; m ^= m >> 4; m ^= m >> 8; m ^= m >> 16;
+        if (lb) m |= (unsigned)((r << lb) / n) << 27;
         key[r] = m;
     }
 }
@@ -63,7 +67,7 @@ __global__ void k_row_masks(const int* __restrict__ table, int n_off, long long 
 __global__ void k_build_tiles(const int* __restrict__ table, int n_off, long long n, const int* __restrict__ sorted_rows,
                               const unsigned* __restrict__ sorted_key, KeyBits kb, long long nt, int* __restrict__ perm,
                               int* __restrict__ tstab, unsigned* __restrict__ tile_mask, unsigned* __restrict__ tile_cost,
-                              unsigned* __restrict__ tile_xkey) {
+                              unsigned* __restrict__ tile_xkey, int lb) {
     // one thread per (tile, lane i); 16 threads of a tile are adjacent
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < nt * 16;
          e += (long long)gridDim.x * blockDim.x) {
@@ -72,7 +76,7 @@ __global__ void k_build_tiles(const int* __restrict__ table, int n_off, long lon
         const bool ok = e < n;
         const int row = ok ? sorted_rows[e] : -1;
         perm[e] = row;
-        const unsigned rank = ok ? sorted_key[e] : 0u;
+        const unsigned rank = ok ? (lb ? sorted_key[e] & 0x7FFFFFFu : sorted_key[e]) : 0u;      // (without the bin bits)
         const unsigned key = rank ^ (rank >> 1);            // Gray code of the rank = the permuted mask
         unsigned m = 0;                                     // the real offset mask: undo the key's bit permutation
         for (int o = 0; o < n_off; ++o) {
@@ -125,6 +129,10 @@ extern "C" int scn_tiles_build_x(const int32_t* table, int n_off, int64_t n, int
     if (n == 0) return SCN_OK;
     SCN_REQUIRE(table && perm && tstab && tile_mask && tile_order && scratch);
     SCN_REQUIRE(n < 2147483647LL / 32);
+    // with_x: bit 0 = also the XCD-local hand-out order; bits 8-10 = log2 of the row bins in the sort key (27-offset tables)
+    const int lb = n_off == 27 ? (with_x >> 8) & 7 : 0;
+    SCN_REQUIRE(lb <= 5);
+    with_x &= 1;
     const int64_t nt = cdiv(n, 16);
     char* p = (char*)scratch;
     unsigned* mask = (unsigned*)p;          p += align256(4 * n);
@@ -138,13 +146,13 @@ extern "C" int scn_tiles_build_x(const int32_t* table, int n_off, int64_t n, int
     void* sort_scr2 = p;
     hipStream_t st = S(stream);
     const KeyBits kb = make_key_bits(n_off);
-    hipLaunchKernelGGL(k_row_masks, dim3(scn::ew_grid(n, 256)), dim3(256), 0, st, table, n_off, (long long)n, kb, mask);
+    hipLaunchKernelGGL(k_row_masks, dim3(scn::ew_grid(n, 256)), dim3(256), 0, st, table, n_off, (long long)n, kb, mask, lb);
     SCN_LAUNCH_CHECK();
-    int rc = scn::sort_pairs(mask, nullptr, n, n_off, mask_sorted, rows_sorted, sort_scr, st);
+    int rc = scn::sort_pairs(mask, nullptr, n, n_off + lb, mask_sorted, rows_sorted, sort_scr, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_build_tiles, dim3(scn::ew_grid(nt * 16, 256)), dim3(256), 0, st, table, n_off, (long long)n,
                        (const int*)rows_sorted, (const unsigned*)mask_sorted, kb, (long long)nt, perm, tstab, tile_mask,
-                       cost, with_x ? xkey : (unsigned*)nullptr);
+                       cost, with_x ? xkey : (unsigned*)nullptr, lb);
     SCN_LAUNCH_CHECK();
     rc = scn::sort_pairs(cost, nullptr, nt, 6, cost_sorted, tile_order, sort_scr2, st);
     if (rc) return rc;

@@ -348,6 +348,9 @@ FUSED_INDEX = os.environ.get("SCN_PYRAMID_FUSED", "1") != "0"
 # default of Metadata.xcd_order (SCN_XCD_ORDER=1: every Metadata builds the second order; 0: nobody does)
 XCD_ORDER_DEFAULT = os.environ.get("SCN_XCD_ORDER", "") == "1"
 XCD_ORDER_BF16 = os.environ.get("SCN_XCD_ORDER", "") != "0"     # bf16-storage networks ask for it
+# with the XCD-local order: the LEVEL-0 SubM tiles are sorted by (row bin, mask) -- 8 row ranges = regions of the scene -- instead
+# of by mask alone (round 6, profiles/r6_bin_tiles.txt; the fused build does the same: scn_pyramid2.hip `lbins`)
+BIN_TILES = os.environ.get("SCN_TB_NO_BINS", "0") in ("", "0")
 
 
 @dataclass
@@ -362,8 +365,10 @@ class Tiles(_Views):
     has_x: bool = False             # tile_order's buffer continues with the XCD-local order and its bin starts (scn_tiles_build_x)
 
 
-def build_tiles(table: torch.Tensor, n_off: int, n: int, with_x: bool = False) -> Tiles:
-    """with_x: also the XCD-local hand-out order of the bf16 tile kernel (behind the first order, in the same buffer)."""
+def build_tiles(table: torch.Tensor, n_off: int, n: int, with_x: bool = False, log2_bins: int = 0) -> Tiles:
+    """with_x: also the XCD-local hand-out order of the bf16 tile kernel (behind the first order, in the same buffer).
+    log2_bins: the rows are sorted by (row bin, offset mask) instead of by mask alone -- 2^log2_bins row ranges (regions of the
+    scene: rows are numbered in mesh order), each mask-sorted on its own (27-offset tables; the bf16 tile kernels, round 6)."""
     lib = L.lib()
     dev = table.device
     nt = (n + 15) // 16
@@ -373,7 +378,7 @@ def build_tiles(table: torch.Tensor, n_off: int, n: int, with_x: bool = False) -
     order_buf = _empty(lib.scn_tiles_order_ints(n, 1 if with_x else 0), torch.int32, dev)
     scratch = _empty(lib.scn_tiles_scratch_bytes(n_off, n), torch.uint8, dev)
     L.check(lib.scn_tiles_build_x(L.ptr(table), n_off, n, L.ptr(perm), L.ptr(tstab), L.ptr(tile_mask),
-                                  L.ptr(order_buf), 1 if with_x else 0, L.ptr(scratch), L.stream()))
+                                  L.ptr(order_buf), (1 if with_x else 0) | (int(log2_bins) << 8), L.ptr(scratch), L.stream()))
     return Tiles(perm, tstab, tile_mask, n_off, n, order_buf[:nt] if with_x else order_buf, bool(with_x))
 
 
@@ -648,6 +653,9 @@ class Metadata:
         return self
 
     # ---- rulebooks ----------------------------------------------------------------------------------
+    def _is_input_size(self, size) -> bool:
+        return self.input_size is not None and tuple(int(v) for v in size) == tuple(int(v) for v in self.input_size)
+
     def grid(self, size) -> Grid:
         size = tuple(int(s) for s in size)
         if size not in self.grids:
@@ -669,7 +677,9 @@ class Metadata:
                                            L.ptr(table), L.stream()))
                 # (filters above 3^3 -- 125 offsets -- have no mask tiles: the tile kernels hold a tile's offsets in 27 bits)
                 rb = SubmRulebook(table, compact_rules(table, k ** 3, g.n), k, g.n,
-                                  build_tiles(table, k ** 3, g.n, with_x=self.xcd_order) if k ** 3 <= 27 else None)
+                                  build_tiles(table, k ** 3, g.n, with_x=self.xcd_order,
+                                              log2_bins=3 if (self.xcd_order and k == 3 and self._is_input_size(size)
+                                                              and BIN_TILES) else 0) if k ** 3 <= 27 else None)
             self.subm[key] = rb
         if k == 3:
             self._note_levels(size, 1)

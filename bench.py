@@ -398,11 +398,10 @@ def roofline(dom, d, sampled, args):
     """`roofline` object of the contract for the dominant kernel (HIP events around its launches, live)."""
     us = d["ms"] * 1e3 / d["launches"]
     traffic = None
-    # separate rocprofv3 --pmc passes (tools/collect_traffic.py, tools/collect_r5.sh); round 5: one file, an entry per
+    # separate rocprofv3 --pmc passes (tools/collect_traffic.py, tools/collect_r6.sh); since round 5: one file, an entry per
     # (workload, storage type) -- the bf16 lines have counter bytes too
-    tfile = os.path.join(ROOT, "profiles", "r5_traffic.json")
-    if not os.path.exists(tfile):
-        tfile = os.path.join(ROOT, "profiles", "r4_traffic.json")
+    tfile = next((t for t in (os.path.join(ROOT, "profiles", f"r{r}_traffic.json") for r in (6, 5, 4)) if os.path.exists(t)),
+                 os.path.join(ROOT, "profiles", "r6_traffic.json"))
     try:
         with open(tfile) as f:
             t = json.load(f)
@@ -685,8 +684,11 @@ def forward_only_child(args):
     for p in job.model.parameters():
         p.requires_grad_(False)
     n = max(5, min(20, args.steps))
-    for _ in range(4):
-        job.forward_only()
+    t_w = time.perf_counter()
+    k = 0
+    while k < 8 or time.perf_counter() - t_w < 2.0:        # a fresh process starts on an idle chip: let the clocks and the
+        job.forward_only()                                 # caching allocator settle before anything is timed
+        k += 1
     job.finish()
     torch.cuda.synchronize()
     gc.collect()

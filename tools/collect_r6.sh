@@ -52,7 +52,9 @@ t cfg3_bf16 cfg3 bf16 --workload cfg3 --dtype bf16
 t cfg3rpn_bf16 cfg3-rpn bf16 --workload cfg3-rpn --dtype bf16
 t cfg5_bf16 cfg5 bf16 --workload cfg5 --dtype bf16
 t cfg5 cfg5 f32 --workload cfg5
-python3 $R/tools/merge_traffic.py $O/traffic.json $O/traffic_cfg2.json $O/traffic_cfg2_bf16.json $O/traffic_cfg3_bf16.json $O/traffic_cfg3rpn_bf16.json $O/traffic_cfg5_bf16.json $O/traffic_cfg5.json
+t ref_crop_rpn ref-crop-rpn f32 --workload ref-crop-rpn
+t ref_crop_rpn_bf16 ref-crop-rpn bf16 --workload ref-crop-rpn --dtype bf16
+python3 $R/tools/merge_traffic.py $O/traffic.json $O/traffic_cfg2.json $O/traffic_cfg2_bf16.json $O/traffic_cfg3_bf16.json $O/traffic_cfg3rpn_bf16.json $O/traffic_cfg5_bf16.json $O/traffic_cfg5.json $O/traffic_ref_crop_rpn.json $O/traffic_ref_crop_rpn_bf16.json
 fi
 if [ $PART = all ] || [ $PART = sq ]; then
 cd $R; bash tools/collect_sq.sh > $O/sq_collect.log 2>&1; python3 tools/sq_report.py gpurun_out/sq > $O/sq_counters_fp32.txt 2>&1; echo "sq rc=$?"

@@ -71,6 +71,12 @@ def values():
             "refrpn_ms": f"{L('ref_crop_rpn')['ms_per_step']:.1f}", "refrpn_bf16_ms": f"{L('ref_crop_rpn_bf16')['ms_per_step']:.1f}",
             "refrpn_fo": f"{L('ref_crop_rpn')['forward_only_ms']:.1f}", "refrpn_bf16_fo": f"{L('ref_crop_rpn_bf16')['forward_only_ms']:.1f}",
             "cpu16": f"{cb['value'] / 1e3:.0f}", "cpu1": f"{cb['single_thread_value'] / 1e3:.1f}", "index_ms": f"{d['index_build_ms']:.2f}",
+            "x16": f"{d['value'] / cb['value']:.0f}", "x1": f"{d['value'] / cb['single_thread_value']:.0f}",
+            "noprefetch": f"{d['ms_per_step_no_prefetch']:.2f}", "dropin": f"{d['dropin']['ms_per_step']:.2f}",
+            "dropin_pf": f"{d['dropin']['ms_per_step_index_prefetching']:.2f}",
+            "dropin_bf16": f"{d['dropin']['bf16']['ms_per_step']:.2f}",
+            "dropin_bf16_pf": f"{d['dropin']['bf16']['ms_per_step_index_prefetching']:.2f}",
+            "changing": f"{d['changing_scenes']['ms_per_step']:.2f}",
             "TABLE": table()}
 
 
@@ -89,5 +95,19 @@ if __name__ == "__main__":
     assert not left, left
     open(p, "w").write(s)
     print("DESIGN.md filled;", len(v), "values")
+    # the round-6 block between the markers (text: docs/baseline_r6.md)
+    bp = os.path.join(ROOT, "BASELINE.md")
+    b = open(bp).read()
+    blk = open(os.path.join(ROOT, "docs", "baseline_r6.md")).read()
+    for k, val in v.items():
+        blk = blk.replace(f"@@{k}@@", val)
+    assert not re.findall(r"@@\w+@@", blk)
+    m0, m1 = "<!-- R6 BEGIN -->\n", "<!-- R6 END -->\n"
+    if m0 in b:
+        b = b[:b.index(m0)] + m0 + blk + m1 + b[b.index(m1) + len(m1):]
+    else:
+        b = b.replace("## 3. Results\n\n", "## 3. Results\n\n" + m0 + blk + m1, 1)
+    open(bp, "w").write(b)
+    print("BASELINE.md round-6 block written")
     if "--table" in sys.argv:
         print(v["TABLE"])

@@ -57,7 +57,10 @@ extern "C" {
 /*   4  round 5: + scn_debug_set / scn_debug_get (developer switches no longer follow the ambient environment per launch);
  *      scn_exec_timing_collect forgets only the records it returned; + scn_nms_bits / scn_nms_scratch_bytes, scn_dilate_gather_fwd / _bwd,
  *      scn_parent_lookup_div, scn_topk_boxes / scn_topk_scratch_bytes, scn_cell_map (117 entry points) */
-#define SCN_ABI_VERSION 4
+/*   5  round 6: + scn_conv_tiles_chain / scn_conv_tiles_chain_counts (119 entry points); scn_tiles_build_x: bits 8-10 of `with_x`
+ *      = log2 of the row bins in the sort key of a 27-offset table (0: as before); scn_pyramid_build_ex with
+ *      SCN_PYRAMID_XCD_ORDER sorts level 0 by (row bin, mask); switches SCN_TS_PROG, SCN_TS_NO_CHAIN, SCN_TB_NO_BINS */
+#define SCN_ABI_VERSION 5
 
 /* flags for the gather-GEMM entry points */
 #define SCN_F_RELU_IN 1      /* use max(X,0) as the input slab (fuses scn.ReLU before a conv, module_factory.py:88,173-176) */
@@ -262,7 +265,11 @@ int scn_tiles_build(const int32_t* table, int n_off, int64_t n, int32_t* perm, i
  * range is a region of the scene), [9] bin starts in that second list (bin_start[8] = NT).  scn_conv_tiles_bf16 with
  * SCN_F_TILE_ORDER_X hands the tiles of bin x to the workgroups of XCD x: their row gathers then meet in one L2 (the bf16 tile
  * kernel waits for L2 misses at the fine levels: 87 -> 71 us per launch at 600 k voxels, 24.5 -> 21.5 at 150 k; the fp32
- * kernel is bound by its matrix pipe and loses to the shorter per-bin lists, so it keeps the first order). */
+ * kernel is bound by its matrix pipe and loses to the shorter per-bin lists, so it keeps the first order).
+ * Round 6 (ABI 5): `with_x` bit 0 = the second order; bits 8-10 = lb, log2 of the ROW BINS in the sort key of a 27-offset table
+ * (0 = the plain mask sort; lb <= 5): rows are sorted by (row * 2^lb / n, offset mask), so a tile's 16 rows come from one
+ * region of the scene -- what the bf16 builds use at level 0 with lb = 3 (600 k voxels: 71 -> 53 us per launch; results are
+ * independent of the row order inside the tile tables).  scn_tiles_order_ints takes bit 0 only. */
 int64_t scn_tiles_order_ints(int64_t n, int with_x);
 int scn_tiles_build_x(const int32_t* table, int n_off, int64_t n, int32_t* perm, int32_t* tstab, uint32_t* tile_mask,
                       int32_t* tile_order, int with_x, void* scratch, scn_stream_t stream);

@@ -145,7 +145,7 @@ EXPORTS = tuple(_SIGS)
 F_RELU_IN, F_W_TRANSPOSED, F_OFF_REVERSE, F_RESIDUAL_LAST, F_SPLIT_SUM, F_GEMM_V1 = 1, 2, 4, 8, 16, 32
 F_TILE_ORDER_X = 64
 OK, EINVAL, ESIZE, EHASH, EHIP = 0, 1, 2, 3, 4
-ABI_VERSION = 4                 # include/scn_mi355x.h SCN_ABI_VERSION this host layer was written against
+ABI_VERSION = 5                 # include/scn_mi355x.h SCN_ABI_VERSION this host layer was written against
 PYRAMID_MAX_LEVELS, PYRAMID_LEVEL_STRIDE = 8, 72
 PYRAMID_TWO_QUEUES = 1
 PYRAMID_XCD_ORDER = 2

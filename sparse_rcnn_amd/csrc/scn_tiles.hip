@@ -171,7 +171,7 @@ extern "C" int scn_tiles_build_x(const int32_t* table, int n_off, int64_t n, int
 extern "C" int64_t scn_tiles_order_ints(int64_t n, int with_x) {
     if (n < 0) return -1;
     const int64_t nt = cdiv(n, 16);
-    return with_x ? 2 * nt + 16 : nt;
+    return (with_x & 1) ? 2 * nt + 16 : nt;          // (bit 0: the second order; bits 8-10 are the row-bin count of the sort key)
 }
 
 extern "C" int scn_tiles_build(const int32_t* table, int n_off, int64_t n, int32_t* perm, int32_t* tstab,

@@ -26,7 +26,7 @@ static uint32_t lcg(void) { lcg_state = lcg_state * 1664525u + 1013904223u; retu
 static float frand(void) { return (float)(lcg() % 20001) / 10000.0f - 1.0f; }
 
 int main(void) {
-    if (scn_abi_version() != SCN_ABI_VERSION || SCN_ABI_VERSION != 4) { fprintf(stderr, "ABI version\n"); return 1; }
+    if (scn_abi_version() != SCN_ABI_VERSION || SCN_ABI_VERSION != 5) { fprintf(stderr, "ABI version\n"); return 1; }
     /* ---- scene: points with duplicates, two samples ------------------------------------------------ */
     static int64_t coords[NPTS][4];
     for (int p = 0; p < NPTS; ++p) {

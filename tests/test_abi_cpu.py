@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     # and the Python binding table covers the header
     assert sorted(scn.EXPORTS) == declared_functions()
     loaded = scn.load_library()
-    assert loaded.scn_abi_version() == 4          # include/scn_mi355x.h: history of the ABI
+    assert loaded.scn_abi_version() == 5          # include/scn_mi355x.h: history of the ABI
     assert loaded.scn_hash_capacity(1000) == 2048 and loaded.scn_hash_capacity(0) == 1024
     assert loaded.scn_rules_blocks(27, 5000) == 27 * 5
     # the step executor's plan records: the ctypes structures of executor.py have the C layout

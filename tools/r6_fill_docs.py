@@ -87,14 +87,17 @@ if __name__ == "__main__":
     s = open(p).read()
     if "@@" in s:
         open(tpl, "w").write(s)                       # first run: keep the template
-    else:
+    elif os.path.exists(tpl):
         s = open(tpl).read()
-    for k, val in v.items():
-        s = s.replace(f"@@{k}@@", val)
-    left = re.findall(r"@@\w+@@", s)
-    assert not left, left
-    open(p, "w").write(s)
-    print("DESIGN.md filled;", len(v), "values")
+    if "@@" in s:
+        for k, val in v.items():
+            s = s.replace(f"@@{k}@@", val)
+        left = re.findall(r"@@\w+@@", s)
+        assert not left, left
+        open(p, "w").write(s)
+        print("DESIGN.md filled;", len(v), "values")
+    else:
+        print("DESIGN.md has no placeholders and there is no docs/DESIGN.template.md: left as it is")
     # the round-6 block between the markers (text: docs/baseline_r6.md)
     bp = os.path.join(ROOT, "BASELINE.md")
     b = open(bp).read()

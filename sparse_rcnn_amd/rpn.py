@@ -301,8 +301,9 @@ class MultiLevelRpn(nn.Module):
 
 class RoiSelector(nn.Module):
     """`RoiSelector(num_keep_pre_nms, num_keep_post_nms, thresh_nms, detach=True)` (proposal_selector.py:23-50):
-    forward(rpn_bbox, rpn_score, anchors) -> (roi_score, roi_bbox, roi_index) lists per sample.  Where the reference calls
-    `anchor_description(rpn_bbox)`, this takes the anchors tensor and decodes with `decode_boxes`."""
+    forward(rpn_bbox, rpn_score, anchors[, scene_shape]) -> (roi_score, roi_bbox, roi_index) lists per sample.  `anchors` is
+    either the anchors tensor [N, 2, 3] (decoded with `decode_boxes` AFTER the top-k, clipped to `scene_shape` when given) or --
+    the reference's own third argument -- a callable `anchor_description` that maps rpn_bbox to boxes (decoded before the top-k)."""
 
     def __init__(self, num_keep_pre_nms=1024, num_keep_post_nms=64, thresh_nms=0.5, detach=True):
         super().__init__()
@@ -319,6 +320,10 @@ class RoiSelector(nn.Module):
         flags = getattr(rpn_score, "cell_flags", [])
         if self.detach:
             rpn_bbox, rpn_score = rpn_bbox.detach(), rpn_score.detach()
+        if callable(anchors) and not torch.is_tensor(anchors):
+            # the reference's own call: `anchor_description(rpn_bbox)` -- an AnchorDescriptionMultiLevel (anchor.py:218-227) or
+            # any callable that turns the deltas into clipped (start, stop) boxes -- decodes every anchor before the selection
+            return self.proposal_selector.start(torch.sigmoid(rpn_score), anchors(rpn_bbox)) + (flags,)
         if scene_shape is not None and not torch.is_tensor(scene_shape):
             key = (tuple(float(v) for v in scene_shape), str(rpn_bbox.device))
             t = self._scene_cache.get(key)
@@ -334,3 +339,35 @@ class RoiSelector(nn.Module):
             raise L.ScnError("DenseRpn: rows of a level tensor lie outside its spatial_size / batch (scn_cell_map counted "
                              f"{[int(f[0]) for f in state[4]]}): its Metadata and its coordinates disagree")
         return out
+
+
+class _TrainValSelector(nn.Module):
+    """Training-mode / evaluation-mode pair of selectors (the reference wraps its two RoiSelectors in a `ConditionalStage`,
+    custom_container.py:102-116: every call and attribute goes to the member that matches `self.training`)."""
+
+    def __init__(self, train_module, val_module):
+        super().__init__()
+        self.train_module, self.val_module = train_module, val_module
+
+    def _member(self):
+        return self.train_module if self.training else self.val_module
+
+    def forward(self, *a, **kw):
+        return self._member()(*a, **kw)
+
+    def start(self, *a, **kw):
+        return self._member().start(*a, **kw)
+
+    def finish(self, state):
+        return self._member().finish(state)
+
+
+def get_roi_selector(num_keep_pre_nms=1000, num_keep_post_nms=500, thresh_nms=0.5, val_num_keep_pre_nms=None,
+                     val_num_keep_post_nms=None, val_thresh_nms=None):
+    """`get_roi_selector` (proposal_selector.py:6-20) with the reference's defaults: one RoiSelector, or -- when evaluation has
+    its own numbers (scannet_config/run.py:847-853: 1024 / 256 / 0.5 in training, 1024 / 32 or 256 / 0.3 in evaluation) -- a pair
+    that follows `module.training`."""
+    sel = RoiSelector(num_keep_pre_nms, num_keep_post_nms, thresh_nms)
+    if val_num_keep_pre_nms:
+        sel = _TrainValSelector(sel, RoiSelector(val_num_keep_pre_nms, val_num_keep_post_nms, val_thresh_nms))
+    return sel

@@ -1867,3 +1867,30 @@ def test_dense_rpn_stack_on_the_tile_kernels_equals_the_miopen_engine(gpu):
         outs.append((bb.float(), sc.float()))
     for u, v in zip(*outs):
         assert float((u - v).abs().max()) <= 3e-2 * max(float(v.abs().max()), 1e-6)
+
+
+def test_roi_selector_takes_the_references_anchor_description_callable(gpu):
+    """`RoiSelector.forward(rpn_bbox, rpn_score, anchor_description)` (proposal_selector.py:34-50): the reference hands over a
+    callable that decodes and clips (`AnchorDescriptionMultiLevel.forward`, anchor.py:218-227).  Both forms -- the callable
+    (decode every anchor, then select) and the anchors tensor + scene shape (select, then decode the selected) -- give the same
+    proposals bit for bit."""
+    from sparse_rcnn_amd import rpn as R
+    g = torch.Generator().manual_seed(5)
+    n, scene = 6000, (96.0, 80.0, 48.0)
+    ctr = torch.rand(n, 3, generator=g) * torch.tensor(scene)
+    size = torch.rand(n, 3, generator=g) * 20 + 4
+    anchors = torch.stack([ctr, size], 1).to(gpu)
+    rpn_bbox = (torch.randn(2, n, 2, 3, generator=g) * 0.2).to(gpu)
+    rpn_score = torch.randn(2, n, generator=g).to(gpu)
+    sel = R.RoiSelector(512, 40, 0.4)
+
+    def anchor_description(deltas):                       # what the reference's module computes, as a plain callable
+        return R.decode_boxes(anchors, deltas, scene)
+    a = sel(rpn_bbox, rpn_score, anchors, scene)
+    b = sel(rpn_bbox, rpn_score, anchor_description)
+    for x, y in zip(a, b):
+        assert len(x) == len(y) == 2
+        for u, v in zip(x, y):
+            assert torch.equal(u.cpu(), v.cpu())
+    assert all(1 <= len(s) <= 40 for s in a[0])
+    assert float(a[1][0].min()) >= 0.0 and float((a[1][0] - torch.tensor(scene, device=a[1][0].device)).max()) <= 0.0    # clipped

@@ -77,3 +77,16 @@ def test_roi_selector_raises_on_rows_outside_the_volume():
     with pytest.raises(Exception, match="outside its spatial_size"):
         sel.finish((None, None, None, None, [flag]))
     assert sel.finish((None, None, None, None, [torch.zeros(1, dtype=torch.int32)])) == ([], [], [])
+
+
+def test_get_roi_selector_follows_training_mode_like_the_references_conditional_stage():
+    """proposal_selector.py:6-20 / custom_container.py:102-116: one selector, or a train / eval pair chosen by `.training`
+    (scannet_config/run.py:847-853: 1024 / 256 / 0.5 against 1024 / 32 / 0.3)."""
+    one = R.get_roi_selector(1024, 256, 0.5)
+    assert isinstance(one, R.RoiSelector) and one.proposal_selector.num_keep_post_nms == 256
+    pair = R.get_roi_selector(1024, 256, 0.5, val_num_keep_pre_nms=1024, val_num_keep_post_nms=32, val_thresh_nms=0.3)
+    assert pair._member().proposal_selector.num_keep_post_nms == 256 and pair._member().proposal_selector.thresh_nms == 0.5
+    pair.eval()
+    assert pair._member().proposal_selector.num_keep_post_nms == 32 and pair._member().proposal_selector.thresh_nms == 0.3
+    pair.train()
+    assert pair._member() is pair.train_module

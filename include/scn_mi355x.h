@@ -57,7 +57,7 @@ extern "C" {
 /*   4  round 5: + scn_debug_set / scn_debug_get (developer switches no longer follow the ambient environment per launch);
  *      scn_exec_timing_collect forgets only the records it returned; + scn_nms_bits / scn_nms_scratch_bytes, scn_dilate_gather_fwd / _bwd,
  *      scn_parent_lookup_div, scn_topk_boxes / scn_topk_scratch_bytes, scn_cell_map (117 entry points) */
-/*   5  round 6: + scn_conv_tiles_chain / scn_conv_tiles_chain_counts (119 entry points); scn_tiles_build_x: bits 8-10 of `with_x`
+/*   5  round 6: + scn_conv_tiles_chain / scn_conv_tiles_chain_counts, scn_wgrad_tiles32 / _scratch_bytes (121 entry points); scn_tiles_build_x: bits 8-10 of `with_x`
  *      = log2 of the row bins in the sort key of a 27-offset table (0: as before); scn_pyramid_build_ex with
  *      SCN_PYRAMID_XCD_ORDER sorts level 0 by (row bin, mask); switches SCN_TS_PROG, SCN_TS_NO_CHAIN, SCN_TB_NO_BINS */
 #define SCN_ABI_VERSION 5
@@ -740,6 +740,17 @@ int scn_exec_run_streams(const scn_exec_op* ops, int n_ops, const scn_exec_level
  * sums of a pass run behind its last op and belong to no record. */
 int scn_exec_timing_enable(int on);
 int64_t scn_exec_timing_collect(float* ms, int64_t* info, int64_t cap);
+
+/* Round 6 (experiment, opt-in; nothing in the package calls it): the weight gradient of a SubM 3^3 layer with 32 input and 32
+ * output channels in TILE-major form -- one row gather per rule: the dY rows of a mask-sorted tile are loaded once into LDS and
+ * serve every offset of the tile, the offsets are dealt to the waves of a workgroup (profiles/r6_wgrad_one_gather.txt).  Serves
+ * the same call sites as scn_wgrad_rules (the weight gradient of scn.SubmanifoldConvolution: module_factory.py:396-414).
+ * X [n_in][32], dY [n_out][32] fp32; tstab / tile_mask / perm from scn_tiles_build over the layer's 27-offset table;
+ * prefix_host[28] = the rule prefix (weights of the offset -> wave deal); dW [27][32][32]; scratch >= scn_wgrad_tiles32_scratch_bytes(). */
+int64_t scn_wgrad_tiles32_scratch_bytes(void);
+int scn_wgrad_tiles32(const float* X, int64_t n_in, const float* dY, int64_t n_out, const int32_t* tstab,
+                      const uint32_t* tile_mask, const int32_t* perm, const int64_t* prefix_host, float* dW, void* scratch,
+                      int relu_in, scn_stream_t stream);
 
 #ifdef __cplusplus
 }

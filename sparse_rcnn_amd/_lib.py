@@ -57,6 +57,8 @@ _SIGS = {
     "scn_conv_tiles": (C.c_int, [p, i64, i32, p, p, p, p, i32, i64, p, p, p, p, p, i32, i32, p, p, p]),
     "scn_conv_tiles_chain": (C.c_int, [i32, p, i64, i32, p, p, p, p, i32, i64, i32, p, p, p]),
     "scn_conv_tiles_chain_counts": (None, [C.POINTER(i64), i32]),
+    "scn_wgrad_tiles32_scratch_bytes": (i64, []),
+    "scn_wgrad_tiles32": (C.c_int, [p, i64, p, i64, p, p, p, p, p, p, i32, p]),
     "scn_conv_tiles_path_counts": (None, [C.POINTER(i64), i32]),
     "scn_conv_tiles_split_count": (i64, [i32]),
     "scn_conv_tiles_finish": (C.c_int, [i32, i64, p, p, p, p, i32, i32, p, p]),

@@ -1894,3 +1894,41 @@ def test_roi_selector_takes_the_references_anchor_description_callable(gpu):
             assert torch.equal(u.cpu(), v.cpu())
     assert all(1 <= len(s) <= 40 for s in a[0])
     assert float(a[1][0].min()) >= 0.0 and float((a[1][0] - torch.tensor(scene, device=a[1][0].device)).max()) <= 0.0    # clipped
+
+
+def test_tile_major_weight_gradient_agrees_with_the_rule_major_kernel(gpu):
+    """scn_wgrad_tiles32 (round 6, experiment (c): one row gather per rule, dY tiles through LDS, offsets dealt to waves;
+    profiles/r6_wgrad_one_gather.txt) computes the weight gradient of a 32 -> 32 SubM 3^3 layer (module_factory.py:396-414) from
+    the forward kernel's tile tables: equal to an fp64 evaluation of the rules within 2e-6 of the scale, as the product kernel
+    (scn_wgrad_rules) is; deterministic; with and without the fused input ReLU; a level whose last tile is ragged."""
+    from sparse_rcnn_amd import _lib as L
+    lib = L.lib()
+    scn, coords, feats, fg, x, scene, size = _input(gpu, seed=31, cin=4, grid=(40, 36, 20), n=9003, batch=2, dup=200)
+    rb = x.metadata.subm_rulebook(tuple(int(s) for s in size), 3)
+    n, r, t = rb.n, rb.rules, rb.tiles
+    assert n % 16 != 0
+    g = torch.Generator(device="cuda").manual_seed(2)
+    X = torch.randn(n, 32, device=gpu, generator=g)
+    dY = torch.randn(n, 32, device=gpu, generator=g)
+    ph = r.prefix_host
+    s0 = torch.empty(lib.scn_wgrad_scratch_bytes(32, 32, ph, 27), dtype=torch.uint8, device=gpu)
+    s1 = torch.empty(lib.scn_wgrad_tiles32_scratch_bytes(), dtype=torch.uint8, device=gpu)
+    for relu in (0, 1):
+        dW0 = torch.empty(27, 32, 32, device=gpu)
+        dW1 = torch.full((27, 32, 32), float("nan"), device=gpu)
+        L.check(lib.scn_wgrad_rules(L.ptr(X), 32, L.ptr(dY), 32, L.ptr(r.in_rows), L.ptr(r.out_rows), ph, 27, L.ptr(dW0), L.ptr(s0),
+                                    relu, L.stream()))
+        L.check(lib.scn_wgrad_tiles32(L.ptr(X), n, L.ptr(dY), n, L.ptr(t.tstab), L.ptr(t.tile_mask), L.ptr(t.perm), ph, L.ptr(dW1),
+                                      L.ptr(s1), relu, L.stream()))
+        again = torch.empty_like(dW1)
+        L.check(lib.scn_wgrad_tiles32(L.ptr(X), n, L.ptr(dY), n, L.ptr(t.tstab), L.ptr(t.tile_mask), L.ptr(t.perm), ph, L.ptr(again),
+                                      L.ptr(s1), relu, L.stream()))
+        Xr = X.clamp_min(0) if relu else X
+        ref = torch.zeros(27, 32, 32, device=gpu, dtype=torch.float64)
+        for o in range(27):
+            a, b = int(ph[o]), int(ph[o + 1])
+            if b > a:
+                ref[o] = Xr[r.in_rows[a:b].long()].double().t() @ dY[r.out_rows[a:b].long()].double()
+        sc = float(ref.abs().max())
+        assert torch.equal(dW1, again)
+        assert float((dW1.double() - ref).abs().max()) <= 2e-6 * sc and float((dW0.double() - ref).abs().max()) <= 2e-6 * sc
